@@ -1,0 +1,184 @@
+/*
+ * mbavo.h -- C ABI of the MI355X-native blur-aware photometric tracking path.
+ *
+ * Drop-in boundary for the hot path of ethliup/MBA-VO (src/ba_tracker).  Every
+ * entry point names the reference interface it replaces (paths relative to the
+ * reference's src/).  Plain pointers and sizes only; `d_` = device (HIP) memory,
+ * `h_` = host memory.  All functions return 0 on success, a positive hipError_t
+ * value on a HIP failure, or a negative MBAVO_E_* code; none of them falls back
+ * to a CPU path -- without a usable HIP device the compute entry points fail.
+ *
+ * The C++ API with the reference's exact signatures (namespace SLAM::VO) is in
+ * mba-vo_amd/csrc/ba_tracker.h and is exported by the same shared library.
+ */
+#ifndef MBAVO_H
+#define MBAVO_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MBAVO_E_ARG (-1)      /* bad argument (null pointer, unsupported spline degree, ...) */
+#define MBAVO_E_RANGE (-2)    /* a blur sample fell outside the spline's knot range (SplineFunctor.h:13-19 has no check) */
+#define MBAVO_E_NODEVICE (-3) /* no HIP device: the product has no CPU fallback */
+
+typedef struct mbavo_ctx mbavo_ctx;
+
+/* One alignment problem = the argument list of evaluate_cost_hessian_gradient
+ * (ba_tracker/spline_update_step.h:70-87) plus the CudaSharedStorages fields it
+ * reads (spline_update_step.h:18-58), as POD.  All pointers are DEVICE pointers
+ * except h_start_idx. */
+typedef struct mbavo_problem {
+    int S;                                /* n_vir_poses_per_frame */
+    int F;                                /* n_frames */
+    int K;                                /* num_keypoints */
+    int P;                                /* patch_size */
+    int N;                                /* num_ctrl_knots */
+    int H, W;                             /* im_size_HW */
+    const unsigned char *d_ref_img;       /* cuda_ref_img, H*W u8 */
+    const float *d_ref_dIxy;              /* cuda_dIxy_ref, H*W*2 interleaved [dx,dy] */
+    const unsigned char *const *d_cur_imgs; /* storages.cuda_cur_images: device array of F device pointers */
+    const double *d_kp_xy;                /* keypoint i at d_kp_xy[i*kp_stride + {0,1}] */
+    int kp_stride;                        /* 2 = packed xy; 3 = Core::Vector2d array, pointer at .values */
+    const double *d_kp_z;                 /* storages.cuda_keypoint_depth_z, K */
+    const int *d_pattern;                 /* storages.cuda_local_patch_pattern_xy, P*2 (dx,dy) */
+    const unsigned char *d_outlier;       /* storages.cuda_keypoints_outlier_flags, K, or NULL */
+    int num_bad;                          /* storages.num_bad_keypoints */
+    double intrinsics[4];                 /* fx fy cx cy at this pyramid level */
+    const double *d_cap_time;             /* storages.cuda_img_cap_time, F */
+    const double *d_exp_time;             /* storages.cuda_img_exp_time, F */
+    double t0, dt;                        /* spline_start_time, spline_sample_dt */
+    const double *d_knots_t;              /* storages.cuda_spline_ctrl_knots_data_t, 3N */
+    const double *d_knots_R;              /* storages.cuda_spline_ctrl_knots_data_R, 4N xyzw */
+    const int *h_start_idx;               /* cpu_ctrl_knot_start_indices, F (host; only read by host merges) */
+    double huber_a;
+} mbavo_problem;
+
+/* ---- context: owns all device scratch (replaces initialize/free_shared_cuda_storages,
+ * ba_tracker/spline_update_step.cpp:9-95, for the fused path) */
+int mbavo_create(mbavo_ctx **out, int device_id);
+int mbavo_destroy(mbavo_ctx *ctx);
+int mbavo_set_stream(mbavo_ctx *ctx, void *hip_stream); /* NULL = default stream */
+int mbavo_packed_len(int spline_deg_k);                 /* E = (6k+1)(6k+2)/2 */
+
+/* ---- fused evaluation of B independent problems in one pass (poses -> residual /
+ * Jacobian -> packed normal-equation blocks).  Replaces steps (1)-(5) of
+ * evaluate_cost_hessian_gradient (spline_update_step.cpp:127-227) for every problem.
+ * Asynchronous on the context's stream.
+ *   d_frame_blocks: sum_b F_b rows of E doubles, problem-major then frame:
+ *                   [cost | g_local (6k) | upper(H_local)] == cuda_frame_cost_gradient_hessian_tR
+ *   d_patch_cost  : sum_b F_b*K_b doubles (slot 0 of every patch block), or NULL
+ *   d_valid       : sum_b F_b doubles, number of in-bounds pixels per frame, or NULL
+ * with_hessian = 0 is the reference's cost-only mode (H/g slots left untouched). */
+int mbavo_eval_batch(mbavo_ctx *ctx, int B, const mbavo_problem *h_problems, int spline_deg_k,
+                     int with_hessian, double *d_frame_blocks, double *d_patch_cost, double *d_valid);
+
+/* synchronous single problem, host outputs == evaluate_cost_hessian_gradient
+ * (spline_update_step.h:70-87): h_H is the 6N x 6N column-major system, h_g 6N;
+ * pass NULL, NULL for cost-only.  d_patch_blocks (F*K*E, may be NULL) receives slot 0
+ * of every patch block at stride E like cuda_patch_cost_gradient_hessian_tR. */
+int mbavo_eval(mbavo_ctx *ctx, const mbavo_problem *h_problem, int spline_deg_k,
+               double *h_total_cost, double *h_H, double *h_g, double *d_patch_blocks);
+
+/* ---- the reference's five launchers, one call each (device buffers caller-owned,
+ * synchronous like the reference). */
+/* compute_virtual_camera_poses (ba_tracker/compute_virtual_camera_poses.h:18-33) */
+int mbavo_compute_virtual_camera_poses(int S, int F, const double *d_cap, const double *d_exp, int spline_deg_k,
+                                       double t0, double dt, const double *d_knots_t, const double *d_knots_R,
+                                       double *d_poses, double *d_J_t, double *d_J_R);
+/* compute_local_patches_xy (ba_tracker/compute_local_patches_xy.h:10-18); xy arrays are Core::Vector2d (24 B) */
+int mbavo_compute_local_patches_xy(int S, int F, const double *d_poses, const void *d_keypoints_vec2d,
+                                   const double *d_kp_z, int K, const double intrinsics[4], const int HW[2],
+                                   void *d_local_patches_vec2d);
+/* compute_pixel_jacobian_residual (ba_tracker/compute_hessian_gradients_cost.h:11-29) */
+int mbavo_compute_pixel_jacobian_residual(const unsigned char *d_I_ref, const float *d_dIxy_ref,
+                                          const unsigned char *const *d_I_cur_imgs, int S, int F,
+                                          const double *d_poses, int spline_deg_k, const double *d_J_t,
+                                          const double *d_J_R, const void *d_local_patches_vec2d,
+                                          const double *d_kp_z, int K, const int *d_pattern, int P,
+                                          const double intrinsics[4], const int HW[2],
+                                          double *d_pixel_residuals, double *d_pixel_jacobians_or_null);
+/* compute_patch_cost_gradient_hessian (compute_hessian_gradients_cost.h:52-60) */
+int mbavo_compute_patch_cost_gradient_hessian(int F, int K, int P, int spline_deg_k, const double *d_residuals,
+                                              const double *d_jacobians_or_null, double huber_a,
+                                              double inv_num_residuals, double *d_patch_blocks);
+/* compute_frame_cost_gradient_hessian (compute_hessian_gradients_cost.h:62-68) */
+int mbavo_compute_frame_cost_gradient_hessian(int F, int K, int spline_deg_k, const double *d_patch_blocks,
+                                              int eval_gradient_hessian, const unsigned char *d_outlier_or_null,
+                                              double *d_frame_blocks);
+/* merge_hessian_gradient_cost (ba_tracker/merge_hessian_gradient_cost.h:8-15): D2H + scatter */
+int mbavo_merge_hessian_gradient_cost(int F, int spline_deg_k, const double *d_frame_blocks, const int *h_start_idx,
+                                      int N, double *h_total_cost, double *h_H, double *h_g);
+/* the scatter alone, on host blocks (merge_hessian_gradient_cost.cpp:39-86) */
+int mbavo_merge_host(int F, int spline_deg_k, const double *h_frame_blocks, const int *h_start_idx, int N,
+                     double *h_total_cost, double *h_H, double *h_g);
+/* solve_normal_equation (ba_tracker/solve_normal_equation.h:10-35): x = -A^+ b; 0 = Jacobi SVD, 1 = LDLT */
+int mbavo_solve_normal_equation(const double *h_A_colmajor, const double *h_b, int n, int solver_type, double *h_x);
+
+/* ---- host control flow that decides how often the path runs */
+/* LevenbergMarquardtStrategy (ba_tracker/levenberg_marquardt_strategy.h:8-27) */
+typedef struct mbavo_lm mbavo_lm;
+mbavo_lm *mbavo_lm_new(void);
+void mbavo_lm_delete(mbavo_lm *);
+void mbavo_lm_reset(mbavo_lm *);
+void mbavo_lm_step_accepted(mbavo_lm *, double step_quality);
+void mbavo_lm_step_rejected(mbavo_lm *);
+double mbavo_lm_get_radius(mbavo_lm *);
+/* TrustRegionStepEvaluator (ba_tracker/trust_region_step_evaluator.h:37-80) */
+typedef struct mbavo_tr mbavo_tr;
+mbavo_tr *mbavo_tr_new(int max_consecutive_nonmonotonic_steps);
+void mbavo_tr_delete(mbavo_tr *);
+void mbavo_tr_reset(mbavo_tr *, double initial_cost);
+double mbavo_tr_step_quality(mbavo_tr *, double cost, double model_cost_change);
+void mbavo_tr_step_accepted(mbavo_tr *, double cost, double model_cost_change);
+
+/* SplineSE3 pieces (core/common/Spline.h:222-330) on flat knot arrays */
+int mbavo_spline_get_pose(int spline_deg_k, double t0, double dt, const double *h_knots_t, const double *h_knots_R,
+                          int N, double t, double h_t_out[3], double h_q_out_xyzw[4],
+                          double *h_J_t_or_null /*3x3k*/, double *h_J_R_or_null /*4x3k*/);
+int mbavo_spline_plus(const double *h_knots_t, const double *h_knots_R, int N, const double *h_step /*6N*/,
+                      double *h_cand_t, double *h_cand_R);
+int mbavo_segment_start_index(double t, double t0, double dt); /* SplineFunctor.h:13-19 */
+
+/* ---- LM loop over the pyramid: BlurAwareDirectTracker::optimizeTrajectory
+ * (ba_tracker/blur_aware_direct_tracker.cpp:544-924) on device-resident levels */
+typedef struct mbavo_level {
+    int H, W, K, P, S;
+    const unsigned char *d_ref_img;
+    const float *d_ref_dIxy;
+    const unsigned char *const *d_cur_imgs; /* device array of F device pointers */
+    const double *d_kp_xy;                  /* packed K*2 */
+    const double *d_kp_z;
+    const int *d_pattern;
+} mbavo_level;
+typedef struct mbavo_track_opts {
+    int num_levels, spline_deg_k, max_num_iterations, max_consecutive_nonmonotonic_steps, solver_type;
+    double intrinsics[4]; /* level 0 */
+    double huber_k, min_step_quality, min_abs_cost_decrease, max_chi_square_error;
+} mbavo_track_opts;
+typedef struct mbavo_trace_rec {
+    int level, iter, kind; /* 0 initial evaluation, 1 accepted, 2 rejected, 3 invalid step */
+    int num_outliers;
+    double radius, eval_cost, candidate_cost, model_change, quality;
+} mbavo_trace_rec;
+/* knots are updated in place; returns the number of trace records (>= 0) or an error (< 0) */
+int mbavo_optimize_trajectory(mbavo_ctx *ctx, const mbavo_track_opts *opts, const mbavo_level *levels, int F,
+                              const double *h_cap, const double *h_exp, double t0, double dt,
+                              double *h_knots_t, double *h_knots_R, int N, int *h_start_idx_out,
+                              double *h_final_cost, mbavo_trace_rec *trace, int trace_cap);
+
+/* ---- keyframe input producers on device (core/measurements/ImagePyramid.h:59-99,
+ * core/image_proc/Gradient.h:16-75) */
+int mbavo_pyramid_down_u8(const unsigned char *d_src, int H, int W, unsigned char *d_dst, void *hip_stream);
+int mbavo_image_gradients_u8(const unsigned char *d_src, int H, int W, float *d_dIxy, void *hip_stream);
+
+/* ---- multi-GPU: in-place sum of the packed blocks over all ranks (RCCL over xGMI).
+ * `rccl_comm` is an ncclComm_t created by the caller; count in doubles. */
+int mbavo_allreduce_blocks(mbavo_ctx *ctx, void *rccl_comm, double *d_blocks, long long count);
+
+const char *mbavo_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Builds libmbavo.so (HIP kernels + host code + C ABI) for gfx950, in-tree.
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-result"
+mkdir -p build
+pids=()
+for f in csrc/engine.hip csrc/ba_tracker.hip csrc/image_ops.hip; do
+  o=build/$(basename "$f").o
+  if [ ! -f "$o" ] || [ -n "$(find csrc -newer "$o" -print -quit)" ] || [ ../include/mbavo.h -nt "$o" ]; then
+    $HIPCC $FLAGS -c "$f" -o "$o" & pids+=($!)
+  fi
+done
+for f in csrc/host_math.cpp csrc/tracker.cpp csrc/c_api.cpp; do
+  o=build/$(basename "$f").o
+  if [ ! -f "$o" ] || [ -n "$(find csrc -newer "$o" -print -quit)" ] || [ ../include/mbavo.h -nt "$o" ]; then
+    $HIPCC $FLAGS -x hip -c "$f" -o "$o" & pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libmbavo.so build/*.o -ldl
+echo "built $(pwd)/libmbavo.so"

@@ -1,0 +1,168 @@
+"""ctypes binding of libmbavo.so (include/mbavo.h).  No CPU fallback: if the library is
+missing or no HIP device is usable, the compute entry points raise."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmbavo.so")
+_LIB = None
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+vp = C.c_void_p
+
+
+class Problem(C.Structure):
+    """struct mbavo_problem"""
+    _fields_ = [
+        ("S", C.c_int), ("F", C.c_int), ("K", C.c_int), ("P", C.c_int), ("N", C.c_int),
+        ("H", C.c_int), ("W", C.c_int),
+        ("d_ref_img", vp), ("d_ref_dIxy", vp), ("d_cur_imgs", vp),
+        ("d_kp_xy", vp), ("kp_stride", C.c_int), ("d_kp_z", vp), ("d_pattern", vp),
+        ("d_outlier", vp), ("num_bad", C.c_int), ("intrinsics", C.c_double * 4),
+        ("d_cap_time", vp), ("d_exp_time", vp), ("t0", C.c_double), ("dt", C.c_double),
+        ("d_knots_t", vp), ("d_knots_R", vp), ("h_start_idx", c_ip), ("huber_a", C.c_double),
+    ]
+
+
+class Level(C.Structure):
+    """struct mbavo_level"""
+    _fields_ = [
+        ("H", C.c_int), ("W", C.c_int), ("K", C.c_int), ("P", C.c_int), ("S", C.c_int),
+        ("d_ref_img", vp), ("d_ref_dIxy", vp), ("d_cur_imgs", vp),
+        ("d_kp_xy", vp), ("d_kp_z", vp), ("d_pattern", vp),
+    ]
+
+
+class TrackOpts(C.Structure):
+    """struct mbavo_track_opts"""
+    _fields_ = [
+        ("num_levels", C.c_int), ("spline_deg_k", C.c_int), ("max_num_iterations", C.c_int),
+        ("max_consecutive_nonmonotonic_steps", C.c_int), ("solver_type", C.c_int),
+        ("intrinsics", C.c_double * 4), ("huber_k", C.c_double), ("min_step_quality", C.c_double),
+        ("min_abs_cost_decrease", C.c_double), ("max_chi_square_error", C.c_double),
+    ]
+
+
+class TraceRec(C.Structure):
+    """struct mbavo_trace_rec"""
+    _fields_ = [
+        ("level", C.c_int), ("iter", C.c_int), ("kind", C.c_int), ("num_outliers", C.c_int),
+        ("radius", C.c_double), ("eval_cost", C.c_double), ("candidate_cost", C.c_double),
+        ("model_change", C.c_double), ("quality", C.c_double),
+    ]
+
+
+# every symbol include/mbavo.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "mbavo_create", "mbavo_destroy", "mbavo_set_stream", "mbavo_packed_len", "mbavo_eval_batch", "mbavo_eval",
+    "mbavo_compute_virtual_camera_poses", "mbavo_compute_local_patches_xy", "mbavo_compute_pixel_jacobian_residual",
+    "mbavo_compute_patch_cost_gradient_hessian", "mbavo_compute_frame_cost_gradient_hessian",
+    "mbavo_merge_hessian_gradient_cost", "mbavo_merge_host", "mbavo_solve_normal_equation",
+    "mbavo_lm_new", "mbavo_lm_delete", "mbavo_lm_reset", "mbavo_lm_step_accepted", "mbavo_lm_step_rejected",
+    "mbavo_lm_get_radius", "mbavo_tr_new", "mbavo_tr_delete", "mbavo_tr_reset", "mbavo_tr_step_quality",
+    "mbavo_tr_step_accepted", "mbavo_spline_get_pose", "mbavo_spline_plus", "mbavo_segment_start_index",
+    "mbavo_optimize_trajectory", "mbavo_pyramid_down_u8", "mbavo_image_gradients_u8", "mbavo_allreduce_blocks",
+    "mbavo_version",
+]
+
+
+def build(quiet=True):
+    """hipcc --offload-arch=gfx950 build of libmbavo.so (cross-compiles without a GPU)."""
+    subprocess.run(["bash", os.path.join(_HERE, "build.sh")], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+    return LIB_PATH
+
+
+def load():
+    """Load libmbavo.so; raises if it has not been built (the product has no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libmbavo.so is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    L = C.CDLL(LIB_PATH)
+    L.mbavo_version.restype = C.c_char_p
+    L.mbavo_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.mbavo_destroy.argtypes = [vp]
+    L.mbavo_set_stream.argtypes = [vp, vp]
+    L.mbavo_packed_len.argtypes = [C.c_int]
+    L.mbavo_eval_batch.argtypes = [vp, C.c_int, C.POINTER(Problem), C.c_int, C.c_int, vp, vp, vp]
+    L.mbavo_eval.argtypes = [vp, C.POINTER(Problem), C.c_int, c_dp, c_dp, c_dp, vp]
+    L.mbavo_compute_virtual_camera_poses.argtypes = [C.c_int, C.c_int, vp, vp, C.c_int, C.c_double, C.c_double,
+                                                     vp, vp, vp, vp, vp]
+    L.mbavo_compute_local_patches_xy.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, c_dp, c_ip, vp]
+    L.mbavo_compute_pixel_jacobian_residual.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp,
+                                                        C.c_int, vp, C.c_int, c_dp, c_ip, vp, vp]
+    L.mbavo_compute_patch_cost_gradient_hessian.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_double,
+                                                            C.c_double, vp]
+    L.mbavo_compute_frame_cost_gradient_hessian.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp]
+    L.mbavo_merge_hessian_gradient_cost.argtypes = [C.c_int, C.c_int, vp, c_ip, C.c_int, c_dp, c_dp, c_dp]
+    L.mbavo_merge_host.argtypes = [C.c_int, C.c_int, c_dp, c_ip, C.c_int, c_dp, c_dp, c_dp]
+    L.mbavo_solve_normal_equation.argtypes = [c_dp, c_dp, C.c_int, C.c_int, c_dp]
+    L.mbavo_lm_new.restype = vp
+    for n in ("mbavo_lm_delete", "mbavo_lm_reset", "mbavo_lm_step_rejected"):
+        getattr(L, n).argtypes = [vp]
+        getattr(L, n).restype = None
+    L.mbavo_lm_step_accepted.argtypes = [vp, C.c_double]
+    L.mbavo_lm_step_accepted.restype = None
+    L.mbavo_lm_get_radius.argtypes = [vp]
+    L.mbavo_lm_get_radius.restype = C.c_double
+    L.mbavo_tr_new.restype = vp
+    L.mbavo_tr_new.argtypes = [C.c_int]
+    L.mbavo_tr_delete.argtypes = [vp]
+    L.mbavo_tr_delete.restype = None
+    L.mbavo_tr_reset.argtypes = [vp, C.c_double]
+    L.mbavo_tr_reset.restype = None
+    L.mbavo_tr_step_quality.argtypes = [vp, C.c_double, C.c_double]
+    L.mbavo_tr_step_quality.restype = C.c_double
+    L.mbavo_tr_step_accepted.argtypes = [vp, C.c_double, C.c_double]
+    L.mbavo_tr_step_accepted.restype = None
+    L.mbavo_spline_get_pose.argtypes = [C.c_int, C.c_double, C.c_double, c_dp, c_dp, C.c_int, C.c_double,
+                                        c_dp, c_dp, c_dp, c_dp]
+    L.mbavo_spline_plus.argtypes = [c_dp, c_dp, C.c_int, c_dp, c_dp, c_dp]
+    L.mbavo_segment_start_index.argtypes = [C.c_double, C.c_double, C.c_double]
+    L.mbavo_optimize_trajectory.argtypes = [vp, C.POINTER(TrackOpts), C.POINTER(Level), C.c_int, c_dp, c_dp,
+                                            C.c_double, C.c_double, c_dp, c_dp, C.c_int, c_ip, c_dp,
+                                            C.POINTER(TraceRec), C.c_int]
+    L.mbavo_pyramid_down_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.mbavo_image_gradients_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.mbavo_allreduce_blocks.argtypes = [vp, vp, vp, C.c_longlong]
+    _LIB = L
+    return L
+
+
+def dp(a):
+    return None if a is None else a.ctypes.data_as(c_dp)
+
+
+def ip(a):
+    return None if a is None else a.ctypes.data_as(c_ip)
+
+
+def check(rc, what="mbavo call"):
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (what, rc))
+
+
+class Context:
+    """mbavo_ctx wrapper."""
+
+    def __init__(self, device_id=0, stream=None):
+        self.lib = load()
+        self.handle = vp()
+        check(self.lib.mbavo_create(C.byref(self.handle), int(device_id)), "mbavo_create")
+        if stream is not None:
+            check(self.lib.mbavo_set_stream(self.handle, vp(stream)), "mbavo_set_stream")
+
+    def close(self):
+        if self.handle:
+            self.lib.mbavo_destroy(self.handle)
+            self.handle = vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

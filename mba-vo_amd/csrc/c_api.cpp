@@ -1,0 +1,257 @@
+// c_api.cpp -- the extern "C" boundary declared in include/mbavo.h.
+// Thin POD wrappers over the C++ ba_tracker API (ba_tracker.h), the fused engine
+// (engine.h) and the host control flow (host_math.h, tracker.h).
+#include "../../include/mbavo.h"
+#include "ba_tracker.h"
+#include "engine.h"
+#include "host_math.h"
+#include "se3_math.h"
+#include "tracker.h"
+
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <new>
+#include <vector>
+
+using namespace SLAM;
+
+struct mbavo_ctx
+{
+    mbavo::Engine *engine;
+};
+struct mbavo_lm
+{
+    VO::LevenbergMarquardtStrategy impl;
+};
+struct mbavo_tr
+{
+    VO::TrustRegionStepEvaluator impl;
+    explicit mbavo_tr(int m) : impl(m) {}
+};
+
+static int packed_len(int k)
+{
+    const int nd = 6 * k + 1;
+    return nd * (nd + 1) / 2;
+}
+
+extern "C"
+{
+    const char *mbavo_version(void) { return "mbavo-mi355x 0.1 (gfx950)"; }
+
+    int mbavo_packed_len(int k) { return packed_len(k); }
+
+    int mbavo_create(mbavo_ctx **out, int device_id)
+    {
+        if (!out) return MBAVO_E_ARG;
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n)
+        {
+            fprintf(stderr, "mbavo: no usable HIP device (count=%d, requested %d); there is no CPU fallback\n", n, device_id);
+            return MBAVO_E_NODEVICE;
+        }
+        hipError_t e = hipSetDevice(device_id);
+        if (e != hipSuccess) return (int)e;
+        mbavo_ctx *c = new (std::nothrow) mbavo_ctx;
+        if (!c) return MBAVO_E_ARG;
+        c->engine = new mbavo::Engine(device_id);
+        *out = c;
+        return 0;
+    }
+
+    int mbavo_destroy(mbavo_ctx *ctx)
+    {
+        if (!ctx) return MBAVO_E_ARG;
+        delete ctx->engine;
+        delete ctx;
+        return 0;
+    }
+
+    int mbavo_set_stream(mbavo_ctx *ctx, void *s)
+    {
+        if (!ctx) return MBAVO_E_ARG;
+        ctx->engine->set_stream((hipStream_t)s);
+        return 0;
+    }
+
+    int mbavo_eval_batch(mbavo_ctx *ctx, int B, const mbavo_problem *probs, int k, int with_hessian,
+                         double *d_frame_blocks, double *d_patch_cost, double *d_valid)
+    {
+        if (!ctx) return MBAVO_E_ARG;
+        return ctx->engine->evaluate(B, probs, k, with_hessian != 0, d_frame_blocks, d_patch_cost, d_valid, nullptr);
+    }
+
+    int mbavo_eval(mbavo_ctx *ctx, const mbavo_problem *p, int k, double *h_cost, double *h_H, double *h_g,
+                   double *d_patch_blocks)
+    {
+        if (!ctx || !p || !h_cost || (h_H && !h_g) || !p->h_start_idx) return MBAVO_E_ARG;
+        mbavo::Engine &eng = *ctx->engine;
+        const int E = packed_len(k);
+        const size_t n = (size_t)p->F * E;
+        double *d_fb = eng.scratch_frame_blocks(n);
+        double *h_fb = eng.host_frame_blocks(n);
+        if (!d_fb || !h_fb) return (int)hipErrorOutOfMemory;
+        int rc = eng.evaluate(1, p, k, h_H != nullptr, d_fb, nullptr, nullptr, d_patch_blocks);
+        if (rc) return rc;
+        hipError_t e = hipMemcpyAsync(h_fb, d_fb, n * sizeof(double), hipMemcpyDeviceToHost, eng.stream());
+        if (e == hipSuccess) e = hipStreamSynchronize(eng.stream());
+        if (e != hipSuccess) return (int)e;
+        if (eng.fetch_status() != 0) return MBAVO_E_RANGE;
+        mbavo::merge_blocks_host(p->F, k, h_fb, p->h_start_idx, p->N, h_cost, h_H, h_g);
+        return 0;
+    }
+
+    // ---- the five launchers (the C++ versions abort on HIP errors like a device assert would)
+    int mbavo_compute_virtual_camera_poses(int S, int F, const double *d_cap, const double *d_exp, int k, double t0,
+                                           double dt, const double *d_kt, const double *d_kR, double *d_poses,
+                                           double *d_J_t, double *d_J_R)
+    {
+        if ((k != 2 && k != 4) || !d_cap || !d_exp || !d_kt || !d_kR || !d_poses || ((d_J_t == nullptr) != (d_J_R == nullptr)))
+            return MBAVO_E_ARG;
+        VO::compute_virtual_camera_poses(S, F, d_cap, d_exp, k, t0, dt, d_kt, d_kR, d_poses, d_J_t, d_J_R);
+        return 0;
+    }
+
+    static void fill(Core::VectorX<double, 4> &i4, Core::VectorX<int, 2> &hw, const double intr[4], const int HW[2])
+    {
+        i4.nDim = 4; hw.nDim = 2;
+        for (int i = 0; i < 4; ++i) i4.values[i] = intr[i];
+        hw.values[0] = HW[0]; hw.values[1] = HW[1];
+    }
+
+    int mbavo_compute_local_patches_xy(int S, int F, const double *d_poses, const void *d_kps, const double *d_z, int K,
+                                       const double intr[4], const int HW[2], void *d_out)
+    {
+        if (!d_poses || !d_kps || !d_z || !intr || !HW || !d_out) return MBAVO_E_ARG;
+        Core::VectorX<double, 4> i4; Core::VectorX<int, 2> hw;
+        fill(i4, hw, intr, HW);
+        VO::compute_local_patches_xy(S, F, d_poses, (const Core::Vector2d *)d_kps, d_z, K, i4, hw, (Core::Vector2d *)d_out);
+        return 0;
+    }
+
+    int mbavo_compute_pixel_jacobian_residual(const unsigned char *d_I_ref, const float *d_dIxy,
+                                              const unsigned char *const *d_I_cur, int S, int F, const double *d_poses,
+                                              int k, const double *d_J_t, const double *d_J_R, const void *d_centres,
+                                              const double *d_z, int K, const int *d_pattern, int P, const double intr[4],
+                                              const int HW[2], double *d_res, double *d_jac)
+    {
+        if ((k != 2 && k != 4) || !d_I_ref || !d_I_cur || !d_poses || !d_centres || !d_z || !d_pattern || !d_res ||
+            (d_jac && (!d_J_t || !d_J_R || !d_dIxy)))
+            return MBAVO_E_ARG;
+        Core::VectorX<double, 4> i4; Core::VectorX<int, 2> hw;
+        fill(i4, hw, intr, HW);
+        VO::compute_pixel_jacobian_residual(d_I_ref, d_dIxy, d_I_cur, S, F, d_poses, k, d_J_t, d_J_R,
+                                            (const Core::Vector2d *)d_centres, d_z, K, d_pattern, P, i4, hw, nullptr,
+                                            d_res, d_jac);
+        return 0;
+    }
+
+    int mbavo_compute_patch_cost_gradient_hessian(int F, int K, int P, int k, const double *d_res, const double *d_jac,
+                                                  double huber_a, double inv, double *d_blocks)
+    {
+        if ((k != 2 && k != 4) || !d_res || !d_blocks) return MBAVO_E_ARG;
+        VO::compute_patch_cost_gradient_hessian(F, K, P, k, d_res, d_jac, huber_a, inv, d_blocks);
+        return 0;
+    }
+
+    int mbavo_compute_frame_cost_gradient_hessian(int F, int K, int k, const double *d_blocks, int eval_gh,
+                                                  const unsigned char *d_flags, double *d_frame_blocks)
+    {
+        if ((k != 2 && k != 4) || !d_blocks || !d_frame_blocks) return MBAVO_E_ARG;
+        VO::compute_frame_cost_gradient_hessian(F, K, k, d_blocks, eval_gh != 0, d_flags, d_frame_blocks);
+        return 0;
+    }
+
+    int mbavo_merge_hessian_gradient_cost(int F, int k, const double *d_fb, const int *h_start, int N, double *h_cost,
+                                          double *h_H, double *h_g)
+    {
+        if (!d_fb || !h_start || !h_cost || (h_H && !h_g)) return MBAVO_E_ARG;
+        VO::merge_hessian_gradient_cost(F, k, d_fb, h_start, N, h_cost, h_H, h_g);
+        return 0;
+    }
+
+    int mbavo_merge_host(int F, int k, const double *h_fb, const int *h_start, int N, double *h_cost, double *h_H,
+                         double *h_g)
+    {
+        if (!h_fb || !h_start || !h_cost || (h_H && !h_g)) return MBAVO_E_ARG;
+        mbavo::merge_blocks_host(F, k, h_fb, h_start, N, h_cost, h_H, h_g);
+        return 0;
+    }
+
+    int mbavo_solve_normal_equation(const double *A, const double *b, int n, int type, double *x)
+    {
+        if (!A || !b || !x || n < 1) return MBAVO_E_ARG;
+        return mbavo::solve_normal_equation_host(A, b, n, type, x) < 0 ? MBAVO_E_ARG : 0;
+    }
+
+    // ---- LM / trust region
+    mbavo_lm *mbavo_lm_new(void) { return new mbavo_lm(); }
+    void mbavo_lm_delete(mbavo_lm *p) { delete p; }
+    void mbavo_lm_reset(mbavo_lm *p) { p->impl.reset(); }
+    void mbavo_lm_step_accepted(mbavo_lm *p, double q) { p->impl.step_accepted(q); }
+    void mbavo_lm_step_rejected(mbavo_lm *p) { p->impl.step_rejected(); }
+    double mbavo_lm_get_radius(mbavo_lm *p) { return p->impl.get_radius(); }
+    mbavo_tr *mbavo_tr_new(int m) { return new mbavo_tr(m); }
+    void mbavo_tr_delete(mbavo_tr *p) { delete p; }
+    void mbavo_tr_reset(mbavo_tr *p, double c) { p->impl.reset(c); }
+    double mbavo_tr_step_quality(mbavo_tr *p, double c, double m) { return p->impl.StepQuality(c, m); }
+    void mbavo_tr_step_accepted(mbavo_tr *p, double c, double m) { p->impl.StepAccepted(c, m); }
+
+    // ---- spline
+    int mbavo_spline_get_pose(int k, double t0, double dt, const double *kt, const double *kR, int N, double t,
+                              double t_out[3], double q_out[4], double *J_t, double *J_R)
+    {
+        if ((k != 2 && k != 4) || !kt || !kR || !t_out || !q_out) return MBAVO_E_ARG;
+        Core::SplineSE3 s(t0, dt);
+        s.setSplineDegK(k);
+        for (int i = 0; i < N; ++i) s.InsertControlKnot(kR + 4 * i, kt + 3 * i);
+        return s.GetPose(t, q_out, t_out, J_R, J_t) ? 0 : MBAVO_E_RANGE;
+    }
+
+    int mbavo_spline_plus(const double *kt, const double *kR, int N, const double *step, double *cand_t, double *cand_R)
+    {
+        if (!kt || !kR || !step || !cand_t || !cand_R) return MBAVO_E_ARG;
+        Core::SplineSE3 s;
+        for (int i = 0; i < N; ++i) s.InsertControlKnot(kR + 4 * i, kt + 3 * i);
+        s.Plus_t(step, cand_t);
+        s.Plus_R(step + 3 * N, cand_R);
+        return 0;
+    }
+
+    int mbavo_segment_start_index(double t, double t0, double dt)
+    {
+        int idx;
+        double u;
+        mbavo::spline_segment(t, t0, dt, idx, u);
+        return idx;
+    }
+
+    int mbavo_optimize_trajectory(mbavo_ctx *ctx, const mbavo_track_opts *o, const mbavo_level *levels, int F,
+                                  const double *h_cap, const double *h_exp, double t0, double dt, double *kt, double *kR,
+                                  int N, int *start_idx_out, double *final_cost, mbavo_trace_rec *trace, int cap)
+    {
+        if (!ctx || !o || !levels || !h_cap || !h_exp || !kt || !kR) return MBAVO_E_ARG;
+        return mbavo::optimize_trajectory(*ctx->engine, *o, levels, F, h_cap, h_exp, t0, dt, kt, kR, N, start_idx_out,
+                                          final_cost, trace, cap);
+    }
+
+    // ---- RCCL: resolved at run time so that the library loads on hosts without RCCL
+    int mbavo_allreduce_blocks(mbavo_ctx *ctx, void *comm, double *d_blocks, long long count)
+    {
+        if (!ctx || !comm || !d_blocks || count < 0) return MBAVO_E_ARG;
+        typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
+        static allreduce_fn fn = nullptr;
+        if (!fn)
+        {
+            void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) { fprintf(stderr, "mbavo: cannot load librccl.so: %s\n", dlerror()); return MBAVO_E_NODEVICE; }
+            fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
+            if (!fn) return MBAVO_E_NODEVICE;
+        }
+        // ncclDouble = 8, ncclSum = 0 (rccl.h); one fused in-place all-reduce of the packed blocks
+        const int rc = fn(d_blocks, d_blocks, (size_t)count, 8, 0, comm, ctx->engine->stream());
+        return rc == 0 ? 0 : -2000 - rc;
+    }
+}

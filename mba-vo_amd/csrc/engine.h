@@ -1,0 +1,107 @@
+// engine.h -- fused batch evaluation engine (HIP).  Internal to the library.
+//
+// One call evaluates B independent alignment problems (pyramid levels of one
+// pair, or many keyframe pairs) with three launches on one stream:
+//   k_pose_table  : F*S blur-sample poses + pose-to-knot Jacobians per problem
+//                   (the work of compute_virtual_camera_poses.cu:9-110)
+//   k_fused       : patch centres, per-pixel residual / 1x6k Jacobian over the S
+//                   samples, Huber, packed outer products, per-tile partial sums
+//                   (compute_local_patches_xy.cu, compute_hessian_gradients_cost.cu:23-239)
+//   k_finalize    : fixed-order sum of the tile partials into the per-frame packed
+//                   blocks (compute_hessian_gradients_cost.cu:247-283)
+// No intermediate of the reference pipeline (per-sample Jacobians, per-pixel rows,
+// per-patch blocks) is materialised in HBM.
+#ifndef MBAVO_ENGINE_H
+#define MBAVO_ENGINE_H
+
+#include "../../include/mbavo.h"
+#include <hip/hip_runtime.h>
+#include <vector>
+
+namespace mbavo
+{
+    // device-visible descriptor of one problem
+    struct ProblemDesc
+    {
+        const unsigned char *ref_img;
+        const float *ref_dIxy;
+        const unsigned char *const *cur_imgs;
+        const double *kp_xy;
+        const double *kp_z;
+        const int *pattern;
+        const unsigned char *outlier;
+        const double *cap, *exp_t;
+        const double *knots_t, *knots_R;
+        double fx, fy, cx, cy;
+        double t0, dt;
+        double huber_a;
+        double inv_num_residuals;
+        int S, F, K, P, N, H, W, kp_stride;
+        int pose_base;        // first PoseEntry of this problem (entry = f*S + s)
+        int bf_base;          // first (problem, frame) slot
+        long long pixel_base; // first pixel of this problem in the rho scratch (f*K*P + kp*P + p)
+        long long patch_base; // first patch of this problem in the patch-cost output (f*K + kp)
+    };
+
+    // a tile = a contiguous keypoint range of one (problem, frame), handled by one workgroup
+    struct TileDesc
+    {
+        int prob, frame, kp_begin, kp_count;
+    };
+
+    class Engine
+    {
+    public:
+        explicit Engine(int device);
+        ~Engine();
+        void set_stream(hipStream_t s) { stream_ = s; }
+        hipStream_t stream() const { return stream_; }
+        int device() const { return device_; }
+
+        // asynchronous; see mbavo_eval_batch
+        int evaluate(int B, const mbavo_problem *probs, int kdeg, bool with_hessian,
+                     double *d_frame_blocks, double *d_patch_cost, double *d_valid,
+                     double *d_patch_blocks_strided /* B == 1 only, stride E, may be null */);
+
+        // range status of the last evaluate (valid after a stream sync): non-zero if a
+        // blur sample's knot segment had to be clamped into [0, N-k]
+        int fetch_status();
+
+        int total_bf() const { return total_bf_; }
+
+        // persistent staging owned by the context (used by mbavo_eval / tracker)
+        double *scratch_frame_blocks(size_t n_doubles);
+        double *host_frame_blocks(size_t n_doubles);
+
+    private:
+        int ensure(void **ptr, size_t *cap, size_t bytes);
+        int rebuild_layout(int B, const mbavo_problem *probs, int kdeg);
+
+        int device_;
+        hipStream_t stream_ = nullptr;
+        int num_cus_ = 256;
+
+        // cached layout of the last problem list
+        std::vector<ProblemDesc> h_descs_;
+        std::vector<TileDesc> h_tiles_;
+        std::vector<int> h_bf_tile_begin_; // nBF + 1
+        std::vector<int> h_bf_prob_;       // nBF
+        int cached_kdeg_ = 0;
+        int total_bf_ = 0, total_entries_ = 0;
+        long long total_pixels_ = 0, total_patches_ = 0;
+        bool layout_uploaded_ = false;
+
+        void *d_descs_ = nullptr; size_t cap_descs_ = 0;
+        void *d_tiles_ = nullptr; size_t cap_tiles_ = 0;
+        void *d_bf_tile_begin_ = nullptr; size_t cap_bf_ = 0;
+        void *d_bf_prob_ = nullptr; size_t cap_bfp_ = 0;
+        void *d_poses_ = nullptr; size_t cap_poses_ = 0;
+        void *d_rho_ = nullptr; size_t cap_rho_ = 0;
+        void *d_partials_ = nullptr; size_t cap_partials_ = 0;
+        void *d_status_ = nullptr;
+        void *d_fb_ = nullptr; size_t cap_fb_ = 0;
+        void *h_fb_ = nullptr; size_t cap_hfb_ = 0;
+    };
+} // namespace mbavo
+
+#endif

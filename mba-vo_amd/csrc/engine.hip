@@ -1,0 +1,480 @@
+// engine.hip -- fused batch evaluation kernels for gfx950 (MI355X) and their host driver.
+//
+// Work mapping:
+//   * one lane = one pixel (keypoint x pattern entry); the S blur samples run
+//     sequentially in registers, so the reference's S-wide shared-memory
+//     reductions and its per-sample Jacobian scratch do not exist here;
+//   * the per-sample pose table is read with wave-uniform addresses (scalar loads);
+//   * a workgroup = 8 wave64.  Each wave computes the weighted rows [r | J] of its
+//     own 64 pixels, parks them in LDS ([row entry][lane], conflict-free), and then
+//     every wave accumulates ITS eighth of the packed upper-triangular outer
+//     product (41 of 325 entries for k = 4) for all 512 pixels in registers.  The
+//     accumulators live across the whole tile loop and are reduced once per
+//     workgroup with wave butterflies -- no atomics, fixed summation order.
+#include "engine.h"
+#include "pixel_math.h"
+#include "se3_math.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <utility>
+
+namespace mbavo
+{
+#define HIP_TRY(expr)                                                                       \
+    do                                                                                      \
+    {                                                                                       \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+        {                                                                                   \
+            fprintf(stderr, "mbavo: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), \
+                    __FILE__, __LINE__);                                                    \
+            return (int)e_;                                                                 \
+        }                                                                                   \
+    } while (0)
+
+    constexpr int kWavesPerGroup = 8;
+    constexpr int kThreads = kWavesPerGroup * 64;
+
+    template <int KD>
+    struct Pack
+    {
+        static constexpr int ND = 6 * KD + 1;
+        static constexpr int E = ND * (ND + 1) / 2;
+        static constexpr int EPW = (E + kWavesPerGroup - 1) / kWavesPerGroup; // entries per wave
+        static constexpr int PSTRIDE = E + 2; // partial: [nvalid | g,H sums (1..E-1) | cost | spare]
+    };
+
+    // packed index e -> (i, j), i <= j, row-major upper triangle (compute_hessian_gradients_cost.cu:217-229)
+    template <int ND>
+    __host__ __device__ constexpr int tri_row(int e)
+    {
+        int i = 0;
+        while (e >= ND - i) { e -= ND - i; ++i; }
+        return i;
+    }
+    template <int ND>
+    __host__ __device__ constexpr int tri_col(int e)
+    {
+        int i = 0;
+        while (e >= ND - i) { e -= ND - i; ++i; }
+        return i + e;
+    }
+
+    // ------------------------------------------------------------------ pose table
+    template <int KD, bool WITH_J>
+    __global__ void k_pose_table(const ProblemDesc *__restrict__ descs, int B, int total_entries,
+                                 PoseEntry<KD> *__restrict__ table, int *__restrict__ status)
+    {
+        const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+        if (gid >= total_entries) return;
+        int lo = 0, hi = B - 1; // last problem with pose_base <= gid
+        while (lo < hi)
+        {
+            const int mid = (lo + hi + 1) >> 1;
+            if (descs[mid].pose_base <= gid) lo = mid; else hi = mid - 1;
+        }
+        const ProblemDesc &d = descs[lo];
+        const int local = gid - d.pose_base;
+        const int f = local / d.S, s = local - f * d.S;
+        const double t_cap = d.cap[f], t_mu = d.exp_t[f];
+        // sample time (compute_virtual_camera_poses.cu:33): S == 1 samples the START of the exposure
+        const double t = t_cap - t_mu * 0.5 + s * t_mu / (d.S - 1 + 1e-8);
+        int idx;
+        double u;
+        spline_segment(t, d.t0, d.dt, idx, u);
+        if (idx < 0 || idx + KD > d.N)
+        { // the reference reads out of bounds here; clamp for memory safety and report
+            atomicOr(status, 1);
+            idx = idx < 0 ? 0 : d.N - KD;
+        }
+        PoseEntry<KD> pe;
+        trans_coeffs<KD>(u, pe.c);
+        spline_translation<KD>(d.knots_t + 3 * idx, pe.c, pe.t);
+        if (!WITH_J)
+        {
+            for (int i = 0; i < 12 * KD; ++i) pe.JR[i] = 0.0;
+        }
+        const Quat q = spline_rotation<KD, WITH_J>(d.knots_R + 4 * idx, u, pe.JR);
+        pe.q[0] = q.x; pe.q[1] = q.y; pe.q[2] = q.z; pe.q[3] = q.w;
+        rotation_entries(pe.q, pe.R);
+        table[gid] = pe;
+    }
+
+    // ------------------------------------------------------------------ fused kernel
+    template <int KD, int W, int I>
+    __device__ __forceinline__ void acc_one(double (&acc)[Pack<KD>::EPW], const double (&r)[Pack<KD>::ND])
+    {
+        constexpr int e = W * Pack<KD>::EPW + I;
+        if constexpr (e > 0 && e < Pack<KD>::E)
+        {
+            constexpr int i = tri_row<Pack<KD>::ND>(e), j = tri_col<Pack<KD>::ND>(e);
+            acc[I] = fma(r[i], r[j], acc[I]);
+        }
+    }
+    template <int KD, int W, int... Is>
+    __device__ __forceinline__ void acc_wave(double (&acc)[Pack<KD>::EPW], const double *__restrict__ rows,
+                                             int lane, std::integer_sequence<int, Is...>)
+    {
+        constexpr int ND = Pack<KD>::ND;
+#pragma unroll 1
+        for (int grp = 0; grp < kWavesPerGroup; ++grp)
+        {
+            double r[ND];
+#pragma unroll
+            for (int i = 0; i < ND; ++i) r[i] = rows[(grp * ND + i) * 64 + lane];
+            (acc_one<KD, W, Is>(acc, r), ...);
+        }
+    }
+
+    __device__ __forceinline__ double wave_sum(double v)
+    {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
+
+    template <int KD, bool WITH_J>
+    __global__ __launch_bounds__(kThreads) void k_fused(const ProblemDesc *__restrict__ descs,
+                                                        const TileDesc *__restrict__ tiles,
+                                                        const PoseEntry<KD> *__restrict__ table,
+                                                        double *__restrict__ rho_out,
+                                                        double *__restrict__ patch_cost,
+                                                        double *__restrict__ patch_blocks_strided,
+                                                        double *__restrict__ partials)
+    {
+        constexpr int ND = Pack<KD>::ND, E = Pack<KD>::E, EPW = Pack<KD>::EPW, PS = Pack<KD>::PSTRIDE;
+        extern __shared__ __attribute__((aligned(16))) double lds[];
+        double *rows = lds;                                               // [8][ND][64] (WITH_J only)
+        double *red = lds + (WITH_J ? kWavesPerGroup * ND * 64 : 0);      // [2][8]
+
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const TileDesc tile = tiles[blockIdx.x];
+        const ProblemDesc &d = descs[tile.prob];
+        const int S = d.S, K = d.K, P = d.P, frame = tile.frame;
+        Camera cam;
+        cam.fx = d.fx; cam.fy = d.fy; cam.cx = d.cx; cam.cy = d.cy; cam.H = d.H; cam.W = d.W;
+        const PoseEntry<KD> *__restrict__ ftab = table + d.pose_base + frame * S;
+        const PoseEntry<KD> &mid = ftab[S / 2]; // patch centres use sample S/2 (compute_local_patches_xy.cu:26)
+        const unsigned char *__restrict__ I_cur = d.cur_imgs[frame];
+        const long long pix0 = d.pixel_base + ((long long)frame * K + tile.kp_begin) * P;
+        const int npx = tile.kp_count * P;
+
+        double acc[EPW];
+#pragma unroll
+        for (int i = 0; i < EPW; ++i) acc[i] = 0.0;
+        int nvalid = 0;
+
+        for (int base = 0; base < npx; base += kThreads)
+        {
+            const int g = base + (int)threadIdx.x;
+            double res = 0.0, w = 0.0, rho = 0.0;
+            bool keep = false;
+            double Jrow[WITH_J ? 6 * KD : 1];
+            if (g < npx)
+            {
+                const int kpl = g / P, pp = g - kpl * P;
+                const int kp = tile.kp_begin + kpl;
+                const bool flagged = d.outlier != nullptr && d.outlier[kp] == 1;
+                const double kx = d.kp_xy[(size_t)kp * d.kp_stride], ky = d.kp_xy[(size_t)kp * d.kp_stride + 1];
+                const double kz = d.kp_z[kp];
+                double pcx, pcy;
+                patch_centre(mid.t, mid.q, kx, ky, kz, cam, pcx, pcy);
+                const bool valid = pixel_row<KD, WITH_J>(ftab, S, cam, d.ref_img, d.ref_dIxy, I_cur, pcx, pcy, kz,
+                                                         d.pattern[2 * pp], d.pattern[2 * pp + 1], res, Jrow);
+                huber_weight(res, d.huber_a, w, rho);
+                rho_out[pix0 + g] = rho;
+                nvalid += valid ? 1 : 0;
+                keep = valid && !flagged;
+            }
+            if (WITH_J)
+            {
+                double *mine = rows + (wave * ND) * 64 + lane;
+                mine[0] = keep ? w * res : 0.0;
+#pragma unroll
+                for (int i = 0; i < 6 * KD; ++i) mine[(1 + i) * 64] = keep ? w * Jrow[i] : 0.0;
+                __syncthreads();
+                using Seq = std::make_integer_sequence<int, EPW>;
+                switch (wave)
+                {
+                case 0: acc_wave<KD, 0>(acc, rows, lane, Seq{}); break;
+                case 1: acc_wave<KD, 1>(acc, rows, lane, Seq{}); break;
+                case 2: acc_wave<KD, 2>(acc, rows, lane, Seq{}); break;
+                case 3: acc_wave<KD, 3>(acc, rows, lane, Seq{}); break;
+                case 4: acc_wave<KD, 4>(acc, rows, lane, Seq{}); break;
+                case 5: acc_wave<KD, 5>(acc, rows, lane, Seq{}); break;
+                case 6: acc_wave<KD, 6>(acc, rows, lane, Seq{}); break;
+                default: acc_wave<KD, 7>(acc, rows, lane, Seq{}); break;
+                }
+                __syncthreads();
+            }
+        }
+
+        // per-patch cost = slot 0 of the reference's patch block (:232-238), and the
+        // tile's share of the frame cost (outlier patches skipped, :265-272)
+        __syncthreads();
+        double cost_local = 0.0;
+        const double inv = d.inv_num_residuals;
+        for (int kpl = threadIdx.x; kpl < tile.kp_count; kpl += kThreads)
+        {
+            const double *r = rho_out + pix0 + (long long)kpl * P;
+            double sum = 0.0;
+            for (int p = 0; p < P; ++p) sum += r[p];
+            const double c = sum * inv;
+            const int kp = tile.kp_begin + kpl;
+            const long long patch = (long long)frame * K + kp;
+            if (patch_cost) patch_cost[d.patch_base + patch] = c;
+            if (patch_blocks_strided) patch_blocks_strided[patch * E] = c;
+            if (!(d.outlier != nullptr && d.outlier[kp] == 1)) cost_local += c;
+        }
+        const double wc = wave_sum(cost_local);
+        const double wv = wave_sum((double)nvalid);
+        if (lane == 0) { red[wave] = wc; red[kWavesPerGroup + wave] = wv; }
+        __syncthreads();
+        double *out = partials + (size_t)blockIdx.x * PS;
+        if (threadIdx.x == 0)
+        {
+            double c = 0.0, v = 0.0;
+            for (int i = 0; i < kWavesPerGroup; ++i) { c += red[i]; v += red[kWavesPerGroup + i]; }
+            out[0] = v;
+            out[E] = c;
+        }
+        if (WITH_J)
+        {
+#pragma unroll
+            for (int i = 0; i < EPW; ++i)
+            {
+                const double s = wave_sum(acc[i]);
+                const int e = wave * EPW + i;
+                if (lane == 0 && e > 0 && e < E) out[e] = s;
+            }
+        }
+    }
+
+    // ------------------------------------------------------------------ finalize
+    template <int KD, bool WITH_J>
+    __global__ void k_finalize(const ProblemDesc *__restrict__ descs, const int *__restrict__ bf_prob,
+                               const int *__restrict__ bf_tile_begin, const double *__restrict__ partials,
+                               double *__restrict__ frame_blocks, double *__restrict__ valid_out)
+    {
+        constexpr int E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
+        const int bf = blockIdx.x;
+        const int t0 = bf_tile_begin[bf], t1 = bf_tile_begin[bf + 1];
+        const double inv = descs[bf_prob[bf]].inv_num_residuals;
+        if (WITH_J)
+        {
+            for (int e = 1 + threadIdx.x; e < E; e += blockDim.x)
+            {
+                double s = 0.0;
+                for (int t = t0; t < t1; ++t) s += partials[(size_t)t * PS + e];
+                frame_blocks[(size_t)bf * E + e] = s * inv;
+            }
+        }
+        if (threadIdx.x == 0)
+        {
+            double c = 0.0, v = 0.0;
+            for (int t = t0; t < t1; ++t) { c += partials[(size_t)t * PS + E]; v += partials[(size_t)t * PS]; }
+            frame_blocks[(size_t)bf * E] = c;
+            if (valid_out) valid_out[bf] = v;
+        }
+    }
+
+    // ------------------------------------------------------------------ host driver
+    Engine::Engine(int device) : device_(device)
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            num_cus_ = prop.multiProcessorCount;
+    }
+
+    Engine::~Engine()
+    {
+        void *bufs[] = {d_descs_, d_tiles_, d_bf_tile_begin_, d_bf_prob_, d_poses_, d_rho_, d_partials_,
+                        d_status_, d_fb_};
+        for (void *p : bufs)
+            if (p) (void)hipFree(p);
+        if (h_fb_) (void)hipHostFree(h_fb_);
+    }
+
+    int Engine::ensure(void **ptr, size_t *cap, size_t bytes)
+    {
+        if (bytes <= *cap && *ptr) return 0;
+        if (*ptr) HIP_TRY(hipFree(*ptr));
+        *ptr = nullptr;
+        size_t want = bytes + bytes / 4 + 256;
+        HIP_TRY(hipMalloc(ptr, want));
+        *cap = want;
+        return 0;
+    }
+
+    double *Engine::scratch_frame_blocks(size_t n)
+    {
+        if (ensure(&d_fb_, &cap_fb_, n * sizeof(double)) != 0) return nullptr;
+        return (double *)d_fb_;
+    }
+
+    double *Engine::host_frame_blocks(size_t n)
+    {
+        if (n * sizeof(double) > cap_hfb_ || !h_fb_)
+        {
+            if (h_fb_) (void)hipHostFree(h_fb_);
+            h_fb_ = nullptr;
+            cap_hfb_ = n * sizeof(double) + 4096;
+            if (hipHostMalloc(&h_fb_, cap_hfb_, hipHostMallocDefault) != hipSuccess) { h_fb_ = nullptr; cap_hfb_ = 0; }
+        }
+        return (double *)h_fb_;
+    }
+
+    static int env_int(const char *name, int dflt)
+    {
+        const char *v = getenv(name);
+        return v && *v ? atoi(v) : dflt;
+    }
+
+    int Engine::rebuild_layout(int B, const mbavo_problem *probs, int kdeg)
+    {
+        std::vector<ProblemDesc> descs((size_t)B);
+        long long pixels = 0, patches = 0;
+        int entries = 0, bf = 0;
+        for (int b = 0; b < B; ++b)
+        {
+            const mbavo_problem &p = probs[b];
+            if (p.S < 1 || p.F < 1 || p.K < 0 || p.P < 1 || p.N < kdeg || !p.d_ref_img || !p.d_cur_imgs ||
+                !p.d_kp_xy || !p.d_kp_z || !p.d_pattern || !p.d_cap_time || !p.d_exp_time || !p.d_knots_t ||
+                !p.d_knots_R || (p.kp_stride != 2 && p.kp_stride != 3) || p.H < 2 || p.W < 2)
+                return MBAVO_E_ARG;
+            ProblemDesc &d = descs[b];
+            memset(&d, 0, sizeof(d));
+            d.ref_img = p.d_ref_img; d.ref_dIxy = p.d_ref_dIxy; d.cur_imgs = p.d_cur_imgs;
+            d.kp_xy = p.d_kp_xy; d.kp_z = p.d_kp_z; d.pattern = p.d_pattern; d.outlier = p.d_outlier;
+            d.cap = p.d_cap_time; d.exp_t = p.d_exp_time; d.knots_t = p.d_knots_t; d.knots_R = p.d_knots_R;
+            d.fx = p.intrinsics[0]; d.fy = p.intrinsics[1]; d.cx = p.intrinsics[2]; d.cy = p.intrinsics[3];
+            d.t0 = p.t0; d.dt = p.dt; d.huber_a = p.huber_a;
+            // 1/((K - num_bad)*F*P), counting out-of-bounds pixels (spline_update_step.cpp:116-117)
+            const int num_residuals = (p.K - p.num_bad) * p.F * p.P;
+            d.inv_num_residuals = 1.0 / num_residuals;
+            d.S = p.S; d.F = p.F; d.K = p.K; d.P = p.P; d.N = p.N; d.H = p.H; d.W = p.W; d.kp_stride = p.kp_stride;
+            d.pose_base = entries; d.bf_base = bf; d.pixel_base = pixels; d.patch_base = patches;
+            entries += p.F * p.S;
+            bf += p.F;
+            pixels += (long long)p.F * p.K * p.P;
+            patches += (long long)p.F * p.K;
+        }
+        const bool same = kdeg == cached_kdeg_ && descs.size() == h_descs_.size() &&
+                          memcmp(descs.data(), h_descs_.data(), descs.size() * sizeof(ProblemDesc)) == 0;
+        if (same && layout_uploaded_) return 0;
+
+        // tiles: contiguous keypoint ranges, sized so the grid has a few workgroups per CU
+        const int tiles_per_cu = env_int("MBAVO_TILES_PER_CU", 2);
+        const long long target_tiles = (long long)num_cus_ * (tiles_per_cu > 0 ? tiles_per_cu : 1);
+        long long px_per_tile = (pixels + target_tiles - 1) / target_tiles;
+        px_per_tile = ((px_per_tile + kThreads - 1) / kThreads) * kThreads;
+        if (px_per_tile < kThreads) px_per_tile = kThreads;
+        std::vector<TileDesc> tiles;
+        std::vector<int> bf_tile_begin, bf_prob;
+        for (int b = 0; b < B; ++b)
+        {
+            const ProblemDesc &d = descs[b];
+            long long kpt = px_per_tile / d.P;
+            if (kpt < 1) kpt = 1;
+            for (int f = 0; f < d.F; ++f)
+            {
+                bf_tile_begin.push_back((int)tiles.size());
+                bf_prob.push_back(b);
+                for (long long k0 = 0; k0 < d.K; k0 += kpt)
+                {
+                    TileDesc t;
+                    t.prob = b; t.frame = f; t.kp_begin = (int)k0;
+                    t.kp_count = (int)((d.K - k0) < kpt ? (d.K - k0) : kpt);
+                    tiles.push_back(t);
+                }
+            }
+        }
+        bf_tile_begin.push_back((int)tiles.size());
+
+        h_descs_.swap(descs);
+        h_tiles_.swap(tiles);
+        h_bf_tile_begin_.swap(bf_tile_begin);
+        h_bf_prob_.swap(bf_prob);
+        cached_kdeg_ = kdeg;
+        total_bf_ = bf; total_entries_ = entries; total_pixels_ = pixels; total_patches_ = patches;
+
+        const size_t pose_bytes = (size_t)entries * (kdeg == 2 ? sizeof(PoseEntry<2>) : sizeof(PoseEntry<4>));
+        const size_t pstride = kdeg == 2 ? Pack<2>::PSTRIDE : Pack<4>::PSTRIDE;
+        int rc;
+        if ((rc = ensure(&d_descs_, &cap_descs_, h_descs_.size() * sizeof(ProblemDesc)))) return rc;
+        if ((rc = ensure(&d_tiles_, &cap_tiles_, (h_tiles_.size() + 1) * sizeof(TileDesc)))) return rc;
+        if ((rc = ensure(&d_bf_tile_begin_, &cap_bf_, h_bf_tile_begin_.size() * sizeof(int)))) return rc;
+        if ((rc = ensure(&d_bf_prob_, &cap_bfp_, (h_bf_prob_.size() + 1) * sizeof(int)))) return rc;
+        if ((rc = ensure(&d_poses_, &cap_poses_, pose_bytes))) return rc;
+        if ((rc = ensure(&d_rho_, &cap_rho_, (size_t)(pixels + 1) * sizeof(double)))) return rc;
+        if ((rc = ensure(&d_partials_, &cap_partials_, (h_tiles_.size() + 1) * pstride * sizeof(double)))) return rc;
+        if (!d_status_) HIP_TRY(hipMalloc(&d_status_, sizeof(int)));
+        // pageable copies are staged synchronously by the runtime, so the vectors may change afterwards
+        HIP_TRY(hipMemcpyAsync(d_descs_, h_descs_.data(), h_descs_.size() * sizeof(ProblemDesc), hipMemcpyHostToDevice, stream_));
+        if (!h_tiles_.empty())
+            HIP_TRY(hipMemcpyAsync(d_tiles_, h_tiles_.data(), h_tiles_.size() * sizeof(TileDesc), hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipMemcpyAsync(d_bf_tile_begin_, h_bf_tile_begin_.data(), h_bf_tile_begin_.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipMemcpyAsync(d_bf_prob_, h_bf_prob_.data(), h_bf_prob_.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+        layout_uploaded_ = true;
+        return 0;
+    }
+
+    template <int KD, bool WITH_J>
+    static int launch_all(hipStream_t st, const ProblemDesc *descs, int B, int entries, const TileDesc *tiles, int ntiles,
+                          const int *bf_prob, const int *bf_tile_begin, int nbf, void *poses, double *rho,
+                          double *patch_cost, double *patch_blocks_strided, double *partials, int *status,
+                          double *frame_blocks, double *valid)
+    {
+        PoseEntry<KD> *table = (PoseEntry<KD> *)poses;
+        hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries + 63) / 64), dim3(64), 0, st, descs, B, entries, table, status);
+        if (ntiles > 0)
+        {
+            const size_t lds = (WITH_J ? (size_t)kWavesPerGroup * Pack<KD>::ND * 64 : 0) * sizeof(double) +
+                               2 * kWavesPerGroup * sizeof(double);
+            static bool attr_set = false;
+            if (!attr_set)
+            {
+                HIP_TRY(hipFuncSetAttribute((const void *)k_fused<KD, WITH_J>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((k_fused<KD, WITH_J>), dim3(ntiles), dim3(kThreads), lds, st, descs, tiles, table, rho,
+                               patch_cost, patch_blocks_strided, partials);
+        }
+        hipLaunchKernelGGL((k_finalize<KD, WITH_J>), dim3(nbf), dim3(256), 0, st, descs, bf_prob, bf_tile_begin, partials,
+                           frame_blocks, valid);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+
+    int Engine::evaluate(int B, const mbavo_problem *probs, int kdeg, bool with_hessian, double *d_frame_blocks,
+                         double *d_patch_cost, double *d_valid, double *d_patch_blocks_strided)
+    {
+        if (B < 1 || !probs || !d_frame_blocks || (kdeg != 2 && kdeg != 4)) return MBAVO_E_ARG;
+        if (d_patch_blocks_strided && B != 1) return MBAVO_E_ARG;
+        HIP_TRY(hipSetDevice(device_));
+        int rc = rebuild_layout(B, probs, kdeg);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(d_status_, 0, sizeof(int), stream_));
+        const ProblemDesc *descs = (const ProblemDesc *)d_descs_;
+        const TileDesc *tiles = (const TileDesc *)d_tiles_;
+        const int ntiles = (int)h_tiles_.size();
+#define MBAVO_LAUNCH(KD, WJ)                                                                                      \
+    launch_all<KD, WJ>(stream_, descs, B, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
+                       (const int *)d_bf_tile_begin_, total_bf_, d_poses_, (double *)d_rho_, d_patch_cost,        \
+                       d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid)
+        if (kdeg == 4) rc = with_hessian ? MBAVO_LAUNCH(4, true) : MBAVO_LAUNCH(4, false);
+        else rc = with_hessian ? MBAVO_LAUNCH(2, true) : MBAVO_LAUNCH(2, false);
+#undef MBAVO_LAUNCH
+        return rc;
+    }
+
+    int Engine::fetch_status()
+    {
+        int s = 0;
+        if (d_status_ && hipMemcpy(&s, d_status_, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        return s;
+    }
+} // namespace mbavo

@@ -1,0 +1,341 @@
+// host_math.cpp -- see host_math.h for the reference counterparts.
+#include "host_math.h"
+#include "se3_math.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace mbavo
+{
+    // Scatter the per-frame packed blocks [cost | g(6k) | upper(H)(6k x 6k)] into the global
+    // system ordered [t_0..t_{N-1} | w_0..w_{N-1}]: local j < 3k -> 3*start + j, else
+    // 3*(N + start) + (j - 3k)   (merge_hessian_gradient_cost.cpp:52-85).
+    void merge_blocks_host(int F, int k, const double *fb, const int *start_idx, int N, double *total_cost,
+                           double *H, double *g)
+    {
+        const int m = 6 * k, ndim = m + 1, E = ndim * (ndim + 1) / 2, n = 6 * N;
+        double cost = 0.0;
+        if (H)
+        {
+            std::fill(H, H + (size_t)n * n, 0.0);
+            std::fill(g, g + n, 0.0);
+        }
+        std::vector<int> gidx(m);
+        for (int f = 0; f < F; ++f)
+        {
+            const double *blk = fb + (size_t)f * E;
+            cost += blk[0];
+            if (!H) continue;
+            const int st = start_idx[f];
+            for (int j = 0; j < m; ++j) gidx[j] = j < 3 * k ? 3 * st + j : 3 * (N + st) + (j - 3 * k);
+            for (int j = 0; j < m; ++j) g[gidx[j]] += blk[1 + j];
+            const double *h = blk + ndim;
+            for (int r = 0; r < m; ++r)
+                for (int c = r; c < m; ++c)
+                {
+                    const double v = *h++;
+                    const int R = gidx[r], C = gidx[c];
+                    H[(size_t)C * n + R] += v;
+                    if (R != C) H[(size_t)R * n + C] += v;
+                }
+        }
+        *total_cost = cost;
+    }
+
+    // Minimum-norm least squares by one-sided (Hestenes) Jacobi: rotate the columns of
+    // G = A until they are orthogonal, G = U S, A V = G.  Singular values below
+    // n * eps * s_max are treated as zero (Eigen's default JacobiSVD rank threshold).
+    static int solve_svd(const double *A, const double *b, int n, double *x)
+    {
+        std::vector<double> G(A, A + (size_t)n * n), V((size_t)n * n, 0.0);
+        for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+        const double eps = std::numeric_limits<double>::epsilon();
+        for (int sweep = 0; sweep < 60; ++sweep)
+        {
+            bool rotated = false;
+            for (int p = 0; p < n - 1; ++p)
+                for (int q = p + 1; q < n; ++q)
+                {
+                    double *gp = &G[(size_t)p * n], *gq = &G[(size_t)q * n];
+                    double a = 0, c = 0, d = 0;
+                    for (int i = 0; i < n; ++i) { a += gp[i] * gp[i]; c += gq[i] * gq[i]; d += gp[i] * gq[i]; }
+                    if (d == 0.0 || std::fabs(d) <= eps * std::sqrt(a * c)) continue;
+                    rotated = true;
+                    const double zeta = (c - a) / (2.0 * d);
+                    const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                    const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+                    double *vp = &V[(size_t)p * n], *vq = &V[(size_t)q * n];
+                    for (int i = 0; i < n; ++i)
+                    {
+                        const double u = gp[i], w = gq[i];
+                        gp[i] = cs * u - sn * w;
+                        gq[i] = sn * u + cs * w;
+                        const double y = vp[i], z = vq[i];
+                        vp[i] = cs * y - sn * z;
+                        vq[i] = sn * y + cs * z;
+                    }
+                }
+            if (!rotated) break;
+        }
+        std::vector<double> s2(n);
+        double smax2 = 0.0;
+        for (int j = 0; j < n; ++j)
+        {
+            double a = 0;
+            for (int i = 0; i < n; ++i) a += G[(size_t)j * n + i] * G[(size_t)j * n + i];
+            s2[j] = a;
+            smax2 = std::max(smax2, a);
+        }
+        const double thr = std::max((double)std::max(n, 1) * eps * std::sqrt(smax2), DBL_MIN);
+        std::fill(x, x + n, 0.0);
+        int rank = 0;
+        for (int j = 0; j < n; ++j)
+        {
+            if (!(std::sqrt(s2[j]) >= thr) || s2[j] == 0.0) continue;
+            ++rank;
+            double dot = 0; // (u_j . b) / s_j = (g_j . b) / s_j^2
+            for (int i = 0; i < n; ++i) dot += G[(size_t)j * n + i] * b[i];
+            dot /= s2[j];
+            for (int i = 0; i < n; ++i) x[i] += V[(size_t)j * n + i] * dot;
+        }
+        return rank;
+    }
+
+    // Symmetric A = P^T L D L^T P with the largest remaining diagonal entry as pivot.
+    static int solve_ldlt(const double *A, const double *b, int n, double *x)
+    {
+        std::vector<double> M(A, A + (size_t)n * n); // full symmetric copy, column-major
+        std::vector<int> order(n);
+        for (int i = 0; i < n; ++i) order[i] = i;
+        auto at = [&](int r, int c) -> double & { return M[(size_t)c * n + r]; };
+        for (int k = 0; k < n; ++k)
+        {
+            int piv = k;
+            for (int i = k + 1; i < n; ++i)
+                if (std::fabs(at(i, i)) > std::fabs(at(piv, piv))) piv = i;
+            if (piv != k)
+            {
+                for (int c = 0; c < n; ++c) std::swap(at(k, c), at(piv, c));
+                for (int r = 0; r < n; ++r) std::swap(at(r, k), at(r, piv));
+                std::swap(order[k], order[piv]);
+            }
+            const double d = at(k, k);
+            if (d == 0.0) continue;
+            for (int i = k + 1; i < n; ++i) at(i, k) /= d; // column of L
+            for (int j = k + 1; j < n; ++j)
+            {
+                const double ljk_d = at(j, k) * d;
+                for (int i = j; i < n; ++i) at(i, j) -= at(i, k) * ljk_d;
+            }
+            for (int j = k + 1; j < n; ++j)
+                for (int i = j + 1; i < n; ++i) at(j, i) = at(i, j); // keep the trailing block symmetric for later pivots
+        }
+        std::vector<double> y(n);
+        for (int i = 0; i < n; ++i) y[i] = b[order[i]];
+        for (int c = 0; c < n; ++c)
+            for (int r = c + 1; r < n; ++r) y[r] -= at(r, c) * y[c];
+        for (int i = 0; i < n; ++i) y[i] = std::fabs(at(i, i)) > DBL_MIN ? y[i] / at(i, i) : 0.0;
+        for (int c = n - 1; c >= 0; --c)
+            for (int r = c + 1; r < n; ++r) y[c] -= at(r, c) * y[r];
+        for (int i = 0; i < n; ++i) x[order[i]] = y[i];
+        return n;
+    }
+
+    int solve_normal_equation_host(const double *A, const double *b, int n, int solver_type, double *x)
+    {
+        int rank;
+        if (solver_type == 0) rank = solve_svd(A, b, n, x);
+        else if (solver_type == 1) rank = solve_ldlt(A, b, n, x);
+        else return -1;
+        for (int i = 0; i < n; ++i) x[i] = -x[i];
+        return rank;
+    }
+} // namespace mbavo
+
+namespace SLAM
+{
+    namespace VO
+    {
+        // radius 1e4, clamped to [10, 1e32]; accepted: r /= max(1/3, 1 - (2q-1)^3);
+        // rejected: r /= f, f *= 2   (levenberg_marquardt_strategy.cpp:9-45)
+        LevenbergMarquardtStrategy::LevenbergMarquardtStrategy()
+            : mRadius(1e4), mMaxRadius(1e32), mMinRadius(10), mDecreaseFactor(2.0) {}
+        void LevenbergMarquardtStrategy::reset() { mRadius = 1e4; mDecreaseFactor = 2.0; }
+        void LevenbergMarquardtStrategy::step_accepted(double q)
+        {
+            mRadius = mRadius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * q - 1.0, 3));
+            mRadius = std::max(std::min(mMaxRadius, mRadius), mMinRadius);
+            mDecreaseFactor = 2.0;
+        }
+        void LevenbergMarquardtStrategy::step_rejected()
+        {
+            mRadius = mRadius / mDecreaseFactor;
+            mRadius = std::max(std::min(mMaxRadius, mRadius), mMinRadius);
+            mDecreaseFactor *= 2.0;
+        }
+        double LevenbergMarquardtStrategy::get_radius() { return mRadius; }
+
+        // Non-monotonic step acceptance, Conn/Gould/Toint Alg. 10.1.2 as Ceres implements it
+        // (trust_region_step_evaluator.cpp:45-126)
+        TrustRegionStepEvaluator::TrustRegionStepEvaluator(int m)
+            : max_consecutive_nonmonotonic_steps_(m), minimum_cost_(0), current_cost_(0), reference_cost_(0),
+              candidate_cost_(0), accumulated_reference_model_cost_change_(0),
+              accumulated_candidate_model_cost_change_(0), num_consecutive_nonmonotonic_steps_(0) {}
+        void TrustRegionStepEvaluator::reset(double c)
+        {
+            minimum_cost_ = current_cost_ = reference_cost_ = candidate_cost_ = c;
+            accumulated_reference_model_cost_change_ = accumulated_candidate_model_cost_change_ = 0.0;
+            num_consecutive_nonmonotonic_steps_ = 0;
+        }
+        double TrustRegionStepEvaluator::StepQuality(double cost, double mcc) const
+        {
+            if (cost >= std::numeric_limits<double>::max()) return std::numeric_limits<double>::lowest();
+            const double now = (current_cost_ - cost) / mcc;
+            const double hist = (reference_cost_ - cost) / (accumulated_reference_model_cost_change_ + mcc);
+            return std::max(now, hist);
+        }
+        void TrustRegionStepEvaluator::StepAccepted(double cost, double mcc)
+        {
+            current_cost_ = cost;
+            accumulated_candidate_model_cost_change_ += mcc;
+            accumulated_reference_model_cost_change_ += mcc;
+            if (current_cost_ < minimum_cost_)
+            {
+                minimum_cost_ = candidate_cost_ = current_cost_;
+                num_consecutive_nonmonotonic_steps_ = 0;
+                accumulated_candidate_model_cost_change_ = 0.0;
+            }
+            else
+            {
+                ++num_consecutive_nonmonotonic_steps_;
+                if (current_cost_ > candidate_cost_)
+                {
+                    candidate_cost_ = current_cost_;
+                    accumulated_candidate_model_cost_change_ = 0.0;
+                }
+            }
+            if (num_consecutive_nonmonotonic_steps_ == max_consecutive_nonmonotonic_steps_)
+            {
+                reference_cost_ = candidate_cost_;
+                accumulated_reference_model_cost_change_ = accumulated_candidate_model_cost_change_;
+            }
+        }
+    } // namespace VO
+
+    namespace Core
+    {
+        using mbavo::Quat;
+
+        void SplineSE3::InsertControlKnot(const double q[4], const double t[3])
+        {
+            mT.insert(mT.end(), t, t + 3);
+            mR.insert(mR.end(), q, q + 4);
+        }
+
+        void SplineSE3::PopFrontControlKnot()
+        {
+            mT.erase(mT.begin(), mT.begin() + 3);
+            mR.erase(mR.begin(), mR.begin() + 4);
+            mT0 += mDt;
+        }
+
+        bool SplineSE3::GetPose(double t, double q_out[4], double t_out[3], double *jR, double *jt) const
+        { // Spline.h:222-281; the reference asserts on the range, here it is a return value
+            int idx;
+            double u;
+            mbavo::spline_segment(t, mT0, mDt, idx, u);
+            if (idx < 0 || idx + mDegK > (int)get_num_knots()) return false;
+            const double *kt = mT.data() + 3 * idx, *kR = mR.data() + 4 * idx;
+            Quat q;
+            if (mDegK == 2)
+            {
+                double c[2];
+                mbavo::trans_coeffs<2>(u, c);
+                mbavo::spline_translation<2>(kt, c, t_out);
+                q = jR ? mbavo::spline_rotation<2, true>(kR, u, jR) : mbavo::spline_rotation<2, false>(kR, u, nullptr);
+                if (jt)
+                {
+                    std::fill(jt, jt + 18, 0.0);
+                    for (int a = 0; a < 3; ++a)
+                        for (int j = 0; j < 2; ++j) jt[a * 6 + 3 * j + a] = c[j];
+                }
+            }
+            else if (mDegK == 4)
+            {
+                double c[4];
+                mbavo::trans_coeffs<4>(u, c);
+                mbavo::spline_translation<4>(kt, c, t_out);
+                q = jR ? mbavo::spline_rotation<4, true>(kR, u, jR) : mbavo::spline_rotation<4, false>(kR, u, nullptr);
+                if (jt)
+                {
+                    std::fill(jt, jt + 36, 0.0);
+                    for (int a = 0; a < 3; ++a)
+                        for (int j = 0; j < 4; ++j) jt[a * 12 + 3 * j + a] = c[j];
+                }
+            }
+            else
+                return false;
+            q_out[0] = q.x; q_out[1] = q.y; q_out[2] = q.z; q_out[3] = q.w;
+            return true;
+        }
+
+        void SplineSE3::TransformByRight(const double dq[4], const double dt[3])
+        { // Spline.h:212-219: t_i += R_i * dt ; R_i = R_i * dR
+            const Quat d{dq[0], dq[1], dq[2], dq[3]};
+            for (size_t i = 0; i < get_num_knots(); ++i)
+            {
+                const Quat R = mbavo::load_quat(&mR[4 * i]);
+                double r[3];
+                mbavo::qrotate(R, dt, r);
+                for (int a = 0; a < 3; ++a) mT[3 * i + a] += r[a];
+                const Quat n = mbavo::qmul(R, d);
+                mR[4 * i] = n.x; mR[4 * i + 1] = n.y; mR[4 * i + 2] = n.z; mR[4 * i + 3] = n.w;
+            }
+        }
+
+        void SplineSE3::UpdateCtrlKnot_t(int s, int num, const double *dt)
+        {
+            for (int i = 0; i < 3 * num; ++i) mT[3 * s + i] += dt[i];
+        }
+
+        void SplineSE3::UpdateCtrlKnot_R(int s, int num, const double *dR)
+        { // Spline.h:294-305: R = normalize(R * exp(w))
+            for (int i = 0; i < num; ++i)
+            {
+                double *r = &mR[4 * (s + i)];
+                const Quat n = mbavo::qmul(mbavo::load_quat(r), mbavo::so3_exp(dR + 3 * i));
+                const double nn = std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z + n.w * n.w);
+                r[0] = n.x / nn; r[1] = n.y / nn; r[2] = n.z / nn; r[3] = n.w / nn;
+            }
+        }
+
+        void SplineSE3::Plus_t(const double *dt, double *cand) const
+        {
+            for (size_t i = 0; i < mT.size(); ++i) cand[i] = mT[i] + dt[i];
+        }
+
+        void SplineSE3::Plus_R(const double *dR, double *cand) const
+        { // Spline.h:317-330: candidate_i = R_i * exp(w_i), not re-normalised
+            for (size_t i = 0; i < get_num_knots(); ++i)
+            {
+                const Quat n = mbavo::qmul(mbavo::load_quat(&mR[4 * i]), mbavo::so3_exp(dR + 3 * i));
+                cand[4 * i] = n.x; cand[4 * i + 1] = n.y; cand[4 * i + 2] = n.z; cand[4 * i + 3] = n.w;
+            }
+        }
+
+        void SplineSE3::InvalidParameter(const double *dt, const double *dR)
+        {
+            std::copy(dt, dt + mT.size(), mT.begin());
+            std::copy(dR, dR + mR.size(), mR.begin());
+        }
+
+        void SplineSE3::ResetIdentity()
+        {
+            std::fill(mT.begin(), mT.end(), 0.0);
+            for (size_t i = 0; i < get_num_knots(); ++i) { mR[4 * i] = mR[4 * i + 1] = mR[4 * i + 2] = 0.0; mR[4 * i + 3] = 1.0; }
+        }
+    } // namespace Core
+} // namespace SLAM

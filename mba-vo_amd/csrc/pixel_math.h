@@ -1,0 +1,278 @@
+// pixel_math.h -- per pixel-sample photometric warp, bilinear tap and Jacobian
+// chain (host + device, header only).
+//
+// Computes what compute_pixel_intensity<double> + bilinear_interpolation<double>
+// (ba_tracker/compute_pixel_intensity.h:25-209) and the per-sample chain of
+// kernel_compute_pixel_jacobian_residual (compute_hessian_gradients_cost.cu:
+// 123-153) compute, restructured for one-lane-per-pixel execution:
+//   * everything that depends only on the pixel (unit ray, 1/(D+1e-8)) is hoisted
+//     out of the sample loop; everything that depends only on the pose (rotation
+//     matrix entries, spline weights, J_R) comes from a per-sample table;
+//   * the warped point lies on the plane z = D of the keyframe, so P_z == D and
+//     the reference's second division per sample disappears;
+//   * the twelve dP/dq terms collapse to four dot products sharing m = C1*(dI.rho);
+//   * J_t = kron(c, I3) (SplineFunctor.h:77-90), so the translation chain is
+//     3k multiplies instead of a dense 3x3k product.
+// The fp32 islands of the reference are kept bit-for-bit: sqrtf in the unit ray
+// (:119) and float weights / float accumulation in the bilinear tap (:40-68),
+// with FMA contraction disabled inside them.
+#ifndef MBAVO_PIXEL_MATH_H
+#define MBAVO_PIXEL_MATH_H
+
+#include "core_types.h"
+#include "se3_math.h"
+#include <math.h>
+#include <string.h>
+
+namespace mbavo
+{
+    // One entry per (problem, frame, blur sample), written by the pose kernel.
+    template <int KDEG>
+    struct PoseEntry
+    {
+        double t[3];          // t_c2r
+        double q[4];          // R_c2r xyzw
+        double R[9];          // rotation matrix of q, row-major, reference term order
+        double c[KDEG];       // translation spline weights (J_t = kron(c, I3))
+        double JR[12 * KDEG]; // 4 x 3k row-major d(q)/d(knot local rotations)
+    };
+
+    // rotation matrix entries exactly as compute_pixel_intensity.h:124-126,168-177 forms them
+    MBAVO_HD void rotation_entries(const double q[4], double R[9])
+    {
+        const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+        R[0] = qw * qw + qx * qx - qy * qy - qz * qz;
+        R[1] = -2. * (qw * qz - qx * qy);
+        R[2] = 2. * (qw * qy + qx * qz);
+        R[3] = 2. * (qw * qz + qx * qy);
+        R[4] = qw * qw - qx * qx + qy * qy - qz * qz;
+        R[5] = -2. * (qw * qx - qy * qz);
+        R[6] = -2. * (qw * qy - qx * qz);
+        R[7] = 2. * (qw * qx + qy * qz);
+        R[8] = qw * qw - qx * qx - qy * qy + qz * qz;
+    }
+
+    struct Camera
+    {
+        double fx, fy, cx, cy;
+        int H, W;
+    };
+
+    // unit ray through an integer pixel; z uses the reference's fp32 sqrt (A4)
+    MBAVO_HD void unit_ray(const Camera &cam, double px, double py, double ray[3])
+    {
+        double xh = (px - cam.cx) / cam.fx;
+        double yh = (py - cam.cy) / cam.fy;
+        const double zh = 1. / (double)sqrtf((float)(1. + xh * xh + yh * yh));
+        ray[0] = xh * zh;
+        ray[1] = yh * zh;
+        ray[2] = zh;
+    }
+
+    // Bilinear tap of the u8 image and the interleaved float gradient image.
+    // In-bounds test inclusive (0 <= x <= W-1); the 2x2 window is anchored at
+    // min(floor, size-2) which is value-identical to the reference's zero-weight
+    // taps at the last row/column and never reads outside the buffer (A6).
+    template <bool WITH_GRAD>
+    MBAVO_HD bool bilinear_tap(const unsigned char *__restrict__ I, const float *__restrict__ G,
+                               int H, int W, double x, double y, double &val, double &gx, double &gy)
+    {
+#pragma clang fp contract(off)
+        if (x < 0 || x > W - 1 || y < 0 || y > H - 1) return false;
+        int xi = (int)x, yi = (int)y;
+        xi = xi > W - 2 ? W - 2 : xi;
+        yi = yi > H - 2 ? H - 2 : yi;
+        const float dx = (float)(x - xi);
+        const float dy = (float)(y - yi);
+        const float dxdy = dx * dy;
+        const float w00 = 1.0f - dx - dy + dxdy;
+        const float w01 = dx - dxdy;
+        const float w10 = dy - dxdy;
+        const float w11 = dxdy;
+        const int idx = yi * W + xi;
+        unsigned short r0, r1;
+        memcpy(&r0, I + idx, 2);
+        memcpy(&r1, I + idx + W, 2);
+        const float i00 = (float)(r0 & 0xff), i01 = (float)(r0 >> 8);
+        const float i10 = (float)(r1 & 0xff), i11 = (float)(r1 >> 8);
+        float v = w11 * i11;
+        v = v + w10 * i10;
+        v = v + w01 * i01;
+        v = v + w00 * i00;
+        val = (double)v;
+        if (WITH_GRAD)
+        {
+            float g0[4], g1[4]; // [dx00 dy00 dx01 dy01], [dx10 dy10 dx11 dy11]
+            memcpy(g0, G + 2 * idx, 16);
+            memcpy(g1, G + 2 * (idx + W), 16);
+            float a = w11 * g1[2];
+            a = a + w10 * g1[0];
+            a = a + w01 * g0[2];
+            a = a + w00 * g0[0];
+            float b = w11 * g1[3];
+            b = b + w10 * g1[1];
+            b = b + w01 * g0[3];
+            b = b + w00 * g0[1];
+            gx = (double)a;
+            gy = (double)b;
+        }
+        return true;
+    }
+
+    // One blur sample of one pixel: interpolated keyframe intensity and (WITH_J) its
+    // derivative w.r.t. the sample pose, jt = dI/dt (1x3) and b = dI/dq (1x4, xyzw) --
+    // the 1x7 Jacobian of compute_pixel_intensity.h:155-207.
+    // Returns false when the warp leaves the keyframe image.
+    template <bool WITH_J>
+    MBAVO_HD bool sample_eval(const double t[3], const double q[4], const double R[9], const double ray[3],
+                              double D, double iz, const Camera &cam, const unsigned char *__restrict__ I,
+                              const float *__restrict__ G, double &val, double jt[3], double b[4])
+    {
+        const double rx = R[0] * ray[0] + R[1] * ray[1] + R[2] * ray[2];
+        const double ry = R[3] * ray[0] + R[4] * ray[1] + R[5] * ray[2];
+        const double rz = R[6] * ray[0] + R[7] * ray[1] + R[8] * ray[2]; // == lambda (:124-126)
+        const double C1 = 1. / rz;
+        const double sc = (D - t[2]) * C1;
+        const double Px = sc * rx + t[0];
+        const double Py = sc * ry + t[1];
+        const double u = cam.fx * (Px * iz) + cam.cx;
+        const double v = cam.fy * (Py * iz) + cam.cy;
+        double gx = 0, gy = 0;
+        if (!bilinear_tap<WITH_J>(I, G, cam.H, cam.W, u, v, val, gx, gy)) return false;
+        if (WITH_J)
+        {
+            const double dIx = gx * iz * cam.fx;
+            const double dIy = gy * iz * cam.fy;
+            const double dIz = -iz * iz * (gx * Px * cam.fx + gy * Py * cam.fy);
+            const double dxy = dIx * rx + dIy * ry;
+            const double m = C1 * (dxy + dIz * rz);
+            jt[0] = dIx;
+            jt[1] = dIy;
+            jt[2] = -C1 * dxy; // dIz*(1 - rz*C1) vanishes identically (:199)
+            const double qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+            const double T0 = qx * ray[0] + qy * ray[1] + qz * ray[2];
+            const double T3 = qw * ray[0] + qy * ray[2] - qz * ray[1];
+            const double T2 = qw * ray[1] - qx * ray[2] + qz * ray[0];
+            const double T4 = qw * ray[2] + qx * ray[1] - qy * ray[0];
+            const double g2 = 2. * sc;
+            b[0] = g2 * (dIx * T0 - dIy * T4 + dIz * T2 - T2 * m);
+            b[1] = g2 * (dIx * T4 + dIy * T0 - dIz * T3 + T3 * m);
+            b[2] = g2 * (-dIx * T2 + dIy * T3 + dIz * T0 - T0 * m);
+            b[3] = g2 * (dIx * T3 + dIy * T2 + dIz * T4 - T4 * m);
+        }
+        return true;
+    }
+
+    // sample_eval + chain through the spline: adds the intensity to isum and the
+    // 1 x 6k contribution [jt * kron(c, I3) | b * J_R] to Jrow
+    // (compute_hessian_gradients_cost.cu:136-142).
+    template <int KDEG, bool WITH_J>
+    MBAVO_HD bool sample_accumulate(const PoseEntry<KDEG> &pe, const double ray[3], double D, double iz,
+                                    const Camera &cam, const unsigned char *__restrict__ I,
+                                    const float *__restrict__ G, double &isum, double *Jrow)
+    {
+        double val, jt[3], b[4];
+        if (!sample_eval<WITH_J>(pe.t, pe.q, pe.R, ray, D, iz, cam, I, G, val, jt, b)) return false;
+        isum += val;
+        if (WITH_J)
+        {
+#pragma unroll
+            for (int j = 0; j < KDEG; ++j)
+            {
+                Jrow[3 * j + 0] += pe.c[j] * jt[0];
+                Jrow[3 * j + 1] += pe.c[j] * jt[1];
+                Jrow[3 * j + 2] += pe.c[j] * jt[2];
+            }
+#pragma unroll
+            for (int cidx = 0; cidx < 3 * KDEG; ++cidx)
+            {
+                double a = b[0] * pe.JR[cidx];
+                a += b[1] * pe.JR[3 * KDEG + cidx];
+                a += b[2] * pe.JR[6 * KDEG + cidx];
+                a += b[3] * pe.JR[9 * KDEG + cidx];
+                Jrow[3 * KDEG + cidx] += a;
+            }
+        }
+        return true;
+    }
+
+    // patch centre of a keypoint in the current frame at the mid-exposure pose
+    // (compute_local_patches_xy.cu:19-49)
+    MBAVO_HD void patch_centre(const double t_c2r[3], const double q_c2r[4], double kx, double ky, double kz,
+                               const Camera &cam, double &ox, double &oy)
+    {
+        const double P[3] = {kz * (kx - cam.cx) / cam.fx, kz * (ky - cam.cy) / cam.fy, kz};
+        // R_r2c = conj(R_c2r); t_r2c = -(R_r2c * t_c2r); P_c = R_r2c * P + t_r2c
+        const Quat r2c = qconj(Quat{q_c2r[0], q_c2r[1], q_c2r[2], q_c2r[3]});
+        double rt[3], rp[3];
+        qrotate(r2c, t_c2r, rt);
+        qrotate(r2c, P, rp);
+        const double X = rp[0] - rt[0], Y = rp[1] - rt[1], Z = rp[2] - rt[2];
+        ox = X / Z * cam.fx + cam.cx;
+        oy = Y / Z * cam.fy + cam.cy;
+    }
+
+    // Huber weight sqrt(rho') and rho for residual r (compute_hessian_gradients_cost.cu:189-199);
+    // the reference's fp32 square roots are kept (A11).
+    MBAVO_HD void huber_weight(double r, double a, double &w, double &rho)
+    {
+        const double aa = a * a;
+        const double x = 0.5 * r * r;
+        w = 1.;
+        rho = x;
+        if (x > aa)
+        {
+            const double sx = (double)sqrtf((float)x);
+            w = (double)sqrtf((float)(a / (sx + 1e-8)));
+            rho = 2 * a * sx - aa;
+        }
+    }
+
+    // Residual and mean 1 x 6k Jacobian of one pixel over its S blur samples.
+    // A pixel is valid iff its integer location and all S warps are in bounds
+    // (SURVEY A9); otherwise residual = 0, Jrow = 0 and false is returned.
+    // `table` points at the S entries of this pixel's frame.
+    template <int KDEG, bool WITH_J>
+    MBAVO_HD bool pixel_row(const PoseEntry<KDEG> *__restrict__ table, int S, const Camera &cam,
+                            const unsigned char *__restrict__ I_ref, const float *__restrict__ G_ref,
+                            const unsigned char *__restrict__ I_cur, double centre_x, double centre_y,
+                            double depth, int dx, int dy, double &residual, double *Jrow)
+    {
+        residual = 0.0;
+        if (WITH_J)
+        {
+#pragma unroll
+            for (int i = 0; i < 6 * KDEG; ++i) Jrow[i] = 0.0;
+        }
+        const int px = (int)(centre_x + dx); // truncation, A3
+        const int py = (int)(centre_y + dy);
+        if (px < 0 || px > cam.W - 1 || py < 0 || py > cam.H - 1) return false;
+        double ray[3];
+        unit_ray(cam, (double)px, (double)py, ray);
+        const double iz = 1. / (depth + 1e-8); // P_z == plane depth, A7
+        double isum = 0.0;
+        bool ok = true;
+        for (int s = 0; s < S && ok; ++s)
+            ok = sample_accumulate<KDEG, WITH_J>(table[s], ray, depth, iz, cam, I_ref, G_ref, isum, Jrow);
+        if (!ok)
+        {
+            if (WITH_J)
+            {
+#pragma unroll
+                for (int i = 0; i < 6 * KDEG; ++i) Jrow[i] = 0.0;
+            }
+            return false;
+        }
+        const double fS = (double)(float)S; // A8
+        residual = isum / fS - (double)I_cur[py * cam.W + px];
+        if (WITH_J)
+        {
+            const double inv = 1.0 / fS;
+#pragma unroll
+            for (int i = 0; i < 6 * KDEG; ++i) Jrow[i] *= inv;
+        }
+        return true;
+    }
+} // namespace mbavo
+
+#endif

@@ -1,0 +1,369 @@
+// se3_math.h -- SE(3) cumulative B-spline sampling with pose-to-knot Jacobians
+// (host + device, header only).
+//
+// Same quantities as the reference's functors (core/common/SplineFunctor.h:13-365,
+// Quaternion.h:61-283): pose [t | q(xyzw)] on a degree-k (k = 2 linear, 4 cubic)
+// cumulative B-spline and d(pose)/d(knots) for the right-multiplicative local
+// update R_j <- R_j * exp(w_j).  The reference builds the 4x3k rotation Jacobian
+// with 4x4 left/right product matrices staged through global scratch; here a
+// 4x3 Jacobian block is kept as three quaternion columns and every
+// "matrix(q) * block" is a quaternion product, so the whole chain stays in
+// registers.  Small-angle branch thresholds (Quaternion.h:77,100,166) are kept.
+#ifndef MBAVO_SE3_MATH_H
+#define MBAVO_SE3_MATH_H
+
+#include "core_types.h"
+#include <math.h>
+
+namespace mbavo
+{
+    struct Quat
+    {
+        double x, y, z, w;
+    };
+
+    MBAVO_HD Quat qmul(const Quat &a, const Quat &b)
+    { // Hamilton product, term order of Quaternion.h:45-51
+        Quat r;
+        r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+        r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+        r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+        r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+        return r;
+    }
+
+    MBAVO_HD Quat qconj(const Quat &a) { return Quat{-a.x, -a.y, -a.z, a.w}; }
+
+    MBAVO_HD void qrotate(const Quat &q, const double p[3], double o[3])
+    { // q * (p,0) * conj(q)   (Quaternion.h:53-60)
+        const Quat v = qmul(qmul(q, Quat{p[0], p[1], p[2], 0.0}), qconj(q));
+        o[0] = v.x; o[1] = v.y; o[2] = v.z;
+    }
+
+    // A 4x3 Jacobian block d(quaternion)/d(3-vector), stored as its 3 columns.
+    struct Jac43
+    {
+        Quat c[3];
+    };
+    // 3x4 (log) and 4x3 (exp) Jacobians, row-major as in the reference.
+    struct LogJac { double m[12]; };
+    struct ExpJac { double m[12]; };
+
+    // log map with the reference's three branches (Quaternion.h:61-157).
+    template <bool WITH_J>
+    MBAVO_HD void qlog(const Quat &q, double tg[3], LogJac *J)
+    {
+        const double x = q.x, y = q.y, z = q.z, w = q.w;
+        const double sn = x * x + y * y + z * z;
+        double lam, dx = 0, dy = 0, dz = 0, dw = 0;
+        if (sn < 1e-20)
+        {
+            const double www = w * w * w;
+            lam = 2. / w - 2. / 3. * sn / www;
+            if (WITH_J)
+            { // series derivative exactly as the reference writes it (:80-88)
+                dx = 2. / w - 4. / 3. * x / www;
+                dy = 2. / w - 4. / 3. * y / www;
+                dz = 2. / w - 4. / 3. * z / www;
+                dw = -2 / (w * w) + 2 * sn / (www * w);
+            }
+        }
+        else
+        {
+            const double n = sqrt(sn);
+            if (fabs(w) < 1e-10)
+            {
+                const double pi = 3.14159265358979323846;
+                lam = (w > 0 ? pi : -pi) / n;
+                if (WITH_J)
+                {
+                    const double s = (w > 0 ? -lam : lam) / sn;
+                    dx = s * x; dy = s * y; dz = s * z;
+                }
+            }
+            else
+            {
+                lam = 2.0 * atan(n / w) / n;
+                if (WITH_J)
+                {
+                    const double dn = (2 * w - lam) / n;
+                    dx = dn * x / n; dy = dn * y / n; dz = dn * z / n;
+                    dw = -2.;
+                }
+            }
+        }
+        if (WITH_J)
+        {
+            double *m = J->m;
+            m[0] = dx * x + lam; m[1] = dy * x;        m[2] = dz * x;         m[3] = dw * x;
+            m[4] = dx * y;       m[5] = dy * y + lam;  m[6] = dz * y;         m[7] = dw * y;
+            m[8] = dx * z;       m[9] = dy * z;        m[10] = dz * z + lam;  m[11] = dw * z;
+        }
+        tg[0] = lam * x; tg[1] = lam * y; tg[2] = lam * z;
+    }
+
+    // exp map (Quaternion.h:159-233).
+    template <bool WITH_J>
+    MBAVO_HD Quat qexp(const double tg[3], ExpJac *J)
+    {
+        double im, re;
+        const double th2 = tg[0] * tg[0] + tg[1] * tg[1] + tg[2] * tg[2];
+        if (th2 < 1e-20)
+        {
+            const double th4 = th2 * th2;
+            im = 0.5 - 1. / 48. * th2 + 1. / 3840. * th4;
+            re = 1. - 1. / 8. * th2 + 1. / 384. * th4;
+            if (WITH_J)
+            {
+                for (int i = 0; i < 12; ++i) J->m[i] = 0;
+                J->m[0] = 0.5; J->m[4] = 0.5; J->m[8] = 0.5;
+            }
+        }
+        else
+        {
+            const double th = sqrt(th2);
+            const double hs = sin(0.5 * th);
+            im = hs / th;
+            re = cos(0.5 * th);
+            if (WITH_J)
+            {
+                const double x = tg[0], y = tg[1], z = tg[2];
+                const double ux = x / th, uy = y / th, uz = z / th;
+                const double dim = 0.5 * re / th - im / th;
+                const double dre = -0.5 * hs;
+                const double ax = dim * ux, ay = dim * uy, az = dim * uz;
+                double *m = J->m;
+                m[0] = ax * x + im; m[1] = ay * x;      m[2] = az * x;
+                m[3] = ax * y;      m[4] = ay * y + im; m[5] = az * y;
+                m[6] = ax * z;      m[7] = ay * z;      m[8] = az * z + im;
+                m[9] = dre * ux;    m[10] = dre * uy;   m[11] = dre * uz;
+            }
+        }
+        return Quat{im * tg[0], im * tg[1], im * tg[2], re};
+    }
+
+    // d(R * exp(w))/dw at w = 0: columns R * (e_i/2, 0)      (L(R) * [I/2; 0])
+    MBAVO_HD Jac43 local_param_jac(const Quat &R)
+    {
+        Jac43 o;
+        o.c[0] = qmul(R, Quat{0.5, 0, 0, 0});
+        o.c[1] = qmul(R, Quat{0, 0.5, 0, 0});
+        o.c[2] = qmul(R, Quat{0, 0, 0.5, 0});
+        return o;
+    }
+    MBAVO_HD Jac43 lmul(const Quat &q, const Jac43 &M) // L(q) * M : q (x) column
+    {
+        Jac43 o;
+        for (int i = 0; i < 3; ++i) o.c[i] = qmul(q, M.c[i]);
+        return o;
+    }
+    MBAVO_HD Jac43 rmul(const Jac43 &M, const Quat &q) // Rhat(q) * M : column (x) q
+    {
+        Jac43 o;
+        for (int i = 0; i < 3; ++i) o.c[i] = qmul(M.c[i], q);
+        return o;
+    }
+    MBAVO_HD Jac43 conj_cols(const Jac43 &M) // K * M, K = diag(-1,-1,-1,1)
+    {
+        Jac43 o;
+        for (int i = 0; i < 3; ++i) o.c[i] = qconj(M.c[i]);
+        return o;
+    }
+    // dexp(4x3) * (scale * dlog(3x4) * M(4x3))
+    MBAVO_HD Jac43 through_log_exp(const ExpJac &de, double scale, const LogJac &dl, const Jac43 &M)
+    {
+        double t[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+            {
+                const Quat &v = M.c[c];
+                double a = 0.0;
+                a += dl.m[r * 4 + 0] * v.x;
+                a += dl.m[r * 4 + 1] * v.y;
+                a += dl.m[r * 4 + 2] * v.z;
+                a += dl.m[r * 4 + 3] * v.w;
+                t[r][c] = a * scale;
+            }
+        Jac43 o;
+        for (int c = 0; c < 3; ++c)
+        {
+            double v[4];
+            for (int r = 0; r < 4; ++r)
+            {
+                double a = 0.0;
+                a += de.m[r * 3 + 0] * t[0][c];
+                a += de.m[r * 3 + 1] * t[1][c];
+                a += de.m[r * 3 + 2] * t[2][c];
+                v[r] = a;
+            }
+            o.c[c] = Quat{v[0], v[1], v[2], v[3]};
+        }
+        return o;
+    }
+    MBAVO_HD Jac43 jadd(const Jac43 &a, const Jac43 &b)
+    {
+        Jac43 o;
+        for (int i = 0; i < 3; ++i)
+            o.c[i] = Quat{a.c[i].x + b.c[i].x, a.c[i].y + b.c[i].y, a.c[i].z + b.c[i].z, a.c[i].w + b.c[i].w};
+        return o;
+    }
+    // write a 4x3 block into the row-major 4 x ncols matrix at column col0
+    MBAVO_HD void store_block(double *J, int ncols, int col0, const Jac43 &B)
+    {
+        for (int i = 0; i < 3; ++i)
+        {
+            J[0 * ncols + col0 + i] = B.c[i].x;
+            J[1 * ncols + col0 + i] = B.c[i].y;
+            J[2 * ncols + col0 + i] = B.c[i].z;
+            J[3 * ncols + col0 + i] = B.c[i].w;
+        }
+    }
+
+    MBAVO_HD Quat load_quat(const double *p) { return Quat{p[0], p[1], p[2], p[3]}; }
+
+    // segment index + normalised time (SplineFunctor.h:13-19): truncation toward zero
+    MBAVO_HD void spline_segment(double t, double t0, double dt, int &idx, double &u)
+    {
+        const double tn = (t - t0) / dt;
+        idx = (int)tn;
+        u = tn - idx;
+    }
+
+    // basis weights of the translation spline; J_t = kron(coeffs, I3) (SplineFunctor.h:21-94)
+    template <int KDEG>
+    MBAVO_HD void trans_coeffs(double u, double c[KDEG])
+    {
+        if constexpr (KDEG == 2)
+        {
+            c[0] = 1 - u;
+            c[1] = u;
+        }
+        else
+        {
+            const double uu = u * u, uuu = uu * u, s = 1. / 6.;
+            c[0] = s - 0.5 * u + 0.5 * uu - s * uuu;
+            c[1] = 4 * s - uu + 0.5 * uuu;
+            c[2] = s + 0.5 * u + 0.5 * uu - 0.5 * uuu;
+            c[3] = s * uuu;
+        }
+    }
+
+    template <int KDEG>
+    MBAVO_HD void spline_translation(const double *kt, const double c[KDEG], double p[3])
+    {
+        for (int a = 0; a < 3; ++a)
+        {
+            double v = c[0] * kt[a];
+            for (int j = 1; j < KDEG; ++j) v = v + c[j] * kt[3 * j + a];
+            p[a] = v;
+        }
+    }
+
+    // rotation on the cumulative spline + 4 x 3k Jacobian (row-major) w.r.t. the
+    // knots' local parameters.  JR may be nullptr when WITH_J is false.
+    template <int KDEG, bool WITH_J>
+    MBAVO_HD Quat spline_rotation(const double *kR, double u, double *JR)
+    {
+        if constexpr (KDEG == 2)
+        { // SplineFunctor.h:155-217
+            const Quat R0 = load_quat(kR), R1 = load_quat(kR + 4);
+            const Quat R0c = qconj(R0);
+            LogJac dl; ExpJac de;
+            double om[3];
+            qlog<WITH_J>(qmul(R0c, R1), om, &dl);
+            om[0] *= u; om[1] *= u; om[2] *= u;
+            const Quat A0 = qexp<WITH_J>(om, &de);
+            if (WITH_J)
+            {
+                const Jac43 E0 = local_param_jac(R0), E1 = local_param_jac(R1);
+                // R0: direct factor + through R01 = conj(R0) * R1
+                Jac43 a = rmul(E0, A0);
+                Jac43 b = lmul(R0, through_log_exp(de, u, dl, rmul(conj_cols(E0), R1)));
+                store_block(JR, 6, 0, jadd(a, b));
+                // R1: through R01 only
+                Jac43 c = lmul(R0, through_log_exp(de, u, dl, lmul(R0c, E1)));
+                store_block(JR, 6, 3, c);
+            }
+            return qmul(R0, A0);
+        }
+        else
+        { // SplineFunctor.h:219-365
+            const double uu = u * u, uuu = uu * u, s = 1. / 6.;
+            const double c1 = 5 * s + 0.5 * u - 0.5 * uu + s * uuu;
+            const double c2 = s + 0.5 * u + 0.5 * uu - 2 * s * uuu;
+            const double c3 = s * uuu;
+            const Quat R0 = load_quat(kR), R1 = load_quat(kR + 4), R2 = load_quat(kR + 8), R3 = load_quat(kR + 12);
+            const Quat R0c = qconj(R0), R1c = qconj(R1), R2c = qconj(R2);
+            LogJac dl01, dl12, dl23; ExpJac de0, de1, de2;
+            double o01[3], o12[3], o23[3];
+            qlog<WITH_J>(qmul(R0c, R1), o01, &dl01);
+            qlog<WITH_J>(qmul(R1c, R2), o12, &dl12);
+            qlog<WITH_J>(qmul(R2c, R3), o23, &dl23);
+            for (int a = 0; a < 3; ++a) { o01[a] *= c1; o12[a] *= c2; o23[a] *= c3; }
+            const Quat A0 = qexp<WITH_J>(o01, &de0);
+            const Quat A1 = qexp<WITH_J>(o12, &de1);
+            const Quat A2 = qexp<WITH_J>(o23, &de2);
+            const Quat R0A0 = qmul(R0, A0);
+            const Quat R0A0A1 = qmul(R0A0, A1);
+            if (WITH_J)
+            {
+                const Quat A12 = qmul(A1, A2);
+                const Quat A012 = qmul(qmul(A0, A1), A2);
+                const Jac43 E0 = local_param_jac(R0), E1 = local_param_jac(R1);
+                const Jac43 E2 = local_param_jac(R2), E3 = local_param_jac(R3);
+                // knot 0
+                {
+                    Jac43 a = rmul(E0, A012);
+                    Jac43 dA0 = through_log_exp(de0, c1, dl01, rmul(conj_cols(E0), R1));
+                    Jac43 b = lmul(R0, rmul(dA0, A12));
+                    store_block(JR, 12, 0, jadd(a, b));
+                }
+                // knot 1: through R01 (as right factor) and R12 (as conj left factor)
+                {
+                    Jac43 dA0 = through_log_exp(de0, c1, dl01, lmul(R0c, E1));
+                    Jac43 a = lmul(R0, rmul(dA0, A12));
+                    Jac43 dA1 = through_log_exp(de1, c2, dl12, rmul(conj_cols(E1), R2));
+                    Jac43 b = lmul(R0A0, rmul(dA1, A2));
+                    store_block(JR, 12, 3, jadd(a, b));
+                }
+                // knot 2
+                {
+                    Jac43 dA1 = through_log_exp(de1, c2, dl12, lmul(R1c, E2));
+                    Jac43 a = lmul(R0A0, rmul(dA1, A2));
+                    Jac43 dA2 = through_log_exp(de2, c3, dl23, rmul(conj_cols(E2), R3));
+                    Jac43 b = lmul(R0A0A1, dA2);
+                    store_block(JR, 12, 6, jadd(a, b));
+                }
+                // knot 3
+                {
+                    Jac43 dA2 = through_log_exp(de2, c3, dl23, lmul(R2c, E3));
+                    store_block(JR, 12, 9, lmul(R0A0A1, dA2));
+                }
+            }
+            return qmul(R0A0A1, A2);
+        }
+    }
+
+    // SO(3) exponential as a unit quaternion (what Spline.h:302,326 gets from
+    // Sophus::SO3d::exp): series below theta^2 < 1e-20, closed form above.
+    MBAVO_HD Quat so3_exp(const double om[3])
+    {
+        const double th2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+        double im, re;
+        if (th2 < 1e-10 * 1e-10)
+        {
+            const double th4 = th2 * th2;
+            im = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4;
+            re = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4;
+        }
+        else
+        {
+            const double th = sqrt(th2);
+            im = sin(0.5 * th) / th;
+            re = cos(0.5 * th);
+        }
+        return Quat{im * om[0], im * om[1], im * om[2], re};
+    }
+} // namespace mbavo
+
+#endif

@@ -1,0 +1,212 @@
+// tracker.cpp -- coarse-to-fine Levenberg-Marquardt loop of the blur-aware tracker on the
+// fused engine: BlurAwareDirectTracker::optimizeTrajectory / optimizePyramidLevel and the
+// helpers they call (ba_tracker/blur_aware_direct_tracker.cpp:544-924).
+//
+// Control-flow details that decide how often the hot path runs and which step is taken
+// are kept as in the reference: the damping H.diag += H.diag / radius is applied in
+// place and therefore accumulates over rejected steps (:801-803); the model cost change
+// uses the damped H (:821-823); abs_cost_decrease is recorded before the accept test, so
+// any non-improving step ends the level (:624, :910-924); outlier statistics come from
+// the patch costs of the candidate's cost-only pass, frame 0 only (:639-699); the LM
+// radius and outlier flags are reset per level, the spline is warm-started (:590-606).
+#include "tracker.h"
+#include "host_math.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace mbavo
+{
+#define TRK_HIP(expr)                                                                    \
+    do                                                                                   \
+    {                                                                                    \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+        {                                                                                \
+            fprintf(stderr, "mbavo tracker: %s failed: %s\n", #expr, hipGetErrorString(e_)); \
+            rc_ = (int)e_;                                                               \
+            goto done;                                                                   \
+        }                                                                                \
+    } while (0)
+
+    static int detect_outliers(const double *patch_cost, int K, double chi, std::vector<unsigned char> &flags)
+    { // :639-699
+        double sum = 0.0;
+        std::vector<double> kept;
+        kept.reserve(K);
+        for (int i = 0; i < K; ++i)
+        {
+            const double c = patch_cost[i];
+            if (c < 1e-8) continue;
+            kept.push_back(c);
+            sum += c;
+        }
+        const double mu = sum / kept.size();
+        double var = 0.0;
+        for (double c : kept) var += (c - mu) * (c - mu);
+        var = var / kept.size();
+        const double bound = chi * (double)sqrtf((float)var);
+        int n = 0;
+        for (int i = 0; i < K; ++i)
+            if (std::fabs(patch_cost[i] - mu) > bound) { flags[i] = 1; ++n; }
+        return n;
+    }
+
+    int optimize_trajectory(Engine &eng, const mbavo_track_opts &o, const mbavo_level *levels, int F,
+                            const double *h_cap, const double *h_exp, double t0, double dt, double *knots_t,
+                            double *knots_R, int N, int *start_idx_out, double *final_cost, mbavo_trace_rec *trace,
+                            int trace_cap)
+    {
+        const int k = o.spline_deg_k;
+        if ((k != 2 && k != 4) || F < 1 || N < k || o.num_levels < 1 || o.num_levels > 8) return MBAVO_E_ARG;
+        const int n = 6 * N, ndim = 6 * k + 1, E = ndim * (ndim + 1) / 2;
+        int rc_ = 0, ntrace = 0;
+        hipStream_t st = eng.stream();
+
+        SLAM::Core::SplineSE3 spline(t0, dt);
+        spline.setSplineDegK(k);
+        for (int i = 0; i < N; ++i) spline.InsertControlKnot(knots_R + 4 * i, knots_t + 3 * i);
+
+        std::vector<int> start_idx(F);
+        for (int f = 0; f < F; ++f) start_idx[f] = (int)((h_cap[f] - t0) / dt); // :549-560
+        if (start_idx_out) memcpy(start_idx_out, start_idx.data(), sizeof(int) * F);
+
+        std::vector<double> H((size_t)n * n), g(n), step(n), cand_t(3 * N), cand_R(4 * N), fb((size_t)F * E);
+        SLAM::VO::LevenbergMarquardtStrategy lm;
+        SLAM::VO::TrustRegionStepEvaluator evaluator(o.max_consecutive_nonmonotonic_steps);
+        double eval_cost = 0.0;
+
+        int maxK = 0;
+        for (int l = 0; l < o.num_levels; ++l) maxK = levels[l].K > maxK ? levels[l].K : maxK;
+        double *d_cap = nullptr, *d_exp = nullptr, *d_kt = nullptr, *d_kR = nullptr, *d_fb = nullptr, *d_pc = nullptr;
+        unsigned char *d_flags = nullptr;
+        std::vector<double> h_pc(maxK > 0 ? maxK : 1);
+        std::vector<unsigned char> flags;
+
+        TRK_HIP(hipSetDevice(eng.device()));
+        TRK_HIP(hipMalloc((void **)&d_cap, sizeof(double) * F));
+        TRK_HIP(hipMalloc((void **)&d_exp, sizeof(double) * F));
+        TRK_HIP(hipMalloc((void **)&d_kt, sizeof(double) * 3 * N));
+        TRK_HIP(hipMalloc((void **)&d_kR, sizeof(double) * 4 * N));
+        TRK_HIP(hipMalloc((void **)&d_fb, sizeof(double) * (size_t)F * E));
+        TRK_HIP(hipMalloc((void **)&d_pc, sizeof(double) * (size_t)F * (maxK > 0 ? maxK : 1)));
+        TRK_HIP(hipMalloc((void **)&d_flags, maxK > 0 ? maxK : 1));
+        TRK_HIP(hipMemcpyAsync(d_cap, h_cap, sizeof(double) * F, hipMemcpyHostToDevice, st)); // :701-719
+        TRK_HIP(hipMemcpyAsync(d_exp, h_exp, sizeof(double) * F, hipMemcpyHostToDevice, st));
+        TRK_HIP(hipMemsetAsync(d_fb, 0, sizeof(double) * (size_t)F * E, st));
+
+        for (int li = 0; li < o.num_levels; ++li)
+        {
+            const int lv = o.num_levels - li - 1; // coarse to fine (:571-575)
+            const mbavo_level &L = levels[lv];
+            const int scale = 1 << lv;
+            flags.assign(L.K > 0 ? L.K : 1, 0);
+            TRK_HIP(hipMemsetAsync(d_flags, 0, L.K > 0 ? L.K : 1, st)); // :601
+            mbavo_problem p;
+            memset(&p, 0, sizeof(p));
+            p.S = L.S; p.F = F; p.K = L.K; p.P = L.P; p.N = N; p.H = L.H; p.W = L.W;
+            p.d_ref_img = L.d_ref_img; p.d_ref_dIxy = L.d_ref_dIxy; p.d_cur_imgs = L.d_cur_imgs;
+            p.d_kp_xy = L.d_kp_xy; p.kp_stride = 2; p.d_kp_z = L.d_kp_z; p.d_pattern = L.d_pattern;
+            p.d_outlier = d_flags; p.num_bad = 0;
+            for (int a = 0; a < 4; ++a) p.intrinsics[a] = o.intrinsics[a] / scale; // :766-770
+            p.d_cap_time = d_cap; p.d_exp_time = d_exp; p.t0 = t0; p.dt = dt;
+            p.d_knots_t = d_kt; p.d_knots_R = d_kR; p.h_start_idx = start_idx.data(); p.huber_a = o.huber_k;
+
+            bool check_range = true;
+            // one evaluation at the given knots: H2D knots, fused pass, D2H F*E doubles, host scatter
+            auto evaluate = [&](const double *kt, const double *kR, bool with_h, double *cost) -> int {
+                hipError_t e;
+                if ((e = hipMemcpyAsync(d_kt, kt, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st)) != hipSuccess) return (int)e;
+                if ((e = hipMemcpyAsync(d_kR, kR, sizeof(double) * 4 * N, hipMemcpyHostToDevice, st)) != hipSuccess) return (int)e;
+                int r = eng.evaluate(1, &p, k, with_h, d_fb, d_pc, nullptr, nullptr);
+                if (r) return r;
+                if ((e = hipMemcpyAsync(fb.data(), d_fb, sizeof(double) * (size_t)F * E, hipMemcpyDeviceToHost, st)) != hipSuccess) return (int)e;
+                if ((e = hipStreamSynchronize(st)) != hipSuccess) return (int)e;
+                if (check_range) // depends on the times only, not on the knot values: once per level
+                {
+                    check_range = false;
+                    if (eng.fetch_status() != 0) return MBAVO_E_RANGE;
+                }
+                merge_blocks_host(F, k, fb.data(), start_idx.data(), N, cost, with_h ? H.data() : nullptr,
+                                  with_h ? g.data() : nullptr);
+                return 0;
+            };
+            auto record = [&](int iter, int kind, double cc, double model, double q) {
+                if (trace && ntrace < trace_cap)
+                {
+                    mbavo_trace_rec &r = trace[ntrace];
+                    r.level = lv; r.iter = iter; r.kind = kind; r.num_outliers = p.num_bad;
+                    r.radius = lm.get_radius(); r.eval_cost = eval_cost; r.candidate_cost = cc;
+                    r.model_change = model; r.quality = q;
+                }
+                ++ntrace;
+            };
+
+            if ((rc_ = evaluate(spline.get_knot_data_t(), spline.get_knot_data_R(), true, &eval_cost))) goto done; // iteration 0
+            lm.reset();
+            evaluator.reset(eval_cost);
+            record(0, 0, 0.0, 0.0, 0.0);
+
+            int iter = 0;
+            double abs_dec = 1e10;
+            for (;;)
+            {
+                ++iter; // finalizeIterationAndCheckIfMinimizerCanContinue (:910-924)
+                if (iter > o.max_num_iterations) break;
+                if (abs_dec < o.min_abs_cost_decrease) break;
+
+                // computeTrustRegionStep (:799-831)
+                const double iradius = 1. / lm.get_radius();
+                for (int i = 0; i < n; ++i) H[(size_t)i * n + i] += H[(size_t)i * n + i] * iradius;
+                if (solve_normal_equation_host(H.data(), g.data(), n, o.solver_type, step.data()) < 0) { rc_ = MBAVO_E_ARG; goto done; }
+                double gx = 0.0, xHx = 0.0;
+                for (int i = 0; i < n; ++i) gx += g[i] * step[i];
+                for (int r = 0; r < n; ++r)
+                {
+                    double a = 0.0;
+                    for (int c = 0; c < n; ++c) a += H[(size_t)c * n + r] * step[c];
+                    xHx += step[r] * a;
+                }
+                const double model = -(gx + 0.5 * xHx);
+                if (model < 0) { lm.step_rejected(); record(iter, 3, 0.0, model, 0.0); continue; } // handleInvalidStep
+
+                // computeCandidatePointAndEvaluateCost (:833-883)
+                spline.Plus_t(step.data(), cand_t.data());
+                spline.Plus_R(step.data() + 3 * N, cand_R.data());
+                double cand_cost = 0.0;
+                if ((rc_ = evaluate(cand_t.data(), cand_R.data(), false, &cand_cost))) goto done;
+
+                abs_dec = eval_cost - cand_cost;
+                const double quality = evaluator.StepQuality(cand_cost, model);
+                if (quality > o.min_step_quality && cand_cost < eval_cost)
+                { // isStepSuccessful (:890-894) -> detectOutliers + handleSuccessfulStep (:896-903)
+                    TRK_HIP(hipMemcpy(h_pc.data(), d_pc, sizeof(double) * L.K, hipMemcpyDeviceToHost));
+                    p.num_bad = detect_outliers(h_pc.data(), L.K, o.max_chi_square_error, flags);
+                    TRK_HIP(hipMemcpyAsync(d_flags, flags.data(), L.K, hipMemcpyHostToDevice, st));
+                    spline.InvalidParameter(cand_t.data(), cand_R.data());
+                    if ((rc_ = evaluate(spline.get_knot_data_t(), spline.get_knot_data_R(), true, &eval_cost))) goto done;
+                    lm.step_accepted(quality);
+                    evaluator.StepAccepted(eval_cost, model);
+                    record(iter, 1, cand_cost, model, quality);
+                    continue;
+                }
+                lm.step_rejected(); // handleUnsuccessfulStep
+                record(iter, 2, cand_cost, model, quality);
+            }
+        }
+        memcpy(knots_t, spline.get_knot_data_t(), sizeof(double) * 3 * N);
+        memcpy(knots_R, spline.get_knot_data_R(), sizeof(double) * 4 * N);
+        if (final_cost) *final_cost = eval_cost;
+    done:
+        if (d_cap) (void)hipFree(d_cap);
+        if (d_exp) (void)hipFree(d_exp);
+        if (d_kt) (void)hipFree(d_kt);
+        if (d_kR) (void)hipFree(d_kR);
+        if (d_fb) (void)hipFree(d_fb);
+        if (d_pc) (void)hipFree(d_pc);
+        if (d_flags) (void)hipFree(d_flags);
+        return rc_ ? (rc_ > 0 ? -1000 - rc_ : rc_) : ntrace;
+    }
+} // namespace mbavo

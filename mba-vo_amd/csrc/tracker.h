@@ -1,0 +1,15 @@
+// tracker.h -- LM loop over the pyramid on the fused engine (see tracker.cpp).
+#ifndef MBAVO_TRACKER_H
+#define MBAVO_TRACKER_H
+
+#include "engine.h"
+
+namespace mbavo
+{
+    int optimize_trajectory(Engine &eng, const mbavo_track_opts &opts, const mbavo_level *levels, int F,
+                            const double *h_cap, const double *h_exp, double t0, double dt, double *knots_t,
+                            double *knots_R, int N, int *start_idx_out, double *final_cost, mbavo_trace_rec *trace,
+                            int trace_cap);
+}
+
+#endif

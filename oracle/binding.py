@@ -1,0 +1,245 @@
+"""ctypes binding of the CPU oracle (test infrastructure, NOT product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  `lib()` is the plain-C restatement (oracle/mbavo_oracle.c);
+`ref()` is the reference's own compilable sources (oracle/_ref, built in the
+build container only; None when absent).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+_REF = None
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+c_fp = C.POINTER(C.c_float)
+c_u8p = C.POINTER(C.c_ubyte)
+
+
+def dp(a):
+    return None if a is None else a.ctypes.data_as(c_dp)
+
+
+def ip(a):
+    return None if a is None else a.ctypes.data_as(c_ip)
+
+
+def fp(a):
+    return None if a is None else a.ctypes.data_as(c_fp)
+
+
+def u8p(a):
+    return None if a is None else a.ctypes.data_as(c_u8p)
+
+
+class OrcProblem(C.Structure):
+    _fields_ = [
+        ("S", C.c_int), ("F", C.c_int), ("K", C.c_int), ("P", C.c_int),
+        ("k", C.c_int), ("N", C.c_int), ("H", C.c_int), ("W", C.c_int),
+        ("ref_img", c_u8p), ("ref_dIxy", c_fp), ("cur_imgs", C.POINTER(c_u8p)),
+        ("kp_xy", c_dp), ("kp_z", c_dp), ("pattern", c_ip), ("outlier", c_u8p),
+        ("num_bad", C.c_int), ("intr", C.c_double * 4),
+        ("cap", c_dp), ("exp_t", c_dp), ("t0", C.c_double), ("dt", C.c_double),
+        ("knots_t", c_dp), ("knots_R", c_dp), ("start_idx", c_ip), ("huber_a", C.c_double),
+    ]
+
+
+class OrcLevel(C.Structure):
+    _fields_ = [
+        ("H", C.c_int), ("W", C.c_int), ("K", C.c_int), ("P", C.c_int), ("S", C.c_int),
+        ("ref_img", c_u8p), ("ref_dIxy", c_fp), ("cur_imgs", C.POINTER(c_u8p)),
+        ("kp_xy", c_dp), ("kp_z", c_dp), ("pattern", c_ip),
+    ]
+
+
+class OrcTrackOpts(C.Structure):
+    _fields_ = [
+        ("num_levels", C.c_int), ("k", C.c_int), ("max_num_iterations", C.c_int),
+        ("max_nonmono", C.c_int), ("solver_type", C.c_int), ("intr", C.c_double * 4),
+        ("huber_k", C.c_double), ("min_step_quality", C.c_double),
+        ("min_abs_cost_decrease", C.c_double), ("max_chi_square_error", C.c_double),
+    ]
+
+
+class OrcTraceRec(C.Structure):
+    _fields_ = [
+        ("level", C.c_int), ("iter", C.c_int), ("kind", C.c_int), ("num_outliers", C.c_int),
+        ("radius", C.c_double), ("eval_cost", C.c_double), ("candidate_cost", C.c_double),
+        ("model_change", C.c_double), ("quality", C.c_double),
+    ]
+
+
+class OrcLm(C.Structure):
+    _fields_ = [("radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
+                ("decrease_factor", C.c_double)]
+
+
+class OrcTr(C.Structure):
+    _fields_ = [("max_nonmono", C.c_int), ("minimum_cost", C.c_double), ("current_cost", C.c_double),
+                ("reference_cost", C.c_double), ("candidate_cost", C.c_double),
+                ("acc_ref", C.c_double), ("acc_cand", C.c_double), ("num_nonmono", C.c_int)]
+
+
+def build(quiet=True):
+    """Compile the C restatement and, when /root/reference is present, oracle/_ref."""
+    subprocess.run(["make", "-C", _HERE, "all"], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libmbavo_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_tr_quality.restype = C.c_double
+        L.orc_optimize_trajectory.restype = C.c_int
+        L.orc_solve_normal_equation.restype = C.c_int
+        L.orc_bilinear.restype = C.c_int
+        L.orc_pixel_intensity.restype = C.c_int
+        L.orc_bilinear.argtypes = [c_u8p, c_fp, C.c_int, C.c_int, C.c_double, C.c_double, c_dp]
+        L.orc_pixel_intensity.argtypes = [c_u8p, c_fp, C.c_int, C.c_int, c_dp, c_dp, C.c_double,
+                                          C.c_double, C.c_double, C.c_double, C.c_double,
+                                          C.c_double, C.c_double, c_dp, c_dp]
+        L.orc_spline_segment.argtypes = [C.c_double, C.c_double, C.c_double, c_ip, c_dp]
+        for n in ("orc_c2_vec3", "orc_c4_vec3", "orc_c2_rot3", "orc_c4_rot3"):
+            getattr(L, n).argtypes = [c_dp, C.c_double, c_dp, c_dp]
+        L.orc_compute_virtual_camera_poses.argtypes = [
+            C.c_int, C.c_int, c_dp, c_dp, C.c_int, C.c_double, C.c_double, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip]
+        L.orc_compute_local_patches_xy.argtypes = [C.c_int, C.c_int, c_dp, c_dp, c_dp, C.c_int, c_dp, c_dp]
+        L.orc_compute_pixel_jacobian_residual.argtypes = [
+            c_u8p, c_fp, C.POINTER(c_u8p), C.c_int, C.c_int, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp, C.c_int,
+            c_ip, C.c_int, c_dp, C.c_int, C.c_int, c_dp, c_dp]
+        L.orc_compute_patch_cost_gradient_hessian.argtypes = [
+            C.c_int, C.c_int, C.c_int, C.c_int, c_dp, c_dp, C.c_double, C.c_double, c_dp]
+        L.orc_compute_frame_cost_gradient_hessian.argtypes = [
+            C.c_int, C.c_int, C.c_int, c_dp, C.c_int, c_u8p, c_dp]
+        L.orc_merge_hessian_gradient_cost.argtypes = [C.c_int, C.c_int, c_dp, c_ip, C.c_int, c_dp, c_dp, c_dp]
+        L.orc_evaluate.argtypes = [C.POINTER(OrcProblem), c_dp, c_dp, c_dp, c_dp, c_dp]
+        L.orc_evaluate_fast.argtypes = [C.POINTER(OrcProblem), C.c_int, c_dp, c_dp, c_dp, c_dp]
+        L.orc_solve_normal_equation.argtypes = [c_dp, c_dp, C.c_int, C.c_int, c_dp]
+        L.orc_tr_quality.argtypes = [C.POINTER(OrcTr), C.c_double, C.c_double]
+        L.orc_tr_reset.argtypes = [C.POINTER(OrcTr), C.c_double]
+        L.orc_tr_accepted.argtypes = [C.POINTER(OrcTr), C.c_double, C.c_double]
+        L.orc_tr_init.argtypes = [C.POINTER(OrcTr), C.c_int]
+        L.orc_lm_accepted.argtypes = [C.POINTER(OrcLm), C.c_double]
+        L.orc_plus_t.argtypes = [c_dp, c_dp, C.c_int, c_dp]
+        L.orc_plus_R.argtypes = [c_dp, c_dp, C.c_int, c_dp]
+        L.orc_pyramid_down_u8.argtypes = [c_u8p, C.c_int, C.c_int, c_u8p]
+        L.orc_image_gradients_u8.argtypes = [c_u8p, C.c_int, C.c_int, c_fp, c_fp]
+        L.orc_warp_image.argtypes = [c_u8p, C.c_int, C.c_int, c_dp, c_dp, C.c_double, c_dp, c_u8p]
+        L.orc_synthesize_blur.argtypes = [c_u8p, C.c_int, C.c_int, C.c_double, c_dp, C.c_int, C.c_double,
+                                          C.c_double, c_dp, c_dp, C.c_double, C.c_double, C.c_int, c_u8p]
+        L.orc_optimize_trajectory.argtypes = [
+            C.POINTER(OrcTrackOpts), C.POINTER(OrcLevel), C.c_int, c_dp, c_dp, C.c_double, C.c_double,
+            c_dp, c_dp, C.c_int, c_ip, c_dp, C.POINTER(OrcTraceRec), C.c_int]
+        _LIB = L
+    return _LIB
+
+
+def ref():
+    """The reference's own compilable sources (oracle/_ref), or None."""
+    global _REF
+    if _REF is None:
+        path = os.path.join(_HERE, "_ref", "libmbavo_ref.so")
+        if not os.path.exists(path):
+            return None
+        R = C.CDLL(path)
+        R.ref_bilinear.restype = C.c_int
+        R.ref_pixel_intensity.restype = C.c_int
+        R.ref_bilinear.argtypes = [c_u8p, c_fp, C.c_int, C.c_int, C.c_double, C.c_double, c_dp]
+        R.ref_pixel_intensity.argtypes = [c_u8p, c_fp, C.c_int, C.c_int, c_dp, c_dp, C.c_double,
+                                          C.c_double, C.c_double, C.c_double, C.c_double,
+                                          C.c_double, C.c_double, c_dp, c_dp]
+        R.ref_spline_segment.argtypes = [C.c_double, C.c_double, C.c_double, c_ip, c_dp]
+        for n in ("ref_c2_vec3", "ref_c4_vec3", "ref_c2_rot3", "ref_c4_rot3"):
+            getattr(R, n).argtypes = [c_dp, C.c_double, c_dp, c_dp]
+        R.ref_pyramid_u8.argtypes = [c_u8p, C.c_int, C.c_int, C.c_int, C.POINTER(c_u8p)]
+        R.ref_image_gradients_u8.argtypes = [c_u8p, C.c_int, C.c_int, c_fp, c_fp]
+        R.ref_lm_new.restype = C.c_void_p
+        R.ref_tr_new.restype = C.c_void_p
+        R.ref_tr_new.argtypes = [C.c_int]
+        for n in ("ref_lm_delete", "ref_lm_reset", "ref_lm_rejected", "ref_tr_delete"):
+            getattr(R, n).argtypes = [C.c_void_p]
+        R.ref_lm_accepted.argtypes = [C.c_void_p, C.c_double]
+        R.ref_lm_radius.argtypes = [C.c_void_p]
+        R.ref_lm_radius.restype = C.c_double
+        R.ref_tr_reset.argtypes = [C.c_void_p, C.c_double]
+        R.ref_tr_quality.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        R.ref_tr_quality.restype = C.c_double
+        R.ref_tr_accepted.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        _REF = R
+    return _REF
+
+
+# --------------------------------------------------------------------------
+# numpy-level helpers shared by tests / smoke / bench
+# --------------------------------------------------------------------------
+def packed_len(k):
+    nd = 6 * k + 1
+    return nd * (nd + 1) // 2
+
+
+def make_problem(S, F, K, P, k, N, H, W, ref_img, ref_dIxy, cur_imgs, kp_xy, kp_z, pattern,
+                 intr, cap, exp_t, t0, dt, knots_t, knots_R, start_idx, huber_a,
+                 outlier=None, num_bad=0):
+    """Returns (OrcProblem, keepalive list)."""
+    keep = [ref_img, ref_dIxy, cur_imgs, kp_xy, kp_z, pattern, cap, exp_t, knots_t, knots_R, start_idx, outlier]
+    cur_arr = (c_u8p * F)(*[u8p(c) for c in cur_imgs])
+    keep.append(cur_arr)
+    p = OrcProblem()
+    p.S, p.F, p.K, p.P, p.k, p.N, p.H, p.W = S, F, K, P, k, N, H, W
+    p.ref_img = u8p(ref_img)
+    p.ref_dIxy = fp(ref_dIxy)
+    p.cur_imgs = cur_arr
+    p.kp_xy = dp(kp_xy)
+    p.kp_z = dp(kp_z)
+    p.pattern = ip(pattern)
+    p.outlier = u8p(outlier) if outlier is not None else None
+    p.num_bad = num_bad
+    for i in range(4):
+        p.intr[i] = float(intr[i])
+    p.cap = dp(cap)
+    p.exp_t = dp(exp_t)
+    p.t0, p.dt = float(t0), float(dt)
+    p.knots_t = dp(knots_t)
+    p.knots_R = dp(knots_R)
+    p.start_idx = ip(start_idx)
+    p.huber_a = float(huber_a)
+    return p, keep
+
+
+def evaluate(prob, with_hessian=True, patch_blocks=None):
+    """orc_evaluate -> dict(cost, H, g, frame_blocks, patch_blocks)."""
+    L = lib()
+    E = packed_len(prob.k)
+    n = 6 * prob.N
+    if patch_blocks is None:
+        patch_blocks = np.zeros(prob.F * prob.K * E)
+    frame_blocks = np.zeros(prob.F * E)
+    cost = np.zeros(1)
+    H = np.zeros(n * n) if with_hessian else None
+    g = np.zeros(n) if with_hessian else None
+    L.orc_evaluate(C.byref(prob), dp(patch_blocks), dp(frame_blocks), dp(cost), dp(H), dp(g))
+    return dict(cost=float(cost[0]), H=None if H is None else H.reshape(n, n).T.copy(), g=g,
+                frame_blocks=frame_blocks.reshape(prob.F, E),
+                patch_blocks=patch_blocks.reshape(prob.F, prob.K, E))
+
+
+def evaluate_fast(prob, num_threads=1, with_hessian=True):
+    L = lib()
+    E = packed_len(prob.k)
+    n = 6 * prob.N
+    frame_blocks = np.zeros(prob.F * E)
+    cost = np.zeros(1)
+    H = np.zeros(n * n) if with_hessian else None
+    g = np.zeros(n) if with_hessian else None
+    L.orc_evaluate_fast(C.byref(prob), int(num_threads), dp(frame_blocks), dp(cost), dp(H), dp(g))
+    return dict(cost=float(cost[0]), H=None if H is None else H.reshape(n, n).T.copy(), g=g,
+                frame_blocks=frame_blocks.reshape(prob.F, E))
