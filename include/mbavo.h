@@ -176,6 +176,12 @@ int mbavo_image_gradients_u8(const unsigned char *d_src, int H, int W, float *d_
  * `rccl_comm` is an ncclComm_t created by the caller; count in doubles. */
 int mbavo_allreduce_blocks(mbavo_ctx *ctx, void *rccl_comm, double *d_blocks, long long count);
 
+/* ---- measurement: HIP-event timing of the dominant kernel (the fused residual/Jacobian/JtJ
+ * kernel) on the context's stream.  enable != 0 starts a fresh collection; read returns the summed
+ * duration in ms and the number of timed launches (blocks until the recorded events completed). */
+int mbavo_profile(mbavo_ctx *ctx, int enable);
+int mbavo_profile_read(mbavo_ctx *ctx, double *h_fused_ms_sum, int *h_launches);
+
 const char *mbavo_version(void);
 
 #ifdef __cplusplus

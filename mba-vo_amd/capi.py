@@ -64,7 +64,7 @@ SYMBOLS = [
     "mbavo_lm_get_radius", "mbavo_tr_new", "mbavo_tr_delete", "mbavo_tr_reset", "mbavo_tr_step_quality",
     "mbavo_tr_step_accepted", "mbavo_spline_get_pose", "mbavo_spline_plus", "mbavo_segment_start_index",
     "mbavo_optimize_trajectory", "mbavo_pyramid_down_u8", "mbavo_image_gradients_u8", "mbavo_allreduce_blocks",
-    "mbavo_version",
+    "mbavo_profile", "mbavo_profile_read", "mbavo_version",
 ]
 
 
@@ -129,6 +129,8 @@ def load():
     L.mbavo_pyramid_down_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.mbavo_image_gradients_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.mbavo_allreduce_blocks.argtypes = [vp, vp, vp, C.c_longlong]
+    L.mbavo_profile.argtypes = [vp, C.c_int]
+    L.mbavo_profile_read.argtypes = [vp, c_dp, c_ip]
     _LIB = L
     return L
 

@@ -236,6 +236,19 @@ extern "C"
                                           final_cost, trace, cap);
     }
 
+    int mbavo_profile(mbavo_ctx *ctx, int enable)
+    {
+        if (!ctx) return MBAVO_E_ARG;
+        ctx->engine->profile_enable(enable != 0);
+        return 0;
+    }
+
+    int mbavo_profile_read(mbavo_ctx *ctx, double *ms, int *n)
+    {
+        if (!ctx) return MBAVO_E_ARG;
+        return ctx->engine->profile_read(ms, n);
+    }
+
     // ---- RCCL: resolved at run time so that the library loads on hosts without RCCL
     int mbavo_allreduce_blocks(mbavo_ctx *ctx, void *comm, double *d_blocks, long long count)
     {

@@ -69,6 +69,11 @@ namespace mbavo
 
         int total_bf() const { return total_bf_; }
 
+        // optional per-launch timing of the dominant kernel (k_fused) with HIP events on the
+        // engine's stream; read back after a stream sync (bench.py roofline leg)
+        void profile_enable(bool on);
+        int profile_read(double *fused_ms_sum, int *launches);
+
         // persistent staging owned by the context (used by mbavo_eval / tracker)
         double *scratch_frame_blocks(size_t n_doubles);
         double *host_frame_blocks(size_t n_doubles);
@@ -101,6 +106,14 @@ namespace mbavo
         void *d_status_ = nullptr;
         void *d_fb_ = nullptr; size_t cap_fb_ = 0;
         void *h_fb_ = nullptr; size_t cap_hfb_ = 0;
+
+        bool prof_on_ = false;
+        std::vector<hipEvent_t> prof_ev_; // pairs (start, stop)
+        int prof_used_ = 0;
+
+    public:
+        // called by the launch helper around k_fused
+        void prof_mark(bool start);
     };
 } // namespace mbavo
 

@@ -296,6 +296,7 @@ namespace mbavo
         for (void *p : bufs)
             if (p) (void)hipFree(p);
         if (h_fb_) (void)hipHostFree(h_fb_);
+        for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
     }
 
     int Engine::ensure(void **ptr, size_t *cap, size_t bytes)
@@ -423,7 +424,7 @@ namespace mbavo
     }
 
     template <int KD, bool WITH_J>
-    static int launch_all(hipStream_t st, const ProblemDesc *descs, int B, int entries, const TileDesc *tiles, int ntiles,
+    static int launch_all(Engine *eng, hipStream_t st, const ProblemDesc *descs, int B, int entries, const TileDesc *tiles, int ntiles,
                           const int *bf_prob, const int *bf_tile_begin, int nbf, void *poses, double *rho,
                           double *patch_cost, double *patch_blocks_strided, double *partials, int *status,
                           double *frame_blocks, double *valid)
@@ -440,8 +441,10 @@ namespace mbavo
                 HIP_TRY(hipFuncSetAttribute((const void *)k_fused<KD, WITH_J>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr_set = true;
             }
+            eng->prof_mark(true);
             hipLaunchKernelGGL((k_fused<KD, WITH_J>), dim3(ntiles), dim3(kThreads), lds, st, descs, tiles, table, rho,
                                patch_cost, patch_blocks_strided, partials);
+            eng->prof_mark(false);
         }
         hipLaunchKernelGGL((k_finalize<KD, WITH_J>), dim3(nbf), dim3(256), 0, st, descs, bf_prob, bf_tile_begin, partials,
                            frame_blocks, valid);
@@ -462,13 +465,54 @@ namespace mbavo
         const TileDesc *tiles = (const TileDesc *)d_tiles_;
         const int ntiles = (int)h_tiles_.size();
 #define MBAVO_LAUNCH(KD, WJ)                                                                                      \
-    launch_all<KD, WJ>(stream_, descs, B, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
+    launch_all<KD, WJ>(this, stream_, descs, B, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
                        (const int *)d_bf_tile_begin_, total_bf_, d_poses_, (double *)d_rho_, d_patch_cost,        \
                        d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid)
         if (kdeg == 4) rc = with_hessian ? MBAVO_LAUNCH(4, true) : MBAVO_LAUNCH(4, false);
         else rc = with_hessian ? MBAVO_LAUNCH(2, true) : MBAVO_LAUNCH(2, false);
 #undef MBAVO_LAUNCH
         return rc;
+    }
+
+    void Engine::profile_enable(bool on)
+    {
+        prof_on_ = on;
+        prof_used_ = 0;
+    }
+
+    void Engine::prof_mark(bool start)
+    {
+        if (!prof_on_) return;
+        const int idx = prof_used_ * 2 + (start ? 0 : 1);
+        if (idx >= (int)prof_ev_.size())
+        {
+            if (prof_ev_.size() >= 2 * 8192) { if (!start) ++prof_used_; return; } // cap; later launches are not timed
+            hipEvent_t e0, e1;
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
+            prof_ev_.push_back(e0);
+            prof_ev_.push_back(e1);
+        }
+        (void)hipEventRecord(prof_ev_[idx], stream_);
+        if (!start) ++prof_used_;
+    }
+
+    int Engine::profile_read(double *ms_sum, int *launches)
+    {
+        double sum = 0.0;
+        int n = 0;
+        const int pairs = prof_used_ < (int)prof_ev_.size() / 2 ? prof_used_ : (int)prof_ev_.size() / 2;
+        for (int i = 0; i < pairs; ++i)
+        {
+            float ms = 0.f;
+            hipError_t e = hipEventSynchronize(prof_ev_[2 * i + 1]);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, prof_ev_[2 * i], prof_ev_[2 * i + 1]);
+            if (e != hipSuccess) return (int)e;
+            sum += ms;
+            ++n;
+        }
+        if (ms_sum) *ms_sum = sum;
+        if (launches) *launches = n;
+        return 0;
     }
 
     int Engine::fetch_status()

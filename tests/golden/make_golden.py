@@ -1,0 +1,148 @@
+"""Generates tests/golden/ref_vectors.npz by EXECUTING THE REFERENCE's own code.
+
+Runs only in the build container, where /root/reference exists: oracle/_ref is the
+reference's compilable sources (header-only __CPU_AND_CUDA_CODE__ math,
+levenberg_marquardt_strategy.cpp, trust_region_step_evaluator.cpp) compiled from
+where they lie (oracle/Makefile).  The file written here contains inputs and the
+reference's outputs only -- no reference source text.  The oracle (and through it
+the HIP path) is pinned against these vectors by tests/test_oracle_golden.py.
+
+    python tests/golden/make_golden.py
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import binding as B  # noqa: E402
+import mba_vo_amd  # noqa: E402,F401
+from mba_vo_amd import synth  # noqa: E402
+
+R = B.ref()
+assert R is not None, "oracle/_ref is not built (needs /root/reference): make -C oracle"
+out = {}
+rng = np.random.default_rng(20260929)
+
+# ---- ABI sizes (Vector.h:11-18,72)
+sz = (C.c_int * 4)()
+R.ref_sizes(sz)
+out["abi_sizes"] = np.array(list(sz), np.int32)
+
+# ---- quaternion log / exp incl. the small-angle and |w| < 1e-10 branches (Quaternion.h:61-233)
+qs = rng.normal(size=(64, 4))
+qs /= np.linalg.norm(qs, axis=1, keepdims=True)
+qs[0] = [0, 0, 0, 1]
+qs[1] = [1e-12, -2e-12, 1e-12, 1]
+qs[2] = [0.6, 0.0, 0.8, 5e-11]
+qs[3] = [0.6, 0.0, 0.8, -5e-11]
+qs[4] = [3e-11, 0, 0, -1.0]
+tg = rng.normal(size=(64, 3)) * np.logspace(-12, 0.3, 64)[:, None]
+tg[0] = 0
+log_t, log_J, exp_q, exp_J = np.zeros((64, 3)), np.zeros((64, 12)), np.zeros((64, 4)), np.zeros((64, 12))
+for i in range(64):
+    R.ref_quat_log(B.dp(qs[i]), B.dp(log_t[i]), B.dp(log_J[i]))
+    R.ref_quat_exp(B.dp(tg[i]), B.dp(exp_q[i]), B.dp(exp_J[i]))
+out.update(quat_in=qs, tangent_in=tg, log_t=log_t, log_J=log_J, exp_q=exp_q, exp_J=exp_J)
+
+# ---- spline functors on the harness spline (test/test_blur_aware_tracker_modules.cpp:24-67)
+kt, kR = synth.harness_spline()
+out.update(knots_t=kt, knots_R=kR)
+us = np.array([0.0, 1e-9, 0.1, 0.25, 0.5, 0.75, 0.999999, 0.3333333333])
+for k, nm in ((2, "c2"), (4, "c4")):
+    P, JT, Q, JR = [], [], [], []
+    for idx in range(0, 7 - k + 1):
+        for u in us:
+            p, jt, q, jr = np.zeros(3), np.zeros(9 * k), np.zeros(4), np.zeros(12 * k)
+            getattr(R, "ref_%s_vec3" % nm)(B.dp(np.ascontiguousarray(kt[idx:].ravel())), u, B.dp(p), B.dp(jt))
+            getattr(R, "ref_%s_rot3" % nm)(B.dp(np.ascontiguousarray(kR[idx:].ravel())), u, B.dp(q), B.dp(jr))
+            P.append(p); JT.append(jt); Q.append(q); JR.append(jr)
+    out.update({nm + "_p": np.array(P), nm + "_Jt": np.array(JT), nm + "_q": np.array(Q), nm + "_JR": np.array(JR)})
+out["spline_us"] = us
+# identical consecutive knots: the tracker's two identity start knots hit the series branch (A23)
+ident = np.array([0, 0, 0, 1.0] * 4)
+q, jr = np.zeros(4), np.zeros(48)
+R.ref_c4_rot3(B.dp(ident), 0.37, B.dp(q), B.dp(jr))
+out.update(ident_q=q, ident_JR=jr)
+# segment indices (SplineFunctor.h:13-19), incl. negative times (truncation toward zero)
+ts = np.array([-0.7, -0.2, 0.0, 0.2499999, 0.25, 0.5, 0.74, 1.0, 2.999, 3.0])
+idxs, uu = np.zeros(len(ts), np.int32), np.zeros(len(ts))
+for i, t in enumerate(ts):
+    ii, u_ = C.c_int(), C.c_double()
+    R.ref_spline_segment(float(t), 0.0, 0.5, C.byref(ii), C.byref(u_))
+    idxs[i], uu[i] = ii.value, u_.value
+out.update(seg_t=ts, seg_idx=idxs, seg_u=uu)
+
+# ---- compute_pixel_intensity / bilinear on the harness ramp image and a texture
+H, W = 480, 640
+imgs = {"ramp": synth.ramp_image(H, W), "noise": synth.noise_image(H, W, seed=5)}
+for name, img in imgs.items():
+    g = np.zeros((H, W, 2), np.float32)
+    R.ref_image_gradients_u8(B.u8p(img), H, W, B.fp(g), None)
+    n = 256
+    q = rng.normal(size=(n, 4)) * 0.04
+    q[:, 3] = 1
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    t = rng.normal(size=(n, 3)) * 0.2
+    D = rng.uniform(5, 10, n)
+    xy = np.stack([rng.uniform(-3, W + 3, n), rng.uniform(-3, H + 3, n)], 1)
+    xy[:8] = [[0, 0], [W - 1, H - 1], [W - 1, 0], [0, H - 1], [320, 240], [1, 1], [W - 2, H - 2], [20.5, 20.5]]
+    q[:4] = [0, 0, 0, 1]
+    t[:4] = 0  # identity pose: exact border taps (A6)
+    val, jac, ok = np.zeros(n), np.zeros((n, 7)), np.zeros(n, np.int32)
+    for i in range(n):
+        v = np.zeros(1)
+        ok[i] = R.ref_pixel_intensity(B.u8p(img), B.fp(g), H, W, B.dp(q[i]), B.dp(t[i]), float(D[i]),
+                                      320.0, 320.0, 320.0, 240.0, float(xy[i, 0]), float(xy[i, 1]), B.dp(v), B.dp(jac[i]))
+        val[i] = v[0] if ok[i] else 0.0
+        if not ok[i]:
+            jac[i] = 0
+    bxy = np.stack([rng.uniform(-1, W, 128), rng.uniform(-1, H, 128)], 1)
+    bxy[:6] = [[0, 0], [W - 1, H - 1], [W - 1, 10.25], [10.75, H - 1], [W - 1.0000001, 3], [5, 5]]
+    bv, bok = np.zeros((128, 3)), np.zeros(128, np.int32)
+    for i in range(128):
+        bok[i] = R.ref_bilinear(B.u8p(img), B.fp(g), H, W, float(bxy[i, 0]), float(bxy[i, 1]), B.dp(bv[i]))
+        if not bok[i]:
+            bv[i] = 0
+    out.update({"pi_%s_q" % name: q, "pi_%s_t" % name: t, "pi_%s_D" % name: D, "pi_%s_xy" % name: xy,
+                "pi_%s_val" % name: val, "pi_%s_jac" % name: jac, "pi_%s_ok" % name: ok,
+                "bl_%s_xy" % name: bxy, "bl_%s_val" % name: bv, "bl_%s_ok" % name: bok})
+
+# ---- pyramid + gradients (ImagePyramid.h:59-99, Gradient.h:16-75) on a 50x66 random image (odd halves)
+small = rng.integers(0, 256, (50, 66), dtype=np.uint8)
+lv = [np.zeros((50 // 2 ** l, 66 // 2 ** l), np.uint8) for l in range(1, 4)]
+arr = (B.c_u8p * 3)(*[B.u8p(a) for a in lv])
+R.ref_pyramid_u8(B.u8p(small), 50, 66, 4, arr)
+g = np.zeros((50, 66, 2), np.float32)
+mag = np.zeros((50, 66), np.float32)
+R.ref_image_gradients_u8(B.u8p(small), 50, 66, B.fp(g), B.fp(mag))
+out.update(pyr_src=small, pyr_l1=lv[0], pyr_l2=lv[1], pyr_l3=lv[2], grad_xy=g, grad_mag=mag)
+
+# ---- LM strategy + trust-region evaluator driven by a fixed script
+lm = R.ref_lm_new()
+tr = R.ref_tr_new(5)
+R.ref_tr_reset(tr, 100.0)
+script_q = rng.uniform(-0.5, 1.5, 40)
+script_c = 100.0 + np.cumsum(rng.normal(-1.0, 3.0, 40))
+script_m = rng.uniform(0.1, 5.0, 40)
+radii, quals = [], []
+for i in range(40):
+    ql = R.ref_tr_quality(tr, float(script_c[i]), float(script_m[i]))
+    quals.append(ql)
+    if script_q[i] > 0.5:
+        R.ref_lm_accepted(lm, float(script_q[i]))
+        R.ref_tr_accepted(tr, float(script_c[i]), float(script_m[i]))
+    else:
+        R.ref_lm_rejected(lm)
+    if i == 25:
+        R.ref_lm_reset(lm)
+    radii.append(R.ref_lm_radius(lm))
+R.ref_lm_delete(lm)
+R.ref_tr_delete(tr)
+out.update(lm_q=script_q, lm_c=script_c, lm_m=script_m, lm_radii=np.array(radii), tr_quality=np.array(quals))
+
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_vectors.npz")
+np.savez_compressed(path, **out)
+print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -1,0 +1,127 @@
+"""-m gpu: the fused evaluation (mbavo_eval / mbavo_eval_batch) against the oracle's
+evaluate_cost_hessian_gradient restatement.  Tolerances: 1e-9 relative on the fp64 blocks
+(observed ~1e-15), exact validity counts; stated per assertion."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import scenes
+from mba_vo_amd import synth
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+CASES = {
+    "k4_S8_P8_F2": dict(S=8, F=2, k=4, P=8, K=145),
+    "k2_S8_P8": dict(S=8, F=1, k=2, P=8, K=145),
+    "k4_S1_dense_sharp": dict(H=96, W=128, S=1, F=1, k=4, P=1, kp="dense", margin=0),   # config 0 shape, small
+    "k2_S1_dense_sharp": dict(H=60, W=80, S=1, F=1, k=2, P=1, kp="dense", margin=0),
+    "k4_S8_P5_border_outliers": dict(S=8, F=2, k=4, P=5, K=300, kp="border", outlier_frac=0.1),
+    "k4_S16_P8_F3": dict(S=16, F=3, k=4, P=8, K=500),
+    "k2_S4_huber_small": dict(S=4, F=1, k=2, P=8, K=145, huber=0.1),
+    "k4_S3_nonpow2": dict(S=3, F=1, k=4, P=7, K=100),
+    "k4_ramp_same": dict(S=8, F=2, k=4, P=8, K=145, image="ramp", cur="same"),
+    "k4_K1": dict(S=8, F=1, k=4, P=8, K=1),
+    "k4_P128": dict(S=4, F=1, k=4, P=128, K=9),
+    "k4_6knots_C5shape": dict(H=135, W=240, S=16, F=2, k=4, P=1, kp="dense", margin=2, N=6),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_fused_eval_matches_oracle(orc, mbavo, gpu_ctx, name):
+    import torch
+    sc = scenes.Scene(**CASES[name])
+    p, keep = sc.oracle_problem(orc)
+    ro = orc.evaluate(p)
+    d = scenes.DeviceScene(sc, vec2d=("P8" in name))
+    E = sc.E
+    pb = torch.full((sc.F * sc.K * E,), -1.0, dtype=torch.float64, device="cuda:0")
+    rg = scenes.gpu_eval(gpu_ctx, d, patch_blocks=pb)
+    assert abs(rg["cost"] - ro["cost"]) <= RTOL * abs(ro["cost"])
+    assert _rel(rg["H"], ro["H"]) < RTOL and _rel(rg["g"], ro["g"]) < RTOL
+    assert np.array_equal(rg["H"], rg["H"].T)
+    # slot 0 of every patch block, stride E, like cuda_patch_cost_gradient_hessian_tR; other slots untouched
+    pbh = pb.cpu().numpy().reshape(sc.F, sc.K, E)
+    assert _rel(pbh[:, :, 0], ro["patch_blocks"][:, :, 0]) < RTOL
+    assert (pbh[:, :, 1:] == -1.0).all()
+    # cost-only mode (nullptr, nullptr): same cost, computed without the gradient taps
+    rc = scenes.gpu_eval(gpu_ctx, d, with_hessian=False)
+    roc = orc.evaluate(p, with_hessian=False)
+    assert abs(rc["cost"] - roc["cost"]) <= RTOL * abs(roc["cost"])
+    assert abs(rc["cost"] - rg["cost"]) <= 1e-12 * abs(rg["cost"])
+    # batch entry point on the same problem: per-frame packed blocks, patch costs, valid-pixel counts
+    fb, pc, valid = scenes.gpu_eval_batch(gpu_ctx, [d], sc.k)
+    assert _rel(fb, ro["frame_blocks"]) < RTOL
+    assert _rel(pc, ro["patch_blocks"][:, :, 0].ravel()) < RTOL
+    res = np.zeros(sc.F * sc.K * sc.P)
+    # validity from the oracle's stage 3 (a pixel is valid iff current pixel and all S warps are in bounds)
+    o_valid = _oracle_valid_counts(orc, sc)
+    assert np.array_equal(valid, o_valid)
+
+
+def _oracle_valid_counts(orc, sc):
+    O = orc.lib()
+    k, S, F, K, P = sc.k, sc.S, sc.F, sc.K, sc.P
+    poses, Jt, JR = np.zeros(F * S * 7), np.zeros(F * S * 9 * k), np.zeros(F * S * 12 * k)
+    O.orc_compute_virtual_camera_poses(S, F, orc.dp(sc.cap), orc.dp(sc.exp), k, sc.t0, sc.dt, orc.dp(sc.knots_t),
+                                       orc.dp(sc.knots_R), orc.dp(poses), orc.dp(Jt), orc.dp(JR), None)
+    c = np.zeros(F * K * 2)
+    O.orc_compute_local_patches_xy(S, F, orc.dp(poses), orc.dp(sc.kp_xy), orc.dp(sc.kp_z), K, orc.dp(sc.intr), orc.dp(c))
+    # use an all-255 current image so that a valid pixel can never have residual exactly 0
+    cur = np.full((sc.H, sc.W), 255, np.uint8)
+    ref = np.minimum(sc.ref, 254)
+    curs = (orc.c_u8p * F)(*[orc.u8p(cur)] * F)
+    res = np.zeros(F * K * P)
+    O.orc_compute_pixel_jacobian_residual(orc.u8p(ref), None, curs, S, F, orc.dp(poses), k, None, None, orc.dp(c),
+                                          orc.dp(sc.kp_z), K, orc.ip(sc.pattern), P, orc.dp(sc.intr), sc.H, sc.W,
+                                          orc.dp(res), None)
+    return (res.reshape(F, K * P) != 0).sum(1).astype(np.float64)
+
+
+def test_batch_of_mixed_problems(orc, mbavo, gpu_ctx):
+    """One launch over problems of different image size, S, P, F (pyramid levels / independent pairs)."""
+    kws = [dict(S=8, F=1, k=4, P=8, K=145, seed=1), dict(H=240, W=320, S=4, F=2, k=4, P=1, kp="dense", margin=60, seed=2),
+           dict(H=120, W=160, S=8, F=1, k=4, P=5, K=77, seed=3, margin=10), dict(S=1, F=3, k=4, P=8, K=33, seed=4)]
+    scs = [scenes.Scene(**kw) for kw in kws]
+    ds = [scenes.DeviceScene(s) for s in scs]
+    fb, pc, valid = scenes.gpu_eval_batch(gpu_ctx, ds, 4)
+    row, prow = 0, 0
+    for sc in scs:
+        p, keep = sc.oracle_problem(orc)
+        ro = orc.evaluate(p)
+        assert _rel(fb[row:row + sc.F], ro["frame_blocks"]) < RTOL
+        n = sc.F * sc.K
+        assert _rel(pc[prow:prow + n], ro["patch_blocks"][:, :, 0].ravel()) < RTOL
+        row += sc.F
+        prow += n
+    # a second call with the same list must reuse the cached layout and give identical bits
+    fb2, _, _ = scenes.gpu_eval_batch(gpu_ctx, ds, 4)
+    assert np.array_equal(fb, fb2)
+
+
+def test_out_of_range_spline_is_reported(orc, mbavo, gpu_ctx):
+    """The reference reads past the knot array when a blur sample leaves the spline (SplineFunctor.h:13-19
+    has no check); here the evaluation returns MBAVO_E_RANGE."""
+    sc = scenes.Scene(S=8, F=1, k=4, P=8, K=50)
+    sc.cap = sc.cap + 10.0
+    d = scenes.DeviceScene(sc)
+    p = d.problem()
+    cost = np.zeros(1)
+    rc = gpu_ctx.lib.mbavo_eval(gpu_ctx.handle, C.byref(p), 4, mbavo.capi.dp(cost), None, None, None)
+    assert rc == -2
+
+
+def test_bad_arguments_rejected(mbavo, gpu_ctx):
+    sc = scenes.Scene(S=8, F=1, k=4, P=8, K=50)
+    d = scenes.DeviceScene(sc)
+    p = d.problem()
+    cost = np.zeros(1)
+    assert gpu_ctx.lib.mbavo_eval(gpu_ctx.handle, C.byref(p), 3, mbavo.capi.dp(cost), None, None, None) == -1
+    p.d_ref_img = None
+    assert gpu_ctx.lib.mbavo_eval(gpu_ctx.handle, C.byref(p), 4, mbavo.capi.dp(cost), None, None, None) == -1

@@ -1,0 +1,121 @@
+"""Host-side product code (no GPU needed) through the C ABI, checked against the oracle:
+merge scatter, normal-equation solve, LM / trust-region classes, spline evaluation / update."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from mba_vo_amd import synth
+
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vectors.npz"))
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_merge_host_matches_oracle(orc, mbavo, k):
+    L = mbavo.load()
+    rng = np.random.default_rng(1)
+    F, N = 3, 6
+    E = synth.packed_len(k)
+    fb = rng.uniform(-1, 1, F * E)
+    start = np.array([0, 1, 2 if k == 4 else 4], np.int32)
+    n = 6 * N
+    c1, H1, g1 = np.zeros(1), np.zeros(n * n), np.zeros(n)
+    c2, H2, g2 = np.zeros(1), np.full(n * n, 3.0), np.full(n, 3.0)  # callee must zero H, g (merge...cpp:33-37)
+    orc.lib().orc_merge_hessian_gradient_cost(F, k, orc.dp(fb), orc.ip(start), N, orc.dp(c1), orc.dp(H1), orc.dp(g1))
+    assert L.mbavo_merge_host(F, k, mbavo.capi.dp(fb), mbavo.capi.ip(start), N, mbavo.capi.dp(c2), mbavo.capi.dp(H2), mbavo.capi.dp(g2)) == 0
+    assert c1[0] == c2[0] and np.array_equal(H1, H2) and np.array_equal(g1, g2)
+    c3 = np.zeros(1)
+    assert L.mbavo_merge_host(F, k, mbavo.capi.dp(fb), mbavo.capi.ip(start), N, mbavo.capi.dp(c3), None, None) == 0
+    assert c3[0] == c1[0]
+
+
+def test_solve_normal_equation(orc, mbavo):
+    L = mbavo.load()
+    rng = np.random.default_rng(2)
+    n = 48
+    A = rng.uniform(-1, 1, (n, n))
+    A = A.T @ A
+    x = rng.uniform(-1, 1, n)
+    b = A @ (-x)
+    Af = A.ravel(order="F").copy()
+    for solver in (0, 1):
+        out, ref = np.zeros(n), np.zeros(n)
+        assert L.mbavo_solve_normal_equation(mbavo.capi.dp(Af), mbavo.capi.dp(b), n, solver, mbavo.capi.dp(out)) == 0
+        orc.lib().orc_solve_normal_equation(orc.dp(Af), orc.dp(b), n, solver, orc.dp(ref))
+        assert np.abs(out - x).max() < 1e-8          # the harness' own bound (:1199-1201)
+        assert np.abs(out - ref).max() < 1e-9
+    assert L.mbavo_solve_normal_equation(mbavo.capi.dp(Af), mbavo.capi.dp(b), n, 7, mbavo.capi.dp(out)) != 0
+    # LM-damped, badly scaled normal equations as the tracker produces them (t-block ~1e1, w-block ~1e4)
+    J = rng.normal(size=(400, 24)) * np.r_[np.ones(12), 60 * np.ones(12)]
+    Hd = J.T @ J
+    Hd[np.diag_indices(24)] *= 1 + 1e-4
+    g = J.T @ rng.normal(size=400)
+    for solver in (0, 1):
+        out, ref = np.zeros(24), np.zeros(24)
+        L.mbavo_solve_normal_equation(mbavo.capi.dp(Hd.ravel(order="F").copy()), mbavo.capi.dp(g), 24, solver, mbavo.capi.dp(out))
+        orc.lib().orc_solve_normal_equation(orc.dp(Hd.ravel(order="F").copy()), orc.dp(g), 24, solver, orc.dp(ref))
+        assert np.abs(Hd @ out + g).max() < 1e-8 * np.abs(g).max()
+        assert np.abs(out - ref).max() <= 1e-10 * np.abs(ref).max()
+    # rank-deficient (knots no frame touches): SVD path returns the minimum-norm solution
+    Hs = np.zeros((36, 36))
+    Hs[:24, :24] = Hd
+    gs = np.r_[g, np.zeros(12)]
+    out, ref = np.zeros(36), np.zeros(36)
+    L.mbavo_solve_normal_equation(mbavo.capi.dp(Hs.ravel(order="F").copy()), mbavo.capi.dp(gs), 36, 0, mbavo.capi.dp(out))
+    orc.lib().orc_solve_normal_equation(orc.dp(Hs.ravel(order="F").copy()), orc.dp(gs), 36, 0, orc.dp(ref))
+    assert np.abs(out[24:]).max() == 0 and np.abs(out - ref).max() <= 1e-10 * np.abs(ref).max()
+
+
+def test_lm_and_trust_region_follow_reference_script(mbavo):
+    """Same script as tests/golden (outputs produced by the reference's own classes): bit-exact."""
+    L = mbavo.load()
+    lm, tr = L.mbavo_lm_new(), L.mbavo_tr_new(5)
+    L.mbavo_tr_reset(tr, 100.0)
+    for i in range(40):
+        assert L.mbavo_tr_step_quality(tr, float(G["lm_c"][i]), float(G["lm_m"][i])) == G["tr_quality"][i]
+        if G["lm_q"][i] > 0.5:
+            L.mbavo_lm_step_accepted(lm, float(G["lm_q"][i]))
+            L.mbavo_tr_step_accepted(tr, float(G["lm_c"][i]), float(G["lm_m"][i]))
+        else:
+            L.mbavo_lm_step_rejected(lm)
+        if i == 25:
+            L.mbavo_lm_reset(lm)
+        assert L.mbavo_lm_get_radius(lm) == G["lm_radii"][i]
+    L.mbavo_lm_delete(lm)
+    L.mbavo_tr_delete(tr)
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_spline_get_pose_and_plus(orc, mbavo, k):
+    L = mbavo.load()
+    kt, kR = synth.harness_spline()
+    kt, kR = np.ascontiguousarray(kt.ravel()), np.ascontiguousarray(kR.ravel())
+    nm = "c2" if k == 2 else "c4"
+    for t in (0.26, 0.7, 1.23456, (7 - k) * 0.5 + 0.49):
+        p, q, jt, jr = np.zeros(3), np.zeros(4), np.zeros(9 * k), np.zeros(12 * k)
+        assert L.mbavo_spline_get_pose(k, 0.0, 0.5, mbavo.capi.dp(kt), mbavo.capi.dp(kR), 7, t, mbavo.capi.dp(p),
+                                       mbavo.capi.dp(q), mbavo.capi.dp(jt), mbavo.capi.dp(jr)) == 0
+        idx = L.mbavo_segment_start_index(t, 0.0, 0.5)
+        u = t / 0.5 - idx
+        po, qo, jto, jro = np.zeros(3), np.zeros(4), np.zeros(9 * k), np.zeros(12 * k)
+        getattr(orc.lib(), "orc_%s_vec3" % nm)(orc.dp(kt[3 * idx:].copy()), u, orc.dp(po), orc.dp(jto))
+        getattr(orc.lib(), "orc_%s_rot3" % nm)(orc.dp(kR[4 * idx:].copy()), u, orc.dp(qo), orc.dp(jro))
+        assert np.abs(p - po).max() < 1e-13 and np.abs(q - qo).max() < 1e-15
+        assert np.abs(jt - jto).max() < 1e-15 and np.abs(jr - jro).max() < 1e-13
+    # out of the knot range: the reference asserts (Spline.h:232-234); here an error code
+    assert L.mbavo_spline_get_pose(k, 0.0, 0.5, mbavo.capi.dp(kt), mbavo.capi.dp(kR), 7, 99.0, mbavo.capi.dp(p),
+                                   mbavo.capi.dp(q), None, None) == -2
+    # Plus_t / Plus_R (Spline.h:307-330)
+    step = np.random.default_rng(3).normal(size=42) * 0.01
+    ct, cR, ot, oR = np.zeros(21), np.zeros(28), np.zeros(21), np.zeros(28)
+    assert L.mbavo_spline_plus(mbavo.capi.dp(kt), mbavo.capi.dp(kR), 7, mbavo.capi.dp(step), mbavo.capi.dp(ct), mbavo.capi.dp(cR)) == 0
+    orc.lib().orc_plus_t(orc.dp(kt), orc.dp(step), 7, orc.dp(ot))
+    orc.lib().orc_plus_R(orc.dp(kR), orc.dp(step[21:].copy()), 7, orc.dp(oR))
+    assert np.array_equal(ct, ot) and np.abs(cR - oR).max() < 1e-15
+
+
+def test_segment_start_index_golden(mbavo):
+    L = mbavo.load()
+    for t, i_ref in zip(G["seg_t"], G["seg_idx"]):
+        assert L.mbavo_segment_start_index(float(t), 0.0, 0.5) == i_ref
