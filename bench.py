@@ -72,7 +72,7 @@ def cpu_baseline(probs, budget_s):
     evaluation of the coarser levels for scale.  Returns (dict, frame_blocks of the last run)."""
     from oracle import binding as B
     B.build()
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     E = B.packed_len(probs[0].k)
     plist, keeps = [], []
     for p in probs:

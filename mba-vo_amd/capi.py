@@ -82,6 +82,13 @@ def load():
         return _LIB
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libmbavo.so is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
+    # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  It must be the first HIP runtime in
+    # the process, so that libmbavo.so binds to the SAME runtime instance as the torch tensors / streams it is
+    # handed; two runtimes in one process do not see each other's devices or allocations.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.mbavo_version.restype = C.c_char_p
     L.mbavo_create.argtypes = [C.POINTER(vp), C.c_int]

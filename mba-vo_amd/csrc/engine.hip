@@ -254,30 +254,40 @@ namespace mbavo
     }
 
     // ------------------------------------------------------------------ finalize
+    // Sum of the tile partials of one (problem, frame) in a fixed order: 16 tile-lanes each add
+    // every 16th tile, then a fixed tree over the tile-lanes.  grid = (nBF, ceil((E+1)/16)),
+    // block = 16 entries x 16 tile-lanes.  Slot E of a partial is the tile's cost share, slot 0 its
+    // valid-pixel count.
     template <int KD, bool WITH_J>
-    __global__ void k_finalize(const ProblemDesc *__restrict__ descs, const int *__restrict__ bf_prob,
-                               const int *__restrict__ bf_tile_begin, const double *__restrict__ partials,
-                               double *__restrict__ frame_blocks, double *__restrict__ valid_out)
+    __global__ __launch_bounds__(256) void k_finalize(const ProblemDesc *__restrict__ descs,
+                                                      const int *__restrict__ bf_prob,
+                                                      const int *__restrict__ bf_tile_begin,
+                                                      const double *__restrict__ partials,
+                                                      double *__restrict__ frame_blocks,
+                                                      double *__restrict__ valid_out)
     {
         constexpr int E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
+        __shared__ double sm[16][17];
         const int bf = blockIdx.x;
+        const int el = threadIdx.x & 15, tl = threadIdx.x >> 4;
+        const int e = blockIdx.y * 16 + el; // partial slot 0..E
         const int t0 = bf_tile_begin[bf], t1 = bf_tile_begin[bf + 1];
-        const double inv = descs[bf_prob[bf]].inv_num_residuals;
-        if (WITH_J)
+        double s = 0.0;
+        if (e <= E && (WITH_J || e == 0 || e == E))
+            for (int t = t0 + tl; t < t1; t += 16) s += partials[(size_t)t * PS + e];
+        sm[tl][el] = s;
+        __syncthreads();
+        for (int h = 8; h >= 1; h >>= 1)
         {
-            for (int e = 1 + threadIdx.x; e < E; e += blockDim.x)
-            {
-                double s = 0.0;
-                for (int t = t0; t < t1; ++t) s += partials[(size_t)t * PS + e];
-                frame_blocks[(size_t)bf * E + e] = s * inv;
-            }
+            if (tl < h) sm[tl][el] += sm[tl + h][el];
+            __syncthreads();
         }
-        if (threadIdx.x == 0)
+        if (tl == 0 && e <= E)
         {
-            double c = 0.0, v = 0.0;
-            for (int t = t0; t < t1; ++t) { c += partials[(size_t)t * PS + E]; v += partials[(size_t)t * PS]; }
-            frame_blocks[(size_t)bf * E] = c;
-            if (valid_out) valid_out[bf] = v;
+            const double v = sm[0][el];
+            if (e == 0) { if (valid_out) valid_out[bf] = v; }
+            else if (e == E) frame_blocks[(size_t)bf * E] = v; // cost: patch costs are already scaled
+            else if (WITH_J) frame_blocks[(size_t)bf * E + e] = v * descs[bf_prob[bf]].inv_num_residuals;
         }
     }
 
@@ -446,8 +456,8 @@ namespace mbavo
                                patch_cost, patch_blocks_strided, partials);
             eng->prof_mark(false);
         }
-        hipLaunchKernelGGL((k_finalize<KD, WITH_J>), dim3(nbf), dim3(256), 0, st, descs, bf_prob, bf_tile_begin, partials,
-                           frame_blocks, valid);
+        hipLaunchKernelGGL((k_finalize<KD, WITH_J>), dim3(nbf, (Pack<KD>::E + 1 + 15) / 16), dim3(256), 0, st, descs, bf_prob,
+                           bf_tile_begin, partials, frame_blocks, valid);
         HIP_TRY(hipGetLastError());
         return 0;
     }

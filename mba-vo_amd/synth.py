@@ -52,6 +52,26 @@ def noise_image(H=480, W=640, seed=1, smooth=3):
     return np.ascontiguousarray((a * 255.0).astype(np.uint8))
 
 
+def texture_image(H=480, W=640, seed=1, octaves=(64, 32, 16, 8, 4)):
+    """Multi-scale value noise (one bilinear-upsampled random lattice per octave, amplitude ~ cell
+    size): has image gradients at every pyramid level, unlike white-ish noise."""
+    rng = np.random.default_rng(seed)
+    acc = np.zeros((H, W))
+    yy, xx = np.mgrid[0:H, 0:W]
+    for cell in octaves:
+        gh, gw = H // cell + 2, W // cell + 2
+        lat = rng.random((gh, gw))
+        fy, fx = yy / cell, xx / cell
+        y0, x0 = fy.astype(int), fx.astype(int)
+        ty, tx = fy - y0, fx - x0
+        ty, tx = ty * ty * (3 - 2 * ty), tx * tx * (3 - 2 * tx)
+        v = (lat[y0, x0] * (1 - ty) * (1 - tx) + lat[y0, x0 + 1] * (1 - ty) * tx +
+             lat[y0 + 1, x0] * ty * (1 - tx) + lat[y0 + 1, x0 + 1] * ty * tx)
+        acc += v * cell
+    acc = (acc - acc.min()) / (acc.max() - acc.min())
+    return np.ascontiguousarray((acc * 255.0).astype(np.uint8))
+
+
 def shapes_image(H=480, W=640, blur=2):
     """Rectangles / triangles scene of generate_synthetic_data.cpp:11-125 (fg 255 on
     bg 0), lightly box-blurred so the gradient is non-zero near edges."""

@@ -24,6 +24,7 @@ def orc():
 @pytest.fixture(scope="session")
 def mbavo():
     """The product package; builds libmbavo.so if it is missing (hipcc cross-compiles on CPU)."""
+    import torch  # noqa: F401  (first HIP runtime in the process, see mba-vo_amd/capi.py:load)
     import mba_vo_amd
     if not os.path.exists(mba_vo_amd.LIB_PATH):
         mba_vo_amd.build()

@@ -1,0 +1,6 @@
+#!/bin/bash
+# builds tests/harness/harness_bin against the in-tree libmbavo.so (gfx950)
+set -e
+cd "$(dirname "$0")"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -std=c++17 -I ../../mba-vo_amd/csrc harness.cpp \
+    -L ../../mba-vo_amd -lmbavo -Wl,-rpath,'$ORIGIN/../../mba-vo_amd' -o harness_bin

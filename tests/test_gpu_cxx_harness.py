@@ -1,0 +1,19 @@
+"""-m gpu: the C++ module harness (tests/harness/harness.cpp) -- the counterpart of the reference's
+test_blur_aware_tracker_modules, driving the SLAM::VO free functions with hipMalloc'd pointers."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_cxx_module_harness(mbavo):
+    exe = os.path.join(HERE, "harness", "harness_bin")
+    if not os.path.exists(exe):
+        subprocess.run(["bash", os.path.join(HERE, "harness", "build.sh")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-4000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "HARNESS PASSED" in r.stdout

@@ -1,0 +1,78 @@
+"""-m gpu: BASELINE.json's full sizes, checked through size-independent properties (the oracle takes
+seconds per evaluation there and is used once, multi-threaded, on the headline workload):
+  * additivity: blocks of all keypoints == sum of blocks over a split of the keypoints (sum of partial sums);
+  * batch invariance: a problem evaluated alone == the same problem inside a batch, bit for bit;
+  * cost-only pass == slot 0 of the H/g pass;  * run-to-run bit reproducibility (no atomics)."""
+import numpy as np
+import pytest
+
+from mba_vo_amd import synth, workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, probs, with_h=True):
+    import torch
+    dw = wl.DeviceWorkload(probs)
+    dw.step(ctx, with_h)
+    torch.cuda.synchronize()
+    return dw.frame_blocks.cpu().numpy().reshape(dw.nbf, dw.E).copy(), dw.valid.cpu().numpy().copy()
+
+
+def _split(p, lo, hi):
+    q = wl.Prob(p.ref, p.cur, p.kp_xy[lo:hi], p.kp_z[lo:hi], p.pattern, p.intr, p.S, p.k, p.N, p.cap, p.exp,
+                p.t0, p.dt, p.knots_t, p.knots_R, p.huber, grad=p.grad)
+    return q
+
+
+def test_c2_dense_full_size_properties(orc, mbavo, gpu_ctx):
+    probs = wl.pyramid_pair(480, 640, 4, S=8, k=4, N=4, mode="dense", seed=1)   # configs[1]
+    fb, valid = _run(gpu_ctx, probs)
+    fb2, _ = _run(gpu_ctx, probs)
+    assert np.array_equal(fb, fb2)                                  # fixed summation order, run to run
+    assert valid.sum() > 0.95 * sum(p.K for p in probs)
+    # alone vs in the batch
+    for i, p in enumerate(probs):
+        alone, _ = _run(gpu_ctx, [p])
+        assert np.array_equal(alone[0], fb[i])
+    # additivity over a keypoint split of level 0 (un-normalise by the residual counts)
+    p0 = probs[0]
+    cut = p0.K // 3 + 7
+    a, va = _run(gpu_ctx, [_split(p0, 0, cut)])
+    b, vb = _run(gpu_ctx, [_split(p0, cut, p0.K)])
+    whole = fb[0] * (p0.K * p0.P)
+    parts = a[0] * (cut * p0.P) + b[0] * ((p0.K - cut) * p0.P)
+    assert np.abs(whole - parts).max() <= 1e-11 * np.abs(whole).max()
+    assert va[0] + vb[0] == valid[0]
+    # cost-only mode
+    fc, _ = _run(gpu_ctx, probs, with_h=False)
+    assert np.abs(fc[:, 0] - fb[:, 0]).max() <= 1e-12 * np.abs(fb[:, 0]).max()
+    # the oracle once, multi-threaded, on the whole headline workload (fp64 blocks, 1e-9 relative)
+    for i, p in enumerate(probs):
+        op, keep = orc.make_problem(p.S, p.F, p.K, p.P, p.k, p.N, p.H, p.W, p.ref, p.grad, p.cur, p.kp_xy, p.kp_z,
+                                    p.pattern, p.intr, p.cap, p.exp, p.t0, p.dt, p.knots_t, p.knots_R, p.start_idx, p.huber)
+        ro = orc.evaluate_fast(op, num_threads=8)
+        assert np.abs(ro["frame_blocks"][0] - fb[i]).max() <= 1e-9 * np.abs(fb[i]).max()
+
+
+def test_c3_batch64_and_c5_1080p_properties(orc, mbavo, gpu_ctx):
+    probs = wl.pair_batch(64, S=8, k=4, N=4, mode="semidense", seed=1)           # configs[2]
+    fb, valid = _run(gpu_ctx, probs)
+    for i in (0, 17, 63):
+        alone, _ = _run(gpu_ctx, [probs[i]])
+        assert np.array_equal(alone[0], fb[i])
+    # independent pairs: permuting the batch permutes the blocks
+    perm = np.random.default_rng(0).permutation(64)
+    fbp, _ = _run(gpu_ctx, [probs[j] for j in perm])
+    assert np.array_equal(fbp, fb[perm])
+    # configs[4]: 1920x1080, S = 16, 6 control poses
+    big = wl.pyramid_pair(1080, 1920, 1, S=16, k=4, N=6, mode="dense", seed=2)
+    fb5, v5 = _run(gpu_ctx, big)
+    p = big[0]
+    cut = p.K // 2
+    a, _ = _run(gpu_ctx, [_split(p, 0, cut)])
+    b, _ = _run(gpu_ctx, [_split(p, cut, p.K)])
+    whole = fb5[0] * p.K
+    parts = a[0] * cut + b[0] * (p.K - cut)
+    assert np.abs(whole - parts).max() <= 1e-11 * np.abs(whole).max()
+    assert v5[0] > 0.95 * p.K

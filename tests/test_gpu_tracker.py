@@ -1,0 +1,36 @@
+"""-m gpu: the LM loop on the fused engine against the oracle's loop on the same synthetic blurred
+sequence.  Integer outputs (knot start indices, accept / reject sequence, outlier counts) must be
+identical; costs 1e-9 relative; converged trajectory and ATE within 1e-5 (north_star)."""
+import numpy as np
+import pytest
+
+import tracking
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("k4_semidense", dict(H=120, W=160, levels=3, S=8, k=4, seed=1)),
+    ("k2_semidense", dict(H=120, W=160, levels=3, S=8, k=2, seed=2)),
+    ("k4_dense_2frames", dict(H=96, W=128, levels=2, S=4, k=4, F=2, seed=3, mode="dense")),
+    ("k4_ldlt", dict(H=120, W=160, levels=3, S=8, k=4, seed=4)),
+])
+def test_tracker_matches_oracle(orc, mbavo, gpu_ctx, name, kw):
+    sc = tracking.make_tracking_scene(orc, **kw)
+    opts = dict(tracking.OPTS)
+    if "ldlt" in name:
+        opts["solver_type"] = 1
+    ro = tracking.run_oracle_tracker(orc, sc, opts)
+    rg = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, opts)
+    assert np.array_equal(ro["start"], rg["start"])                      # bit-identical pose (knot segment) indices
+    assert len(ro["trace"]) == len(rg["trace"])
+    for a, b in zip(ro["trace"], rg["trace"]):
+        assert a[:4] == b[:4], (a, b)                                    # level, iteration, accept/reject kind, #outliers
+        assert a[4] == pytest.approx(b[4], rel=1e-9)                     # LM radius
+        assert a[5] == pytest.approx(b[5], rel=1e-9, abs=1e-12)          # evaluation cost
+        assert a[6] == pytest.approx(b[6], rel=1e-9, abs=1e-12)          # candidate cost
+    assert np.abs(ro["kt"] - rg["kt"]).max() < 1e-9 and np.abs(ro["kR"] - rg["kR"]).max() < 1e-9
+    ate_o, ate_g = tracking.ate(orc, sc, ro["kt"], ro["kR"]), tracking.ate(orc, sc, rg["kt"], rg["kR"])
+    assert abs(ate_o - ate_g) <= 1e-5
+    assert rg["cost"] < rg["trace"][0][5]                                # and it actually tracked
+    assert tracking.flow_error(orc, sc, rg["kt"], rg["kR"]) < tracking.flow_error(orc, sc, sc["kt0"], sc["kR0"])
