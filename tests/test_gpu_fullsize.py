@@ -1,7 +1,8 @@
 """-m gpu: BASELINE.json's full sizes, checked through size-independent properties (the oracle takes
 seconds per evaluation there and is used once, multi-threaded, on the headline workload):
   * additivity: blocks of all keypoints == sum of blocks over a split of the keypoints (sum of partial sums);
-  * batch invariance: a problem evaluated alone == the same problem inside a batch, bit for bit;
+  * batch invariance: a problem evaluated alone == the same problem inside a batch (the tile partition, hence the
+    summation grouping, depends on the batch: 1e-12 relative, not bitwise);
   * cost-only pass == slot 0 of the H/g pass;  * run-to-run bit reproducibility (no atomics)."""
 import numpy as np
 import pytest
@@ -34,7 +35,7 @@ def test_c2_dense_full_size_properties(orc, mbavo, gpu_ctx):
     # alone vs in the batch
     for i, p in enumerate(probs):
         alone, _ = _run(gpu_ctx, [p])
-        assert np.array_equal(alone[0], fb[i])
+        assert np.abs(alone[0] - fb[i]).max() <= 1e-12 * np.abs(fb[i]).max()
     # additivity over a keypoint split of level 0 (un-normalise by the residual counts)
     p0 = probs[0]
     cut = p0.K // 3 + 7
@@ -60,11 +61,11 @@ def test_c3_batch64_and_c5_1080p_properties(orc, mbavo, gpu_ctx):
     fb, valid = _run(gpu_ctx, probs)
     for i in (0, 17, 63):
         alone, _ = _run(gpu_ctx, [probs[i]])
-        assert np.array_equal(alone[0], fb[i])
+        assert np.abs(alone[0] - fb[i]).max() <= 1e-12 * np.abs(fb[i]).max()
     # independent pairs: permuting the batch permutes the blocks
     perm = np.random.default_rng(0).permutation(64)
     fbp, _ = _run(gpu_ctx, [probs[j] for j in perm])
-    assert np.array_equal(fbp, fb[perm])
+    assert np.abs(fbp - fb[perm]).max() <= 1e-12 * np.abs(fb).max()
     # configs[4]: 1920x1080, S = 16, 6 control poses
     big = wl.pyramid_pair(1080, 1920, 1, S=16, k=4, N=6, mode="dense", seed=2)
     fb5, v5 = _run(gpu_ctx, big)
