@@ -63,8 +63,8 @@ namespace mbavo
                      double *d_frame_blocks, double *d_patch_cost, double *d_valid,
                      double *d_patch_blocks_strided /* B == 1 only, stride E, may be null */);
 
-        // range status of the last evaluate (valid after a stream sync): non-zero if a
-        // blur sample's knot segment had to be clamped into [0, N-k]
+        // range status since the previous fetch (call after a stream sync): non-zero if a blur
+        // sample's knot segment had to be clamped into [0, N-k]
         int fetch_status();
 
         int total_bf() const { return total_bf_; }
@@ -104,6 +104,7 @@ namespace mbavo
         void *d_rho_ = nullptr; size_t cap_rho_ = 0;
         void *d_partials_ = nullptr; size_t cap_partials_ = 0;
         void *d_status_ = nullptr;
+        int status_seen_ = 0;
         void *d_fb_ = nullptr; size_t cap_fb_ = 0;
         void *h_fb_ = nullptr; size_t cap_hfb_ = 0;
 

@@ -5,12 +5,16 @@
 //     sequentially in registers, so the reference's S-wide shared-memory
 //     reductions and its per-sample Jacobian scratch do not exist here;
 //   * the per-sample pose table is read with wave-uniform addresses (scalar loads);
-//   * a workgroup = 8 wave64.  Each wave computes the weighted rows [r | J] of its
-//     own 64 pixels, parks them in LDS ([row entry][lane], conflict-free), and then
-//     every wave accumulates ITS eighth of the packed upper-triangular outer
-//     product (41 of 325 entries for k = 4) for all 512 pixels in registers.  The
-//     accumulators live across the whole tile loop and are reduced once per
-//     workgroup with wave butterflies -- no atomics, fixed summation order.
+//   * each wave parks the weighted rows [r | J] of its own 64 pixels in a private LDS
+//     slab ([pixel][entry]) and feeds them back to the matrix core as BOTH operands of
+//     v_mfma_f64_16x16x4_f64: rows^T * rows, 4 pixels per instruction, the 25 row
+//     entries padded to 2 x 16 -> three 16x16 accumulator tiles (00, 01, 11) per wave
+//     (24 VGPRs).  The FP64 matrix pipe runs beside the FP64 VALU pipe that the other
+//     wave of the SIMD is using for its sample loop, so the 325-entry outer product
+//     costs no VALU issue slots, needs no cross-wave barrier and frees ~60 VGPRs
+//     compared with per-lane VALU accumulators (measured: see DESIGN.md).
+//   * accumulators live across the whole tile loop and are reduced once per
+//     workgroup in a fixed order -- no atomics.
 #include "engine.h"
 #include "pixel_math.h"
 #include "se3_math.h"
@@ -62,9 +66,22 @@ namespace mbavo
         return i + e;
     }
 
+    __device__ __forceinline__ int tri_row_rt(int e, int nd)
+    {
+        int i = 0;
+        while (e >= nd - i) { e -= nd - i; ++i; }
+        return i;
+    }
+    __device__ __forceinline__ int tri_col_rt(int e, int nd)
+    {
+        int i = 0;
+        while (e >= nd - i) { e -= nd - i; ++i; }
+        return i + e;
+    }
+
     // ------------------------------------------------------------------ pose table
     template <int KD, bool WITH_J>
-    __global__ void k_pose_table(const ProblemDesc *__restrict__ descs, int B, int total_entries,
+    __global__ __launch_bounds__(64) void k_pose_table(const ProblemDesc *__restrict__ descs, int B, int total_entries,
                                  PoseEntry<KD> *__restrict__ table, int *__restrict__ status)
     {
         const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -86,7 +103,7 @@ namespace mbavo
         spline_segment(t, d.t0, d.dt, idx, u);
         if (idx < 0 || idx + KD > d.N)
         { // the reference reads out of bounds here; clamp for memory safety and report
-            atomicOr(status, 1);
+            atomicAdd(status, 1);
             idx = idx < 0 ? 0 : d.N - KD;
         }
         PoseEntry<KD> pe;
@@ -103,30 +120,62 @@ namespace mbavo
     }
 
     // ------------------------------------------------------------------ fused kernel
-    template <int KD, int W, int I>
-    __device__ __forceinline__ void acc_one(double (&acc)[Pack<KD>::EPW], const double (&r)[Pack<KD>::ND])
+    typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+    // Per-wave outer-product accumulation on the FP64 matrix core.
+    //   slab: this wave's rows, [64 pixels][ND] doubles, written by lane == pixel.
+    //   v_mfma_f64_16x16x4_f64: D[16x16] += A[16x4] * B[4x16]; lane l supplies A[i = l&15][k = l>>4] and
+    //   B[k = l>>4][j = l&15]; D: col = l&15, row = (l>>4) + 4*reg.  With k = pixel and i, j = row entries,
+    //   A == B^T == rows^T, so one LDS read per 16-entry half feeds both operands.
+    template <int ND>
+    struct OuterAcc
     {
-        constexpr int e = W * Pack<KD>::EPW + I;
-        if constexpr (e > 0 && e < Pack<KD>::E)
+        static constexpr int HALVES = ND > 16 ? 2 : 1;
+        f64x4 t00, t01, t11;
+
+        __device__ __forceinline__ void clear()
         {
-            constexpr int i = tri_row<Pack<KD>::ND>(e), j = tri_col<Pack<KD>::ND>(e);
-            acc[I] = fma(r[i], r[j], acc[I]);
+            t00 = f64x4{0, 0, 0, 0};
+            t01 = f64x4{0, 0, 0, 0};
+            t11 = f64x4{0, 0, 0, 0};
         }
-    }
-    template <int KD, int W, int... Is>
-    __device__ __forceinline__ void acc_wave(double (&acc)[Pack<KD>::EPW], const double *__restrict__ rows,
-                                             int lane, std::integer_sequence<int, Is...>)
-    {
-        constexpr int ND = Pack<KD>::ND;
-#pragma unroll 1
-        for (int grp = 0; grp < kWavesPerGroup; ++grp)
+
+        __device__ __forceinline__ void accumulate(const double *slab, int lane)
         {
-            double r[ND];
+            const int col = lane & 15, kq = lane >> 4;
+            const bool has1 = HALVES == 2 && (16 + col) < ND;
+#pragma unroll 4
+            for (int step = 0; step < 16; ++step)
+            {
+                const double *r = slab + (4 * step + kq) * ND;
+                const double a0 = col < ND ? r[col] : 0.0;
+                t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, t00, 0, 0, 0);
+                if (HALVES == 2)
+                {
+                    const double a1 = has1 ? r[16 + col] : 0.0;
+                    t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, t01, 0, 0, 0);
+                    t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, t11, 0, 0, 0);
+                }
+            }
+        }
+
+        // park the three tiles in LDS as [tile][row][col] (16x16 each)
+        __device__ __forceinline__ void store(double *dst, int lane) const
+        {
+            const int col = lane & 15, kq = lane >> 4;
 #pragma unroll
-            for (int i = 0; i < ND; ++i) r[i] = rows[(grp * ND + i) * 64 + lane];
-            (acc_one<KD, W, Is>(acc, r), ...);
+            for (int reg = 0; reg < 4; ++reg)
+            {
+                const int row = kq + 4 * reg;
+                dst[0 * 256 + row * 16 + col] = t00[reg];
+                if (HALVES == 2)
+                {
+                    dst[1 * 256 + row * 16 + col] = t01[reg];
+                    dst[2 * 256 + row * 16 + col] = t11[reg];
+                }
+            }
         }
-    }
+    };
 
     __device__ __forceinline__ double wave_sum(double v)
     {
@@ -144,10 +193,12 @@ namespace mbavo
                                                         double *__restrict__ patch_blocks_strided,
                                                         double *__restrict__ partials)
     {
-        constexpr int ND = Pack<KD>::ND, E = Pack<KD>::E, EPW = Pack<KD>::EPW, PS = Pack<KD>::PSTRIDE;
+        constexpr int ND = Pack<KD>::ND, E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
+        constexpr int SLAB = 64 * ND; // doubles per wave; also holds the wave's 3 x 256 result tiles at the end
+        static_assert(SLAB >= 3 * 256, "slab too small for the accumulator tiles");
         extern __shared__ __attribute__((aligned(16))) double lds[];
-        double *rows = lds;                                               // [8][ND][64] (WITH_J only)
-        double *red = lds + (WITH_J ? kWavesPerGroup * ND * 64 : 0);      // [2][8]
+        double *rows = lds;                                               // [8 waves][64 pixels][ND] (WITH_J only)
+        double *red = lds + (WITH_J ? kWavesPerGroup * SLAB : 0);         // [2][8]
 
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -156,15 +207,18 @@ namespace mbavo
         const int S = d.S, K = d.K, P = d.P, frame = tile.frame;
         Camera cam;
         cam.fx = d.fx; cam.fy = d.fy; cam.cx = d.cx; cam.cy = d.cy; cam.H = d.H; cam.W = d.W;
+        // The frame's S table entries are read with wave-uniform addresses -> scalar loads.  (Staging the table
+        // in LDS and reading it as a broadcast was measured 1.5x SLOWER on the fused kernel: one ds_read per FMA
+        // operand instead of an SGPR operand.)
         const PoseEntry<KD> *__restrict__ ftab = table + d.pose_base + frame * S;
         const PoseEntry<KD> &mid = ftab[S / 2]; // patch centres use sample S/2 (compute_local_patches_xy.cu:26)
         const unsigned char *__restrict__ I_cur = d.cur_imgs[frame];
         const long long pix0 = d.pixel_base + ((long long)frame * K + tile.kp_begin) * P;
         const int npx = tile.kp_count * P;
 
-        double acc[EPW];
-#pragma unroll
-        for (int i = 0; i < EPW; ++i) acc[i] = 0.0;
+        OuterAcc<ND> acc;
+        acc.clear();
+        double *slab = rows + wave * SLAB;
         int nvalid = 0;
 
         for (int base = 0; base < npx; base += kThreads)
@@ -191,24 +245,19 @@ namespace mbavo
             }
             if (WITH_J)
             {
-                double *mine = rows + (wave * ND) * 64 + lane;
+                // rows of this wave's 64 pixels -> its LDS slab (zero rows for inactive / invalid / outlier pixels)
+                double *mine = slab + lane * ND;
                 mine[0] = keep ? w * res : 0.0;
 #pragma unroll
-                for (int i = 0; i < 6 * KD; ++i) mine[(1 + i) * 64] = keep ? w * Jrow[i] : 0.0;
-                __syncthreads();
-                using Seq = std::make_integer_sequence<int, EPW>;
-                switch (wave)
-                {
-                case 0: acc_wave<KD, 0>(acc, rows, lane, Seq{}); break;
-                case 1: acc_wave<KD, 1>(acc, rows, lane, Seq{}); break;
-                case 2: acc_wave<KD, 2>(acc, rows, lane, Seq{}); break;
-                case 3: acc_wave<KD, 3>(acc, rows, lane, Seq{}); break;
-                case 4: acc_wave<KD, 4>(acc, rows, lane, Seq{}); break;
-                case 5: acc_wave<KD, 5>(acc, rows, lane, Seq{}); break;
-                case 6: acc_wave<KD, 6>(acc, rows, lane, Seq{}); break;
-                default: acc_wave<KD, 7>(acc, rows, lane, Seq{}); break;
-                }
-                __syncthreads();
+                for (int i = 0; i < 6 * KD; ++i) mine[1 + i] = keep ? w * Jrow[i] : 0.0;
+                // same wave reads back what it wrote: LDS executes a wave's operations in order, only the
+                // compiler has to be kept from reordering across this point
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                acc.accumulate(slab, lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         }
 
@@ -243,12 +292,19 @@ namespace mbavo
         }
         if (WITH_J)
         {
-#pragma unroll
-            for (int i = 0; i < EPW; ++i)
+            // every wave parks its three 16x16 tiles in its slab; then entry e of the packed block is the sum of
+            // the 8 waves' tile element (i, j) in wave order
+            acc.store(slab, lane);
+            __syncthreads();
+            for (int e = 1 + threadIdx.x; e < E; e += kThreads)
             {
-                const double s = wave_sum(acc[i]);
-                const int e = wave * EPW + i;
-                if (lane == 0 && e > 0 && e < E) out[e] = s;
+                const int i = tri_row_rt(e, ND), j = tri_col_rt(e, ND);
+                const int t = (i >= 16 ? 2 : (j >= 16 ? 1 : 0));
+                const int off = t * 256 + (i & 15) * 16 + (j & 15);
+                double s_ = 0.0;
+#pragma unroll
+                for (int wv = 0; wv < kWavesPerGroup; ++wv) s_ += rows[wv * SLAB + off];
+                out[e] = s_;
             }
         }
     }
@@ -377,12 +433,31 @@ namespace mbavo
                           memcmp(descs.data(), h_descs_.data(), descs.size() * sizeof(ProblemDesc)) == 0;
         if (same && layout_uploaded_) return 0;
 
-        // tiles: contiguous keypoint ranges, sized so the grid has a few workgroups per CU
-        const int tiles_per_cu = env_int("MBAVO_TILES_PER_CU", 2);
+        // tiles: contiguous keypoint ranges of one (problem, frame).  One workgroup is resident per CU (LDS), so
+        // the tile count must not exceed CUs x rounds or a nearly empty extra round doubles the time: take the
+        // smallest tile size (in pixels) whose tile count fits, found by bisection.
+        const int tiles_per_cu = env_int("MBAVO_TILES_PER_CU", 1);
         const long long target_tiles = (long long)num_cus_ * (tiles_per_cu > 0 ? tiles_per_cu : 1);
-        long long px_per_tile = (pixels + target_tiles - 1) / target_tiles;
-        px_per_tile = ((px_per_tile + kThreads - 1) / kThreads) * kThreads;
-        if (px_per_tile < kThreads) px_per_tile = kThreads;
+        auto count_tiles = [&](long long ppt) {
+            long long n = 0;
+            for (int b = 0; b < B; ++b)
+            {
+                long long kpt = ppt / descs[b].P;
+                if (kpt < 1) kpt = 1;
+                n += (long long)descs[b].F * ((descs[b].K + kpt - 1) / kpt);
+            }
+            return n;
+        };
+        long long lo = kThreads, hi = pixels > kThreads ? pixels : kThreads;
+        if (count_tiles(lo) > target_tiles)
+        {
+            while (lo < hi)
+            {
+                const long long mid = (lo + hi) / 2;
+                if (count_tiles(mid) <= target_tiles) hi = mid; else lo = mid + 1;
+            }
+        }
+        const long long px_per_tile = lo;
         std::vector<TileDesc> tiles;
         std::vector<int> bf_tile_begin, bf_prob;
         for (int b = 0; b < B; ++b)
@@ -422,7 +497,11 @@ namespace mbavo
         if ((rc = ensure(&d_poses_, &cap_poses_, pose_bytes))) return rc;
         if ((rc = ensure(&d_rho_, &cap_rho_, (size_t)(pixels + 1) * sizeof(double)))) return rc;
         if ((rc = ensure(&d_partials_, &cap_partials_, (h_tiles_.size() + 1) * pstride * sizeof(double)))) return rc;
-        if (!d_status_) HIP_TRY(hipMalloc(&d_status_, sizeof(int)));
+        if (!d_status_)
+        { // out-of-range counter: only ever incremented by the pose kernel; fetch_status() reports the delta
+            HIP_TRY(hipMalloc(&d_status_, sizeof(int)));
+            HIP_TRY(hipMemset(d_status_, 0, sizeof(int)));
+        }
         // pageable copies are staged synchronously by the runtime, so the vectors may change afterwards
         HIP_TRY(hipMemcpyAsync(d_descs_, h_descs_.data(), h_descs_.size() * sizeof(ProblemDesc), hipMemcpyHostToDevice, stream_));
         if (!h_tiles_.empty())
@@ -434,7 +513,7 @@ namespace mbavo
     }
 
     template <int KD, bool WITH_J>
-    static int launch_all(Engine *eng, hipStream_t st, const ProblemDesc *descs, int B, int entries, const TileDesc *tiles, int ntiles,
+    static int launch_all(Engine *eng, hipStream_t st, int max_S, const ProblemDesc *descs, int B, int entries, const TileDesc *tiles, int ntiles,
                           const int *bf_prob, const int *bf_tile_begin, int nbf, void *poses, double *rho,
                           double *patch_cost, double *patch_blocks_strided, double *partials, int *status,
                           double *frame_blocks, double *valid)
@@ -443,13 +522,14 @@ namespace mbavo
         hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries + 63) / 64), dim3(64), 0, st, descs, B, entries, table, status);
         if (ntiles > 0)
         {
-            const size_t lds = (WITH_J ? (size_t)kWavesPerGroup * Pack<KD>::ND * 64 : 0) * sizeof(double) +
+            const size_t lds = (WITH_J ? (size_t)kWavesPerGroup * 64 * Pack<KD>::ND : 0) * sizeof(double) +
                                2 * kWavesPerGroup * sizeof(double);
-            static bool attr_set = false;
-            if (!attr_set)
+            (void)max_S;
+            static size_t attr_lds = 0;
+            if (lds > attr_lds)
             {
                 HIP_TRY(hipFuncSetAttribute((const void *)k_fused<KD, WITH_J>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set = true;
+                attr_lds = lds;
             }
             eng->prof_mark(true);
             hipLaunchKernelGGL((k_fused<KD, WITH_J>), dim3(ntiles), dim3(kThreads), lds, st, descs, tiles, table, rho,
@@ -470,12 +550,13 @@ namespace mbavo
         HIP_TRY(hipSetDevice(device_));
         int rc = rebuild_layout(B, probs, kdeg);
         if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(d_status_, 0, sizeof(int), stream_));
         const ProblemDesc *descs = (const ProblemDesc *)d_descs_;
         const TileDesc *tiles = (const TileDesc *)d_tiles_;
         const int ntiles = (int)h_tiles_.size();
+        int max_S = 1;
+        for (const ProblemDesc &pd : h_descs_) max_S = pd.S > max_S ? pd.S : max_S;
 #define MBAVO_LAUNCH(KD, WJ)                                                                                      \
-    launch_all<KD, WJ>(this, stream_, descs, B, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
+    launch_all<KD, WJ>(this, stream_, max_S, descs, B, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
                        (const int *)d_bf_tile_begin_, total_bf_, d_poses_, (double *)d_rho_, d_patch_cost,        \
                        d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid)
         if (kdeg == 4) rc = with_hessian ? MBAVO_LAUNCH(4, true) : MBAVO_LAUNCH(4, false);
@@ -529,6 +610,8 @@ namespace mbavo
     {
         int s = 0;
         if (d_status_ && hipMemcpy(&s, d_status_, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        return s;
+        const int delta = s - status_seen_;
+        status_seen_ = s;
+        return delta;
     }
 } // namespace mbavo

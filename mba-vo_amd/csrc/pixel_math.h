@@ -24,6 +24,15 @@
 #include <math.h>
 #include <string.h>
 
+// Image and table pointers arrive inside descriptor structs, so the compiler sees generic
+// pointers and would emit flat_load_* (which also occupy the LDS queue).  On the device they are
+// re-qualified as global-memory pointers.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MBAVO_GLOBAL __attribute__((address_space(1)))
+#else
+#define MBAVO_GLOBAL
+#endif
+
 namespace mbavo
 {
     // One entry per (problem, frame, blur sample), written by the pose kernel.
@@ -69,53 +78,91 @@ namespace mbavo
         ray[2] = zh;
     }
 
-    // Bilinear tap of the u8 image and the interleaved float gradient image.
+    // Bilinear tap of the u8 image and the interleaved float gradient image, split in two so
+    // that the loads of sample s+1 can be in flight while sample s is consumed.
     // In-bounds test inclusive (0 <= x <= W-1); the 2x2 window is anchored at
     // min(floor, size-2) which is value-identical to the reference's zero-weight
     // taps at the last row/column and never reads outside the buffer (A6).
+    struct __attribute__((packed, aligned(1))) UnalignedU16 { unsigned short v; };
+    struct __attribute__((aligned(8))) Float4A8 { float v[4]; };
+
+    struct TapLoads
+    {
+        float w00, w01, w10, w11;
+        unsigned short r0, r1; // image rows y, y+1: bytes (x, x+1)
+        float g0[4], g1[4];    // gradient rows: [dx(x) dy(x) dx(x+1) dy(x+1)]
+        bool ok;
+    };
+
     template <bool WITH_GRAD>
-    MBAVO_HD bool bilinear_tap(const unsigned char *__restrict__ I, const float *__restrict__ G,
-                               int H, int W, double x, double y, double &val, double &gx, double &gy)
+    MBAVO_HD void tap_fetch(const unsigned char *__restrict__ I, const float *__restrict__ G, int H, int W,
+                            double x, double y, TapLoads &t)
     {
 #pragma clang fp contract(off)
-        if (x < 0 || x > W - 1 || y < 0 || y > H - 1) return false;
+        t.ok = !(x < 0 || x > W - 1 || y < 0 || y > H - 1);
+        if (!t.ok) return;
         int xi = (int)x, yi = (int)y;
         xi = xi > W - 2 ? W - 2 : xi;
         yi = yi > H - 2 ? H - 2 : yi;
         const float dx = (float)(x - xi);
         const float dy = (float)(y - yi);
         const float dxdy = dx * dy;
-        const float w00 = 1.0f - dx - dy + dxdy;
-        const float w01 = dx - dxdy;
-        const float w10 = dy - dxdy;
-        const float w11 = dxdy;
+        t.w00 = 1.0f - dx - dy + dxdy;
+        t.w01 = dx - dxdy;
+        t.w10 = dy - dxdy;
+        t.w11 = dxdy;
+#if defined(MBAVO_EXP_NO_TAPS) // timing experiment only: every tap hits the same address
+        const int idx = (xi + yi) & 1;
+#else
         const int idx = yi * W + xi;
-        unsigned short r0, r1;
-        memcpy(&r0, I + idx, 2);
-        memcpy(&r1, I + idx + W, 2);
-        const float i00 = (float)(r0 & 0xff), i01 = (float)(r0 >> 8);
-        const float i10 = (float)(r1 & 0xff), i11 = (float)(r1 >> 8);
-        float v = w11 * i11;
-        v = v + w10 * i10;
-        v = v + w01 * i01;
-        v = v + w00 * i00;
+#endif
+        const MBAVO_GLOBAL unsigned char *Ig = (const MBAVO_GLOBAL unsigned char *)I;
+        t.r0 = ((const MBAVO_GLOBAL UnalignedU16 *)(Ig + idx))->v;
+        t.r1 = ((const MBAVO_GLOBAL UnalignedU16 *)(Ig + idx + W))->v;
+        if (WITH_GRAD)
+        {
+            const MBAVO_GLOBAL float *Gg = (const MBAVO_GLOBAL float *)G;
+            const Float4A8 a = *(const MBAVO_GLOBAL Float4A8 *)(Gg + 2 * idx);
+            const Float4A8 b = *(const MBAVO_GLOBAL Float4A8 *)(Gg + 2 * (idx + W));
+            for (int i = 0; i < 4; ++i) { t.g0[i] = a.v[i]; t.g1[i] = b.v[i]; }
+        }
+    }
+
+    // float weights, float accumulation, order w11*I11 + w10*I10 + w01*I01 + w00*I00 (:56-68)
+    template <bool WITH_GRAD>
+    MBAVO_HD void tap_blend(const TapLoads &t, double &val, double &gx, double &gy)
+    {
+#pragma clang fp contract(off)
+        const float i00 = (float)(t.r0 & 0xff), i01 = (float)(t.r0 >> 8);
+        const float i10 = (float)(t.r1 & 0xff), i11 = (float)(t.r1 >> 8);
+        float v = t.w11 * i11;
+        v = v + t.w10 * i10;
+        v = v + t.w01 * i01;
+        v = v + t.w00 * i00;
         val = (double)v;
         if (WITH_GRAD)
         {
-            float g0[4], g1[4]; // [dx00 dy00 dx01 dy01], [dx10 dy10 dx11 dy11]
-            memcpy(g0, G + 2 * idx, 16);
-            memcpy(g1, G + 2 * (idx + W), 16);
-            float a = w11 * g1[2];
-            a = a + w10 * g1[0];
-            a = a + w01 * g0[2];
-            a = a + w00 * g0[0];
-            float b = w11 * g1[3];
-            b = b + w10 * g1[1];
-            b = b + w01 * g0[3];
-            b = b + w00 * g0[1];
+            float a = t.w11 * t.g1[2];
+            a = a + t.w10 * t.g1[0];
+            a = a + t.w01 * t.g0[2];
+            a = a + t.w00 * t.g0[0];
+            float b = t.w11 * t.g1[3];
+            b = b + t.w10 * t.g1[1];
+            b = b + t.w01 * t.g0[3];
+            b = b + t.w00 * t.g0[1];
             gx = (double)a;
             gy = (double)b;
         }
+    }
+
+    template <bool WITH_GRAD>
+    MBAVO_HD bool bilinear_tap(const unsigned char *__restrict__ I, const float *__restrict__ G,
+                               int H, int W, double x, double y, double &val, double &gx, double &gy)
+    {
+        TapLoads t;
+        tap_fetch<WITH_GRAD>(I, G, H, W, x, y, t);
+        if (!t.ok) return false;
+        tap_blend<WITH_GRAD>(t, val, gx, gy);
         return true;
     }
 
@@ -228,10 +275,87 @@ namespace mbavo
         }
     }
 
+    // geometry of one sample up to the tap address, with the tap loads issued
+    struct SampleInFlight
+    {
+        double C1, sc, Px, Py;
+        TapLoads taps;
+    };
+
+    template <int KDEG, bool WITH_J>
+    MBAVO_HD void sample_issue(const PoseEntry<KDEG> &pe, const double ray[3], double D, double iz, const Camera &cam,
+                               const unsigned char *__restrict__ I, const float *__restrict__ G, SampleInFlight &f)
+    {
+        const double *R = pe.R;
+        const double rx = R[0] * ray[0] + R[1] * ray[1] + R[2] * ray[2];
+        const double ry = R[3] * ray[0] + R[4] * ray[1] + R[5] * ray[2];
+        const double rz = R[6] * ray[0] + R[7] * ray[1] + R[8] * ray[2];
+        f.C1 = 1. / rz;
+        f.sc = (D - pe.t[2]) * f.C1;
+        f.Px = f.sc * rx + pe.t[0];
+        f.Py = f.sc * ry + pe.t[1];
+        const double u = cam.fx * (f.Px * iz) + cam.cx;
+        const double v = cam.fy * (f.Py * iz) + cam.cy;
+        tap_fetch<WITH_J>(I, G, cam.H, cam.W, u, v, f.taps);
+    }
+
+    template <int KDEG, bool WITH_J>
+    MBAVO_HD void sample_retire(const PoseEntry<KDEG> &pe, const SampleInFlight &f, const double ray[3], double iz,
+                                const Camera &cam, double &isum, double *Jrow)
+    {
+        double val, gx = 0, gy = 0;
+        tap_blend<WITH_J>(f.taps, val, gx, gy);
+        isum += val;
+        if (WITH_J)
+        {
+            const double *R = pe.R;
+            const double rx = R[0] * ray[0] + R[1] * ray[1] + R[2] * ray[2];
+            const double ry = R[3] * ray[0] + R[4] * ray[1] + R[5] * ray[2];
+            const double rz = R[6] * ray[0] + R[7] * ray[1] + R[8] * ray[2];
+            const double dIx = gx * iz * cam.fx;
+            const double dIy = gy * iz * cam.fy;
+            const double dIz = -iz * iz * (gx * f.Px * cam.fx + gy * f.Py * cam.fy);
+            const double dxy = dIx * rx + dIy * ry;
+            const double m = f.C1 * (dxy + dIz * rz);
+            const double jt[3] = {dIx, dIy, -f.C1 * dxy};
+            const double qx = pe.q[0], qy = pe.q[1], qz = pe.q[2], qw = pe.q[3];
+            const double T0 = qx * ray[0] + qy * ray[1] + qz * ray[2];
+            const double T3 = qw * ray[0] + qy * ray[2] - qz * ray[1];
+            const double T2 = qw * ray[1] - qx * ray[2] + qz * ray[0];
+            const double T4 = qw * ray[2] + qx * ray[1] - qy * ray[0];
+            const double g2 = 2. * f.sc;
+            const double b[4] = {g2 * (dIx * T0 - dIy * T4 + dIz * T2 - T2 * m),
+                                 g2 * (dIx * T4 + dIy * T0 - dIz * T3 + T3 * m),
+                                 g2 * (-dIx * T2 + dIy * T3 + dIz * T0 - T0 * m),
+                                 g2 * (dIx * T3 + dIy * T2 + dIz * T4 - T4 * m)};
+#pragma unroll
+            for (int j = 0; j < KDEG; ++j)
+            {
+                Jrow[3 * j + 0] += pe.c[j] * jt[0];
+                Jrow[3 * j + 1] += pe.c[j] * jt[1];
+                Jrow[3 * j + 2] += pe.c[j] * jt[2];
+            }
+#if defined(MBAVO_EXP_NO_CHAIN) // timing experiment only
+            Jrow[3 * KDEG] += b[0] + b[1] + b[2] + b[3];
+#else
+#pragma unroll
+            for (int cidx = 0; cidx < 3 * KDEG; ++cidx)
+            {
+                double a = b[0] * pe.JR[cidx];
+                a += b[1] * pe.JR[3 * KDEG + cidx];
+                a += b[2] * pe.JR[6 * KDEG + cidx];
+                a += b[3] * pe.JR[9 * KDEG + cidx];
+                Jrow[3 * KDEG + cidx] += a;
+            }
+#endif
+        }
+    }
+
     // Residual and mean 1 x 6k Jacobian of one pixel over its S blur samples.
     // A pixel is valid iff its integer location and all S warps are in bounds
     // (SURVEY A9); otherwise residual = 0, Jrow = 0 and false is returned.
-    // `table` points at the S entries of this pixel's frame.
+    // `table` points at the S entries of this pixel's frame.  The sample loop is software
+    // pipelined: the tap loads of sample s+1 are issued before sample s is consumed.
     template <int KDEG, bool WITH_J>
     MBAVO_HD bool pixel_row(const PoseEntry<KDEG> *__restrict__ table, int S, const Camera &cam,
                             const unsigned char *__restrict__ I_ref, const float *__restrict__ G_ref,
@@ -247,13 +371,21 @@ namespace mbavo
         const int px = (int)(centre_x + dx); // truncation, A3
         const int py = (int)(centre_y + dy);
         if (px < 0 || px > cam.W - 1 || py < 0 || py > cam.H - 1) return false;
+        const double cur = (double)((const MBAVO_GLOBAL unsigned char *)I_cur)[py * cam.W + px];
         double ray[3];
         unit_ray(cam, (double)px, (double)py, ray);
         const double iz = 1. / (depth + 1e-8); // P_z == plane depth, A7
         double isum = 0.0;
         bool ok = true;
-        for (int s = 0; s < S && ok; ++s)
-            ok = sample_accumulate<KDEG, WITH_J>(table[s], ray, depth, iz, cam, I_ref, G_ref, isum, Jrow);
+        SampleInFlight cur_s, nxt_s;
+        sample_issue<KDEG, WITH_J>(table[0], ray, depth, iz, cam, I_ref, G_ref, cur_s);
+        for (int s = 0; s < S; ++s)
+        {
+            if (s + 1 < S) sample_issue<KDEG, WITH_J>(table[s + 1], ray, depth, iz, cam, I_ref, G_ref, nxt_s);
+            ok = ok && cur_s.taps.ok;
+            if (ok) sample_retire<KDEG, WITH_J>(table[s], cur_s, ray, iz, cam, isum, Jrow);
+            cur_s = nxt_s;
+        }
         if (!ok)
         {
             if (WITH_J)
@@ -264,7 +396,7 @@ namespace mbavo
             return false;
         }
         const double fS = (double)(float)S; // A8
-        residual = isum / fS - (double)I_cur[py * cam.W + px];
+        residual = isum / fS - cur;
         if (WITH_J)
         {
             const double inv = 1.0 / fS;

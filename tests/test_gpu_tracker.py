@@ -28,7 +28,7 @@ def test_tracker_matches_oracle(orc, mbavo, gpu_ctx, name, kw):
     assert len(ro["trace"]) == len(rg["trace"])
     for a, b in zip(ro["trace"], rg["trace"]):
         assert a[:4] == b[:4], (a, b)                                    # level, iteration, accept/reject kind, #outliers
-        assert a[4] == pytest.approx(b[4], rel=1e-6)                     # LM radius
+        assert a[4] == pytest.approx(b[4], rel=1e-4)                     # LM radius (a ratio of small cost differences)
         assert a[5] == pytest.approx(b[5], rel=1e-6, abs=1e-12)          # evaluation cost
         assert a[6] == pytest.approx(b[6], rel=1e-6, abs=1e-12)          # candidate cost
     # weakly observed knot components (a single short exposure hardly constrains the outer knots) amplify the
