@@ -38,7 +38,10 @@ namespace mbavo
         }                                                                                   \
     } while (0)
 
-    constexpr int kWavesPerGroup = 8;
+#ifndef MBAVO_WAVES_PER_GROUP
+#define MBAVO_WAVES_PER_GROUP 8
+#endif
+    constexpr int kWavesPerGroup = MBAVO_WAVES_PER_GROUP;
     constexpr int kThreads = kWavesPerGroup * 64;
 
     template <int KD>
@@ -109,13 +112,13 @@ namespace mbavo
         PoseEntry<KD> pe;
         trans_coeffs<KD>(u, pe.c);
         spline_translation<KD>(d.knots_t + 3 * idx, pe.c, pe.t);
-        if (!WITH_J)
-        {
-            for (int i = 0; i < 12 * KD; ++i) pe.JR[i] = 0.0;
-        }
-        const Quat q = spline_rotation<KD, WITH_J>(d.knots_R + 4 * idx, u, pe.JR);
+        double JR[12 * KD];
+        const Quat q = spline_rotation<KD, WITH_J>(d.knots_R + 4 * idx, u, JR);
         pe.q[0] = q.x; pe.q[1] = q.y; pe.q[2] = q.z; pe.q[3] = q.w;
         rotation_entries(pe.q, pe.R);
+        if (WITH_J) tangent_jacobian<KD>(pe.q, JR, pe.A);
+        else
+            for (int i = 0; i < 9 * KD; ++i) pe.A[i] = 0.0;
         table[gid] = pe;
     }
 

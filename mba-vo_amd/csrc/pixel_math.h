@@ -43,8 +43,29 @@ namespace mbavo
         double q[4];          // R_c2r xyzw
         double R[9];          // rotation matrix of q, row-major, reference term order
         double c[KDEG];       // translation spline weights (J_t = kron(c, I3))
-        double JR[12 * KDEG]; // 4 x 3k row-major d(q)/d(knot local rotations)
+        double A[9 * KDEG];   // 3 x 3k row-major d(body-frame rotation of the pose)/d(knot local rotations)
     };
+
+    // The reference chains dI/dq (1x4) through J_R = dq/dw (4x3k).  I does not depend on |q| (the warped point
+    // is (D - t_z) * rho / rho_z with rho = R_h(q) ray, homogeneous in q), so dI/dq is tangent to the unit sphere
+    // at q and equals 2 * L3(q) * phi, where phi = dI/d(body-frame rotation) and L3(q) = first three columns of
+    // the left-product matrix (Quaternion.h:239-260).  Hence dI/dq * J_R == phi * A with A = 2 * L3(q)^T * J_R:
+    // a 3x3k table instead of 4x3k, and phi (below) is cheaper to form than dI/dq.
+    template <int KDEG>
+    MBAVO_HD void tangent_jacobian(const double q[4], const double *JR /*4 x 3k*/, double *A /*3 x 3k*/)
+    {
+        const double x = q[0], y = q[1], z = q[2], w = q[3];
+        const double L3[4][3] = {{w, -z, y}, {z, w, -x}, {-y, x, w}, {-x, -y, -z}}; // rows: qx qy qz qw
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3 * KDEG; ++c)
+            {
+                double v = L3[0][a] * JR[c];
+                v += L3[1][a] * JR[3 * KDEG + c];
+                v += L3[2][a] * JR[6 * KDEG + c];
+                v += L3[3][a] * JR[9 * KDEG + c];
+                A[a * 3 * KDEG + c] = 2.0 * v;
+            }
+    }
 
     // rotation matrix entries exactly as compute_pixel_intensity.h:124-126,168-177 forms them
     MBAVO_HD void rotation_entries(const double q[4], double R[9])
@@ -210,44 +231,12 @@ namespace mbavo
         return true;
     }
 
-    // sample_eval + chain through the spline: adds the intensity to isum and the
-    // 1 x 6k contribution [jt * kron(c, I3) | b * J_R] to Jrow
-    // (compute_hessian_gradients_cost.cu:136-142).
-    template <int KDEG, bool WITH_J>
-    MBAVO_HD bool sample_accumulate(const PoseEntry<KDEG> &pe, const double ray[3], double D, double iz,
-                                    const Camera &cam, const unsigned char *__restrict__ I,
-                                    const float *__restrict__ G, double &isum, double *Jrow)
-    {
-        double val, jt[3], b[4];
-        if (!sample_eval<WITH_J>(pe.t, pe.q, pe.R, ray, D, iz, cam, I, G, val, jt, b)) return false;
-        isum += val;
-        if (WITH_J)
-        {
-#pragma unroll
-            for (int j = 0; j < KDEG; ++j)
-            {
-                Jrow[3 * j + 0] += pe.c[j] * jt[0];
-                Jrow[3 * j + 1] += pe.c[j] * jt[1];
-                Jrow[3 * j + 2] += pe.c[j] * jt[2];
-            }
-#pragma unroll
-            for (int cidx = 0; cidx < 3 * KDEG; ++cidx)
-            {
-                double a = b[0] * pe.JR[cidx];
-                a += b[1] * pe.JR[3 * KDEG + cidx];
-                a += b[2] * pe.JR[6 * KDEG + cidx];
-                a += b[3] * pe.JR[9 * KDEG + cidx];
-                Jrow[3 * KDEG + cidx] += a;
-            }
-        }
-        return true;
-    }
-
     // patch centre of a keypoint in the current frame at the mid-exposure pose
     // (compute_local_patches_xy.cu:19-49)
     MBAVO_HD void patch_centre(const double t_c2r[3], const double q_c2r[4], double kx, double ky, double kz,
                                const Camera &cam, double &ox, double &oy)
     {
+#pragma clang fp contract(off)
         const double P[3] = {kz * (kx - cam.cx) / cam.fx, kz * (ky - cam.cy) / cam.fy, kz};
         // R_r2c = conj(R_c2r); t_r2c = -(R_r2c * t_c2r); P_c = R_r2c * P + t_r2c
         const Quat r2c = qconj(Quat{q_c2r[0], q_c2r[1], q_c2r[2], q_c2r[3]});
@@ -311,23 +300,17 @@ namespace mbavo
             const double *R = pe.R;
             const double rx = R[0] * ray[0] + R[1] * ray[1] + R[2] * ray[2];
             const double ry = R[3] * ray[0] + R[4] * ray[1] + R[5] * ray[2];
-            const double rz = R[6] * ray[0] + R[7] * ray[1] + R[8] * ray[2];
+            // dI/dt (compute_pixel_intensity.h:197-199; the dI/dP_z term of [2] cancels identically)
             const double dIx = gx * iz * cam.fx;
             const double dIy = gy * iz * cam.fy;
-            const double dIz = -iz * iz * (gx * f.Px * cam.fx + gy * f.Py * cam.fy);
-            const double dxy = dIx * rx + dIy * ry;
-            const double m = f.C1 * (dxy + dIz * rz);
-            const double jt[3] = {dIx, dIy, -f.C1 * dxy};
-            const double qx = pe.q[0], qy = pe.q[1], qz = pe.q[2], qw = pe.q[3];
-            const double T0 = qx * ray[0] + qy * ray[1] + qz * ray[2];
-            const double T3 = qw * ray[0] + qy * ray[2] - qz * ray[1];
-            const double T2 = qw * ray[1] - qx * ray[2] + qz * ray[0];
-            const double T4 = qw * ray[2] + qx * ray[1] - qy * ray[0];
-            const double g2 = 2. * f.sc;
-            const double b[4] = {g2 * (dIx * T0 - dIy * T4 + dIz * T2 - T2 * m),
-                                 g2 * (dIx * T4 + dIy * T0 - dIz * T3 + T3 * m),
-                                 g2 * (-dIx * T2 + dIy * T3 + dIz * T0 - T0 * m),
-                                 g2 * (dIx * T3 + dIy * T2 + dIz * T4 - T4 * m)};
+            const double jt[3] = {dIx, dIy, -f.C1 * (dIx * rx + dIy * ry)};
+            // phi = dI/d(body rotation) = sc * ray x (R^T * dI/dt): the same derivative the reference forms as
+            // twelve dP/dq terms (:179-206), restricted to the tangent space
+            const double w0 = R[0] * jt[0] + R[3] * jt[1] + R[6] * jt[2];
+            const double w1 = R[1] * jt[0] + R[4] * jt[1] + R[7] * jt[2];
+            const double w2 = R[2] * jt[0] + R[5] * jt[1] + R[8] * jt[2];
+            const double phi[3] = {f.sc * (ray[1] * w2 - ray[2] * w1), f.sc * (ray[2] * w0 - ray[0] * w2),
+                                   f.sc * (ray[0] * w1 - ray[1] * w0)};
 #pragma unroll
             for (int j = 0; j < KDEG; ++j)
             {
@@ -336,15 +319,14 @@ namespace mbavo
                 Jrow[3 * j + 2] += pe.c[j] * jt[2];
             }
 #if defined(MBAVO_EXP_NO_CHAIN) // timing experiment only
-            Jrow[3 * KDEG] += b[0] + b[1] + b[2] + b[3];
+            Jrow[3 * KDEG] += phi[0] + phi[1] + phi[2];
 #else
 #pragma unroll
             for (int cidx = 0; cidx < 3 * KDEG; ++cidx)
             {
-                double a = b[0] * pe.JR[cidx];
-                a += b[1] * pe.JR[3 * KDEG + cidx];
-                a += b[2] * pe.JR[6 * KDEG + cidx];
-                a += b[3] * pe.JR[9 * KDEG + cidx];
+                double a = phi[0] * pe.A[cidx];
+                a += phi[1] * pe.A[3 * KDEG + cidx];
+                a += phi[2] * pe.A[6 * KDEG + cidx];
                 Jrow[3 * KDEG + cidx] += a;
             }
 #endif

@@ -23,7 +23,10 @@ namespace mbavo
     };
 
     MBAVO_HD Quat qmul(const Quat &a, const Quat &b)
-    { // Hamilton product, term order of Quaternion.h:45-51
+    { // Hamilton product, term order of Quaternion.h:45-51.  No FMA contraction: patch centres computed with it
+      // are truncated to integer pixels (compute_hessian_gradients_cost.cu:69-70), so the last bit decides
+      // which pixel is read when a centre falls on an integer
+#pragma clang fp contract(off)
         Quat r;
         r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
         r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;

@@ -125,3 +125,20 @@ def test_bad_arguments_rejected(mbavo, gpu_ctx):
     assert gpu_ctx.lib.mbavo_eval(gpu_ctx.handle, C.byref(p), 3, mbavo.capi.dp(cost), None, None, None) == -1
     p.d_ref_img = None
     assert gpu_ctx.lib.mbavo_eval(gpu_ctx.handle, C.byref(p), 4, mbavo.capi.dp(cost), None, None, None) == -1
+
+
+def test_zero_motion_dense_integer_centres(orc, mbavo, gpu_ctx):
+    """Identity spline + dense integer keypoints: every patch centre lands (up to rounding) ON an integer and is
+    then truncated (compute_hessian_gradients_cost.cu:69-70), so one differing last bit would read a different
+    pixel.  The centre computation is kept free of FMA contraction; residual-derived outputs must match exactly."""
+    sc = scenes.Scene(H=120, W=160, S=4, F=1, k=4, P=1, kp="dense", margin=0, z_range=(3.0, 30.0))
+    sc.knots_t[:] = 0.0
+    sc.knots_R[:] = np.tile([0.0, 0.0, 0.0, 1.0], sc.N)
+    sc.intr = np.array([83.3, 79.9, 80.2, 59.7])   # non-dyadic intrinsics: (z*(x-cx)/fx)/z*fx+cx is not exact
+    p, keep = sc.oracle_problem(orc)
+    ro = orc.evaluate(p)
+    d = scenes.DeviceScene(sc)
+    fb, pc, valid = scenes.gpu_eval_batch(gpu_ctx, [d], sc.k)
+    assert np.array_equal(valid, _oracle_valid_counts(orc, sc))
+    assert np.array_equal(pc, ro["patch_blocks"][:, :, 0].ravel())      # per-pixel Huber cost: bit-exact
+    assert _rel(fb, ro["frame_blocks"]) < RTOL
