@@ -257,8 +257,10 @@ extern "C"
         static allreduce_fn fn = nullptr;
         if (!fn)
         {
-            void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-            if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            // the SONAME first: binds to the RCCL instance the process already uses (e.g. the one PyTorch ships),
+            // which is the instance the caller's ncclComm_t belongs to
+            void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
             if (!h) { fprintf(stderr, "mbavo: cannot load librccl.so: %s\n", dlerror()); return MBAVO_E_NODEVICE; }
             fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
             if (!fn) return MBAVO_E_NODEVICE;

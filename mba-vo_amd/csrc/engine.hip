@@ -39,7 +39,7 @@ namespace mbavo
     } while (0)
 
 #ifndef MBAVO_WAVES_PER_GROUP
-#define MBAVO_WAVES_PER_GROUP 8
+#define MBAVO_WAVES_PER_GROUP 12
 #endif
     constexpr int kWavesPerGroup = MBAVO_WAVES_PER_GROUP;
     constexpr int kThreads = kWavesPerGroup * 64;

@@ -142,3 +142,25 @@ def test_zero_motion_dense_integer_centres(orc, mbavo, gpu_ctx):
     assert np.array_equal(valid, _oracle_valid_counts(orc, sc))
     assert np.array_equal(pc, ro["patch_blocks"][:, :, 0].ravel())      # per-pixel Huber cost: bit-exact
     assert _rel(fb, ro["frame_blocks"]) < RTOL
+
+
+def test_rccl_allreduce_entry_point(mbavo, gpu_ctx):
+    """mbavo_allreduce_blocks on a 1-rank RCCL communicator (the box has one GPU): in-place sum == identity;
+    exercises the run-time binding to librccl and the stream ordering with the evaluation."""
+    import ctypes as C
+    import torch
+    rccl = C.CDLL("librccl.so.1")
+    comm = C.c_void_p()
+    devs = (C.c_int * 1)(0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, devs) == 0
+    sc = scenes.Scene(S=4, F=2, k=4, P=8, K=60)
+    d = scenes.DeviceScene(sc)
+    arr = (mbavo.capi.Problem * 1)(d.problem())
+    fb = torch.zeros(sc.F * sc.E, dtype=torch.float64, device="cuda:0")
+    assert gpu_ctx.lib.mbavo_eval_batch(gpu_ctx.handle, 1, arr, 4, 1, fb.data_ptr(), None, None) == 0
+    ref = fb.clone()
+    assert gpu_ctx.lib.mbavo_allreduce_blocks(gpu_ctx.handle, comm, fb.data_ptr(), fb.numel()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(fb, ref) and float(ref.abs().max()) > 0
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)
