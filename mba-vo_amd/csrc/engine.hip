@@ -125,30 +125,31 @@ namespace mbavo
     // ------------------------------------------------------------------ fused kernel
     typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-    // Per-wave outer-product accumulation on the FP64 matrix core.
-    //   slab: this wave's rows, [64 pixels][ND] doubles, written by lane == pixel.
-    //   v_mfma_f64_16x16x4_f64: D[16x16] += A[16x4] * B[4x16]; lane l supplies A[i = l&15][k = l>>4] and
-    //   B[k = l>>4][j = l&15]; D: col = l&15, row = (l>>4) + 4*reg.  With k = pixel and i, j = row entries,
-    //   A == B^T == rows^T, so one LDS read per 16-entry half feeds both operands.
+#if !defined(MBAVO_OUTER_VALU)
+    // Per-wave outer product on v_mfma_f64_16x16x4_f64 (rows^T * rows, 25 entries padded to 2 x 16 -> three
+    // 16x16 tiles, 24 accumulator VGPRs).  On gfx950 the f64 MFMA runs at the FP64 VALU rate and competes with it
+    // for the FP64 pipe, and the padded tiles do 2.4x the useful flops (~15 us of a 58 us kernel) -- it still wins
+    // over the register-blocked VALU variant below because that one needs 50 accumulator VGPRs and spills at 3
+    // waves/SIMD (measured 57.6 us vs 75.1 us at 12 waves, 61.6 us at 8 waves).
     template <int ND>
     struct OuterAcc
     {
         static constexpr int HALVES = ND > 16 ? 2 : 1;
+        static constexpr int STRIDE = ND;
+#if defined(MBAVO_HALF_SLAB)
+        static constexpr int ROWS = 32; // rows parked per round: lanes 0-31, then lanes 32-63
+#else
+        static constexpr int ROWS = 64;
+#endif
+        static constexpr int SLAB = ROWS * ND > 768 ? ROWS * ND : 768;
         f64x4 t00, t01, t11;
-
-        __device__ __forceinline__ void clear()
-        {
-            t00 = f64x4{0, 0, 0, 0};
-            t01 = f64x4{0, 0, 0, 0};
-            t11 = f64x4{0, 0, 0, 0};
-        }
-
+        __device__ __forceinline__ void init(int) { t00 = f64x4{0, 0, 0, 0}; t01 = t00; t11 = t00; }
         __device__ __forceinline__ void accumulate(const double *slab, int lane)
         {
             const int col = lane & 15, kq = lane >> 4;
             const bool has1 = HALVES == 2 && (16 + col) < ND;
 #pragma unroll 4
-            for (int step = 0; step < 16; ++step)
+            for (int step = 0; step < ROWS / 4; ++step)
             {
                 const double *r = slab + (4 * step + kq) * ND;
                 const double a0 = col < ND ? r[col] : 0.0;
@@ -161,8 +162,6 @@ namespace mbavo
                 }
             }
         }
-
-        // park the three tiles in LDS as [tile][row][col] (16x16 each)
         __device__ __forceinline__ void store(double *dst, int lane) const
         {
             const int col = lane & 15, kq = lane >> 4;
@@ -171,14 +170,98 @@ namespace mbavo
             {
                 const int row = kq + 4 * reg;
                 dst[0 * 256 + row * 16 + col] = t00[reg];
-                if (HALVES == 2)
-                {
-                    dst[1 * 256 + row * 16 + col] = t01[reg];
-                    dst[2 * 256 + row * 16 + col] = t11[reg];
-                }
+                if (HALVES == 2) { dst[1 * 256 + row * 16 + col] = t01[reg]; dst[2 * 256 + row * 16 + col] = t11[reg]; }
             }
         }
+        // sum of element (i, j), i <= j, over the waves' parked tiles
+        static __device__ __forceinline__ double gather(const double *rows, int i, int j)
+        {
+            const int t = (i >= 16 ? 2 : (j >= 16 ? 1 : 0));
+            const int off = t * 256 + (i & 15) * 16 + (j & 15);
+            double s = 0.0;
+            for (int wv = 0; wv < kWavesPerGroup; ++wv) s += rows[wv * SLAB + off];
+            return s;
+        }
     };
+#else
+    // Per-wave outer-product accumulation, register-blocked on the FP64 VALU.
+    //   slab: this wave's weighted rows, [64 pixels][STRIDE] doubles (zero padded), written by lane == pixel.
+    //   The (6k+1) row entries are cut into NB blocks of 5; lane l owns ONE 5x5 block pair (bi <= bj) of the
+    //   upper triangle for ONE group of pixels (k = 4: 15 block pairs x 4 groups of 16 pixels = 60 lanes).  Per
+    //   pixel it reads 5 + 5 row entries from LDS (lanes of one group/block share addresses -> broadcast, the
+    //   rest fall on distinct banks) and issues 25 FMAs: 400 FMA issues per 64 pixels instead of 325 for the
+    //   bare packed triangle, with no cross-wave exchange and 25 accumulators per lane.  (The same product on
+    //   v_mfma_f64_16x16x4_f64 needs three padded 16x16 tiles = 768 FMA-equivalents per 64 pixels on the SAME
+    //   FP64 pipe: measured slower, see MBAVO_OUTER_MFMA.)
+    template <int ND>
+    struct OuterAcc
+    {
+        static constexpr int BS = 5;
+        static constexpr int NB = (ND + BS - 1) / BS;
+        static constexpr int NBP = NB * (NB + 1) / 2;
+        static constexpr int G = 64 / NBP;             // pixel groups
+        static constexpr int PPG = (64 + G - 1) / G;   // pixels per group
+        static constexpr int STRIDE = NB * BS;
+        static constexpr int ROWS = 64;
+        static constexpr int SLAB = 64 * STRIDE > G * NBP * BS * BS ? 64 * STRIDE : G * NBP * BS * BS;
+        double a[BS * BS];
+        int off_i, off_j, px0;
+        bool live;
+
+        __device__ __forceinline__ void init(int lane)
+        {
+#pragma unroll
+            for (int i = 0; i < BS * BS; ++i) a[i] = 0.0;
+            const int bp = lane % NBP, grp = lane / NBP;
+            int bi = 0, rem = bp;
+            while (rem >= NB - bi) { rem -= NB - bi; ++bi; }
+            off_i = bi * BS;
+            off_j = (bi + rem) * BS;
+            px0 = grp * PPG;
+            live = grp < G;
+        }
+
+        __device__ __forceinline__ void accumulate(const double *slab, int)
+        {
+            if (!live) return;
+#pragma unroll 2
+            for (int p = 0; p < PPG; ++p)
+            {
+                const int px = px0 + p;
+                if (px >= 64) break;
+                const double *r = slab + px * STRIDE;
+                double u[BS], v[BS];
+#pragma unroll
+                for (int i = 0; i < BS; ++i) { u[i] = r[off_i + i]; v[i] = r[off_j + i]; }
+#pragma unroll
+                for (int i = 0; i < BS; ++i)
+#pragma unroll
+                    for (int j = 0; j < BS; ++j) a[i * BS + j] = fma(u[i], v[j], a[i * BS + j]);
+            }
+        }
+
+        // park the block in LDS as [group][block pair][5][5]
+        __device__ __forceinline__ void store(double *dst, int lane) const
+        {
+            if (!live) return;
+            double *o = dst + lane * (BS * BS); // lane == grp * NBP + bp
+#pragma unroll
+            for (int i = 0; i < BS * BS; ++i) o[i] = a[i];
+        }
+
+        // sum of element (i, j), i <= j, over waves and pixel groups, in a fixed order
+        static __device__ __forceinline__ double gather(const double *rows, int i, int j)
+        {
+            const int bi = i / BS, bj = j / BS;
+            const int bp = bi * NB - bi * (bi - 1) / 2 + (bj - bi);
+            const int off = bp * (BS * BS) + (i - bi * BS) * BS + (j - bj * BS);
+            double s = 0.0;
+            for (int wv = 0; wv < kWavesPerGroup; ++wv)
+                for (int g = 0; g < G; ++g) s += rows[wv * SLAB + g * NBP * (BS * BS) + off];
+            return s;
+        }
+    };
+#endif
 
     __device__ __forceinline__ double wave_sum(double v)
     {
@@ -197,8 +280,8 @@ namespace mbavo
                                                         double *__restrict__ partials)
     {
         constexpr int ND = Pack<KD>::ND, E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
-        constexpr int SLAB = 64 * ND; // doubles per wave; also holds the wave's 3 x 256 result tiles at the end
-        static_assert(SLAB >= 3 * 256, "slab too small for the accumulator tiles");
+        constexpr int SLAB = OuterAcc<ND>::SLAB;     // doubles per wave: rows, and the parked accumulators at the end
+        constexpr int RS = OuterAcc<ND>::STRIDE;     // row stride (>= ND, zero padded)
         extern __shared__ __attribute__((aligned(16))) double lds[];
         double *rows = lds;                                               // [8 waves][64 pixels][ND] (WITH_J only)
         double *red = lds + (WITH_J ? kWavesPerGroup * SLAB : 0);         // [2][8]
@@ -213,14 +296,26 @@ namespace mbavo
         // The frame's S table entries are read with wave-uniform addresses -> scalar loads.  (Staging the table
         // in LDS and reading it as a broadcast was measured 1.5x SLOWER on the fused kernel: one ds_read per FMA
         // operand instead of an SGPR operand.)
+#if defined(MBAVO_EXP_LDS_TABLE) // experiment: table staged in LDS and read as a broadcast
+        PoseEntry<KD> *ltab = (PoseEntry<KD> *)(red + 2 * kWavesPerGroup);
+        {
+            const MBAVO_GLOBAL double *src = (const MBAVO_GLOBAL double *)(table + d.pose_base + frame * S);
+            double *dst = (double *)ltab;
+            const int n = S * (int)(sizeof(PoseEntry<KD>) / sizeof(double));
+            for (int i = threadIdx.x; i < n; i += kThreads) dst[i] = src[i];
+        }
+        __syncthreads();
+        const PoseEntry<KD> *__restrict__ ftab = ltab;
+#else
         const PoseEntry<KD> *__restrict__ ftab = table + d.pose_base + frame * S;
+#endif
         const PoseEntry<KD> &mid = ftab[S / 2]; // patch centres use sample S/2 (compute_local_patches_xy.cu:26)
         const unsigned char *__restrict__ I_cur = d.cur_imgs[frame];
         const long long pix0 = d.pixel_base + ((long long)frame * K + tile.kp_begin) * P;
         const int npx = tile.kp_count * P;
 
         OuterAcc<ND> acc;
-        acc.clear();
+        acc.init(lane);
         double *slab = rows + wave * SLAB;
         int nvalid = 0;
 
@@ -238,7 +333,11 @@ namespace mbavo
                 const double kx = d.kp_xy[(size_t)kp * d.kp_stride], ky = d.kp_xy[(size_t)kp * d.kp_stride + 1];
                 const double kz = d.kp_z[kp];
                 double pcx, pcy;
+#if defined(MBAVO_EXP_NO_CENTRE) // timing experiment switch
+                pcx = kx + mid.t[0]; pcy = ky + mid.t[1];
+#else
                 patch_centre(mid.t, mid.q, kx, ky, kz, cam, pcx, pcy);
+#endif
                 const bool valid = pixel_row<KD, WITH_J>(ftab, S, cam, d.ref_img, d.ref_dIxy, I_cur, pcx, pcy, kz,
                                                          d.pattern[2 * pp], d.pattern[2 * pp + 1], res, Jrow);
                 huber_weight(res, d.huber_a, w, rho);
@@ -248,19 +347,31 @@ namespace mbavo
             }
             if (WITH_J)
             {
-                // rows of this wave's 64 pixels -> its LDS slab (zero rows for inactive / invalid / outlier pixels)
-                double *mine = slab + lane * ND;
-                mine[0] = keep ? w * res : 0.0;
+                // rows of this wave's 64 pixels -> its LDS slab (zero rows for inactive / invalid / outlier pixels),
+                // ROWS at a time; the same wave reads back what it wrote: LDS executes a wave's operations in
+                // order, only the compiler has to be kept from reordering across these points
+                constexpr int ROUNDS = 64 / OuterAcc<ND>::ROWS;
 #pragma unroll
-                for (int i = 0; i < 6 * KD; ++i) mine[1 + i] = keep ? w * Jrow[i] : 0.0;
-                // same wave reads back what it wrote: LDS executes a wave's operations in order, only the
-                // compiler has to be kept from reordering across this point
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                acc.accumulate(slab, lane);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                for (int rd = 0; rd < ROUNDS; ++rd)
+                {
+                    if (ROUNDS == 1 || (lane / OuterAcc<ND>::ROWS) == rd)
+                    {
+                        double *mine = slab + (lane % OuterAcc<ND>::ROWS) * RS;
+                        mine[0] = keep ? w * res : 0.0;
+#pragma unroll
+                        for (int i = 0; i < 6 * KD; ++i) mine[1 + i] = keep ? w * Jrow[i] : 0.0;
+#pragma unroll
+                        for (int i = ND; i < RS; ++i) mine[i] = 0.0;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if !defined(MBAVO_EXP_NO_MFMA) // timing experiment switch
+                    acc.accumulate(slab, lane);
+#endif
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
         }
 
@@ -295,19 +406,14 @@ namespace mbavo
         }
         if (WITH_J)
         {
-            // every wave parks its three 16x16 tiles in its slab; then entry e of the packed block is the sum of
-            // the 8 waves' tile element (i, j) in wave order
+            // every wave parks its accumulators in its slab; entry e = (i, j) of the packed block is then the sum
+            // over waves (and pixel groups) in a fixed order
             acc.store(slab, lane);
             __syncthreads();
             for (int e = 1 + threadIdx.x; e < E; e += kThreads)
             {
                 const int i = tri_row_rt(e, ND), j = tri_col_rt(e, ND);
-                const int t = (i >= 16 ? 2 : (j >= 16 ? 1 : 0));
-                const int off = t * 256 + (i & 15) * 16 + (j & 15);
-                double s_ = 0.0;
-#pragma unroll
-                for (int wv = 0; wv < kWavesPerGroup; ++wv) s_ += rows[wv * SLAB + off];
-                out[e] = s_;
+                out[e] = OuterAcc<ND>::gather(rows, i, j);
             }
         }
     }
@@ -525,8 +631,12 @@ namespace mbavo
         hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries + 63) / 64), dim3(64), 0, st, descs, B, entries, table, status);
         if (ntiles > 0)
         {
-            const size_t lds = (WITH_J ? (size_t)kWavesPerGroup * 64 * Pack<KD>::ND : 0) * sizeof(double) +
-                               2 * kWavesPerGroup * sizeof(double);
+            const size_t lds = (WITH_J ? (size_t)kWavesPerGroup * OuterAcc<Pack<KD>::ND>::SLAB : 0) * sizeof(double) +
+                               2 * kWavesPerGroup * sizeof(double)
+#if defined(MBAVO_EXP_LDS_TABLE)
+                               + (size_t)max_S * sizeof(PoseEntry<KD>)
+#endif
+                ;
             (void)max_S;
             static size_t attr_lds = 0;
             if (lds > attr_lds)

@@ -267,7 +267,7 @@ namespace mbavo
     // geometry of one sample up to the tap address, with the tap loads issued
     struct SampleInFlight
     {
-        double C1, sc, Px, Py;
+        double C1, sc, rx, ry;
         TapLoads taps;
     };
 
@@ -276,15 +276,15 @@ namespace mbavo
                                const unsigned char *__restrict__ I, const float *__restrict__ G, SampleInFlight &f)
     {
         const double *R = pe.R;
-        const double rx = R[0] * ray[0] + R[1] * ray[1] + R[2] * ray[2];
-        const double ry = R[3] * ray[0] + R[4] * ray[1] + R[5] * ray[2];
+        f.rx = R[0] * ray[0] + R[1] * ray[1] + R[2] * ray[2];
+        f.ry = R[3] * ray[0] + R[4] * ray[1] + R[5] * ray[2];
         const double rz = R[6] * ray[0] + R[7] * ray[1] + R[8] * ray[2];
         f.C1 = 1. / rz;
         f.sc = (D - pe.t[2]) * f.C1;
-        f.Px = f.sc * rx + pe.t[0];
-        f.Py = f.sc * ry + pe.t[1];
-        const double u = cam.fx * (f.Px * iz) + cam.cx;
-        const double v = cam.fy * (f.Py * iz) + cam.cy;
+        const double Px = f.sc * f.rx + pe.t[0];
+        const double Py = f.sc * f.ry + pe.t[1];
+        const double u = cam.fx * (Px * iz) + cam.cx;
+        const double v = cam.fy * (Py * iz) + cam.cy;
         tap_fetch<WITH_J>(I, G, cam.H, cam.W, u, v, f.taps);
     }
 
@@ -298,8 +298,7 @@ namespace mbavo
         if (WITH_J)
         {
             const double *R = pe.R;
-            const double rx = R[0] * ray[0] + R[1] * ray[1] + R[2] * ray[2];
-            const double ry = R[3] * ray[0] + R[4] * ray[1] + R[5] * ray[2];
+            const double rx = f.rx, ry = f.ry;
             // dI/dt (compute_pixel_intensity.h:197-199; the dI/dP_z term of [2] cancels identically)
             const double dIx = gx * iz * cam.fx;
             const double dIy = gy * iz * cam.fy;
@@ -359,14 +358,25 @@ namespace mbavo
         const double iz = 1. / (depth + 1e-8); // P_z == plane depth, A7
         double isum = 0.0;
         bool ok = true;
-        SampleInFlight cur_s, nxt_s;
-        sample_issue<KDEG, WITH_J>(table[0], ray, depth, iz, cam, I_ref, G_ref, cur_s);
-        for (int s = 0; s < S; ++s)
+        // two samples in flight, ping-pong (no struct copies): the taps of sample s+1 are issued before sample s retires
+        SampleInFlight fa, fb;
+#if defined(MBAVO_EXP_ONE_ENTRY) // timing experiment: every sample uses table[0] (loads hoisted out of the loop)
+#define MBAVO_TAB(i) table[0]
+#else
+#define MBAVO_TAB(i) table[i]
+#endif
+        sample_issue<KDEG, WITH_J>(MBAVO_TAB(0), ray, depth, iz, cam, I_ref, G_ref, fa);
+        for (int s = 0; s < S; s += 2)
         {
-            if (s + 1 < S) sample_issue<KDEG, WITH_J>(table[s + 1], ray, depth, iz, cam, I_ref, G_ref, nxt_s);
-            ok = ok && cur_s.taps.ok;
-            if (ok) sample_retire<KDEG, WITH_J>(table[s], cur_s, ray, iz, cam, isum, Jrow);
-            cur_s = nxt_s;
+            if (s + 1 < S) sample_issue<KDEG, WITH_J>(MBAVO_TAB(s + 1), ray, depth, iz, cam, I_ref, G_ref, fb);
+            ok = ok && fa.taps.ok;
+            if (ok) sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, iz, cam, isum, Jrow);
+            if (s + 1 < S)
+            {
+                if (s + 2 < S) sample_issue<KDEG, WITH_J>(MBAVO_TAB(s + 2), ray, depth, iz, cam, I_ref, G_ref, fa);
+                ok = ok && fb.taps.ok;
+                if (ok) sample_retire<KDEG, WITH_J>(MBAVO_TAB(s + 1), fb, ray, iz, cam, isum, Jrow);
+            }
         }
         if (!ok)
         {
