@@ -83,11 +83,15 @@ namespace mbavo
     }
 
     // ------------------------------------------------------------------ pose table
+    // grid = (ceil(entries / 64), WITH_J ? KD : 1): one lane per (problem, frame, blur sample) and, with
+    // Jacobians, one WAVE per knot (blockIdx.y): the four 4x3 Jacobian blocks of a sample are independent given
+    // the shared logs / exps, so they run side by side instead of back to back on one latency-bound lane.
     template <int KD, bool WITH_J>
     __global__ __launch_bounds__(64) void k_pose_table(const ProblemDesc *__restrict__ descs, int B, int total_entries,
-                                 PoseEntry<KD> *__restrict__ table, int *__restrict__ status)
+                                                       PoseEntry<KD> *__restrict__ table, int *__restrict__ status)
     {
         const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+        const int knot = blockIdx.y;
         if (gid >= total_entries) return;
         int lo = 0, hi = B - 1; // last problem with pose_base <= gid
         while (lo < hi)
@@ -106,20 +110,44 @@ namespace mbavo
         spline_segment(t, d.t0, d.dt, idx, u);
         if (idx < 0 || idx + KD > d.N)
         { // the reference reads out of bounds here; clamp for memory safety and report
-            atomicAdd(status, 1);
+            if (knot == 0) atomicAdd(status, 1);
             idx = idx < 0 ? 0 : d.N - KD;
         }
-        PoseEntry<KD> pe;
-        trans_coeffs<KD>(u, pe.c);
-        spline_translation<KD>(d.knots_t + 3 * idx, pe.c, pe.t);
-        double JR[12 * KD];
-        const Quat q = spline_rotation<KD, WITH_J>(d.knots_R + 4 * idx, u, JR);
-        pe.q[0] = q.x; pe.q[1] = q.y; pe.q[2] = q.z; pe.q[3] = q.w;
-        rotation_entries(pe.q, pe.R);
-        if (WITH_J) tangent_jacobian<KD>(pe.q, JR, pe.A);
+        PoseEntry<KD> &pe = table[gid];
+        Quat q;
+        if (WITH_J)
+        {
+            Jac43 blk;
+            q = spline_rotation_knot<KD>(d.knots_R + 4 * idx, u, knot, blk);
+            // tangent form of this knot's block: A[a][3*knot + c] = 2 * L3(q)^T[a] . blk.c[c]   (pixel_math.h)
+            const double L3[4][3] = {{q.w, -q.z, q.y}, {q.z, q.w, -q.x}, {-q.y, q.x, q.w}, {-q.x, -q.y, -q.z}};
+            for (int a = 0; a < 3; ++a)
+                for (int c = 0; c < 3; ++c)
+                {
+                    const Quat &v = blk.c[c];
+                    double r = L3[0][a] * v.x;
+                    r += L3[1][a] * v.y;
+                    r += L3[2][a] * v.z;
+                    r += L3[3][a] * v.w;
+                    pe.A[a * 3 * KD + 3 * knot + c] = 2.0 * r;
+                }
+        }
         else
+        {
+            q = spline_rotation<KD, false>(d.knots_R + 4 * idx, u, nullptr);
             for (int i = 0; i < 9 * KD; ++i) pe.A[i] = 0.0;
-        table[gid] = pe;
+        }
+        if (knot == 0)
+        {
+            double c[KD], p[3], qv[4] = {q.x, q.y, q.z, q.w}, R[9];
+            trans_coeffs<KD>(u, c);
+            spline_translation<KD>(d.knots_t + 3 * idx, c, p);
+            rotation_entries(qv, R);
+            for (int i = 0; i < 3; ++i) pe.t[i] = p[i];
+            for (int i = 0; i < 4; ++i) pe.q[i] = qv[i];
+            for (int i = 0; i < 9; ++i) pe.R[i] = R[i];
+            for (int i = 0; i < KD; ++i) pe.c[i] = c[i];
+        }
     }
 
     // ------------------------------------------------------------------ fused kernel
@@ -628,7 +656,7 @@ namespace mbavo
                           double *frame_blocks, double *valid)
     {
         PoseEntry<KD> *table = (PoseEntry<KD> *)poses;
-        hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries + 63) / 64), dim3(64), 0, st, descs, B, entries, table, status);
+        hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries + 63) / 64, WITH_J ? KD : 1), dim3(64), 0, st, descs, B, entries, table, status);
         if (ntiles > 0)
         {
             const size_t lds = (WITH_J ? (size_t)kWavesPerGroup * OuterAcc<Pack<KD>::ND>::SLAB : 0) * sizeof(double) +

@@ -347,6 +347,87 @@ namespace mbavo
         }
     }
 
+    // Same spline sample as spline_rotation, but only the 4x3 Jacobian block of ONE knot j (0 <= j < KDEG):
+    // the pose-table kernel spreads the knots of a sample over separate waves (the blocks are independent
+    // given the shared logs / exps), which cuts its latency-bound critical path.
+    template <int KDEG>
+    MBAVO_HD Quat spline_rotation_knot(const double *kR, double u, int j, Jac43 &block)
+    {
+        if constexpr (KDEG == 2)
+        {
+            const Quat R0 = load_quat(kR), R1 = load_quat(kR + 4);
+            const Quat R0c = qconj(R0);
+            LogJac dl; ExpJac de;
+            double om[3];
+            qlog<true>(qmul(R0c, R1), om, &dl);
+            om[0] *= u; om[1] *= u; om[2] *= u;
+            const Quat A0 = qexp<true>(om, &de);
+            if (j == 0)
+            {
+                const Jac43 E0 = local_param_jac(R0);
+                block = jadd(rmul(E0, A0), lmul(R0, through_log_exp(de, u, dl, rmul(conj_cols(E0), R1))));
+            }
+            else
+                block = lmul(R0, through_log_exp(de, u, dl, lmul(R0c, local_param_jac(R1))));
+            return qmul(R0, A0);
+        }
+        else
+        {
+            const double uu = u * u, uuu = uu * u, s = 1. / 6.;
+            const double c1 = 5 * s + 0.5 * u - 0.5 * uu + s * uuu;
+            const double c2 = s + 0.5 * u + 0.5 * uu - 2 * s * uuu;
+            const double c3 = s * uuu;
+            const Quat R0 = load_quat(kR), R1 = load_quat(kR + 4), R2 = load_quat(kR + 8), R3 = load_quat(kR + 12);
+            const Quat R0c = qconj(R0), R1c = qconj(R1), R2c = qconj(R2);
+            LogJac dl01, dl12, dl23; ExpJac de0, de1, de2;
+            double o01[3], o12[3], o23[3];
+            qlog<true>(qmul(R0c, R1), o01, &dl01);
+            qlog<true>(qmul(R1c, R2), o12, &dl12);
+            qlog<true>(qmul(R2c, R3), o23, &dl23);
+            for (int a = 0; a < 3; ++a) { o01[a] *= c1; o12[a] *= c2; o23[a] *= c3; }
+            const Quat A0 = qexp<true>(o01, &de0);
+            const Quat A1 = qexp<true>(o12, &de1);
+            const Quat A2 = qexp<true>(o23, &de2);
+            const Quat R0A0 = qmul(R0, A0);
+            const Quat R0A0A1 = qmul(R0A0, A1);
+            const Quat A12 = qmul(A1, A2);
+            switch (j)
+            {
+            case 0:
+            {
+                const Jac43 E0 = local_param_jac(R0);
+                const Quat A012 = qmul(qmul(A0, A1), A2);
+                const Jac43 dA0 = through_log_exp(de0, c1, dl01, rmul(conj_cols(E0), R1));
+                block = jadd(rmul(E0, A012), lmul(R0, rmul(dA0, A12)));
+                break;
+            }
+            case 1:
+            {
+                const Jac43 E1 = local_param_jac(R1);
+                const Jac43 dA0 = through_log_exp(de0, c1, dl01, lmul(R0c, E1));
+                const Jac43 dA1 = through_log_exp(de1, c2, dl12, rmul(conj_cols(E1), R2));
+                block = jadd(lmul(R0, rmul(dA0, A12)), lmul(R0A0, rmul(dA1, A2)));
+                break;
+            }
+            case 2:
+            {
+                const Jac43 E2 = local_param_jac(R2);
+                const Jac43 dA1 = through_log_exp(de1, c2, dl12, lmul(R1c, E2));
+                const Jac43 dA2 = through_log_exp(de2, c3, dl23, rmul(conj_cols(E2), R3));
+                block = jadd(lmul(R0A0, rmul(dA1, A2)), lmul(R0A0A1, dA2));
+                break;
+            }
+            default:
+            {
+                const Jac43 dA2 = through_log_exp(de2, c3, dl23, lmul(R2c, local_param_jac(R3)));
+                block = lmul(R0A0A1, dA2);
+                break;
+            }
+            }
+            return qmul(R0A0A1, A2);
+        }
+    }
+
     // SO(3) exponential as a unit quaternion (what Spline.h:302,326 gets from
     // Sophus::SO3d::exp): series below theta^2 < 1e-20, closed form above.
     MBAVO_HD Quat so3_exp(const double om[3])
