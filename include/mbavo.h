@@ -52,6 +52,10 @@ typedef struct mbavo_problem {
     const double *d_knots_R;              /* storages.cuda_spline_ctrl_knots_data_R, 4N xyzw */
     const int *h_start_idx;               /* cpu_ctrl_knot_start_indices, F (host; only read by host merges) */
     double huber_a;
+    int grad_fp16;                        /* 0: d_ref_dIxy is float [dx,dy] per pixel (reference layout, Gradient.h:16-75);
+                                             1: d_ref_dIxy is IEEE half [dx,dy] per pixel (4 B/pixel, BASELINE configs[4]).
+                                             Central differences of an 8-bit image are multiples of 0.5 in [-127.5, 127.5],
+                                             exactly representable in fp16, so both formats give bit-identical results. */
 } mbavo_problem;
 
 /* ---- context: owns all device scratch (replaces initialize/free_shared_cuda_storages,
@@ -171,6 +175,8 @@ int mbavo_optimize_trajectory(mbavo_ctx *ctx, const mbavo_track_opts *opts, cons
  * core/image_proc/Gradient.h:16-75) */
 int mbavo_pyramid_down_u8(const unsigned char *d_src, int H, int W, unsigned char *d_dst, void *hip_stream);
 int mbavo_image_gradients_u8(const unsigned char *d_src, int H, int W, float *d_dIxy, void *hip_stream);
+/* same gradient image stored as IEEE half pairs (fp16 pyramid, mbavo_problem.grad_fp16 = 1) */
+int mbavo_image_gradients_u8_half(const unsigned char *d_src, int H, int W, void *d_dIxy_half, void *hip_stream);
 
 /* ---- multi-GPU: in-place sum of the packed blocks over all ranks (RCCL over xGMI).
  * `rccl_comm` is an ncclComm_t created by the caller; count in doubles. */

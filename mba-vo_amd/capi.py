@@ -23,6 +23,7 @@ class Problem(C.Structure):
         ("d_outlier", vp), ("num_bad", C.c_int), ("intrinsics", C.c_double * 4),
         ("d_cap_time", vp), ("d_exp_time", vp), ("t0", C.c_double), ("dt", C.c_double),
         ("d_knots_t", vp), ("d_knots_R", vp), ("h_start_idx", c_ip), ("huber_a", C.c_double),
+        ("grad_fp16", C.c_int),
     ]
 
 
@@ -63,7 +64,7 @@ SYMBOLS = [
     "mbavo_lm_new", "mbavo_lm_delete", "mbavo_lm_reset", "mbavo_lm_step_accepted", "mbavo_lm_step_rejected",
     "mbavo_lm_get_radius", "mbavo_tr_new", "mbavo_tr_delete", "mbavo_tr_reset", "mbavo_tr_step_quality",
     "mbavo_tr_step_accepted", "mbavo_spline_get_pose", "mbavo_spline_plus", "mbavo_segment_start_index",
-    "mbavo_optimize_trajectory", "mbavo_pyramid_down_u8", "mbavo_image_gradients_u8", "mbavo_allreduce_blocks",
+    "mbavo_optimize_trajectory", "mbavo_pyramid_down_u8", "mbavo_image_gradients_u8", "mbavo_image_gradients_u8_half", "mbavo_allreduce_blocks",
     "mbavo_profile", "mbavo_profile_read", "mbavo_version",
 ]
 
@@ -135,6 +136,7 @@ def load():
                                             C.POINTER(TraceRec), C.c_int]
     L.mbavo_pyramid_down_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.mbavo_image_gradients_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.mbavo_image_gradients_u8_half.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.mbavo_allreduce_blocks.argtypes = [vp, vp, vp, C.c_longlong]
     L.mbavo_profile.argtypes = [vp, C.c_int]
     L.mbavo_profile_read.argtypes = [vp, c_dp, c_ip]

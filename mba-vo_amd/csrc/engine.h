@@ -36,7 +36,7 @@ namespace mbavo
         double t0, dt;
         double huber_a;
         double inv_num_residuals;
-        int S, F, K, P, N, H, W, kp_stride;
+        int S, F, K, P, N, H, W, kp_stride, grad_fp16;
         int pose_base;        // first PoseEntry of this problem (entry = f*S + s)
         int bf_base;          // first (problem, frame) slot
         long long pixel_base; // first pixel of this problem in the rho scratch (f*K*P + kp*P + p)

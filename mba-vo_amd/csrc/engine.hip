@@ -320,7 +320,7 @@ namespace mbavo
         const ProblemDesc &d = descs[tile.prob];
         const int S = d.S, K = d.K, P = d.P, frame = tile.frame;
         Camera cam;
-        cam.fx = d.fx; cam.fy = d.fy; cam.cx = d.cx; cam.cy = d.cy; cam.H = d.H; cam.W = d.W;
+        cam.fx = d.fx; cam.fy = d.fy; cam.cx = d.cx; cam.cy = d.cy; cam.H = d.H; cam.W = d.W; cam.grad_fp16 = d.grad_fp16;
         // The frame's S table entries are read with wave-uniform addresses -> scalar loads.  (Staging the table
         // in LDS and reading it as a broadcast was measured 1.5x SLOWER on the fused kernel: one ds_read per FMA
         // operand instead of an SGPR operand.)
@@ -560,6 +560,7 @@ namespace mbavo
             const int num_residuals = (p.K - p.num_bad) * p.F * p.P;
             d.inv_num_residuals = 1.0 / num_residuals;
             d.S = p.S; d.F = p.F; d.K = p.K; d.P = p.P; d.N = p.N; d.H = p.H; d.W = p.W; d.kp_stride = p.kp_stride;
+            d.grad_fp16 = p.grad_fp16 ? 1 : 0;
             d.pose_base = entries; d.bf_base = bf; d.pixel_base = pixels; d.patch_base = patches;
             entries += p.F * p.S;
             bf += p.F;

@@ -2,6 +2,7 @@
 // central-difference gradient image (core/measurements/ImagePyramid.h:59-99,
 // core/image_proc/Gradient.h:16-75).  Pure streaming kernels (HBM-bound).
 #include "../../include/mbavo.h"
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
 namespace mbavo
@@ -33,7 +34,29 @@ namespace mbavo
         }
         g[i] = v;
     }
+    // the same differences stored as half pairs: every value is a multiple of 0.5 in [-127.5, 127.5] -> exact
+    __global__ void k_gradients_half(const unsigned char *__restrict__ src, int H, int W, __half2 *__restrict__ g)
+    {
+        const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+        if (x >= W || y >= H) return;
+        const size_t i = (size_t)y * W + x;
+        float dx = 0.f, dy = 0.f;
+        if (!(x == 0 || y == 0 || x == W - 1 || y == H - 1))
+        {
+            dx = 0.5f * ((float)src[i + 1] - (float)src[i - 1]);
+            dy = 0.5f * ((float)src[i + W] - (float)src[i - W]);
+        }
+        g[i] = __floats2half2_rn(dx, dy);
+    }
 } // namespace mbavo
+
+extern "C" int mbavo_image_gradients_u8_half(const unsigned char *d_src, int H, int W, void *d_dIxy_half, void *stream)
+{
+    if (!d_src || !d_dIxy_half || H < 1 || W < 1) return MBAVO_E_ARG;
+    hipLaunchKernelGGL(mbavo::k_gradients_half, dim3((W + 255) / 256, H), dim3(256), 0, (hipStream_t)stream, d_src, H, W,
+                       (__half2 *)d_dIxy_half);
+    return (int)hipGetLastError();
+}
 
 extern "C" int mbavo_pyramid_down_u8(const unsigned char *d_src, int H, int W, unsigned char *d_dst, void *stream)
 {

@@ -86,6 +86,7 @@ namespace mbavo
     {
         double fx, fy, cx, cy;
         int H, W;
+        int grad_fp16 = 0; // gradient image stored as half pairs (4 B/pixel) instead of float pairs
     };
 
     // unit ray through an integer pixel; z uses the reference's fp32 sqrt (A4)
@@ -106,6 +107,27 @@ namespace mbavo
     // taps at the last row/column and never reads outside the buffer (A6).
     struct __attribute__((packed, aligned(1))) UnalignedU16 { unsigned short v; };
     struct __attribute__((aligned(8))) Float4A8 { float v[4]; };
+    struct __attribute__((aligned(4))) Half4A4 { unsigned short v[4]; };
+
+    // IEEE half -> float (exact); subnormals and signed zeros included, inf/nan not needed for gradients
+    MBAVO_HD float half_bits_to_float(unsigned short h)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (float)__builtin_bit_cast(_Float16, h);
+#else
+        const unsigned sign = (unsigned)(h & 0x8000u) << 16;
+        const int e = (h >> 10) & 0x1f;
+        const unsigned m = h & 0x3ffu;
+        float v;
+        if (e == 0) v = (float)m * 5.9604644775390625e-08f; // m * 2^-24
+        else
+        {
+            unsigned bits = ((unsigned)(e + 112) << 23) | (m << 13);
+            memcpy(&v, &bits, 4);
+        }
+        return sign ? -v : v;
+#endif
+    }
 
     struct TapLoads
     {
@@ -117,7 +139,7 @@ namespace mbavo
 
     template <bool WITH_GRAD>
     MBAVO_HD void tap_fetch(const unsigned char *__restrict__ I, const float *__restrict__ G, int H, int W,
-                            double x, double y, TapLoads &t)
+                            double x, double y, TapLoads &t, int grad_fp16 = 0)
     {
 #pragma clang fp contract(off)
         t.ok = !(x < 0 || x > W - 1 || y < 0 || y > H - 1);
@@ -142,10 +164,20 @@ namespace mbavo
         t.r1 = ((const MBAVO_GLOBAL UnalignedU16 *)(Ig + idx + W))->v;
         if (WITH_GRAD)
         {
-            const MBAVO_GLOBAL float *Gg = (const MBAVO_GLOBAL float *)G;
-            const Float4A8 a = *(const MBAVO_GLOBAL Float4A8 *)(Gg + 2 * idx);
-            const Float4A8 b = *(const MBAVO_GLOBAL Float4A8 *)(Gg + 2 * (idx + W));
-            for (int i = 0; i < 4; ++i) { t.g0[i] = a.v[i]; t.g1[i] = b.v[i]; }
+            if (grad_fp16)
+            { // 8 bytes per row pair instead of 16
+                const MBAVO_GLOBAL unsigned short *Gh = (const MBAVO_GLOBAL unsigned short *)G;
+                const Half4A4 a = *(const MBAVO_GLOBAL Half4A4 *)(Gh + 2 * idx);
+                const Half4A4 b = *(const MBAVO_GLOBAL Half4A4 *)(Gh + 2 * (idx + W));
+                for (int i = 0; i < 4; ++i) { t.g0[i] = half_bits_to_float(a.v[i]); t.g1[i] = half_bits_to_float(b.v[i]); }
+            }
+            else
+            {
+                const MBAVO_GLOBAL float *Gg = (const MBAVO_GLOBAL float *)G;
+                const Float4A8 a = *(const MBAVO_GLOBAL Float4A8 *)(Gg + 2 * idx);
+                const Float4A8 b = *(const MBAVO_GLOBAL Float4A8 *)(Gg + 2 * (idx + W));
+                for (int i = 0; i < 4; ++i) { t.g0[i] = a.v[i]; t.g1[i] = b.v[i]; }
+            }
         }
     }
 
@@ -285,7 +317,7 @@ namespace mbavo
         const double Py = f.sc * f.ry + pe.t[1];
         const double u = cam.fx * (Px * iz) + cam.cx;
         const double v = cam.fy * (Py * iz) + cam.cy;
-        tap_fetch<WITH_J>(I, G, cam.H, cam.W, u, v, f.taps);
+        tap_fetch<WITH_J>(I, G, cam.H, cam.W, u, v, f.taps, cam.grad_fp16);
     }
 
     template <int KDEG, bool WITH_J>

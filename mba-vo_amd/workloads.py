@@ -31,6 +31,7 @@ class Prob:
         self.knots_t, self.knots_R = np.ascontiguousarray(knots_t, np.float64).ravel(), np.ascontiguousarray(knots_R, np.float64).ravel()
         self.start_idx = np.array([synth.segment_start_index(c, t0, dt) for c in self.cap], np.int32)
         self.outlier, self.num_bad = None, 0
+        self.grad_fp16 = False  # upload the gradient image as IEEE half pairs (BASELINE configs[4])
 
     @property
     def pixel_samples(self):
@@ -110,7 +111,13 @@ class DeviceWorkload:
         B = len(probs)
         self.array = (capi.Problem * B)()
         for b, p in enumerate(probs):
-            ref, grad = up(p.ref), up(p.grad)
+            ref = up(p.ref)
+            if p.grad_fp16:
+                if not hasattr(p, "_grad_half"):
+                    p._grad_half = np.ascontiguousarray(p.grad.astype(np.float16))
+                grad = up(p._grad_half)
+            else:
+                grad = up(p.grad)
             curs = [up(c) for c in p.cur]
             cur_ptrs = torch.tensor([c.data_ptr() for c in curs], dtype=torch.int64, device=device)
             xy, z, pat = up(p.kp_xy), up(p.kp_z), up(p.pattern)
@@ -128,6 +135,7 @@ class DeviceWorkload:
             q.d_knots_t, q.d_knots_R = kt.data_ptr(), kR.data_ptr()
             q.h_start_idx = p.start_idx.ctypes.data_as(C.POINTER(C.c_int))
             q.huber_a = p.huber
+            q.grad_fp16 = 1 if p.grad_fp16 else 0
         self.B = B
         self.k = probs[0].k
         self.E = synth.packed_len(self.k)

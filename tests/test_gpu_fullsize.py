@@ -77,3 +77,25 @@ def test_c3_batch64_and_c5_1080p_properties(orc, mbavo, gpu_ctx):
     parts = a[0] * cut + b[0] * (p.K - cut)
     assert np.abs(whole - parts).max() <= 1e-11 * np.abs(whole).max()
     assert v5[0] > 0.95 * p.K
+
+
+def test_c5_fp16_gradient_pyramid(orc, mbavo, gpu_ctx):
+    """configs[4]: 1920x1080, S = 16, 6 control poses, fp32 vs fp16 gradient pyramid.  Stated tolerance: 0.
+    Central differences of an 8-bit image are multiples of 0.5 within [-127.5, 127.5], all exactly representable in
+    IEEE half, and taps are widened to fp32 before the (unchanged) fp32 blend -- so the packed blocks must be
+    bit-identical while the gradient image takes 4 instead of 8 bytes per pixel."""
+    import torch
+    big = wl.pyramid_pair(1080, 1920, 1, S=16, k=4, N=6, mode="dense", seed=2)
+    assert np.array_equal(big[0].grad.astype(np.float16).astype(np.float32), big[0].grad)
+    fb32, v32 = _run(gpu_ctx, big)
+    for p in big:
+        p.grad_fp16 = True
+    fb16, v16 = _run(gpu_ctx, big)
+    assert np.array_equal(fb16, fb32) and np.array_equal(v16, v32)
+    # the device producer of the half-precision gradient image matches the host one
+    src = torch.from_numpy(big[0].ref).to("cuda:0")
+    H, W = big[0].ref.shape
+    g = torch.zeros(H * W * 2, dtype=torch.float16, device="cuda:0")
+    assert gpu_ctx.lib.mbavo_image_gradients_u8_half(src.data_ptr(), H, W, g.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(g.cpu().numpy().reshape(H, W, 2), big[0].grad.astype(np.float16))
