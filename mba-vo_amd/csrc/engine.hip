@@ -557,8 +557,8 @@ namespace mbavo
             d.fx = p.intrinsics[0]; d.fy = p.intrinsics[1]; d.cx = p.intrinsics[2]; d.cy = p.intrinsics[3];
             d.t0 = p.t0; d.dt = p.dt; d.huber_a = p.huber_a;
             // 1/((K - num_bad)*F*P), counting out-of-bounds pixels (spline_update_step.cpp:116-117)
-            const int num_residuals = (p.K - p.num_bad) * p.F * p.P;
-            d.inv_num_residuals = 1.0 / num_residuals;
+            const long long num_residuals = (long long)(p.K - p.num_bad) * p.F * p.P;
+            d.inv_num_residuals = num_residuals > 0 ? 1.0 / (double)num_residuals : 0.0; // empty problem: all-zero blocks
             d.S = p.S; d.F = p.F; d.K = p.K; d.P = p.P; d.N = p.N; d.H = p.H; d.W = p.W; d.kp_stride = p.kp_stride;
             d.grad_fp16 = p.grad_fp16 ? 1 : 0;
             d.pose_base = entries; d.bf_base = bf; d.pixel_base = pixels; d.patch_base = patches;
@@ -586,7 +586,7 @@ namespace mbavo
             }
             return n;
         };
-        long long lo = kThreads, hi = pixels > kThreads ? pixels : kThreads;
+        long long lo = env_int("MBAVO_MIN_TILE_PX", 256), hi = pixels > lo ? pixels : lo;
         if (count_tiles(lo) > target_tiles)
         {
             while (lo < hi)

@@ -142,13 +142,19 @@ namespace mbavo
                             double x, double y, TapLoads &t, int grad_fp16 = 0)
     {
 #pragma clang fp contract(off)
-        t.ok = !(x < 0 || x > W - 1 || y < 0 || y > H - 1);
+        // Branch-free: an out-of-bounds (or NaN) coordinate only clears t.ok; its window is clamped into the image
+        // so the loads stay legal and the garbage it produces is discarded by the caller.  Keeping the sample loop
+        // free of divergent control flow lets the compiler overlap the issue of sample s+1 with the retire of s.
+        t.ok = !(x < 0 || x > W - 1 || y < 0 || y > H - 1) && x == x && y == y;
+#if defined(MBAVO_TAP_EARLY_RETURN)
         if (!t.ok) return;
-        int xi = (int)x, yi = (int)y;
+#endif
+        const double xs = t.ok ? x : 0.0, ys = t.ok ? y : 0.0;
+        int xi = (int)xs, yi = (int)ys;
         xi = xi > W - 2 ? W - 2 : xi;
         yi = yi > H - 2 ? H - 2 : yi;
-        const float dx = (float)(x - xi);
-        const float dy = (float)(y - yi);
+        const float dx = (float)(xs - xi);
+        const float dy = (float)(ys - yi);
         const float dxdy = dx * dy;
         t.w00 = 1.0f - dx - dy + dxdy;
         t.w01 = dx - dxdy;
@@ -402,12 +408,18 @@ namespace mbavo
         {
             if (s + 1 < S) sample_issue<KDEG, WITH_J>(MBAVO_TAB(s + 1), ray, depth, iz, cam, I_ref, G_ref, fb);
             ok = ok && fa.taps.ok;
-            if (ok) sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, iz, cam, isum, Jrow);
+#if !defined(MBAVO_BRANCH_FREE_RETIRE)
+            if (ok)
+#endif
+            sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, iz, cam, isum, Jrow);
             if (s + 1 < S)
             {
                 if (s + 2 < S) sample_issue<KDEG, WITH_J>(MBAVO_TAB(s + 2), ray, depth, iz, cam, I_ref, G_ref, fa);
                 ok = ok && fb.taps.ok;
-                if (ok) sample_retire<KDEG, WITH_J>(MBAVO_TAB(s + 1), fb, ray, iz, cam, isum, Jrow);
+#if !defined(MBAVO_BRANCH_FREE_RETIRE)
+                if (ok)
+#endif
+                sample_retire<KDEG, WITH_J>(MBAVO_TAB(s + 1), fb, ray, iz, cam, isum, Jrow);
             }
         }
         if (!ok)

@@ -763,7 +763,7 @@ void orc_evaluate(const orc_problem *p, double *patch_blocks, double *frame_bloc
     const int S = p->S, F = p->F, K = p->K, P = p->P, k = p->k;
     const int with_j = H != NULL;
     const int num_residuals = (K - p->num_bad) * F * P; /* A13 (:116-117) */
-    const double inv = 1.0 / num_residuals;
+    const double inv = num_residuals > 0 ? 1.0 / num_residuals : 0.0; /* empty problem (reference: division by zero) */
     double *poses = (double *)malloc(sizeof(double) * (size_t)F * S * 7);
     double *Jt = with_j ? (double *)malloc(sizeof(double) * (size_t)F * S * 9 * k) : NULL;
     double *JR = with_j ? (double *)malloc(sizeof(double) * (size_t)F * S * 12 * k) : NULL;
@@ -792,7 +792,7 @@ void orc_evaluate_fast(const orc_problem *p, int num_threads, double *frame_bloc
     const int S = p->S, F = p->F, K = p->K, P = p->P, k = p->k;
     const int n6k = 6 * k, ndim = n6k + 1, E = ndim * (ndim + 1) / 2;
     const int with_j = H != NULL;
-    const double inv = 1.0 / ((K - p->num_bad) * F * P);
+    const double inv = (K - p->num_bad) * F * P > 0 ? 1.0 / ((K - p->num_bad) * F * P) : 0.0;
     if (num_threads < 1) num_threads = 1;
     double *poses = (double *)malloc(sizeof(double) * (size_t)F * S * 7);
     double *Jt = with_j ? (double *)malloc(sizeof(double) * (size_t)F * S * 9 * k) : NULL;

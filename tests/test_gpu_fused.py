@@ -30,6 +30,8 @@ CASES = {
     "k4_K1": dict(S=8, F=1, k=4, P=8, K=1),
     "k4_P128": dict(S=4, F=1, k=4, P=128, K=9),
     "k4_6knots_C5shape": dict(H=135, W=240, S=16, F=2, k=4, P=1, kp="dense", margin=2, N=6),
+    "k4_S64_F16_max_sizes": dict(S=64, F=16, k=4, P=8, K=25, trans_scale=0.002, rot_scale=0.02, exp=0.3),   # reference maxima: 64 samples, 16 frames
+    "k2_S64_F16_max_sizes": dict(S=64, F=16, k=2, P=8, K=25, trans_scale=0.002, rot_scale=0.02, exp=0.3),
 }
 
 
@@ -164,3 +166,23 @@ def test_rccl_allreduce_entry_point(mbavo, gpu_ctx):
     assert torch.equal(fb, ref) and float(ref.abs().max()) > 0
     rccl.ncclCommDestroy.argtypes = [C.c_void_p]
     rccl.ncclCommDestroy(comm)
+
+
+def test_empty_and_ragged_batches(orc, mbavo, gpu_ctx):
+    """K = 0 (no keypoints survived detection) alone and inside a batch: all-zero blocks instead of the reference's
+    division by zero; the neighbours in the batch are unaffected."""
+    full = scenes.Scene(S=4, F=2, k=4, P=8, K=60, seed=3)
+    empty = scenes.Scene(S=4, F=2, k=4, P=8, K=60, seed=4)
+    empty.kp_xy, empty.kp_z, empty.K = np.zeros((0, 2)), np.zeros(0), 0
+    tiny = scenes.Scene(S=8, F=1, k=4, P=3, K=1, seed=5)
+    ds = [scenes.DeviceScene(full), scenes.DeviceScene(empty), scenes.DeviceScene(tiny)]
+    # zero-length device tensors have a null data_ptr: give the empty problem valid (unused) pointers
+    ds[1].kp_xy_ptr, ds[1].kp_z = ds[0].kp_xy_ptr, ds[0].kp_z
+    fb, pc, valid = scenes.gpu_eval_batch(gpu_ctx, ds, 4)
+    assert np.all(fb[2:4] == 0.0) and np.all(valid[2:4] == 0.0)
+    for sc, rows in ((full, slice(0, 2)), (tiny, slice(4, 5))):
+        p, keep = sc.oracle_problem(orc)
+        ro = orc.evaluate(p)
+        assert _rel(fb[rows], ro["frame_blocks"]) < RTOL
+    alone, _, _ = scenes.gpu_eval_batch(gpu_ctx, [ds[1]], 4)
+    assert np.all(alone == 0.0)
