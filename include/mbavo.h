@@ -178,6 +178,14 @@ int mbavo_image_gradients_u8(const unsigned char *d_src, int H, int W, float *d_
 /* same gradient image stored as IEEE half pairs (fp16 pyramid, mbavo_problem.grad_fp16 = 1) */
 int mbavo_image_gradients_u8_half(const unsigned char *d_src, int H, int W, void *d_dIxy_half, void *hip_stream);
 
+/* ---- synthetic blurred frame: synthesize_motion_blurred_img (ba_tracker/generate_synthetic_data.cpp:182-214):
+ * mean of `num_samples` warps of the sharp image along the spline over the exposure, on a fronto-parallel plane.
+ * Knots are host arrays; d_ref / d_out are device u8 images.  Synchronous. */
+int mbavo_synthesize_blur(const unsigned char *d_ref, int H, int W, double plane_depth, const double intrinsics[4],
+                          int spline_deg_k, double t0, double dt, const double *h_knots_t, const double *h_knots_R,
+                          int N, double cap_time, double exp_time, int num_samples, unsigned char *d_out,
+                          void *hip_stream);
+
 /* ---- multi-GPU: in-place sum of the packed blocks over all ranks (RCCL over xGMI).
  * `rccl_comm` is an ncclComm_t created by the caller; count in doubles. */
 int mbavo_allreduce_blocks(mbavo_ctx *ctx, void *rccl_comm, double *d_blocks, long long count);

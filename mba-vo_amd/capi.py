@@ -64,7 +64,7 @@ SYMBOLS = [
     "mbavo_lm_new", "mbavo_lm_delete", "mbavo_lm_reset", "mbavo_lm_step_accepted", "mbavo_lm_step_rejected",
     "mbavo_lm_get_radius", "mbavo_tr_new", "mbavo_tr_delete", "mbavo_tr_reset", "mbavo_tr_step_quality",
     "mbavo_tr_step_accepted", "mbavo_spline_get_pose", "mbavo_spline_plus", "mbavo_segment_start_index",
-    "mbavo_optimize_trajectory", "mbavo_pyramid_down_u8", "mbavo_image_gradients_u8", "mbavo_image_gradients_u8_half", "mbavo_allreduce_blocks",
+    "mbavo_optimize_trajectory", "mbavo_pyramid_down_u8", "mbavo_image_gradients_u8", "mbavo_image_gradients_u8_half", "mbavo_synthesize_blur", "mbavo_allreduce_blocks",
     "mbavo_profile", "mbavo_profile_read", "mbavo_version",
 ]
 
@@ -137,6 +137,8 @@ def load():
     L.mbavo_pyramid_down_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.mbavo_image_gradients_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.mbavo_image_gradients_u8_half.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.mbavo_synthesize_blur.argtypes = [vp, C.c_int, C.c_int, C.c_double, c_dp, C.c_int, C.c_double, C.c_double, c_dp,
+                                        c_dp, C.c_int, C.c_double, C.c_double, C.c_int, vp, vp]
     L.mbavo_allreduce_blocks.argtypes = [vp, vp, vp, C.c_longlong]
     L.mbavo_profile.argtypes = [vp, C.c_int]
     L.mbavo_profile_read.argtypes = [vp, c_dp, c_ip]

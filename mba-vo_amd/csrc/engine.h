@@ -74,6 +74,10 @@ namespace mbavo
         void profile_enable(bool on);
         int profile_read(double *fused_ms_sum, int *launches);
 
+        // named device scratch that persists across calls (grown on demand, freed with the engine): the LM loop
+        // keeps its knots / flags / patch-cost buffers here instead of hipMalloc'ing per call
+        void *named_scratch(int slot, size_t bytes);
+
         // persistent staging owned by the context (used by mbavo_eval / tracker)
         double *scratch_frame_blocks(size_t n_doubles);
         double *host_frame_blocks(size_t n_doubles);
@@ -107,6 +111,9 @@ namespace mbavo
         int status_seen_ = 0;
         void *d_fb_ = nullptr; size_t cap_fb_ = 0;
         void *h_fb_ = nullptr; size_t cap_hfb_ = 0;
+
+        void *slots_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        size_t slot_cap_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
         bool prof_on_ = false;
         std::vector<hipEvent_t> prof_ev_; // pairs (start, stop)

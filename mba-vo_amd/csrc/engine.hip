@@ -499,6 +499,8 @@ namespace mbavo
         for (void *p : bufs)
             if (p) (void)hipFree(p);
         if (h_fb_) (void)hipHostFree(h_fb_);
+        for (void *p : slots_)
+            if (p) (void)hipFree(p);
         for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
     }
 
@@ -511,6 +513,13 @@ namespace mbavo
         HIP_TRY(hipMalloc(ptr, want));
         *cap = want;
         return 0;
+    }
+
+    void *Engine::named_scratch(int slot, size_t bytes)
+    {
+        if (slot < 0 || slot >= 8) return nullptr;
+        if (ensure(&slots_[slot], &slot_cap_[slot], bytes ? bytes : 1) != 0) return nullptr;
+        return slots_[slot];
     }
 
     double *Engine::scratch_frame_blocks(size_t n)

@@ -2,8 +2,11 @@
 // central-difference gradient image (core/measurements/ImagePyramid.h:59-99,
 // core/image_proc/Gradient.h:16-75).  Pure streaming kernels (HBM-bound).
 #include "../../include/mbavo.h"
+#include "host_math.h"
+#include "pixel_math.h"
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+#include <vector>
 
 namespace mbavo
 {
@@ -48,7 +51,78 @@ namespace mbavo
         }
         g[i] = __floats2half2_rn(dx, dy);
     }
+    // Synthetic motion blur (generate_synthetic_data.cpp:127-214): every output pixel is warped into the sharp
+    // image through each of the n sampled poses, every warp is truncated to 8 bits as warp_image() stores it, the n
+    // images are averaged in float and rounded to nearest even like cv::Mat::convertTo(CV_8U).
+    // The warp follows compute_pixel_intensity.h:113-144 operation by operation, without FMA contraction, so the
+    // generator is bit-identical to the CPU one (a 1e-13 difference in the tap coordinate can flip an 8-bit
+    // truncation); this is input synthesis, not the hot path, so the extra flops do not matter.
+    __global__ void k_synth_blur(const unsigned char *__restrict__ ref, int H, int W, double D, double fx, double fy,
+                                 double cx, double cy, const double *__restrict__ poses /*n x 7*/, int n,
+                                 unsigned char *__restrict__ out)
+    {
+#pragma clang fp contract(off)
+        const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+        if (c >= W || r >= H) return;
+        double xh = ((double)c - cx) / fx;
+        double yh = ((double)r - cy) / fy;
+        const double zh = 1. / (double)sqrtf((float)(1. + xh * xh + yh * yh));
+        xh *= zh;
+        yh *= zh;
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i)
+        {
+            const double *p = poses + 7 * i;
+            const double x = p[0], y = p[1], z = p[2], qx = p[3], qy = p[4], qz = p[5], qw = p[6];
+            const double lambda = 2. * xh * (qx * qz - qw * qy) + 2. * yh * (qx * qw + qy * qz) +
+                                  zh * (qw * qw - qx * qx - qy * qy + qz * qz);
+            const double s = (D - z) / lambda;
+            const double pc[3] = {s * xh, s * yh, s * zh};
+            double pr[3];
+            qrotate(Quat{qx, qy, qz, qw}, pc, pr);
+            const double Px = pr[0] + x, Py = pr[1] + y, Pz = pr[2] + z;
+            const double iz = 1. / (Pz + 1e-8);
+            const double u = fx * (Px * iz) + cx, v = fy * (Py * iz) + cy;
+            double val = 0.0, gx, gy;
+            if (!bilinear_tap<false>(ref, nullptr, H, W, u, v, val, gx, gy)) val = 0.0;
+            acc = acc + (float)(unsigned char)val;
+        }
+        const float m = acc / (float)n;
+        int q = (int)rintf(m);
+        q = q < 0 ? 0 : (q > 255 ? 255 : q);
+        out[(size_t)r * W + c] = (unsigned char)q;
+    }
 } // namespace mbavo
+
+extern "C" int mbavo_synthesize_blur(const unsigned char *d_ref, int H, int W, double plane_depth, const double intr[4],
+                                     int k, double t0, double dt, const double *h_knots_t, const double *h_knots_R, int N,
+                                     double cap, double exp_t, int num_samples, unsigned char *d_out, void *stream)
+{
+    if (!d_ref || !d_out || !intr || !h_knots_t || !h_knots_R || (k != 2 && k != 4) || num_samples < 2 || H < 2 || W < 2)
+        return MBAVO_E_ARG;
+    SLAM::Core::SplineSE3 spline(t0, dt);
+    spline.setSplineDegK(k);
+    for (int i = 0; i < N; ++i) spline.InsertControlKnot(h_knots_R + 4 * i, h_knots_t + 3 * i);
+    std::vector<double> poses((size_t)num_samples * 7);
+    for (int i = 0; i < num_samples; ++i)
+    { // sample times of synthesize_motion_blurred_img (:201): cap - exp/2 + i*exp/(n-1)
+        const double t = cap - exp_t * 0.5 + i * exp_t / (num_samples - 1);
+        if (!spline.GetPose(t, &poses[7 * i + 3], &poses[7 * i])) return MBAVO_E_RANGE;
+    }
+    double *d_poses = nullptr;
+    hipError_t e = hipMalloc((void **)&d_poses, poses.size() * sizeof(double));
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(d_poses, poses.data(), poses.size() * sizeof(double), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e == hipSuccess)
+    {
+        hipLaunchKernelGGL(mbavo::k_synth_blur, dim3((W + 127) / 128, H), dim3(128), 0, (hipStream_t)stream, d_ref, H, W,
+                           plane_depth, intr[0], intr[1], intr[2], intr[3], d_poses, num_samples, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(d_poses);
+    return (int)e;
+}
 
 extern "C" int mbavo_image_gradients_u8_half(const unsigned char *d_src, int H, int W, void *d_dIxy_half, void *stream)
 {

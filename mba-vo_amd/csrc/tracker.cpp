@@ -86,13 +86,15 @@ namespace mbavo
         std::vector<unsigned char> flags;
 
         TRK_HIP(hipSetDevice(eng.device()));
-        TRK_HIP(hipMalloc((void **)&d_cap, sizeof(double) * F));
-        TRK_HIP(hipMalloc((void **)&d_exp, sizeof(double) * F));
-        TRK_HIP(hipMalloc((void **)&d_kt, sizeof(double) * 3 * N));
-        TRK_HIP(hipMalloc((void **)&d_kR, sizeof(double) * 4 * N));
-        TRK_HIP(hipMalloc((void **)&d_fb, sizeof(double) * (size_t)F * E));
-        TRK_HIP(hipMalloc((void **)&d_pc, sizeof(double) * (size_t)F * (maxK > 0 ? maxK : 1)));
-        TRK_HIP(hipMalloc((void **)&d_flags, maxK > 0 ? maxK : 1));
+        // engine-owned scratch, reused by every call (no hipMalloc / hipFree in the tracking loop)
+        d_cap = (double *)eng.named_scratch(0, sizeof(double) * F);
+        d_exp = (double *)eng.named_scratch(1, sizeof(double) * F);
+        d_kt = (double *)eng.named_scratch(2, sizeof(double) * 3 * N);
+        d_kR = (double *)eng.named_scratch(3, sizeof(double) * 4 * N);
+        d_fb = (double *)eng.named_scratch(4, sizeof(double) * (size_t)F * E);
+        d_pc = (double *)eng.named_scratch(5, sizeof(double) * (size_t)F * (maxK > 0 ? maxK : 1));
+        d_flags = (unsigned char *)eng.named_scratch(6, maxK > 0 ? maxK : 1);
+        if (!d_cap || !d_exp || !d_kt || !d_kR || !d_fb || !d_pc || !d_flags) { rc_ = (int)hipErrorOutOfMemory; goto done; }
         TRK_HIP(hipMemcpyAsync(d_cap, h_cap, sizeof(double) * F, hipMemcpyHostToDevice, st)); // :701-719
         TRK_HIP(hipMemcpyAsync(d_exp, h_exp, sizeof(double) * F, hipMemcpyHostToDevice, st));
         TRK_HIP(hipMemsetAsync(d_fb, 0, sizeof(double) * (size_t)F * E, st));
@@ -200,13 +202,6 @@ namespace mbavo
         memcpy(knots_R, spline.get_knot_data_R(), sizeof(double) * 4 * N);
         if (final_cost) *final_cost = eval_cost;
     done:
-        if (d_cap) (void)hipFree(d_cap);
-        if (d_exp) (void)hipFree(d_exp);
-        if (d_kt) (void)hipFree(d_kt);
-        if (d_kR) (void)hipFree(d_kR);
-        if (d_fb) (void)hipFree(d_fb);
-        if (d_pc) (void)hipFree(d_pc);
-        if (d_flags) (void)hipFree(d_flags);
         return rc_ ? (rc_ > 0 ? -1000 - rc_ : rc_) : ntrace;
     }
 } // namespace mbavo

@@ -166,3 +166,25 @@ def test_input_producers_on_device(orc, mbavo, gpu_ctx):
         orc.lib().orc_image_gradients_u8(orc.u8p(src), H, W, orc.fp(o_g), None)
         assert np.array_equal(d_dst.cpu().numpy().reshape(H // 2, W // 2), o_dst)
         assert np.array_equal(d_g.cpu().numpy().reshape(H, W, 2), o_g)
+
+
+def test_synthetic_blur_generator_on_device(orc, mbavo, gpu_ctx):
+    """synthesize_motion_blurred_img (generate_synthetic_data.cpp:182-214) on the device == the oracle's, byte for
+    byte: the blurred frames of the tracking tests can be produced by either."""
+    import torch
+    L = mbavo.load()
+    H, W = 120, 160
+    ref = synth.texture_image(H, W, seed=9, octaves=(32, 16, 8, 4))
+    intr = np.array([W / 2.0, W / 2.0, W / 2.0, H / 2.0])
+    for k, N in ((4, 6), (2, 4)):
+        kt, kR = synth.harness_spline(0.02, 0.3, N)
+        kt, kR = np.ascontiguousarray(kt.ravel()), np.ascontiguousarray(kR.ravel())
+        o = np.zeros((H, W), np.uint8)
+        orc.lib().orc_synthesize_blur(orc.u8p(ref), H, W, 7.5, orc.dp(intr), k, 0.0, 0.5, orc.dp(kt), orc.dp(kR), 0.75, 0.1, 16, orc.u8p(o))
+        d_ref = _t(ref)
+        d_out = torch.zeros(H * W, dtype=torch.uint8, device="cuda:0")
+        assert L.mbavo_synthesize_blur(d_ref.data_ptr(), H, W, 7.5, mbavo.capi.dp(intr), k, 0.0, 0.5, mbavo.capi.dp(kt),
+                                       mbavo.capi.dp(kR), N, 0.75, 0.1, 16, d_out.data_ptr(), None) == 0
+        g = d_out.cpu().numpy().reshape(H, W)
+        assert np.array_equal(g, o)
+        assert g.std() > 5 and np.abs(g.astype(int) - ref.astype(int)).max() > 0   # non-trivial image, actually warped
