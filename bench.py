@@ -66,6 +66,23 @@ def build_workload(name, rank, world):
     raise ValueError(name)
 
 
+def measured_hbm_traffic(workload):
+    """HBM bytes per launch of the fused kernel from the committed TCC counter passes (tools/hbm_traffic.sh ->
+    profiles/r01_hbm_counters.json; the counters need rocprofv3, so they are collected outside this process).
+    FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE under-counts 2x on gfx950 (calibrated in the same file on a
+    256 MiB copy: 131084 KiB read), WRITE_SIZE is exact."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_counters.json")
+    if workload != "c2_dense" or not os.path.exists(path):
+        return None
+    try:
+        h = json.load(open(path))
+        rd = [v["mean"] for k, v in h.items() if k.startswith("bench|FETCH_SIZE|") and "k_fused" in k][0]
+        wr = [v["mean"] for k, v in h.items() if k.startswith("bench|WRITE_SIZE|") and "k_fused" in k][0]
+        return (2.0 * rd + wr) * 1024.0
+    except Exception:
+        return None
+
+
 def cpu_baseline(probs, budget_s):
     """Oracle (plain-C port of the reference path) timed on the host cores on the same workload:
     one evaluation with all cores, repeated while the budget allows, plus one single-thread
@@ -184,7 +201,7 @@ def main():
                        "pixel_samples_per_step_per_rank": ps_rank, "pixel_samples_launched": ps_launched,
                        "parallelism": "independent pairs per GPU + all-reduce of packed J^T J blocks" if world > 1 else "1 GPU"},
             "roofline": {"bound": "mfma", "achieved": round(ach_tf, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach_tf / FP64_PEAK_TFLOPS, 5), "traffic": None,
+                         "frac": round(ach_tf / FP64_PEAK_TFLOPS, 5), "traffic": measured_hbm_traffic(args.workload),
                          "kernel": "k_fused<4,true>", "kernel_ms": round(k_ms, 6), "launches_timed": int(nlaunch[0]),
                          "algorithmic_flops_per_launch": flops,
                          "note": "FP64 pipe is the binding roofline (FP64 vector peak == f64 MFMA peak, 78.6 TFLOP/s): "
@@ -192,7 +209,9 @@ def main():
                                  "writes them (SURVEY.md 8d), so CSE in the kernel raises this fraction"},
             "roofline_hbm": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": nbytes,
-                             "note": "compulsory bytes only; compute-bound kernel, low by construction"},
+                             "traffic": measured_hbm_traffic(args.workload),
+                             "note": "compulsory bytes only; compute-bound kernel, low by construction; traffic = "
+                                     "(2*FETCH_SIZE + WRITE_SIZE) KiB from profiles/r01_hbm_counters.json"},
         }
         if not args.no_cpu_baseline:
             cb, fb_cpu = cpu_baseline(probs, args.cpu_seconds)
