@@ -55,7 +55,8 @@ typedef struct mbavo_problem {
     int grad_fp16;                        /* 0: d_ref_dIxy is float [dx,dy] per pixel (reference layout, Gradient.h:16-75);
                                              1: d_ref_dIxy is IEEE half [dx,dy] per pixel (4 B/pixel, BASELINE configs[4]).
                                              Central differences of an 8-bit image are multiples of 0.5 in [-127.5, 127.5],
-                                             exactly representable in fp16, so both formats give bit-identical results. */
+                                             exactly representable in fp16, so both formats see identical tap values (results agree to rounding).
+                                             All problems of one mbavo_eval_batch call must use the same format. */
 } mbavo_problem;
 
 /* ---- context: owns all device scratch (replaces initialize/free_shared_cuda_storages,

@@ -298,7 +298,7 @@ namespace mbavo
         return v;
     }
 
-    template <int KD, bool WITH_J>
+    template <int KD, bool WITH_J, bool HALF_GRAD>
     __global__ __launch_bounds__(kThreads) void k_fused(const ProblemDesc *__restrict__ descs,
                                                         const TileDesc *__restrict__ tiles,
                                                         const PoseEntry<KD> *__restrict__ table,
@@ -320,7 +320,7 @@ namespace mbavo
         const ProblemDesc &d = descs[tile.prob];
         const int S = d.S, K = d.K, P = d.P, frame = tile.frame;
         Camera cam;
-        cam.fx = d.fx; cam.fy = d.fy; cam.cx = d.cx; cam.cy = d.cy; cam.H = d.H; cam.W = d.W; cam.grad_fp16 = d.grad_fp16;
+        cam.fx = d.fx; cam.fy = d.fy; cam.cx = d.cx; cam.cy = d.cy; cam.H = d.H; cam.W = d.W;
         // The frame's S table entries are read with wave-uniform addresses -> scalar loads.  (Staging the table
         // in LDS and reading it as a broadcast was measured 1.5x SLOWER on the fused kernel: one ds_read per FMA
         // operand instead of an SGPR operand.)
@@ -366,7 +366,7 @@ namespace mbavo
 #else
                 patch_centre(mid.t, mid.q, kx, ky, kz, cam, pcx, pcy);
 #endif
-                const bool valid = pixel_row<KD, WITH_J>(ftab, S, cam, d.ref_img, d.ref_dIxy, I_cur, pcx, pcy, kz,
+                const bool valid = pixel_row<KD, WITH_J, HALF_GRAD>(ftab, S, cam, d.ref_img, d.ref_dIxy, I_cur, pcx, pcy, kz,
                                                          d.pattern[2 * pp], d.pattern[2 * pp + 1], res, Jrow);
                 huber_weight(res, d.huber_a, w, rho);
                 rho_out[pix0 + g] = rho;
@@ -660,7 +660,7 @@ namespace mbavo
     }
 
     template <int KD, bool WITH_J>
-    static int launch_all(Engine *eng, hipStream_t st, int max_S, const ProblemDesc *descs, int B, int entries, const TileDesc *tiles, int ntiles,
+    static int launch_all(Engine *eng, hipStream_t st, int max_S, bool half_grad, const ProblemDesc *descs, int B, int entries, const TileDesc *tiles, int ntiles,
                           const int *bf_prob, const int *bf_tile_begin, int nbf, void *poses, double *rho,
                           double *patch_cost, double *patch_blocks_strided, double *partials, int *status,
                           double *frame_blocks, double *valid)
@@ -676,15 +676,22 @@ namespace mbavo
 #endif
                 ;
             (void)max_S;
-            static size_t attr_lds = 0;
-            if (lds > attr_lds)
+            static size_t attr_lds[2] = {0, 0};
+            if (lds > attr_lds[half_grad ? 1 : 0])
             {
-                HIP_TRY(hipFuncSetAttribute((const void *)k_fused<KD, WITH_J>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_lds = lds;
+                if (half_grad)
+                    HIP_TRY(hipFuncSetAttribute((const void *)k_fused<KD, WITH_J, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                else
+                    HIP_TRY(hipFuncSetAttribute((const void *)k_fused<KD, WITH_J, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_lds[half_grad ? 1 : 0] = lds;
             }
             eng->prof_mark(true);
-            hipLaunchKernelGGL((k_fused<KD, WITH_J>), dim3(ntiles), dim3(kThreads), lds, st, descs, tiles, table, rho,
-                               patch_cost, patch_blocks_strided, partials);
+            if (half_grad)
+                hipLaunchKernelGGL((k_fused<KD, WITH_J, true>), dim3(ntiles), dim3(kThreads), lds, st, descs, tiles, table, rho,
+                                   patch_cost, patch_blocks_strided, partials);
+            else
+                hipLaunchKernelGGL((k_fused<KD, WITH_J, false>), dim3(ntiles), dim3(kThreads), lds, st, descs, tiles, table, rho,
+                                   patch_cost, patch_blocks_strided, partials);
             eng->prof_mark(false);
         }
         hipLaunchKernelGGL((k_finalize<KD, WITH_J>), dim3(nbf, (Pack<KD>::E + 1 + 15) / 16), dim3(256), 0, st, descs, bf_prob,
@@ -706,8 +713,12 @@ namespace mbavo
         const int ntiles = (int)h_tiles_.size();
         int max_S = 1;
         for (const ProblemDesc &pd : h_descs_) max_S = pd.S > max_S ? pd.S : max_S;
+        // the gradient storage format selects the kernel instantiation, so it must be the same for the whole batch
+        const bool half_grad = h_descs_[0].grad_fp16 != 0;
+        for (const ProblemDesc &pd : h_descs_)
+            if ((pd.grad_fp16 != 0) != half_grad) return MBAVO_E_ARG;
 #define MBAVO_LAUNCH(KD, WJ)                                                                                      \
-    launch_all<KD, WJ>(this, stream_, max_S, descs, B, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
+    launch_all<KD, WJ>(this, stream_, max_S, half_grad, descs, B, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
                        (const int *)d_bf_tile_begin_, total_bf_, d_poses_, (double *)d_rho_, d_patch_cost,        \
                        d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid)
         if (kdeg == 4) rc = with_hessian ? MBAVO_LAUNCH(4, true) : MBAVO_LAUNCH(4, false);

@@ -86,7 +86,6 @@ namespace mbavo
     {
         double fx, fy, cx, cy;
         int H, W;
-        int grad_fp16 = 0; // gradient image stored as half pairs (4 B/pixel) instead of float pairs
     };
 
     // unit ray through an integer pixel; z uses the reference's fp32 sqrt (A4)
@@ -137,9 +136,12 @@ namespace mbavo
         bool ok;
     };
 
-    template <bool WITH_GRAD>
+    // HALF_GRAD: the gradient image holds IEEE half pairs (4 B/pixel) instead of float pairs.  A compile-time
+    // switch: a run-time branch around the loads makes the compiler wait for ALL outstanding loads (vmcnt(0)) at
+    // the first use, which serialises the sample pipeline.
+    template <bool WITH_GRAD, bool HALF_GRAD = false>
     MBAVO_HD void tap_fetch(const unsigned char *__restrict__ I, const float *__restrict__ G, int H, int W,
-                            double x, double y, TapLoads &t, int grad_fp16 = 0)
+                            double x, double y, TapLoads &t)
     {
 #pragma clang fp contract(off)
         // Branch-free: an out-of-bounds (or NaN) coordinate only clears t.ok; its window is clamped into the image
@@ -170,7 +172,7 @@ namespace mbavo
         t.r1 = ((const MBAVO_GLOBAL UnalignedU16 *)(Ig + idx + W))->v;
         if (WITH_GRAD)
         {
-            if (grad_fp16)
+            if (HALF_GRAD)
             { // 8 bytes per row pair instead of 16
                 const MBAVO_GLOBAL unsigned short *Gh = (const MBAVO_GLOBAL unsigned short *)G;
                 const Half4A4 a = *(const MBAVO_GLOBAL Half4A4 *)(Gh + 2 * idx);
@@ -309,7 +311,7 @@ namespace mbavo
         TapLoads taps;
     };
 
-    template <int KDEG, bool WITH_J>
+    template <int KDEG, bool WITH_J, bool HALF_GRAD = false>
     MBAVO_HD void sample_issue(const PoseEntry<KDEG> &pe, const double ray[3], double D, double iz, const Camera &cam,
                                const unsigned char *__restrict__ I, const float *__restrict__ G, SampleInFlight &f)
     {
@@ -323,7 +325,7 @@ namespace mbavo
         const double Py = f.sc * f.ry + pe.t[1];
         const double u = cam.fx * (Px * iz) + cam.cx;
         const double v = cam.fy * (Py * iz) + cam.cy;
-        tap_fetch<WITH_J>(I, G, cam.H, cam.W, u, v, f.taps, cam.grad_fp16);
+        tap_fetch<WITH_J, HALF_GRAD>(I, G, cam.H, cam.W, u, v, f.taps);
     }
 
     template <int KDEG, bool WITH_J>
@@ -375,7 +377,7 @@ namespace mbavo
     // (SURVEY A9); otherwise residual = 0, Jrow = 0 and false is returned.
     // `table` points at the S entries of this pixel's frame.  The sample loop is software
     // pipelined: the tap loads of sample s+1 are issued before sample s is consumed.
-    template <int KDEG, bool WITH_J>
+    template <int KDEG, bool WITH_J, bool HALF_GRAD = false>
     MBAVO_HD bool pixel_row(const PoseEntry<KDEG> *__restrict__ table, int S, const Camera &cam,
                             const unsigned char *__restrict__ I_ref, const float *__restrict__ G_ref,
                             const unsigned char *__restrict__ I_cur, double centre_x, double centre_y,
@@ -396,31 +398,30 @@ namespace mbavo
         const double iz = 1. / (depth + 1e-8); // P_z == plane depth, A7
         double isum = 0.0;
         bool ok = true;
-        // two samples in flight, ping-pong (no struct copies): the taps of sample s+1 are issued before sample s retires
+        // Samples are processed in pairs: both samples' tap loads are issued, then both are retired, so the loads of
+        // the second overlap the arithmetic of the first and vice versa.  No load is left outstanding across the loop
+        // back-edge: the compiler's s_waitcnt insertion cannot count loop-carried loads and falls back to vmcnt(0),
+        // which would serialise every sample (measured on the ping-pong-across-iterations variant).
         SampleInFlight fa, fb;
 #if defined(MBAVO_EXP_ONE_ENTRY) // timing experiment: every sample uses table[0] (loads hoisted out of the loop)
 #define MBAVO_TAB(i) table[0]
 #else
 #define MBAVO_TAB(i) table[i]
 #endif
-        sample_issue<KDEG, WITH_J>(MBAVO_TAB(0), ray, depth, iz, cam, I_ref, G_ref, fa);
-        for (int s = 0; s < S; s += 2)
+        int s = 0;
+        for (; s + 1 < S; s += 2)
         {
-            if (s + 1 < S) sample_issue<KDEG, WITH_J>(MBAVO_TAB(s + 1), ray, depth, iz, cam, I_ref, G_ref, fb);
-            ok = ok && fa.taps.ok;
-#if !defined(MBAVO_BRANCH_FREE_RETIRE)
-            if (ok)
-#endif
+            sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s), ray, depth, iz, cam, I_ref, G_ref, fa);
+            sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s + 1), ray, depth, iz, cam, I_ref, G_ref, fb);
+            ok = ok && fa.taps.ok && fb.taps.ok;
             sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, iz, cam, isum, Jrow);
-            if (s + 1 < S)
-            {
-                if (s + 2 < S) sample_issue<KDEG, WITH_J>(MBAVO_TAB(s + 2), ray, depth, iz, cam, I_ref, G_ref, fa);
-                ok = ok && fb.taps.ok;
-#if !defined(MBAVO_BRANCH_FREE_RETIRE)
-                if (ok)
-#endif
-                sample_retire<KDEG, WITH_J>(MBAVO_TAB(s + 1), fb, ray, iz, cam, isum, Jrow);
-            }
+            sample_retire<KDEG, WITH_J>(MBAVO_TAB(s + 1), fb, ray, iz, cam, isum, Jrow);
+        }
+        if (s < S)
+        { // odd S (incl. the sharp case S = 1)
+            sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s), ray, depth, iz, cam, I_ref, G_ref, fa);
+            ok = ok && fa.taps.ok;
+            sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, iz, cam, isum, Jrow);
         }
         if (!ok)
         {
