@@ -179,6 +179,17 @@ int mbavo_image_gradients_u8(const unsigned char *d_src, int H, int W, float *d_
 /* same gradient image stored as IEEE half pairs (fp16 pyramid, mbavo_problem.grad_fp16 = 1) */
 int mbavo_image_gradients_u8_half(const unsigned char *d_src, int H, int W, void *d_dIxy_half, void *hip_stream);
 
+/* gradient magnitude image (Gradient.h:56-71, the detector's score) */
+int mbavo_gradient_magnitude_u8(const unsigned char *d_src, int H, int W, float *d_mag, void *hip_stream);
+/* semi-dense keypoints of pyramid level `level` with their depths: candidates = magnitude > score_threshold
+ * (core/feature_detectors/FeatureDetectorSemiDense.cpp:27-43), one per grid cell (FeatureDetectorBase.cpp:49-91;
+ * cell_H/cell_W <= 0: every candidate, row-major), depth at the level-0 position of the H0 x W0 float map
+ * d_depth_z, z < 1e-2 dropped (ba_tracker/blur_aware_direct_tracker.cpp:389-415).  Device in, device out (packed
+ * K x 2 doubles + K doubles, at most `cap` written); *h_count = number found.  Synchronous on the context's stream. */
+int mbavo_detect_semidense(mbavo_ctx *ctx, const unsigned char *d_img, int H, int W, int level, int H0, int W0,
+                           int cell_H, int cell_W, float score_threshold, const float *d_depth_z,
+                           double *d_kp_xy, double *d_kp_z, int cap, int *h_count);
+
 /* ---- synthetic blurred frame: synthesize_motion_blurred_img (ba_tracker/generate_synthetic_data.cpp:182-214):
  * mean of `num_samples` warps of the sharp image along the spline over the exposure, on a fronto-parallel plane.
  * Knots are host arrays; d_ref / d_out are device u8 images.  Synchronous. */
@@ -186,6 +197,45 @@ int mbavo_synthesize_blur(const unsigned char *d_ref, int H, int W, double plane
                           int spline_deg_k, double t0, double dt, const double *h_knots_t, const double *h_knots_R,
                           int N, double cap_time, double exp_time, int num_samples, unsigned char *d_out,
                           void *hip_stream);
+
+/* ---- the caller of the path: BlurAwareDirectTracker (ba_tracker/blur_aware_direct_tracker.{h,cpp}).
+ * Poses are 7 doubles: translation, then unit quaternion x,y,z,w (Core::Transformation's layout). */
+int mbavo_se3_exp(const double h_tangent[6] /*upsilon, omega*/, double h_pose[7]);   /* Transformation::exp (.cpp:171-177) */
+int mbavo_se3_log(const double h_pose[7], double h_tangent[6]);                      /* Transformation::log (.cpp:164-169) */
+int mbavo_transform_mul(const double h_A[7], const double h_B[7], double h_out[7]);  /* operator* (.cpp:109-119) */
+int mbavo_transform_inverse(const double h_A[7], double h_out[7]);                   /* inverse (.cpp:83-90) */
+int mbavo_spline_transform_to(int spline_deg_k, double t0, double dt, double *h_knots_t, double *h_knots_R, int N,
+                              double t, const double h_q_xyzw[4], const double h_t[3]); /* Spline.h:183-200 */
+
+typedef struct mbavo_vo_options { /* BlurAwareDirectTrackerOptions (blur_aware_direct_tracker.h:15-67) */
+    int H, W, num_pyramid_levels;
+    double intrinsics[4];
+    int num_virtual_poses_per_frame[8], patch_size[8];
+    const int *local_patch_pattern_xy[8]; /* host, (dx,dy) pairs; copied at creation */
+    double huber_k;
+    int max_consecutive_nonmonotonic_steps, max_num_iterations, solver_type, spline_deg_k;
+    double min_step_quality, min_abs_cost_decrease;
+    double dt_frame, dt_ctrl_knot, max_chi_square_error;
+    double keyframe_max_flow_mag0, keyframe_max_flow_mag1, keyframe_max_flow_mag2, keyframe_max_blur_kernel_mag;
+    float score_threshold; int grid_selection_cell_H, grid_selection_cell_W; /* reference: 25 / 30 / 30 (.cpp:353-358) */
+} mbavo_vo_options;
+typedef struct mbavo_vo_info {
+    int is_keyframe, num_keypoints0, num_trace, start_idx;
+    double avg_flow, avg_kernel, final_cost;
+} mbavo_vo_info;
+typedef struct mbavo_vo mbavo_vo;
+int mbavo_vo_create(mbavo_ctx *ctx, const mbavo_vo_options *opts, mbavo_vo **out);
+int mbavo_vo_destroy(mbavo_vo *vo);
+/* getSplineTrajectory()->InsertControlKnot(...) before the first frame (the `get_num_knots() == 0` test at .cpp:99) */
+int mbavo_vo_set_spline(mbavo_vo *vo, double t0, double dt, int N, const double *h_knots_t, const double *h_knots_R);
+int mbavo_vo_get_spline(mbavo_vo *vo, double *h_t0, double *h_dt, int *h_N, double *h_knots_t /*3*16*/, double *h_knots_R /*4*16*/);
+int mbavo_vo_num_keypoints(mbavo_vo *vo, int level);
+int mbavo_vo_get_keypoints(mbavo_vo *vo, int level, double *h_xy /*K*2*/, double *h_z /*K*/);
+/* trackFrame (.cpp:88-203): images and the z-depth map of the sharp frame are HOST buffers (H x W), as the
+ * reference's Core::Frame holds them; everything after the upload stays on the device. */
+int mbavo_vo_track_frame(mbavo_vo *vo, const unsigned char *h_sharp, const float *h_depth_z, double sharp_cap_time,
+                         const unsigned char *h_blur, double blur_cap_time, double blur_exp_time,
+                         double h_T_out[7], mbavo_vo_info *info_or_null);
 
 /* ---- multi-GPU: in-place sum of the packed blocks over all ranks (RCCL over xGMI).
  * `rccl_comm` is an ncclComm_t created by the caller; count in doubles. */

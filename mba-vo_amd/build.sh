@@ -6,13 +6,13 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-result"
 mkdir -p build
 pids=()
-for f in csrc/engine.hip csrc/ba_tracker.hip csrc/image_ops.hip; do
+for f in csrc/engine.hip csrc/ba_tracker.hip csrc/image_ops.hip csrc/keyframe_ops.hip; do
   o=build/$(basename "$f").o
   if [ ! -f "$o" ] || [ -n "$(find csrc -newer "$o" -print -quit)" ] || [ ../include/mbavo.h -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" & pids+=($!)
   fi
 done
-for f in csrc/host_math.cpp csrc/tracker.cpp csrc/c_api.cpp; do
+for f in csrc/host_math.cpp csrc/tracker.cpp csrc/vo_frontend.cpp csrc/c_api.cpp; do
   o=build/$(basename "$f").o
   if [ ! -f "$o" ] || [ -n "$(find csrc -newer "$o" -print -quit)" ] || [ ../include/mbavo.h -nt "$o" ]; then
     $HIPCC $FLAGS -x hip -c "$f" -o "$o" & pids+=($!)

@@ -55,6 +55,27 @@ class TraceRec(C.Structure):
     ]
 
 
+class VoOptions(C.Structure):
+    """struct mbavo_vo_options"""
+    _fields_ = [
+        ("H", C.c_int), ("W", C.c_int), ("num_pyramid_levels", C.c_int), ("intrinsics", C.c_double * 4),
+        ("num_virtual_poses_per_frame", C.c_int * 8), ("patch_size", C.c_int * 8),
+        ("local_patch_pattern_xy", c_ip * 8), ("huber_k", C.c_double),
+        ("max_consecutive_nonmonotonic_steps", C.c_int), ("max_num_iterations", C.c_int), ("solver_type", C.c_int),
+        ("spline_deg_k", C.c_int), ("min_step_quality", C.c_double), ("min_abs_cost_decrease", C.c_double),
+        ("dt_frame", C.c_double), ("dt_ctrl_knot", C.c_double), ("max_chi_square_error", C.c_double),
+        ("keyframe_max_flow_mag0", C.c_double), ("keyframe_max_flow_mag1", C.c_double),
+        ("keyframe_max_flow_mag2", C.c_double), ("keyframe_max_blur_kernel_mag", C.c_double),
+        ("score_threshold", C.c_float), ("grid_selection_cell_H", C.c_int), ("grid_selection_cell_W", C.c_int),
+    ]
+
+
+class VoInfo(C.Structure):
+    """struct mbavo_vo_info"""
+    _fields_ = [("is_keyframe", C.c_int), ("num_keypoints0", C.c_int), ("num_trace", C.c_int), ("start_idx", C.c_int),
+                ("avg_flow", C.c_double), ("avg_kernel", C.c_double), ("final_cost", C.c_double)]
+
+
 # every symbol include/mbavo.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "mbavo_create", "mbavo_destroy", "mbavo_set_stream", "mbavo_packed_len", "mbavo_eval_batch", "mbavo_eval",
@@ -66,6 +87,9 @@ SYMBOLS = [
     "mbavo_tr_step_accepted", "mbavo_spline_get_pose", "mbavo_spline_plus", "mbavo_segment_start_index",
     "mbavo_optimize_trajectory", "mbavo_pyramid_down_u8", "mbavo_image_gradients_u8", "mbavo_image_gradients_u8_half", "mbavo_synthesize_blur", "mbavo_allreduce_blocks",
     "mbavo_profile", "mbavo_profile_read", "mbavo_version",
+    "mbavo_gradient_magnitude_u8", "mbavo_detect_semidense", "mbavo_se3_exp", "mbavo_se3_log", "mbavo_transform_mul",
+    "mbavo_transform_inverse", "mbavo_spline_transform_to", "mbavo_vo_create", "mbavo_vo_destroy", "mbavo_vo_set_spline",
+    "mbavo_vo_get_spline", "mbavo_vo_num_keypoints", "mbavo_vo_get_keypoints", "mbavo_vo_track_frame",
 ]
 
 
@@ -140,6 +164,21 @@ def load():
     L.mbavo_synthesize_blur.argtypes = [vp, C.c_int, C.c_int, C.c_double, c_dp, C.c_int, C.c_double, C.c_double, c_dp,
                                         c_dp, C.c_int, C.c_double, C.c_double, C.c_int, vp, vp]
     L.mbavo_allreduce_blocks.argtypes = [vp, vp, vp, C.c_longlong]
+    L.mbavo_gradient_magnitude_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.mbavo_detect_semidense.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                         vp, vp, vp, C.c_int, c_ip]
+    L.mbavo_se3_exp.argtypes = [c_dp, c_dp]
+    L.mbavo_se3_log.argtypes = [c_dp, c_dp]
+    L.mbavo_transform_mul.argtypes = [c_dp, c_dp, c_dp]
+    L.mbavo_transform_inverse.argtypes = [c_dp, c_dp]
+    L.mbavo_spline_transform_to.argtypes = [C.c_int, C.c_double, C.c_double, c_dp, c_dp, C.c_int, C.c_double, c_dp, c_dp]
+    L.mbavo_vo_create.argtypes = [vp, C.POINTER(VoOptions), C.POINTER(vp)]
+    L.mbavo_vo_destroy.argtypes = [vp]
+    L.mbavo_vo_set_spline.argtypes = [vp, C.c_double, C.c_double, C.c_int, c_dp, c_dp]
+    L.mbavo_vo_get_spline.argtypes = [vp, c_dp, c_dp, c_ip, c_dp, c_dp]
+    L.mbavo_vo_num_keypoints.argtypes = [vp, C.c_int]
+    L.mbavo_vo_get_keypoints.argtypes = [vp, C.c_int, c_dp, c_dp]
+    L.mbavo_vo_track_frame.argtypes = [vp, vp, vp, C.c_double, vp, C.c_double, C.c_double, c_dp, C.POINTER(VoInfo)]
     L.mbavo_profile.argtypes = [vp, C.c_int]
     L.mbavo_profile_read.argtypes = [vp, c_dp, c_ip]
     _LIB = L

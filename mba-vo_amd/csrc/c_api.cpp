@@ -7,6 +7,7 @@
 #include "host_math.h"
 #include "se3_math.h"
 #include "tracker.h"
+#include "vo_frontend.h"
 
 #include <cstdio>
 #include <cstring>
@@ -19,6 +20,12 @@ using namespace SLAM;
 struct mbavo_ctx
 {
     mbavo::Engine *engine;
+};
+struct mbavo_vo
+{
+    VO::BlurAwareDirectTracker impl;
+    std::vector<std::vector<int>> patterns; // owns the copies the options point to
+    mbavo_vo(mbavo::Engine &e, const VO::BlurAwareDirectTrackerOptions &o) : impl(e, o) {}
 };
 struct mbavo_lm
 {
@@ -234,6 +241,157 @@ extern "C"
         if (!ctx || !o || !levels || !h_cap || !h_exp || !kt || !kR) return MBAVO_E_ARG;
         return mbavo::optimize_trajectory(*ctx->engine, *o, levels, F, h_cap, h_exp, t0, dt, kt, kR, N, start_idx_out,
                                           final_cost, trace, cap);
+    }
+
+    // ---- trackFrame front end
+    int mbavo_detect_semidense(mbavo_ctx *ctx, const unsigned char *d_img, int H, int W, int level, int H0, int W0, int cell_H,
+                               int cell_W, float thr, const float *d_depth_z, double *d_kp_xy, double *d_kp_z, int cap, int *h_count)
+    {
+        if (!ctx) return MBAVO_E_ARG;
+        return mbavo::detect_semidense(*ctx->engine, d_img, H, W, level, H0, W0, cell_H, cell_W, thr, d_depth_z, d_kp_xy, d_kp_z,
+                                       cap, h_count);
+    }
+
+    int mbavo_se3_exp(const double a[6], double pose[7])
+    {
+        if (!a || !pose) return MBAVO_E_ARG;
+        memcpy(pose, Core::Transformation::exp(a).getData(), sizeof(double) * 7);
+        return 0;
+    }
+    int mbavo_se3_log(const double pose[7], double out[6])
+    {
+        if (!pose || !out) return MBAVO_E_ARG;
+        Core::Transformation::log(Core::Transformation(pose + 3, pose), out);
+        return 0;
+    }
+    int mbavo_transform_mul(const double A[7], const double B[7], double out[7])
+    {
+        if (!A || !B || !out) return MBAVO_E_ARG;
+        const Core::Transformation r = Core::Transformation(A + 3, A) * Core::Transformation(B + 3, B);
+        memcpy(out, r.getData(), sizeof(double) * 7);
+        return 0;
+    }
+    int mbavo_transform_inverse(const double A[7], double out[7])
+    {
+        if (!A || !out) return MBAVO_E_ARG;
+        memcpy(out, Core::Transformation(A + 3, A).inverse().getData(), sizeof(double) * 7);
+        return 0;
+    }
+    int mbavo_spline_transform_to(int k, double t0, double dt, double *kt, double *kR, int N, double t, const double q[4],
+                                  const double p[3])
+    {
+        if ((k != 2 && k != 4) || !kt || !kR || !q || !p || N < k) return MBAVO_E_ARG;
+        Core::SplineSE3 s(t0, dt);
+        s.setSplineDegK(k);
+        for (int i = 0; i < N; ++i) s.InsertControlKnot(kR + 4 * i, kt + 3 * i);
+        if (!s.TransformTo(t, q, p)) return MBAVO_E_RANGE;
+        memcpy(kt, s.get_knot_data_t(), sizeof(double) * 3 * N);
+        memcpy(kR, s.get_knot_data_R(), sizeof(double) * 4 * N);
+        return 0;
+    }
+
+    int mbavo_vo_create(mbavo_ctx *ctx, const mbavo_vo_options *o, mbavo_vo **out)
+    {
+        if (!ctx || !o || !out || o->num_pyramid_levels < 1 || o->num_pyramid_levels > 8) return MBAVO_E_ARG;
+        VO::BlurAwareDirectTrackerOptions v;
+        for (int i = 0; i < 4; ++i) v.intrinsics[i] = o->intrinsics[i];
+        v.im_size_HW[0] = o->H; v.im_size_HW[1] = o->W;
+        v.num_pyramid_levels = o->num_pyramid_levels;
+        std::vector<std::vector<int>> pats(8);
+        for (int l = 0; l < 8; ++l)
+        {
+            v.num_virtual_poses_per_frame[l] = o->num_virtual_poses_per_frame[l];
+            v.patch_size[l] = o->patch_size[l];
+            v.local_patch_pattern_xy[l] = nullptr;
+            if (l < o->num_pyramid_levels)
+            {
+                if (!o->local_patch_pattern_xy[l] || o->patch_size[l] < 1) return MBAVO_E_ARG;
+                pats[l].assign(o->local_patch_pattern_xy[l], o->local_patch_pattern_xy[l] + 2 * o->patch_size[l]);
+                v.local_patch_pattern_xy[l] = pats[l].data();
+            }
+        }
+        v.huber_k = o->huber_k;
+        v.max_consecutive_nonmonotonic_steps = o->max_consecutive_nonmonotonic_steps;
+        v.max_num_iterations = o->max_num_iterations;
+        v.min_step_quality = o->min_step_quality; v.min_abs_cost_decrease = o->min_abs_cost_decrease;
+        v.solver_type = o->solver_type; v.spline_deg_k = o->spline_deg_k;
+        v.dt_frame = o->dt_frame; v.dt_ctrl_knot = o->dt_ctrl_knot; v.max_chi_square_error = o->max_chi_square_error;
+        v.keyframe_max_flow_mag0 = o->keyframe_max_flow_mag0; v.keyframe_max_flow_mag1 = o->keyframe_max_flow_mag1;
+        v.keyframe_max_flow_mag2 = o->keyframe_max_flow_mag2; v.keyframe_max_blur_kernel_mag = o->keyframe_max_blur_kernel_mag;
+        v.score_threshold = o->score_threshold;
+        v.grid_selection_cell_H = o->grid_selection_cell_H; v.grid_selection_cell_W = o->grid_selection_cell_W;
+        if (v.spline_deg_k != 2 && v.spline_deg_k != 4) return MBAVO_E_ARG;
+        mbavo_vo *h = new (std::nothrow) mbavo_vo(*ctx->engine, v);
+        if (!h) return MBAVO_E_ARG;
+        const int st = h->impl.status();
+        if (st != 0) { delete h; return st; }
+        h->patterns.swap(pats);
+        *out = h;
+        return 0;
+    }
+
+    int mbavo_vo_destroy(mbavo_vo *vo)
+    {
+        delete vo;
+        return 0;
+    }
+
+    int mbavo_vo_set_spline(mbavo_vo *vo, double t0, double dt, int N, const double *kt, const double *kR)
+    {
+        if (!vo || N < 0 || N > 16 || (N > 0 && (!kt || !kR))) return MBAVO_E_ARG;
+        Core::SplineSE3 *s = vo->impl.getSplineTrajectory();
+        s->Clear();
+        s->setStartTime(t0); s->setSamplingFreq(dt); s->setSplineDegK(vo->impl.getOptions().spline_deg_k);
+        for (int i = 0; i < N; ++i) s->InsertControlKnot(kR + 4 * i, kt + 3 * i);
+        return 0;
+    }
+
+    int mbavo_vo_get_spline(mbavo_vo *vo, double *t0, double *dt, int *N, double *kt, double *kR)
+    {
+        if (!vo) return MBAVO_E_ARG;
+        Core::SplineSE3 *s = vo->impl.getSplineTrajectory();
+        const int n = (int)s->get_num_knots();
+        if (t0) *t0 = s->getStartTime();
+        if (dt) *dt = s->getSamplingFreq();
+        if (N) *N = n;
+        if (kt && n) memcpy(kt, s->get_knot_data_t(), sizeof(double) * 3 * n);
+        if (kR && n) memcpy(kR, s->get_knot_data_R(), sizeof(double) * 4 * n);
+        return 0;
+    }
+
+    int mbavo_vo_num_keypoints(mbavo_vo *vo, int level)
+    {
+        if (!vo || level < 0 || level >= vo->impl.getOptions().num_pyramid_levels) return MBAVO_E_ARG;
+        return vo->impl.numKeypoints(level);
+    }
+
+    int mbavo_vo_get_keypoints(mbavo_vo *vo, int level, double *xy, double *z)
+    {
+        if (!vo || level < 0 || level >= vo->impl.getOptions().num_pyramid_levels || !xy || !z) return MBAVO_E_ARG;
+        const int K = vo->impl.numKeypoints(level);
+        if (K == 0) return 0;
+        hipError_t e = hipMemcpy(xy, vo->impl.deviceKeypointsXY(level), sizeof(double) * 2 * K, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(z, vo->impl.deviceKeypointsZ(level), sizeof(double) * K, hipMemcpyDeviceToHost);
+        return (int)e;
+    }
+
+    int mbavo_vo_track_frame(mbavo_vo *vo, const unsigned char *sharp, const float *depth_z, double sharp_cap,
+                             const unsigned char *blur, double blur_cap, double blur_exp, double T_out[7], mbavo_vo_info *info)
+    {
+        if (!vo || !T_out) return MBAVO_E_ARG;
+        VO::FrameView s{sharp, sharp_cap, 0.0}, b{blur, blur_cap, blur_exp};
+        Core::Transformation T;
+        VO::TrackInfo ti;
+        const int rc = vo->impl.trackFrame(s, b, depth_z, &T, &ti);
+        if (rc != 0) return rc;
+        memcpy(T_out, T.getData(), sizeof(double) * 7);
+        if (info)
+        {
+            info->is_keyframe = ti.is_keyframe; info->num_keypoints0 = ti.num_keypoints0; info->num_trace = ti.num_trace;
+            info->start_idx = ti.start_idx; info->avg_flow = ti.avg_flow; info->avg_kernel = ti.avg_kernel;
+            info->final_cost = ti.final_cost;
+        }
+        return 0;
     }
 
     int mbavo_profile(mbavo_ctx *ctx, int enable)

@@ -112,8 +112,9 @@ namespace mbavo
         void *d_fb_ = nullptr; size_t cap_fb_ = 0;
         void *h_fb_ = nullptr; size_t cap_hfb_ = 0;
 
-        void *slots_[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        size_t slot_cap_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        static constexpr int kSlots = 12; // 0-6 LM loop (tracker.cpp), 8-10 keyframe detection (keyframe_ops.hip)
+        void *slots_[kSlots] = {};
+        size_t slot_cap_[kSlots] = {};
 
         bool prof_on_ = false;
         std::vector<hipEvent_t> prof_ev_; // pairs (start, stop)

@@ -517,7 +517,7 @@ namespace mbavo
 
     void *Engine::named_scratch(int slot, size_t bytes)
     {
-        if (slot < 0 || slot >= 8) return nullptr;
+        if (slot < 0 || slot >= kSlots) return nullptr;
         if (ensure(&slots_[slot], &slot_cap_[slot], bytes ? bytes : 1) != 0) return nullptr;
         return slots_[slot];
     }

@@ -296,6 +296,22 @@ namespace SLAM
             }
         }
 
+        bool SplineSE3::TransformTo(double t, const double q_target[4], const double t_target[3])
+        { // Spline.h:183-200: dR = R(t)^-1 * R_target, dt = R(t)^-1 * (t_target - t(t)), then TransformByRight
+            double qo[4], po[3];
+            if (!GetPose(t, qo, po)) return false;
+            const double n2 = qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3];
+            if (!(n2 > 0)) return false;
+            const Quat qi{-qo[0] / n2, -qo[1] / n2, -qo[2] / n2, qo[3] / n2}; // Eigen inverse(): conjugate / squaredNorm
+            const Quat dR = mbavo::qmul(qi, mbavo::load_quat(q_target));
+            const double d[3] = {t_target[0] - po[0], t_target[1] - po[1], t_target[2] - po[2]};
+            double dt[3];
+            mbavo::qrotate(qi, d, dt);
+            const double dq[4] = {dR.x, dR.y, dR.z, dR.w};
+            TransformByRight(dq, dt);
+            return true;
+        }
+
         void SplineSE3::UpdateCtrlKnot_t(int s, int num, const double *dt)
         {
             for (int i = 0; i < 3 * num; ++i) mT[3 * s + i] += dt[i];

@@ -83,6 +83,8 @@ namespace SLAM
             bool GetPose(double t, double q_xyzw[4], double t_out[3], double *jacobian_R = nullptr,
                          double *jacobian_t = nullptr) const;
             void TransformByRight(const double dq_xyzw[4], const double dt[3]);
+            // Spline.h:183-200: re-express the spline so that its pose at time t becomes (q, t); false if t is out of range
+            bool TransformTo(double t, const double q_xyzw[4], const double t_target[3]);
             void UpdateCtrlKnot_t(int start_knot_idx, int num_knots, const double *dt);
             void UpdateCtrlKnot_R(int start_knot_idx, int num_knots, const double *dR);
             void Plus_t(const double *dt, double *candidate_t) const;

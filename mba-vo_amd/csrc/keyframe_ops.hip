@@ -1,0 +1,247 @@
+// keyframe_ops.hip -- keyframe pre-processing on device: gradient magnitude, semi-dense
+// keypoint selection and the depth lookup of BlurAwareDirectTracker::tmpProcessKeyframe, so that a new keyframe
+// needs one H2D of the image (+ depth map) and one small D2H of the keypoint count instead of host loops over
+// every pixel of every level.
+//
+//   gradient magnitude   core/image_proc/Gradient.h:56-71       sqrt(dx^2 + dy^2) of the central differences
+//   candidates           FeatureDetectorSemiDense.cpp:27-43      magnitude > score_threshold, row-major order
+//   grid selection       FeatureDetectorBase.cpp:49-91           per cell the first pixel of strictly largest response
+//   depth lookup         blur_aware_direct_tracker.cpp:389-415   z at the level-0 position, drop z < 1e-2
+//
+// Integer / index work: results (positions, order, count) are bit-identical to the CPU restatement.
+// The magnitude is never materialised for the detector: it is recomputed from the u8 image (3 loads per pixel,
+// L2-resident), which is cheaper than writing and re-reading a float image.  One wave per grid cell; the ordered
+// compaction over <= a few thousand cells is a single-block scan.  HBM-bound streaming work, ~1 byte per pixel.
+#include "../../include/mbavo.h"
+#include "engine.h"
+#include "vo_frontend.h"
+#include <cmath>
+#include <hip/hip_runtime.h>
+
+namespace mbavo
+{
+    __device__ __forceinline__ float gradient_magnitude(const unsigned char *__restrict__ src, int H, int W, int x, int y)
+    {
+        if (x == 0 || y == 0 || x == W - 1 || y == H - 1) return 0.f;
+        const size_t i = (size_t)y * W + x;
+        const float dx = 0.5f * ((float)src[i + 1] - (float)src[i - 1]);
+        const float dy = 0.5f * ((float)src[i + W] - (float)src[i - W]);
+        // dx, dy are multiples of 0.5 in [-127.5, 127.5]: the sum of squares is exact in fp32 whatever the
+        // contraction; the reference takes the double sqrt of that float and rounds to float, which equals the
+        // correctly rounded float sqrt (53 >= 2*24 + 2 bits).  sqrtf is the IEEE one here (hipcc's default
+        // -fhip-fp32-correctly-rounded-divide-sqrt); __fsqrt_rn maps to the 1-ulp native instruction.
+        return sqrtf(dx * dx + dy * dy);
+    }
+
+    __global__ void k_grad_mag(const unsigned char *__restrict__ src, int H, int W, float *__restrict__ mag)
+    {
+        const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+        if (x >= W || y >= H) return;
+        mag[(size_t)y * W + x] = gradient_magnitude(src, H, W, x, y);
+    }
+
+    struct CellPick
+    {
+        int x, y, keep;
+        float z;
+    };
+
+    // level-0 depth of a level-`lv` pixel (blur_aware_direct_tracker.cpp:398-400): int(x * 2^lv + 0.5)
+    __device__ __forceinline__ bool depth_of(const float *__restrict__ depth, int W0, double scale, int x, int y, float &z)
+    {
+        const int x0 = (int)((float)x * scale + 0.5), y0 = (int)((float)y * scale + 0.5);
+        z = depth[(size_t)y0 * W0 + x0];
+        return !((double)z < 1e-2);
+    }
+
+    // one wave per grid cell
+    __global__ __launch_bounds__(64) void k_detect_cells(const unsigned char *__restrict__ src, int H, int W, int cell_h,
+                                                         int cell_w, int cells_w, float thr,
+                                                         const float *__restrict__ depth, int W0, double scale,
+                                                         CellPick *__restrict__ picks)
+    {
+        const int ci = blockIdx.x, lane = threadIdx.x;
+        const int y0 = (ci / cells_w) * cell_h, x0 = (ci % cells_w) * cell_w;
+        float best = 0.f; // cv::KeyPoint() has response 0: a pixel must beat it strictly
+        int best_idx = 0x7fffffff;
+        const int n = cell_h * cell_w;
+        for (int i = lane; i < n; i += 64)
+        {
+            const int y = y0 + i / cell_w, x = x0 + i % cell_w;
+            if (y >= H || x >= W) continue;
+            const float m = gradient_magnitude(src, H, W, x, y);
+            if (m > thr && best < m) { best = m; best_idx = y * W + x; } // per lane the scan order is increasing
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+        {
+            const float om = __shfl_xor(best, off);
+            const int oi = __shfl_xor(best_idx, off);
+            if (om > best || (om == best && oi < best_idx)) { best = om; best_idx = oi; }
+        }
+        if (lane == 0)
+        {
+            CellPick p;
+            p.keep = 0; p.x = 0; p.y = 0; p.z = 0.f;
+            if (!(best < 1e-6)) // FeatureDetectorBase.cpp:82-85
+            {
+                p.y = best_idx / W; p.x = best_idx - p.y * W;
+                p.keep = depth_of(depth, W0, scale, p.x, p.y, p.z) ? 1 : 0;
+            }
+            picks[ci] = p;
+        }
+    }
+
+    // ordered compaction of the kept cells: single block, chunked exclusive scan
+    __global__ __launch_bounds__(256) void k_compact_cells(const CellPick *__restrict__ picks, int n, double *__restrict__ kp_xy,
+                                                           double *__restrict__ kp_z, int cap, int *__restrict__ count)
+    {
+        __shared__ int sm[256];
+        __shared__ int base;
+        if (threadIdx.x == 0) base = 0;
+        __syncthreads();
+        for (int c0 = 0; c0 < n; c0 += 256)
+        {
+            const int i = c0 + threadIdx.x;
+            CellPick p;
+            p.keep = 0;
+            if (i < n) p = picks[i];
+            sm[threadIdx.x] = p.keep;
+            __syncthreads();
+            for (int d = 1; d < 256; d <<= 1)
+            {
+                const int v = threadIdx.x >= d ? sm[threadIdx.x - d] : 0;
+                __syncthreads();
+                sm[threadIdx.x] += v;
+                __syncthreads();
+            }
+            const int pos = base + sm[threadIdx.x] - p.keep;
+            if (p.keep && pos < cap)
+            {
+                kp_xy[2 * pos] = (double)p.x; kp_xy[2 * pos + 1] = (double)p.y;
+                kp_z[pos] = (double)p.z;
+            }
+            __syncthreads();
+            if (threadIdx.x == 255) base += sm[255];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *count = base;
+    }
+
+    // ---- no grid selection: every candidate, in row-major order.  Rows are the segments of the ordered compaction.
+    __device__ __forceinline__ bool row_candidate(const unsigned char *__restrict__ src, int H, int W, float thr,
+                                                  const float *__restrict__ depth, int W0, double scale, int x, int y, float &z)
+    {
+        if (x >= W) return false;
+        const float m = gradient_magnitude(src, H, W, x, y);
+        if (!(m > thr)) return false;
+        return depth_of(depth, W0, scale, x, y, z);
+    }
+
+    __global__ __launch_bounds__(64) void k_rows_count(const unsigned char *__restrict__ src, int H, int W, float thr,
+                                                       const float *__restrict__ depth, int W0, double scale,
+                                                       int *__restrict__ row_count)
+    {
+        const int y = blockIdx.x, lane = threadIdx.x;
+        int n = 0;
+        for (int x0 = 0; x0 < W; x0 += 64)
+        {
+            float z;
+            n += __popcll(__ballot(row_candidate(src, H, W, thr, depth, W0, scale, x0 + lane, y, z)));
+        }
+        if (lane == 0) row_count[y] = n;
+    }
+
+    __global__ __launch_bounds__(256) void k_rows_scan(int *__restrict__ row_count, int H, int *__restrict__ count)
+    { // in-place exclusive scan over the rows
+        __shared__ int sm[256];
+        __shared__ int base;
+        if (threadIdx.x == 0) base = 0;
+        __syncthreads();
+        for (int c0 = 0; c0 < H; c0 += 256)
+        {
+            const int i = c0 + threadIdx.x;
+            const int v0 = i < H ? row_count[i] : 0;
+            sm[threadIdx.x] = v0;
+            __syncthreads();
+            for (int d = 1; d < 256; d <<= 1)
+            {
+                const int v = threadIdx.x >= d ? sm[threadIdx.x - d] : 0;
+                __syncthreads();
+                sm[threadIdx.x] += v;
+                __syncthreads();
+            }
+            if (i < H) row_count[i] = base + sm[threadIdx.x] - v0;
+            __syncthreads();
+            if (threadIdx.x == 255) base += sm[255];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *count = base;
+    }
+
+    __global__ __launch_bounds__(64) void k_rows_write(const unsigned char *__restrict__ src, int H, int W, float thr,
+                                                       const float *__restrict__ depth, int W0, double scale,
+                                                       const int *__restrict__ row_off, double *__restrict__ kp_xy,
+                                                       double *__restrict__ kp_z, int cap)
+    {
+        const int y = blockIdx.x, lane = threadIdx.x;
+        int pos = row_off[y];
+        for (int x0 = 0; x0 < W; x0 += 64)
+        {
+            float z = 0.f;
+            const bool c = row_candidate(src, H, W, thr, depth, W0, scale, x0 + lane, y, z);
+            const unsigned long long b = __ballot(c);
+            const int mine = pos + __popcll(b & ((1ull << lane) - 1ull));
+            if (c && mine < cap)
+            {
+                kp_xy[2 * mine] = (double)(x0 + lane); kp_xy[2 * mine + 1] = (double)y;
+                kp_z[mine] = (double)z;
+            }
+            pos += __popcll(b);
+        }
+    }
+
+    int detect_semidense(Engine &eng, const unsigned char *d_img, int H, int W, int level, int im_H0, int im_W0, int cell_H,
+                         int cell_W, float thr, const float *d_depth_z, double *d_kp_xy, double *d_kp_z, int cap, int *h_count)
+    {
+        if (!d_img || !d_depth_z || !d_kp_xy || !d_kp_z || !h_count || H < 1 || W < 1 || level < 0 || level > 30 || cap < 0)
+            return MBAVO_E_ARG;
+        hipStream_t st = eng.stream();
+        const double scale = std::pow(2, level);
+        int *d_count = (int *)eng.named_scratch(8, sizeof(int));
+        if (!d_count) return MBAVO_E_ARG;
+        hipError_t e;
+        if (cell_H > 0 && cell_W > 0)
+        { // FeatureDetectorBase.cpp:56-64
+            const int sf = (int)std::pow(2, level);
+            const int Hl = im_H0 / sf, Wl = im_W0 / sf;
+            const int ch = (int)(cell_H / std::pow(1.414, level)), cw = (int)(cell_W / std::pow(1.414, level));
+            if (ch < 1 || cw < 1) return MBAVO_E_ARG; // the reference divides by zero here
+            const int cells_h = Hl / ch + 1, cells_w = Wl / cw + 1;
+            if ((H - 1) / ch >= cells_h || (W - 1) / cw >= cells_w) return MBAVO_E_RANGE; // std::vector::at would throw
+            const int nc = cells_h * cells_w;
+            CellPick *picks = (CellPick *)eng.named_scratch(9, sizeof(CellPick) * nc);
+            if (!picks) return MBAVO_E_ARG;
+            hipLaunchKernelGGL(k_detect_cells, dim3(nc), dim3(64), 0, st, d_img, H, W, ch, cw, cells_w, thr, d_depth_z, im_W0, scale, picks);
+            hipLaunchKernelGGL(k_compact_cells, dim3(1), dim3(256), 0, st, picks, nc, d_kp_xy, d_kp_z, cap, d_count);
+        }
+        else
+        {
+            int *rows = (int *)eng.named_scratch(9, sizeof(int) * H);
+            if (!rows) return MBAVO_E_ARG;
+            hipLaunchKernelGGL(k_rows_count, dim3(H), dim3(64), 0, st, d_img, H, W, thr, d_depth_z, im_W0, scale, rows);
+            hipLaunchKernelGGL(k_rows_scan, dim3(1), dim3(256), 0, st, rows, H, d_count);
+            hipLaunchKernelGGL(k_rows_write, dim3(H), dim3(64), 0, st, d_img, H, W, thr, d_depth_z, im_W0, scale, rows, d_kp_xy, d_kp_z, cap);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+        if ((e = hipMemcpyAsync(h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return (int)e;
+        return (int)hipStreamSynchronize(st);
+    }
+} // namespace mbavo
+
+extern "C" int mbavo_gradient_magnitude_u8(const unsigned char *d_src, int H, int W, float *d_mag, void *stream)
+{
+    if (!d_src || !d_mag || H < 1 || W < 1) return MBAVO_E_ARG;
+    hipLaunchKernelGGL(mbavo::k_grad_mag, dim3((W + 255) / 256, H), dim3(256), 0, (hipStream_t)stream, d_src, H, W, d_mag);
+    return (int)hipGetLastError();
+}

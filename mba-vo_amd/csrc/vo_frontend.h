@@ -1,0 +1,133 @@
+// vo_frontend.h -- the caller of the hot path: BlurAwareDirectTracker::trackFrame and what it needs
+// (SURVEY.md 8f rows 2-3).
+//
+//   Core::Transformation            core/states/Transformation.{h,cpp} (Eigen / Sophus replaced by flat doubles;
+//                                   exp / log follow Sophus::SE3d's closed forms)
+//   VO::BlurAwareDirectTrackerOptions  ba_tracker/blur_aware_direct_tracker.h:15-67
+//   VO::BlurAwareDirectTracker      ba_tracker/blur_aware_direct_tracker.cpp:14-415 (ctor, trackFrame, isKeyframe,
+//                                   tmpProcessKeyframe, optimizeTrajectory) on device-resident pyramids
+//
+// Core::Frame / Core::CameraBase (sensor and dataset classes, out of scope) are replaced by a POD frame view and the
+// pinhole intrinsics already in the options; GUI members are dropped.
+#ifndef MBAVO_VO_FRONTEND_H
+#define MBAVO_VO_FRONTEND_H
+
+#include "engine.h"
+#include "host_math.h"
+#include <vector>
+
+namespace mbavo
+{
+    // keyframe_ops.hip: semi-dense keypoints of one pyramid level, device in / device out; count to the host
+    int detect_semidense(Engine &eng, const unsigned char *d_img, int H, int W, int level, int im_H0, int im_W0, int cell_H,
+                         int cell_W, float thr, const float *d_depth_z, double *d_kp_xy, double *d_kp_z, int cap, int *h_count);
+}
+
+namespace SLAM
+{
+    namespace Core
+    {
+        class Transformation
+        { // translation (3) then unit quaternion x,y,z,w (Transformation.h: mInternalRepresentation[7])
+        public:
+            Transformation();
+            Transformation(const double q_xyzw[4], const double t[3]); // normalises q (Transformation.cpp:39-45)
+            Transformation inverse() const;
+            Transformation operator*(const Transformation &T) const;
+            void apply(const double P[3], double out[3]) const; // operator*(Vector3d)
+            const double *getData() const { return d; }
+            const double *getRotationData() const { return d + 3; }
+            const double *getTranslationData() const { return d; }
+            static Transformation exp(const double tangent[6]);         // [upsilon, omega]
+            static void log(const Transformation &T, double tangent[6]);
+
+        private:
+            double d[7];
+        };
+    } // namespace Core
+
+    namespace VO
+    {
+        struct BlurAwareDirectTrackerOptions
+        {
+            double intrinsics[4];
+            int im_size_HW[2];
+            int num_pyramid_levels;
+            int num_virtual_poses_per_frame[8];
+            int patch_size[8];
+            const int *local_patch_pattern_xy[8];
+            double huber_k;
+            int max_consecutive_nonmonotonic_steps = 5;
+            int max_num_iterations = 50;
+            double min_step_quality = 0.5;
+            double min_abs_cost_decrease = 0.001;
+            int solver_type = 0; // "SVD_JACOBI" (0) / "LDLT" (1)
+            int spline_deg_k = 2;
+            double dt_frame, dt_ctrl_knot;
+            double max_chi_square_error;
+            double keyframe_max_flow_mag0, keyframe_max_flow_mag1, keyframe_max_flow_mag2, keyframe_max_blur_kernel_mag;
+            // FeatureDetectorOptions as tmpProcessKeyframe sets them (blur_aware_direct_tracker.cpp:353-358)
+            float score_threshold = 25.f;
+            int grid_selection_cell_H = 30, grid_selection_cell_W = 30;
+        };
+
+        struct FrameView
+        { // what trackFrame reads from a Core::Frame: the level-0 image (host memory) and its timing
+            const unsigned char *image;
+            double capture_time, exposure_time;
+        };
+
+        struct TrackInfo
+        {
+            int is_keyframe, num_keypoints0, num_trace, start_idx;
+            double avg_flow, avg_kernel, final_cost;
+        };
+
+        class BlurAwareDirectTracker
+        {
+        public:
+            BlurAwareDirectTracker(mbavo::Engine &engine, const BlurAwareDirectTrackerOptions &options);
+            ~BlurAwareDirectTracker();
+            BlurAwareDirectTracker(const BlurAwareDirectTracker &) = delete;
+            BlurAwareDirectTracker &operator=(const BlurAwareDirectTracker &) = delete;
+
+            // returns 0 or an error code; *T_out = pose of the blurred frame in the world (first keyframe) frame
+            int trackFrame(const FrameView &sharp_frame, const FrameView &blur_frame, const float *depth_z,
+                           Core::Transformation *T_out, TrackInfo *info = nullptr);
+            bool isKeyframe(double *avg_flow = nullptr, double *avg_kernel = nullptr) const;
+            Core::SplineSE3 *getSplineTrajectory() { return &mSpline; }
+            BlurAwareDirectTrackerOptions &getOptions() { return mOptions; }
+            double getFinalEnergy() const { return mEvaluationPointCost; }
+            int numKeypoints(int level) const { return mNumKeypoints[level]; }
+            const double *deviceKeypointsXY(int level) const { return mKpXY[level]; }
+            const double *deviceKeypointsZ(int level) const { return mKpZ[level]; }
+            int status() const { return mStatus; } // allocation status of the constructor
+
+        private:
+            int tmpProcessKeyframe(const FrameView &keyframe, const float *depth_z);
+            int uploadCurrentFrame(const FrameView &frame);
+            int optimizeTrajectory(int *num_trace, int *start_idx);
+
+            mbavo::Engine &mEngine;
+            BlurAwareDirectTrackerOptions mOptions;
+            Core::SplineSE3 mSpline;
+            Core::Transformation mTKeyframe, mTprevB2W;
+            double mNeighFrameVelocity[6], mSplineVelocity[6];
+            double mPrevTimestamp, mEvaluationPointCost;
+            bool mIsFirstFrame;
+            double mCurCap, mCurExp;
+            int mStatus;
+
+            // device-resident pyramids (keyframe: image + gradient; current frame: image) and keypoints
+            unsigned char *mRef[8], *mCur[8];
+            float *mGrad[8], *mDepth;
+            const unsigned char **mCurPtr[8]; // device array of 1 device pointer per level
+            double *mKpXY[8], *mKpZ[8];
+            int *mPattern[8];
+            int mKpCap[8], mNumKeypoints[8];
+            std::vector<double> mHostKpXY0, mHostKpZ0; // level-0 keypoints for the keyframe test
+        };
+    } // namespace VO
+} // namespace SLAM
+
+#endif

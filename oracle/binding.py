@@ -57,6 +57,25 @@ class OrcLevel(C.Structure):
     ]
 
 
+class OrcVoOpts(C.Structure):
+    _fields_ = [
+        ("H", C.c_int), ("W", C.c_int), ("num_levels", C.c_int), ("intr", C.c_double * 4),
+        ("num_virtual_poses", C.c_int * 8), ("patch_size", C.c_int * 8), ("pattern_xy", c_ip * 8),
+        ("huber_k", C.c_double),
+        ("max_nonmono", C.c_int), ("max_num_iterations", C.c_int), ("solver_type", C.c_int), ("spline_deg_k", C.c_int),
+        ("min_step_quality", C.c_double), ("min_abs_cost_decrease", C.c_double),
+        ("dt_frame", C.c_double), ("dt_ctrl_knot", C.c_double), ("max_chi_square_error", C.c_double),
+        ("keyframe_max_flow_mag0", C.c_double), ("keyframe_max_flow_mag1", C.c_double),
+        ("keyframe_max_flow_mag2", C.c_double), ("keyframe_max_blur_kernel_mag", C.c_double),
+        ("score_threshold", C.c_float), ("grid_cell_H", C.c_int), ("grid_cell_W", C.c_int),
+    ]
+
+
+class OrcVoInfo(C.Structure):
+    _fields_ = [("is_keyframe", C.c_int), ("num_keypoints0", C.c_int), ("num_trace", C.c_int), ("start_idx", C.c_int),
+                ("avg_flow", C.c_double), ("avg_kernel", C.c_double), ("final_cost", C.c_double)]
+
+
 class OrcTrackOpts(C.Structure):
     _fields_ = [
         ("num_levels", C.c_int), ("k", C.c_int), ("max_num_iterations", C.c_int),
@@ -139,6 +158,27 @@ def lib():
         L.orc_optimize_trajectory.argtypes = [
             C.POINTER(OrcTrackOpts), C.POINTER(OrcLevel), C.c_int, c_dp, c_dp, C.c_double, C.c_double,
             c_dp, c_dp, C.c_int, c_ip, c_dp, C.POINTER(OrcTraceRec), C.c_int]
+        L.orc_transform_mul.argtypes = [c_dp, c_dp, c_dp]
+        L.orc_transform_inverse.argtypes = [c_dp, c_dp]
+        L.orc_se3_exp.argtypes = [c_dp, c_dp, c_dp]
+        L.orc_se3_log.argtypes = [c_dp, c_dp, c_dp]
+        L.orc_spline_get_pose.argtypes = [C.c_int, C.c_double, C.c_double, c_dp, c_dp, C.c_double, c_dp, c_dp]
+        L.orc_spline_transform_by_right.argtypes = [c_dp, c_dp, C.c_int, c_dp, c_dp]
+        L.orc_spline_transform_to.argtypes = [C.c_int, C.c_double, C.c_double, c_dp, c_dp, C.c_int, C.c_double, c_dp, c_dp]
+        L.orc_detect_semidense.argtypes = [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_float, c_fp, c_fp, C.c_int]
+        L.orc_keypoint_depths.argtypes = [c_fp, C.c_int, C.c_int, c_fp, C.c_int, C.c_int, c_dp, c_dp]
+        L.orc_is_keyframe.argtypes = [c_dp, c_dp, c_dp, C.c_int, C.c_int, C.c_double, C.c_double, c_dp, c_dp,
+                                      C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_dp, c_dp]
+        L.orc_vo_create.restype = C.c_void_p
+        L.orc_vo_create.argtypes = [C.POINTER(OrcVoOpts)]
+        L.orc_vo_destroy.argtypes = [C.c_void_p]
+        L.orc_vo_set_spline.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, c_dp, c_dp]
+        L.orc_vo_num_keypoints.argtypes = [C.c_void_p, C.c_int]
+        L.orc_vo_keypoints.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp]
+        L.orc_vo_spline.argtypes = [C.c_void_p, c_dp, c_dp, c_ip, c_dp, c_dp]
+        L.orc_vo_track_frame.argtypes = [C.c_void_p, c_u8p, c_fp, C.c_double, c_u8p, C.c_double, C.c_double, c_dp,
+                                         C.POINTER(OrcVoInfo)]
         _LIB = L
     return _LIB
 

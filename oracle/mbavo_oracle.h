@@ -168,6 +168,54 @@ int orc_optimize_trajectory(const orc_track_opts *o, const orc_level *levels, in
                             int *start_idx_out /*F*/, double *final_cost,
                             orc_trace_rec *trace, int trace_cap);
 
+/* ==== callers either side of the path (mbavo_oracle_vo.c) ==== */
+/* poses below are 7 doubles: t[3], q[4] xyzw (Transformation's internal layout) */
+void orc_transform_mul(const double A[7], const double B[7], double out[7]);
+void orc_transform_inverse(const double A[7], double out[7]);
+void orc_se3_exp(const double tangent[6] /*upsilon,omega*/, double t[3], double q[4]);   /* Sophus::SE3d::exp */
+void orc_se3_log(const double t[3], const double q[4], double tangent[6]);              /* Sophus::SE3d::log */
+void orc_spline_get_pose(int k, double t0, double dt, const double *kt, const double *kR, double t,
+                         double p[3], double q[4]);
+void orc_spline_transform_by_right(double *kt, double *kR, int N, const double dq[4], const double dt[3]);
+void orc_spline_transform_to(int k, double t0, double dtk, double *kt, double *kR, int N, double t,
+                             const double q_target[4], const double t_target[3]);
+/* returns the number of keypoints found (may exceed cap; only the first cap are written) */
+int orc_detect_semidense(const float *mag, int H, int W, int lv, int im_H0, int im_W0, int cell_H, int cell_W,
+                         float thr, float *out_xy, float *out_resp_or_null, int cap);
+int orc_keypoint_depths(const float *kp_xy, int n, int lv, const float *depth_z, int H0, int W0,
+                        double *out_xy, double *out_z);
+int orc_is_keyframe(const double intr[4], const double *kp_xy, const double *kp_z, int K,
+                    int k, double t0, double dtk, const double *kt, const double *kR,
+                    double cap, double exp_t, double flow_mag0, double flow_mag1, double max_kernel,
+                    double *avg_flow_out, double *avg_kernel_out);
+
+typedef struct orc_vo_opts { /* BlurAwareDirectTrackerOptions (blur_aware_direct_tracker.h:15-67) */
+    int H, W, num_levels;
+    double intr[4];
+    int num_virtual_poses[8], patch_size[8];
+    const int *pattern_xy[8];
+    double huber_k;
+    int max_nonmono, max_num_iterations, solver_type, spline_deg_k;
+    double min_step_quality, min_abs_cost_decrease;
+    double dt_frame, dt_ctrl_knot, max_chi_square_error;
+    double keyframe_max_flow_mag0, keyframe_max_flow_mag1, keyframe_max_flow_mag2, keyframe_max_blur_kernel_mag;
+    float score_threshold; int grid_cell_H, grid_cell_W; /* tmpProcessKeyframe hard-codes 25 / 30 / 30 */
+} orc_vo_opts;
+typedef struct orc_vo_info {
+    int is_keyframe, num_keypoints0, num_trace, start_idx;
+    double avg_flow, avg_kernel, final_cost;
+} orc_vo_info;
+typedef struct orc_vo orc_vo;
+orc_vo *orc_vo_create(const orc_vo_opts *o);
+void orc_vo_destroy(orc_vo *v);
+int orc_vo_set_spline(orc_vo *v, double t0, double dt, int N, const double *kt, const double *kR);
+int orc_vo_num_keypoints(const orc_vo *v, int level);
+void orc_vo_keypoints(const orc_vo *v, int level, double *xy, double *z);
+void orc_vo_spline(const orc_vo *v, double *t0, double *dt, int *N, double *kt, double *kR);
+int orc_vo_track_frame(orc_vo *v, const unsigned char *sharp, const float *depth_z, double sharp_cap,
+                       const unsigned char *blur, double blur_cap, double blur_exp,
+                       double T_out[7], orc_vo_info *info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,178 @@
+"""Synthetic VO sequence for the trackFrame front end, shared by the CPU (oracle) and GPU
+tests: a textured fronto-parallel plane seen by a camera moving along a ground-truth spline; for every time step a
+sharp image (the keyframe candidates), its z-depth map, and a motion-blurred image (the tracked frames), all
+synthesised with the oracle's restatement of generate_synthetic_data.cpp:127-214."""
+import ctypes as C
+
+import numpy as np
+
+from mba_vo_amd import synth
+
+PATTERN8 = synth.PATTERN8
+PATTERN_SMALL = np.array([0, 0, 1, 0, 0, 1, -1, 0, 0, -1, 1, 1, -1, -1, 1, -1], np.int32)
+
+
+def _quat_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def plane_depth_map(H, W, intr, q, t, D):
+    """z-depth, in the camera at pose (q, t) [camera -> plane frame], of the plane z = D of the plane frame."""
+    fx, fy, cx, cy = intr
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    ray = np.stack([(xs - cx) / fx, (ys - cy) / fy, np.ones_like(xs)], -1)
+    rz = ray @ _quat_R(q)[2]
+    return np.ascontiguousarray(((D - t[2]) / rz).astype(np.float32))
+
+
+def make_sequence(orc, H=120, W=160, M=6, k_gt=4, trans_scale=0.15, rot_scale=0.02, D=7.5, exp=0.04, frame_dt=0.1,
+                  t_first=0.1, blur_samples=12, seed=3):
+    L = orc.lib()
+    I0 = synth.texture_image(H, W, seed=seed, octaves=(32, 16, 8, 4))
+    intr = np.array([W / 2.0, W / 2.0, W / 2.0, H / 2.0])
+    N = 7
+    kt, kR = synth.harness_spline(trans_scale, rot_scale, N)
+    kt, kR = np.ascontiguousarray(kt.ravel()), np.ascontiguousarray(kR.ravel())
+    t0, dtk = 0.0, 0.5
+    times = t_first + frame_dt * np.arange(M + 1)
+    sharp, depth, blur, gt = [], [], [], []
+    for t in times:
+        p, q = np.zeros(3), np.zeros(4)
+        L.orc_spline_get_pose(k_gt, t0, dtk, orc.dp(kt), orc.dp(kR), float(t), orc.dp(p), orc.dp(q))
+        img = np.zeros((H, W), np.uint8)
+        L.orc_warp_image(orc.u8p(I0), H, W, orc.dp(q), orc.dp(p), float(D), orc.dp(intr), orc.u8p(img))
+        sharp.append(img)
+        depth.append(plane_depth_map(H, W, intr, q, p, D))
+        b = np.zeros((H, W), np.uint8)
+        L.orc_synthesize_blur(orc.u8p(I0), H, W, float(D), orc.dp(intr), k_gt, t0, dtk, orc.dp(kt), orc.dp(kR), float(t),
+                              float(exp), blur_samples, orc.u8p(b))
+        blur.append(b)
+        gt.append(np.r_[p, q])
+    return dict(H=H, W=W, intr=intr, times=times, exp=exp, frame_dt=frame_dt, sharp=sharp, depth=depth, blur=blur,
+                gt=np.array(gt), D=D)
+
+
+DEFAULTS = dict(levels=3, S=(8, 6, 4), k=2, huber_k=10.0, max_nonmono=5, max_iter=30, solver=0, min_quality=0.5,
+                min_dec=1e-3, chi=3.0, flow0=2.5, flow1=6.0, flow2=0.5, kernel=3.0, thr=3.0, cell=10)
+
+
+def _patterns(levels):
+    return [PATTERN8 if l == 0 else PATTERN_SMALL for l in range(levels)]
+
+
+def fill_oracle_opts(orc, seq, cfg):
+    o = orc.OrcVoOpts()
+    pats = _patterns(cfg["levels"])
+    o.H, o.W, o.num_levels = seq["H"], seq["W"], cfg["levels"]
+    for i in range(4):
+        o.intr[i] = float(seq["intr"][i])
+    for l in range(cfg["levels"]):
+        o.num_virtual_poses[l], o.patch_size[l] = cfg["S"][l], pats[l].size // 2
+        o.pattern_xy[l] = orc.ip(pats[l])
+    o.huber_k, o.max_nonmono, o.max_num_iterations, o.solver_type = cfg["huber_k"], cfg["max_nonmono"], cfg["max_iter"], cfg["solver"]
+    o.spline_deg_k, o.min_step_quality, o.min_abs_cost_decrease = cfg["k"], cfg["min_quality"], cfg["min_dec"]
+    o.dt_frame, o.dt_ctrl_knot, o.max_chi_square_error = seq["frame_dt"], seq["frame_dt"], cfg["chi"]
+    o.keyframe_max_flow_mag0, o.keyframe_max_flow_mag1 = cfg["flow0"], cfg["flow1"]
+    o.keyframe_max_flow_mag2, o.keyframe_max_blur_kernel_mag = cfg["flow2"], cfg["kernel"]
+    o.score_threshold, o.grid_cell_H, o.grid_cell_W = cfg["thr"], cfg["cell"], cfg["cell"]
+    return o, pats
+
+
+def fill_gpu_opts(capi, seq, cfg):
+    o = capi.VoOptions()
+    pats = _patterns(cfg["levels"])
+    o.H, o.W, o.num_pyramid_levels = seq["H"], seq["W"], cfg["levels"]
+    for i in range(4):
+        o.intrinsics[i] = float(seq["intr"][i])
+    for l in range(cfg["levels"]):
+        o.num_virtual_poses_per_frame[l], o.patch_size[l] = cfg["S"][l], pats[l].size // 2
+        o.local_patch_pattern_xy[l] = capi.ip(pats[l])
+    o.huber_k, o.max_consecutive_nonmonotonic_steps = cfg["huber_k"], cfg["max_nonmono"]
+    o.max_num_iterations, o.solver_type = cfg["max_iter"], cfg["solver"]
+    o.spline_deg_k, o.min_step_quality, o.min_abs_cost_decrease = cfg["k"], cfg["min_quality"], cfg["min_dec"]
+    o.dt_frame, o.dt_ctrl_knot, o.max_chi_square_error = seq["frame_dt"], seq["frame_dt"], cfg["chi"]
+    o.keyframe_max_flow_mag0, o.keyframe_max_flow_mag1 = cfg["flow0"], cfg["flow1"]
+    o.keyframe_max_flow_mag2, o.keyframe_max_blur_kernel_mag = cfg["flow2"], cfg["kernel"]
+    o.score_threshold, o.grid_selection_cell_H, o.grid_selection_cell_W = cfg["thr"], cfg["cell"], cfg["cell"]
+    return o, pats
+
+
+def run_oracle_vo(orc, seq, cfg=DEFAULTS):
+    L = orc.lib()
+    o, keep = fill_oracle_opts(orc, seq, cfg)
+    vo = L.orc_vo_create(C.byref(o))
+    assert vo
+    out = []
+    try:
+        for i, t in enumerate(seq["times"]):
+            T = np.zeros(7)
+            info = orc.OrcVoInfo()
+            rc = L.orc_vo_track_frame(vo, orc.u8p(seq["sharp"][i]), orc.fp(seq["depth"][i]), float(t), orc.u8p(seq["blur"][i]),
+                                      float(t), float(seq["exp"]), orc.dp(T), C.byref(info))
+            assert rc == 0
+            K = [L.orc_vo_num_keypoints(vo, l) for l in range(cfg["levels"])]
+            out.append(dict(T=T, is_keyframe=info.is_keyframe, K=K, num_trace=info.num_trace, start_idx=info.start_idx,
+                            avg_flow=info.avg_flow, avg_kernel=info.avg_kernel, cost=info.final_cost))
+        xy, z = np.zeros(2 * out[-1]["K"][0]), np.zeros(out[-1]["K"][0])
+        L.orc_vo_keypoints(vo, 0, orc.dp(xy), orc.dp(z))
+        out[-1]["kp0"] = (xy.reshape(-1, 2), z)
+    finally:
+        L.orc_vo_destroy(vo)
+    return out
+
+
+def run_gpu_vo(mbavo, ctx, seq, cfg=DEFAULTS):
+    capi = mbavo.capi
+    o, keep = fill_gpu_opts(capi, seq, cfg)
+    vo = capi.vp()
+    capi.check(ctx.lib.mbavo_vo_create(ctx.handle, C.byref(o), C.byref(vo)), "mbavo_vo_create")
+    out = []
+    try:
+        for i, t in enumerate(seq["times"]):
+            T = np.zeros(7)
+            info = capi.VoInfo()
+            sharp, depth, blur = seq["sharp"][i], seq["depth"][i], seq["blur"][i]
+            rc = ctx.lib.mbavo_vo_track_frame(vo, sharp.ctypes.data, depth.ctypes.data, float(t), blur.ctypes.data, float(t),
+                                              float(seq["exp"]), capi.dp(T), C.byref(info))
+            assert rc == 0, rc
+            K = [ctx.lib.mbavo_vo_num_keypoints(vo, l) for l in range(cfg["levels"])]
+            out.append(dict(T=T, is_keyframe=info.is_keyframe, K=K, num_trace=info.num_trace, start_idx=info.start_idx,
+                            avg_flow=info.avg_flow, avg_kernel=info.avg_kernel, cost=info.final_cost))
+        xy, z = np.zeros(2 * out[-1]["K"][0]), np.zeros(out[-1]["K"][0])
+        capi.check(ctx.lib.mbavo_vo_get_keypoints(vo, 0, capi.dp(xy), capi.dp(z)), "mbavo_vo_get_keypoints")
+        out[-1]["kp0"] = (xy.reshape(-1, 2), z)
+    finally:
+        ctx.lib.mbavo_vo_destroy(vo)
+    return out
+
+
+def gt_relative(orc, seq):
+    """Ground-truth pose of every frame relative to the first sharp frame (the tracker's world)."""
+    L = orc.lib()
+    T0i = np.zeros(7)
+    L.orc_transform_inverse(orc.dp(np.ascontiguousarray(seq["gt"][0])), orc.dp(T0i))
+    out = []
+    for g in seq["gt"]:
+        T = np.zeros(7)
+        L.orc_transform_mul(orc.dp(T0i), orc.dp(np.ascontiguousarray(g)), orc.dp(T))
+        out.append(T)
+    return np.array(out)
+
+
+def reprojection_error(seq, T_est, T_gt, step=8):
+    """Mean distance (pixels) between where points of the first keyframe land in a frame under the estimated and the
+    ground-truth relative pose: gauge-free (on a plane small rotations and translations trade off)."""
+    H, W = seq["H"], seq["W"]
+    fx, fy, cx, cy = seq["intr"]
+    ys, xs = np.meshgrid(np.arange(4, H - 4, step), np.arange(4, W - 4, step), indexing="ij")
+    z = seq["depth"][0][ys, xs].astype(np.float64)
+    P = np.stack([(xs - cx) / fx * z, (ys - cy) / fy * z, z], -1).reshape(-1, 3)
+    out = []
+    for T in (T_est, T_gt):
+        R = _quat_R(T[3:])
+        Pc = (P - T[:3]) @ R  # R^T (P - t)
+        out.append(np.stack([fx * Pc[:, 0] / Pc[:, 2] + cx, fy * Pc[:, 1] / Pc[:, 2] + cy], 1))
+    return float(np.linalg.norm(out[0] - out[1], axis=1).mean()), float(np.linalg.norm(out[1] - np.stack([xs.ravel(), ys.ravel()], 1), axis=1).mean())

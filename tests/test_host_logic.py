@@ -119,3 +119,36 @@ def test_segment_start_index_golden(mbavo):
     L = mbavo.load()
     for t, i_ref in zip(G["seg_t"], G["seg_idx"]):
         assert L.mbavo_segment_start_index(float(t), 0.0, 0.5) == i_ref
+
+
+def test_transformation_and_spline_frame_change_match_oracle(mbavo, orc):
+    """Core::Transformation exp/log/*/inverse and SplineSE3::TransformTo of the product (host code, no device)
+    against the oracle's restatement; tolerance 1e-14 (same closed forms, different quaternion-rotate grouping)."""
+    import ctypes as C
+    lib, L = mbavo.load(), orc.lib()
+    dp = mbavo.capi.dp
+    rng = np.random.default_rng(4)
+    for scale in (0.0, 1e-12, 1e-4, 0.3, 1.0):
+        a, b = rng.normal(0, 1, 6) * scale, rng.normal(0, 1, 6) * scale
+        A, B, Ao, Bo = np.zeros(7), np.zeros(7), np.zeros(7), np.zeros(7)
+        assert lib.mbavo_se3_exp(dp(a), dp(A)) == 0 and lib.mbavo_se3_exp(dp(b), dp(B)) == 0
+        L.orc_se3_exp(orc.dp(a), orc.dp(Ao), orc.dp(Ao[3:])); L.orc_se3_exp(orc.dp(b), orc.dp(Bo), orc.dp(Bo[3:]))
+        assert np.abs(A - Ao).max() < 1e-14 and np.abs(B - Bo).max() < 1e-14
+        la, lo = np.zeros(6), np.zeros(6)
+        assert lib.mbavo_se3_log(dp(A), dp(la)) == 0
+        L.orc_se3_log(orc.dp(Ao), orc.dp(Ao[3:]), orc.dp(lo))
+        assert np.abs(la - lo).max() < 1e-14 and np.abs(la - a).max() < 1e-12
+        M, Mo, I, Io = np.zeros(7), np.zeros(7), np.zeros(7), np.zeros(7)
+        lib.mbavo_transform_mul(dp(A), dp(B), dp(M)); L.orc_transform_mul(orc.dp(Ao), orc.dp(Bo), orc.dp(Mo))
+        lib.mbavo_transform_inverse(dp(A), dp(I)); L.orc_transform_inverse(orc.dp(Ao), orc.dp(Io))
+        assert np.abs(M - Mo).max() < 1e-14 and np.abs(I - Io).max() < 1e-14
+    for k, N in ((2, 2), (4, 6)):
+        kt, kR = synth.harness_spline(0.1, 0.2, N)
+        kt, kR = np.ascontiguousarray(kt.ravel()), np.ascontiguousarray(kR.ravel())
+        kt2, kR2 = kt.copy(), kR.copy()
+        tgt = np.zeros(7)
+        lib.mbavo_se3_exp(dp(np.array([0.3, -0.2, 0.1, 0.2, 0.1, -0.3])), dp(tgt))
+        assert lib.mbavo_spline_transform_to(k, 0.0, 0.5, dp(kt), dp(kR), N, 0.2, dp(tgt[3:]), dp(tgt)) == 0
+        L.orc_spline_transform_to(k, 0.0, 0.5, orc.dp(kt2), orc.dp(kR2), N, 0.2, orc.dp(tgt[3:]), orc.dp(tgt))
+        assert np.abs(kt - kt2).max() < 1e-13 and np.abs(kR - kR2).max() < 1e-14
+        assert lib.mbavo_spline_transform_to(k, 0.0, 0.5, dp(kt), dp(kR), N, 99.0, dp(tgt[3:]), dp(tgt)) == -2  # MBAVO_E_RANGE

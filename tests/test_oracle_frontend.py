@@ -1,0 +1,156 @@
+"""The oracle's restatement of the callers of the path, checked by closed forms and brute
+force because the reference's own versions need OpenCV / Sophus / Eigen (absent here):
+  * Transformation::exp/log (Sophus::SE3d) against scipy's matrix exponential of the 4x4 twist
+  * semi-dense detector + grid selection against a brute-force numpy restatement of the rule
+  * SplineSE3::TransformTo by its defining property
+  * trackFrame on a synthetic blurred sequence: tracks the ground truth, switches keyframes"""
+import ctypes as C
+
+import numpy as np
+import scipy.linalg as sl
+
+import frontend
+from mba_vo_amd import synth
+
+
+def _R(q):
+    return frontend._quat_R(q)
+
+
+def test_se3_exp_log_against_matrix_exponential(orc):
+    L = orc.lib()
+    rng = np.random.default_rng(0)
+    for scale in (0.0, 1e-12, 1e-6, 1e-3, 0.1, 0.5, 1.0):
+        for _ in range(5):
+            a = rng.normal(0, 1, 6) * scale
+            t, q = np.zeros(3), np.zeros(4)
+            L.orc_se3_exp(orc.dp(a), orc.dp(t), orc.dp(q))
+            w = a[3:]
+            M = np.zeros((4, 4))
+            M[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]
+            M[:3, 3] = a[:3]
+            E = sl.expm(M)
+            assert np.abs(_R(q) - E[:3, :3]).max() < 1e-13
+            assert np.abs(t - E[:3, 3]).max() < 1e-13 * max(1.0, np.abs(a).max())
+            assert abs(np.linalg.norm(q) - 1) < 1e-15
+            back = np.zeros(6)
+            L.orc_se3_log(orc.dp(t), orc.dp(q), orc.dp(back))
+            assert np.abs(back - a).max() < 1e-12
+
+
+def test_transform_algebra(orc):
+    L = orc.lib()
+    rng = np.random.default_rng(1)
+    for _ in range(10):
+        A, B = np.zeros(7), np.zeros(7)
+        for T in (A, B):
+            a = rng.normal(0, 0.7, 6)
+            L.orc_se3_exp(orc.dp(a), orc.dp(T), orc.dp(T[3:]))
+        AB, Ai, I = np.zeros(7), np.zeros(7), np.zeros(7)
+        L.orc_transform_mul(orc.dp(A), orc.dp(B), orc.dp(AB))
+        assert np.abs(_R(AB[3:]) - _R(A[3:]) @ _R(B[3:])).max() < 1e-14
+        assert np.abs(AB[:3] - (_R(A[3:]) @ B[:3] + A[:3])).max() < 1e-14
+        L.orc_transform_inverse(orc.dp(A), orc.dp(Ai))
+        L.orc_transform_mul(orc.dp(A), orc.dp(Ai), orc.dp(I))
+        assert np.abs(I - np.array([0, 0, 0, 0, 0, 0, 1.0])).max() < 1e-14
+
+
+def _brute_detect(mag, lv, H0, W0, cell, thr):
+    """FeatureDetectorSemiDense.cpp:27-43 + FeatureDetectorBase.cpp:49-91 with plain Python loops."""
+    H, W = mag.shape
+    ch, cw = int(cell / 1.414 ** lv), int(cell / 1.414 ** lv)
+    ncw = (W0 // 2 ** lv) // cw + 1
+    nch = (H0 // 2 ** lv) // ch + 1
+    best = {}
+    for y in range(H):
+        for x in range(W):
+            m = mag[y, x]
+            if m > thr:
+                c = (y // ch) * ncw + (x // cw)
+                if best.get(c, (np.float32(0),))[0] < m:
+                    best[c] = (m, x, y)
+    return [(best[c][1], best[c][2]) for c in range(nch * ncw) if c in best and not best[c][0] < 1e-6]
+
+
+def test_semidense_detector_brute_force(orc):
+    L = orc.lib()
+    H0, W0 = 96, 128
+    img = synth.texture_image(H0, W0, seed=5, octaves=(32, 16, 8, 4))
+    img[10:30, 40:90] = 128  # a flat region: empty cells
+    pyr = synth.pyramid(img, 3)
+    depth = np.random.default_rng(2).uniform(0.0, 3.0, (H0, W0)).astype(np.float32)
+    depth[depth < 0.3] = 0.0  # invalid depths
+    dropped = 0
+    for lv, im in enumerate(pyr):
+        H, W = im.shape
+        g, mag = np.zeros((H, W, 2), np.float32), np.zeros((H, W), np.float32)
+        L.orc_image_gradients_u8(orc.u8p(im), H, W, orc.fp(g), orc.fp(mag))
+        for cell, thr in ((12, 3.0), (30, 0.5), (7, 8.0)):
+            xy = np.zeros(2 * H * W, np.float32)
+            n = L.orc_detect_semidense(orc.fp(mag), H, W, lv, H0, W0, cell, cell, thr, orc.fp(xy), None, H * W)
+            want = _brute_detect(mag, lv, H0, W0, cell, thr)
+            assert n == len(want) and n > 0
+            assert [(int(a), int(b)) for a, b in xy[:2 * n].reshape(-1, 2)] == want
+            # depth lookup (blur_aware_direct_tracker.cpp:389-415)
+            oxy, oz = np.zeros(2 * n), np.zeros(n)
+            K = L.orc_keypoint_depths(orc.fp(xy), n, lv, orc.fp(depth), H0, W0, orc.dp(oxy), orc.dp(oz))
+            keep = [(x, y, depth[int(y * 2 ** lv + 0.5), int(x * 2 ** lv + 0.5)]) for x, y in want]
+            keep = [(x, y, z) for x, y, z in keep if not z < 1e-2]
+            assert K == len(keep) and 0 < K <= n
+            dropped += n - K
+            assert np.array_equal(oxy[:2 * K].reshape(-1, 2), np.array([(x, y) for x, y, _ in keep], np.float64))
+            assert np.array_equal(oz[:K], np.array([z for _, _, z in keep], np.float64))
+        # no grid selection: every candidate in row-major order
+        assert dropped > 0
+        xy = np.zeros(2 * H * W, np.float32)
+        n = L.orc_detect_semidense(orc.fp(mag), H, W, lv, H0, W0, 0, 0, 6.0, orc.fp(xy), None, H * W)
+        ys, xs = np.nonzero(mag > 6.0)
+        assert n == len(xs) and np.array_equal(xy[:2 * n].reshape(-1, 2), np.stack([xs, ys], 1).astype(np.float32))
+
+
+def _qmul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def test_spline_transform_to(orc):
+    """Spline.h:183-200 against numpy: dR = R(t)^-1 R*, dt = R(t)^-1 (t* - t(t)); knot_i: t += R_i dt, R_i = R_i dR.
+    The rotation at t becomes the target exactly; the translation only when all knot rotations agree (the reference
+    rotates dt by each knot's own R_i), which is the reference's behaviour, not an error of the restatement."""
+    L = orc.lib()
+    for k, N in ((2, 2), (4, 5)):
+        kt, kR = synth.harness_spline(0.1, 0.2, N)
+        kt0, kR0 = kt.copy(), kR.copy()
+        kt, kR = np.ascontiguousarray(kt.ravel()), np.ascontiguousarray(kR.ravel())
+        ts = 0.1
+        T = np.zeros(7)
+        L.orc_spline_get_pose(k, 0.0, 0.5, orc.dp(kt), orc.dp(kR), ts, orc.dp(T), orc.dp(T[3:]))
+        target = np.zeros(7)
+        L.orc_se3_exp(orc.dp(np.array([0.3, -0.2, 0.1, 0.2, 0.1, -0.3])), orc.dp(target), orc.dp(target[3:]))
+        L.orc_spline_transform_to(k, 0.0, 0.5, orc.dp(kt), orc.dp(kR), N, ts, orc.dp(target[3:]), orc.dp(target))
+        qi = np.array([-T[3], -T[4], -T[5], T[6]]) / np.dot(T[3:], T[3:])
+        dR, dt = _qmul(qi, target[3:]), _R(qi) @ (target[:3] - T[:3])
+        for i in range(N):
+            assert np.abs(kt[3 * i:3 * i + 3] - (kt0[i] + _R(kR0[i]) @ dt)).max() < 1e-14
+            assert np.abs(kR[4 * i:4 * i + 4] - _qmul(kR0[i], dR)).max() < 1e-15
+        after = np.zeros(7)
+        L.orc_spline_get_pose(k, 0.0, 0.5, orc.dp(kt), orc.dp(kR), ts, orc.dp(after), orc.dp(after[3:]))
+        assert np.abs(after[3:] - target[3:]).max() < 1e-14
+        assert np.abs(after[:3] - target[:3]).max() < 1e-4
+
+
+def test_track_frame_sequence(orc):
+    seq = frontend.make_sequence(orc, M=6)
+    out = frontend.run_oracle_vo(orc, seq)
+    gt = frontend.gt_relative(orc, seq)
+    assert out[0]["is_keyframe"] == 1 and np.array_equal(out[0]["T"], [0, 0, 0, 0, 0, 0, 1])
+    kf = [o["is_keyframe"] for o in out]
+    assert 2 <= sum(kf) < len(kf)  # new keyframes are created, but not on every frame
+    for o, g in zip(out[1:], gt[1:]):
+        assert o["start_idx"] == 0 and o["num_trace"] >= 3 and o["K"][0] > 100
+        err, flow = frontend.reprojection_error(seq, o["T"], g)
+        assert err < 0.1 * flow + 0.1, (err, flow)  # pixels; drift accumulates over keyframe changes
+    again = frontend.run_oracle_vo(orc, seq)
+    assert all(np.array_equal(a["T"], b["T"]) for a, b in zip(out, again))
