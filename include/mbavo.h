@@ -172,6 +172,25 @@ int mbavo_optimize_trajectory(mbavo_ctx *ctx, const mbavo_track_opts *opts, cons
                               double *h_knots_t, double *h_knots_R, int N, int *h_start_idx_out,
                               double *h_final_cost, mbavo_trace_rec *trace, int trace_cap);
 
+/* ---- device-side LM over a batch of independent problems (one pyramid level each): optimizePyramidLevel
+ * (ba_tracker/blur_aware_direct_tracker.cpp:590-924) for B problems at once with the packed blocks, the 6N x 6N
+ * assembly / damping / solve (solve_normal_equation.h:10-35), the radius and step-evaluator state and the outlier
+ * statistics all on the device; the host only polls a done-counter every `sync_every` iterations.
+ * Each problem's knots (d_knots_t / d_knots_R, device) are updated in place; d_outlier / num_bad of the input are
+ * ignored (flags start cleared, as at the start of a level).  Trace records as mbavo_optimize_trajectory writes
+ * them (level = 0), `trace_cap` per problem.  Returns 0 or an error. */
+typedef struct mbavo_lm_batch_opts {
+    int spline_deg_k, max_num_iterations, max_consecutive_nonmonotonic_steps, solver_type, sync_every;
+    double min_step_quality, min_abs_cost_decrease, max_chi_square_error;
+} mbavo_lm_batch_opts;
+typedef struct mbavo_lm_batch_result {
+    int iterations, accepted, rejected, invalid, num_outliers, num_trace;
+    double initial_cost, final_cost, radius;
+} mbavo_lm_batch_result;
+int mbavo_lm_batch(mbavo_ctx *ctx, int B, const mbavo_problem *h_problems, const mbavo_lm_batch_opts *opts,
+                   mbavo_lm_batch_result *h_results_or_null /*B*/, mbavo_trace_rec *h_trace_or_null /*B x trace_cap*/,
+                   int trace_cap);
+
 /* ---- keyframe input producers on device (core/measurements/ImagePyramid.h:59-99,
  * core/image_proc/Gradient.h:16-75) */
 int mbavo_pyramid_down_u8(const unsigned char *d_src, int H, int W, unsigned char *d_dst, void *hip_stream);

@@ -55,6 +55,20 @@ class TraceRec(C.Structure):
     ]
 
 
+class LmBatchOpts(C.Structure):
+    """struct mbavo_lm_batch_opts"""
+    _fields_ = [("spline_deg_k", C.c_int), ("max_num_iterations", C.c_int), ("max_consecutive_nonmonotonic_steps", C.c_int),
+                ("solver_type", C.c_int), ("sync_every", C.c_int), ("min_step_quality", C.c_double),
+                ("min_abs_cost_decrease", C.c_double), ("max_chi_square_error", C.c_double)]
+
+
+class LmBatchResult(C.Structure):
+    """struct mbavo_lm_batch_result"""
+    _fields_ = [("iterations", C.c_int), ("accepted", C.c_int), ("rejected", C.c_int), ("invalid", C.c_int),
+                ("num_outliers", C.c_int), ("num_trace", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("radius", C.c_double)]
+
+
 class VoOptions(C.Structure):
     """struct mbavo_vo_options"""
     _fields_ = [
@@ -89,7 +103,7 @@ SYMBOLS = [
     "mbavo_profile", "mbavo_profile_read", "mbavo_version",
     "mbavo_gradient_magnitude_u8", "mbavo_detect_semidense", "mbavo_se3_exp", "mbavo_se3_log", "mbavo_transform_mul",
     "mbavo_transform_inverse", "mbavo_spline_transform_to", "mbavo_vo_create", "mbavo_vo_destroy", "mbavo_vo_set_spline",
-    "mbavo_vo_get_spline", "mbavo_vo_num_keypoints", "mbavo_vo_get_keypoints", "mbavo_vo_track_frame",
+    "mbavo_vo_get_spline", "mbavo_vo_num_keypoints", "mbavo_vo_get_keypoints", "mbavo_vo_track_frame", "mbavo_lm_batch",
 ]
 
 
@@ -179,6 +193,8 @@ def load():
     L.mbavo_vo_num_keypoints.argtypes = [vp, C.c_int]
     L.mbavo_vo_get_keypoints.argtypes = [vp, C.c_int, c_dp, c_dp]
     L.mbavo_vo_track_frame.argtypes = [vp, vp, vp, C.c_double, vp, C.c_double, C.c_double, c_dp, C.POINTER(VoInfo)]
+    L.mbavo_lm_batch.argtypes = [vp, C.c_int, C.POINTER(Problem), C.POINTER(LmBatchOpts), C.POINTER(LmBatchResult),
+                                 C.POINTER(TraceRec), C.c_int]
     L.mbavo_profile.argtypes = [vp, C.c_int]
     L.mbavo_profile_read.argtypes = [vp, c_dp, c_ip]
     _LIB = L

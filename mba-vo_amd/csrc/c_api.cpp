@@ -243,6 +243,13 @@ extern "C"
                                           final_cost, trace, cap);
     }
 
+    int mbavo_lm_batch(mbavo_ctx *ctx, int B, const mbavo_problem *probs, const mbavo_lm_batch_opts *o,
+                       mbavo_lm_batch_result *results, mbavo_trace_rec *trace, int trace_cap)
+    {
+        if (!ctx || !probs || !o || trace_cap < 0) return MBAVO_E_ARG;
+        return mbavo::lm_batch(*ctx->engine, B, probs, *o, results, trace, trace_cap);
+    }
+
     // ---- trackFrame front end
     int mbavo_detect_semidense(mbavo_ctx *ctx, const unsigned char *d_img, int H, int W, int level, int H0, int W0, int cell_H,
                                int cell_W, float thr, const float *d_depth_z, double *d_kp_xy, double *d_kp_z, int cap, int *h_count)

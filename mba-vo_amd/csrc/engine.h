@@ -41,6 +41,10 @@ namespace mbavo
         int bf_base;          // first (problem, frame) slot
         long long pixel_base; // first pixel of this problem in the rho scratch (f*K*P + kp*P + p)
         long long patch_base; // first patch of this problem in the patch-cost output (f*K + kp)
+        // device-side LM (lm_batch.hip): bit 0 = take part in cost-only passes, bit 1 = in H/g passes (null: always);
+        // 1/((K - bad)*F*P) kept on the device because the outlier count changes there (null: the field above)
+        const int *active;
+        const double *inv_ptr;
     };
 
     // a tile = a contiguous keypoint range of one (problem, frame), handled by one workgroup
@@ -61,7 +65,9 @@ namespace mbavo
         // asynchronous; see mbavo_eval_batch
         int evaluate(int B, const mbavo_problem *probs, int kdeg, bool with_hessian,
                      double *d_frame_blocks, double *d_patch_cost, double *d_valid,
-                     double *d_patch_blocks_strided /* B == 1 only, stride E, may be null */);
+                     double *d_patch_blocks_strided /* B == 1 only, stride E, may be null */,
+                     const int *d_active_mask = nullptr /* [B] */, const double *d_inv = nullptr /* [B] */);
+        const ProblemDesc *device_descs() const { return (const ProblemDesc *)d_descs_; }
 
         // range status since the previous fetch (call after a stream sync): non-zero if a blur
         // sample's knot segment had to be clamped into [0, N-k]
@@ -84,7 +90,7 @@ namespace mbavo
 
     private:
         int ensure(void **ptr, size_t *cap, size_t bytes);
-        int rebuild_layout(int B, const mbavo_problem *probs, int kdeg);
+        int rebuild_layout(int B, const mbavo_problem *probs, int kdeg, const int *d_active, const double *d_inv);
 
         int device_;
         hipStream_t stream_ = nullptr;

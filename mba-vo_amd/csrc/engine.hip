@@ -318,6 +318,7 @@ namespace mbavo
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         const TileDesc tile = tiles[blockIdx.x];
         const ProblemDesc &d = descs[tile.prob];
+        if (d.active != nullptr && (*d.active & (WITH_J ? 2 : 1)) == 0) return; // device-side LM: problem sits this pass out
         const int S = d.S, K = d.K, P = d.P, frame = tile.frame;
         Camera cam;
         cam.fx = d.fx; cam.fy = d.fy; cam.cx = d.cx; cam.cy = d.cy; cam.H = d.H; cam.W = d.W;
@@ -407,7 +408,7 @@ namespace mbavo
         // tile's share of the frame cost (outlier patches skipped, :265-272)
         __syncthreads();
         double cost_local = 0.0;
-        const double inv = d.inv_num_residuals;
+        const double inv = d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals;
         for (int kpl = threadIdx.x; kpl < tile.kp_count; kpl += kThreads)
         {
             const double *r = rho_out + pix0 + (long long)kpl * P;
@@ -462,6 +463,8 @@ namespace mbavo
         constexpr int E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
         __shared__ double sm[16][17];
         const int bf = blockIdx.x;
+        const ProblemDesc &pd = descs[bf_prob[bf]];
+        if (pd.active != nullptr && (*pd.active & (WITH_J ? 2 : 1)) == 0) return; // outputs keep their previous values
         const int el = threadIdx.x & 15, tl = threadIdx.x >> 4;
         const int e = blockIdx.y * 16 + el; // partial slot 0..E
         const int t0 = bf_tile_begin[bf], t1 = bf_tile_begin[bf + 1];
@@ -480,7 +483,7 @@ namespace mbavo
             const double v = sm[0][el];
             if (e == 0) { if (valid_out) valid_out[bf] = v; }
             else if (e == E) frame_blocks[(size_t)bf * E] = v; // cost: patch costs are already scaled
-            else if (WITH_J) frame_blocks[(size_t)bf * E + e] = v * descs[bf_prob[bf]].inv_num_residuals;
+            else if (WITH_J) frame_blocks[(size_t)bf * E + e] = v * (pd.inv_ptr != nullptr ? *pd.inv_ptr : pd.inv_num_residuals);
         }
     }
 
@@ -546,7 +549,7 @@ namespace mbavo
         return v && *v ? atoi(v) : dflt;
     }
 
-    int Engine::rebuild_layout(int B, const mbavo_problem *probs, int kdeg)
+    int Engine::rebuild_layout(int B, const mbavo_problem *probs, int kdeg, const int *d_active, const double *d_inv)
     {
         std::vector<ProblemDesc> descs((size_t)B);
         long long pixels = 0, patches = 0;
@@ -570,6 +573,8 @@ namespace mbavo
             d.inv_num_residuals = num_residuals > 0 ? 1.0 / (double)num_residuals : 0.0; // empty problem: all-zero blocks
             d.S = p.S; d.F = p.F; d.K = p.K; d.P = p.P; d.N = p.N; d.H = p.H; d.W = p.W; d.kp_stride = p.kp_stride;
             d.grad_fp16 = p.grad_fp16 ? 1 : 0;
+            d.active = d_active ? d_active + b : nullptr;
+            d.inv_ptr = d_inv ? d_inv + b : nullptr;
             d.pose_base = entries; d.bf_base = bf; d.pixel_base = pixels; d.patch_base = patches;
             entries += p.F * p.S;
             bf += p.F;
@@ -701,12 +706,13 @@ namespace mbavo
     }
 
     int Engine::evaluate(int B, const mbavo_problem *probs, int kdeg, bool with_hessian, double *d_frame_blocks,
-                         double *d_patch_cost, double *d_valid, double *d_patch_blocks_strided)
+                         double *d_patch_cost, double *d_valid, double *d_patch_blocks_strided, const int *d_active,
+                         const double *d_inv)
     {
         if (B < 1 || !probs || !d_frame_blocks || (kdeg != 2 && kdeg != 4)) return MBAVO_E_ARG;
         if (d_patch_blocks_strided && B != 1) return MBAVO_E_ARG;
         HIP_TRY(hipSetDevice(device_));
-        int rc = rebuild_layout(B, probs, kdeg);
+        int rc = rebuild_layout(B, probs, kdeg, d_active, d_inv);
         if (rc) return rc;
         const ProblemDesc *descs = (const ProblemDesc *)d_descs_;
         const TileDesc *tiles = (const TileDesc *)d_tiles_;

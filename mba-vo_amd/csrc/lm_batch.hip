@@ -1,0 +1,666 @@
+// lm_batch.hip -- device-side Levenberg-Marquardt over a batch of independent alignment problems
+// (SURVEY.md 8f row 4): what BlurAwareDirectTracker::optimizePyramidLevel does for ONE problem with a host round trip
+// per evaluation (ba_tracker/blur_aware_direct_tracker.cpp:590-924) runs here for B problems with no host
+// involvement inside an iteration: the packed blocks never leave the device, the 6N x 6N systems are assembled,
+// damped and solved by one wave per problem, the accept / reject decision, the LM radius, the non-monotonic
+// step evaluator and the outlier statistics are per-problem device state.  With a host loop the solve of 512
+// systems (10 ms on one core) dwarfs the 0.16 ms evaluation; here an iteration is eight launches.
+//
+//   merge                ba_tracker/merge_hessian_gradient_cost.cpp:39-86
+//   solve                ba_tracker/solve_normal_equation.h:10-35 (one-sided Jacobi SVD / pivoted LDL^T, the same
+//                        algorithms as host_math.cpp, rows spread over the lanes of a wave)
+//   LM radius            ba_tracker/levenberg_marquardt_strategy.cpp:9-45
+//   step evaluator       ba_tracker/trust_region_step_evaluator.cpp:45-126
+//   loop / outliers      ba_tracker/blur_aware_direct_tracker.cpp:590-699,799-924 (see tracker.cpp for the quirks kept)
+//
+// Per iteration slot:  k_lm_solve -> cost-only pass on the candidates -> k_lm_decide -> H/g pass on the accepted.
+// Problems that are finished, took an invalid step or rejected their step sit the passes out (ProblemDesc::active).
+#include "../../include/mbavo.h"
+#include "engine.h"
+#include "se3_math.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace mbavo
+{
+    struct LmState
+    {
+        double radius, decrease_factor;                                                        // LM strategy
+        double minimum_cost, current_cost, reference_cost, candidate_cost, acc_ref, acc_cand;  // step evaluator
+        double eval_cost, cand_cost, model, abs_dec, quality, initial_cost;
+        int num_nonmono, iter, done, fresh, pending_accept, num_bad, n_accept, n_reject, n_invalid, ntrace;
+    };
+
+    struct LmOpts
+    {
+        int max_it, max_nonmono, solver, trace_cap, max_n, max_N;
+        double min_q, min_dec, chi;
+    };
+
+    namespace
+    {
+        __device__ __forceinline__ double wsum(double v)
+        {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            return v;
+        }
+        __device__ __forceinline__ double wmax(double v)
+        {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+            return v;
+        }
+
+        __device__ void lm_clamp(LmState &s) { s.radius = fmax(fmin(1e32, s.radius), 10.0); }
+        __device__ void lm_reset(LmState &s) { s.radius = 1e4; s.decrease_factor = 2.0; }
+        __device__ void lm_accepted(LmState &s, double q)
+        {
+            s.radius = s.radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * q - 1.0, 3.0));
+            lm_clamp(s);
+            s.decrease_factor = 2.0;
+        }
+        __device__ void lm_rejected(LmState &s)
+        {
+            s.radius = s.radius / s.decrease_factor;
+            lm_clamp(s);
+            s.decrease_factor *= 2.0;
+        }
+        __device__ void tr_reset(LmState &s, double c)
+        {
+            s.minimum_cost = s.current_cost = s.reference_cost = s.candidate_cost = c;
+            s.acc_ref = s.acc_cand = 0.0;
+            s.num_nonmono = 0;
+        }
+        __device__ double tr_quality(const LmState &s, double cost, double mcc)
+        {
+            if (cost >= DBL_MAX) return -DBL_MAX;
+            const double now = (s.current_cost - cost) / mcc;
+            const double hist = (s.reference_cost - cost) / (s.acc_ref + mcc);
+            return fmax(now, hist);
+        }
+        __device__ void tr_accepted(LmState &s, double cost, double mcc, int max_nonmono)
+        {
+            s.current_cost = cost;
+            s.acc_cand += mcc;
+            s.acc_ref += mcc;
+            if (s.current_cost < s.minimum_cost)
+            {
+                s.minimum_cost = s.candidate_cost = s.current_cost;
+                s.num_nonmono = 0;
+                s.acc_cand = 0.0;
+            }
+            else
+            {
+                ++s.num_nonmono;
+                if (s.current_cost > s.candidate_cost)
+                {
+                    s.candidate_cost = s.current_cost;
+                    s.acc_cand = 0.0;
+                }
+            }
+            if (s.num_nonmono == max_nonmono)
+            {
+                s.reference_cost = s.candidate_cost;
+                s.acc_ref = s.acc_cand;
+            }
+        }
+        __device__ void trace_push(LmState &s, mbavo_trace_rec *trace, int cap, int lane, int kind, double cc, double model, double q)
+        {
+            if (trace && s.ntrace < cap && lane == 0)
+            {
+                mbavo_trace_rec &r = trace[s.ntrace];
+                r.level = 0; r.iter = s.iter; r.kind = kind; r.num_outliers = s.num_bad;
+                r.radius = s.radius; r.eval_cost = s.eval_cost; r.candidate_cost = cc; r.model_change = model; r.quality = q;
+            }
+            ++s.ntrace;
+        }
+
+        // x = pinv(A) b by one-sided (Hestenes) Jacobi, the algorithm of host_math.cpp:solve_svd with the rotations of
+        // a sweep taken in round-robin (tournament) order: the n/2 column pairs of a round are disjoint, so ONE LANE
+        // PER PAIR computes its three dot products and applies its rotation with plain sequential loops -- no
+        // cross-lane reduction and one barrier per round instead of one per rotation (the row-cyclic order with
+        // wave-wide reductions measured 2.2 us per rotation, 4.9 ms per 24 x 24 solve; this order 37x less).
+        // G holds A on entry, column-major with leading dimension ld = n + 1 (odd in doubles: the lanes of a round
+        // read different columns at the same row, a stride of n doubles would put them on 4 LDS banks); V the same.
+        __device__ void svd_solve(double *G, double *V, const double *b, double *x, double *tmp, int n, int ld, int lane)
+        {
+            for (int i = lane; i < n * n; i += 64) V[(i / n) * ld + i % n] = (i / n == i % n) ? 1.0 : 0.0;
+            __syncthreads();
+            const double eps = DBL_EPSILON;
+            const int half = n / 2, m1 = n - 1; // n = 6N is even
+            for (int sweep = 0; sweep < 60; ++sweep)
+            {
+                bool rotated = false;
+                for (int r = 0; r < m1; ++r)
+                {
+                    if (lane < half)
+                    {
+                        int p = lane == 0 ? m1 : (r + lane) % m1, q = lane == 0 ? r : (r - lane + m1) % m1;
+                        if (p > q) { const int t = p; p = q; q = t; }
+                        double *gp = G + p * ld, *gq = G + q * ld;
+                        double a = 0, c = 0, d = 0;
+                        for (int i0 = 0; i0 < n; i0 += 6)
+                        { // n = 6N: six rows at a time, all loads issued before the (in-order) accumulation
+                            double u[6], w[6];
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) { u[j] = gp[i0 + j]; w[j] = gq[i0 + j]; }
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) { a += u[j] * u[j]; c += w[j] * w[j]; d += u[j] * w[j]; }
+                        }
+                        if (!(d == 0.0 || fabs(d) <= eps * sqrt(a * c)))
+                        {
+                            rotated = true;
+                            const double zeta = (c - a) / (2.0 * d);
+                            const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                            const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                            double *vp = V + p * ld, *vq = V + q * ld;
+                            for (int i0 = 0; i0 < n; i0 += 6)
+                            {
+                                double u[6], w[6], y[6], z[6];
+#pragma unroll
+                                for (int j = 0; j < 6; ++j) { u[j] = gp[i0 + j]; w[j] = gq[i0 + j]; y[j] = vp[i0 + j]; z[j] = vq[i0 + j]; }
+#pragma unroll
+                                for (int j = 0; j < 6; ++j)
+                                {
+                                    gp[i0 + j] = cs * u[j] - sn * w[j];
+                                    gq[i0 + j] = sn * u[j] + cs * w[j];
+                                    vp[i0 + j] = cs * y[j] - sn * z[j];
+                                    vq[i0 + j] = sn * y[j] + cs * z[j];
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (__ballot(rotated) == 0ull) break;
+            }
+            // squared singular values, one column per lane
+            double smax2 = 0.0;
+            for (int j = lane; j < n; j += 64)
+            {
+                double a = 0;
+                for (int i = 0; i < n; ++i) a += G[j * ld + i] * G[j * ld + i];
+                tmp[j] = a;
+                smax2 = fmax(smax2, a);
+            }
+            smax2 = wmax(smax2);
+            const double thr = fmax((double)(n > 1 ? n : 1) * eps * sqrt(smax2), DBL_MIN);
+            for (int j = lane; j < n; j += 64)
+            {
+                const double s2 = tmp[j];
+                double dot = 0.0;
+                if (sqrt(s2) >= thr && s2 != 0.0)
+                {
+                    for (int i = 0; i < n; ++i) dot += G[j * ld + i] * b[i];
+                    dot /= s2;
+                }
+                tmp[j] = dot;
+            }
+            __syncthreads();
+            for (int i = lane; i < n; i += 64)
+            {
+                double acc = 0.0;
+                for (int j = 0; j < n; ++j)
+                    if (tmp[j] != 0.0) acc += V[j * ld + i] * tmp[j];
+                x[i] = acc;
+            }
+            __syncthreads();
+        }
+
+        // x = A^-1 b by LDL^T with diagonal pivoting (host_math.cpp:solve_ldlt); M holds A on entry
+        __device__ void ldlt_solve(double *M, const double *b, double *x, double *y, int *order, int n, int lane)
+        {
+            for (int i = lane; i < n; i += 64) order[i] = i;
+            __syncthreads();
+            for (int k = 0; k < n; ++k)
+            {
+                // pivot: the largest |diagonal| of the trailing block, the first one on ties
+                double best = -1.0;
+                int piv = 0x7fffffff;
+                for (int i = k + lane; i < n; i += 64)
+                {
+                    const double v = fabs(M[i * n + i]);
+                    if (v > best) { best = v; piv = i; }
+                }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1)
+                {
+                    const double ob = __shfl_xor(best, o, 64);
+                    const int op = __shfl_xor(piv, o, 64);
+                    if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
+                }
+                // the host scan keeps k unless a later entry is strictly larger: identical to first-maximum
+                if (piv != k)
+                {
+                    for (int c = lane; c < n; c += 64) { const double t = M[c * n + k]; M[c * n + k] = M[c * n + piv]; M[c * n + piv] = t; }
+                    __syncthreads();
+                    for (int r = lane; r < n; r += 64) { const double t = M[k * n + r]; M[k * n + r] = M[piv * n + r]; M[piv * n + r] = t; }
+                    if (lane == 0) { const int t = order[k]; order[k] = order[piv]; order[piv] = t; }
+                    __syncthreads();
+                }
+                const double d = M[k * n + k];
+                if (d == 0.0) continue;
+                for (int i = k + 1 + lane; i < n; i += 64) M[k * n + i] /= d; // column k of L
+                __syncthreads();
+                const int m = n - k - 1;
+                for (int idx = lane; idx < m * m; idx += 64)
+                { // lower triangle of the trailing block in place (each entry reads itself and column k only) ...
+                    const int i = k + 1 + idx / m, j = k + 1 + idx % m;
+                    if (i >= j) M[j * n + i] -= M[k * n + i] * (M[k * n + j] * d);
+                }
+                __syncthreads();
+                for (int idx = lane; idx < m * m; idx += 64)
+                { // ... then mirrored, so that later pivots see a full symmetric block
+                    const int i = k + 1 + idx / m, j = k + 1 + idx % m;
+                    if (i > j) M[i * n + j] = M[j * n + i];
+                }
+                __syncthreads();
+            }
+            for (int i = lane; i < n; i += 64) y[i] = b[order[i]];
+            __syncthreads();
+            for (int c = 0; c < n; ++c)
+            {
+                const double yc = y[c];
+                for (int r = c + 1 + lane; r < n; r += 64) y[r] -= M[c * n + r] * yc;
+                __syncthreads();
+            }
+            for (int i = lane; i < n; i += 64) y[i] = fabs(M[i * n + i]) > DBL_MIN ? y[i] / M[i * n + i] : 0.0;
+            __syncthreads();
+            for (int c = n - 1; c >= 0; --c)
+            {
+                double part = 0.0;
+                for (int r = c + 1 + lane; r < n; r += 64) part += M[c * n + r] * y[r];
+                part = wsum(part);
+                if (lane == 0) y[c] -= part;
+                __syncthreads();
+            }
+            for (int i = lane; i < n; i += 64) x[order[i]] = y[i];
+            __syncthreads();
+        }
+    } // namespace
+
+    // One wave per problem: finish the previous accepted step, loop control, damping, solve, model change, candidate.
+    template <int KD>
+    __global__ __launch_bounds__(64) void k_lm_solve(const ProblemDesc *__restrict__ descs, LmState *__restrict__ states, LmOpts o,
+                                                     const double *__restrict__ fb, const int *__restrict__ start_idx,
+                                                     double *__restrict__ Hst, double *__restrict__ gst,
+                                                     double *__restrict__ cur_t, double *__restrict__ cur_R,
+                                                     int *__restrict__ active, mbavo_trace_rec *__restrict__ trace,
+                                                     int *__restrict__ num_done)
+    {
+        constexpr int M6 = 6 * KD, ND = M6 + 1, E = ND * (ND + 1) / 2;
+        extern __shared__ __attribute__((aligned(16))) double lds[];
+        const int b = blockIdx.x, lane = threadIdx.x;
+        const ProblemDesc &d = descs[b];
+        const int N = d.N, n = 6 * N, F = d.F;
+        LmState s = states[b];
+        if (s.done) return;
+        double *H = lds, *V = H + n * n, *g = V + n * (n + 1), *x = g + n, *tmp = x + n;
+        int *order = (int *)(tmp + n);
+        double *Hg = Hst + (size_t)b * o.max_n * o.max_n, *gg = gst + (size_t)b * o.max_n;
+        double *Ct = cur_t + (size_t)b * 3 * o.max_N, *CR = cur_R + (size_t)b * 4 * o.max_N;
+        mbavo_trace_rec *tr = trace ? trace + (size_t)b * o.trace_cap : nullptr;
+
+        if (s.fresh)
+        { // the H/g pass at the current point has completed: its cost is the evaluation-point cost
+            double cost = 0.0;
+            for (int f = 0; f < F; ++f) cost += fb[(size_t)(d.bf_base + f) * E];
+            s.eval_cost = cost;
+            if (s.pending_accept)
+            { // handleSuccessfulStep (:896-903)
+                lm_accepted(s, s.quality);
+                tr_accepted(s, s.eval_cost, s.model, o.max_nonmono);
+                trace_push(s, tr, o.trace_cap, lane, 1, s.cand_cost, s.model, s.quality);
+                ++s.n_accept;
+            }
+            else
+            { // iteration 0 of the level (:590-606)
+                s.initial_cost = cost;
+                lm_reset(s);
+                tr_reset(s, cost);
+                trace_push(s, tr, o.trace_cap, lane, 0, 0.0, 0.0, 0.0);
+            }
+            // merge_hessian_gradient_cost.cpp:39-86, frames in order
+            for (int i = lane; i < n * n; i += 64) H[i] = 0.0;
+            for (int i = lane; i < n; i += 64) g[i] = 0.0;
+            __syncthreads();
+            for (int f = 0; f < F; ++f)
+            {
+                const double *blk = fb + (size_t)(d.bf_base + f) * E;
+                const int st = start_idx[d.bf_base + f];
+                for (int j = lane; j < M6; j += 64)
+                {
+                    const int gi = j < 3 * KD ? 3 * st + j : 3 * (N + st) + (j - 3 * KD);
+                    g[gi] += blk[1 + j];
+                }
+                for (int e = lane; e < M6 * (M6 + 1) / 2; e += 64)
+                {
+                    int r = 0, rem = e;
+                    while (rem >= M6 - r) { rem -= M6 - r; ++r; }
+                    const int c = r + rem;
+                    const int R = r < 3 * KD ? 3 * st + r : 3 * (N + st) + (r - 3 * KD);
+                    const int C = c < 3 * KD ? 3 * st + c : 3 * (N + st) + (c - 3 * KD);
+                    const double v = blk[ND + e];
+                    H[C * n + R] += v;
+                    if (R != C) H[R * n + C] += v;
+                }
+                __syncthreads();
+            }
+            for (int i = lane; i < n * n; i += 64) Hg[i] = H[i];
+            for (int i = lane; i < n; i += 64) gg[i] = g[i];
+            s.fresh = 0;
+            s.pending_accept = 0;
+        }
+        else
+        {
+            for (int i = lane; i < n * n; i += 64) H[i] = Hg[i];
+            for (int i = lane; i < n; i += 64) g[i] = gg[i];
+        }
+        __syncthreads();
+
+        // finalizeIterationAndCheckIfMinimizerCanContinue (:910-924)
+        ++s.iter;
+        if (s.iter > o.max_it || s.abs_dec < o.min_dec)
+        {
+            s.done = 1;
+            --s.iter;
+            if (lane == 0)
+            {
+                active[b] = 0;
+                states[b] = s;
+                atomicAdd(num_done, 1);
+            }
+            // leave the accepted point in the caller's knot buffers
+            double *Wt = const_cast<double *>(d.knots_t), *WR = const_cast<double *>(d.knots_R);
+            for (int i = lane; i < 3 * N; i += 64) Wt[i] = Ct[i];
+            for (int i = lane; i < 4 * N; i += 64) WR[i] = CR[i];
+            return;
+        }
+
+        // computeTrustRegionStep (:799-831): the damping is applied in place and accumulates over rejected steps
+        const double iradius = 1. / s.radius;
+        for (int i = lane; i < n; i += 64)
+        {
+            const double v = H[i * n + i] + H[i * n + i] * iradius;
+            H[i * n + i] = v;
+            Hg[i * n + i] = v;
+        }
+        __syncthreads();
+        // the solvers destroy their matrix: work on a copy in V's place (LDLT) or keep H in V and rotate a copy (SVD)
+        if (o.solver == 1)
+        {
+            for (int i = lane; i < n * n; i += 64) V[i] = H[i];
+            __syncthreads();
+            ldlt_solve(V, g, x, tmp, order, n, lane);
+        }
+        else
+        {
+            double *G = tmp + 2 * n; // third area, n x (n + 1) like V
+            const int ld = n + 1;
+            for (int i = lane; i < n * n; i += 64) G[(i / n) * ld + i % n] = H[i];
+            __syncthreads();
+            svd_solve(G, V, g, x, tmp, n, ld, lane);
+        }
+        for (int i = lane; i < n; i += 64) x[i] = -x[i];
+        __syncthreads();
+        double gx = 0.0, xHx = 0.0;
+        for (int r = lane; r < n; r += 64)
+        {
+            gx += g[r] * x[r];
+            double a = 0.0;
+            for (int c = 0; c < n; ++c) a += H[c * n + r] * x[c];
+            xHx += x[r] * a;
+        }
+        gx = wsum(gx);
+        xHx = wsum(xHx);
+        s.model = -(gx + 0.5 * xHx);
+        if (s.model < 0)
+        { // handleInvalidStep
+            lm_rejected(s);
+            trace_push(s, tr, o.trace_cap, lane, 3, 0.0, s.model, 0.0);
+            ++s.n_invalid;
+            if (lane == 0) { active[b] = 0; states[b] = s; }
+            return;
+        }
+        // computeCandidatePointAndEvaluateCost (:833-883): candidate = current (+) step, into the evaluated buffers
+        double *Wt = const_cast<double *>(d.knots_t), *WR = const_cast<double *>(d.knots_R);
+        for (int i = lane; i < 3 * N; i += 64) Wt[i] = Ct[i] + x[i];
+        for (int i = lane; i < N; i += 64)
+        {
+            const Quat q = qmul(load_quat(CR + 4 * i), so3_exp(x + 3 * N + 3 * i)); // Spline.h:317-330, not re-normalised
+            WR[4 * i] = q.x; WR[4 * i + 1] = q.y; WR[4 * i + 2] = q.z; WR[4 * i + 3] = q.w;
+        }
+        if (lane == 0) { active[b] = 1; states[b] = s; }
+    }
+
+    // One wave per problem, after the cost-only pass on the candidates: step quality, accept / reject, outliers.
+    template <int KD>
+    __global__ __launch_bounds__(64) void k_lm_decide(const ProblemDesc *__restrict__ descs, LmState *__restrict__ states, LmOpts o,
+                                                      const double *__restrict__ fb, const double *__restrict__ patch_cost,
+                                                      double *__restrict__ inv,
+                                                      double *__restrict__ cur_t, double *__restrict__ cur_R,
+                                                      int *__restrict__ active, mbavo_trace_rec *__restrict__ trace)
+    {
+        constexpr int ND = 6 * KD + 1, E = ND * (ND + 1) / 2;
+        const int b = blockIdx.x, lane = threadIdx.x;
+        const ProblemDesc &d = descs[b];
+        LmState s = states[b];
+        if (s.done || active[b] == 0) return; // finished, or an invalid step: nothing was evaluated
+        mbavo_trace_rec *tr = trace ? trace + (size_t)b * o.trace_cap : nullptr;
+        double cost = 0.0;
+        for (int f = 0; f < d.F; ++f) cost += fb[(size_t)(d.bf_base + f) * E];
+        s.cand_cost = cost;
+        s.abs_dec = s.eval_cost - s.cand_cost; // recorded before the accept test (:624)
+        s.quality = tr_quality(s, s.cand_cost, s.model);
+        if (s.quality > o.min_q && s.cand_cost < s.eval_cost)
+        { // isStepSuccessful (:890-894) -> detectOutliersAndUploadToGpu (:639-699): patch costs of frame 0
+            const double *pc = patch_cost + d.patch_base;
+            unsigned char *flags = const_cast<unsigned char *>(d.outlier);
+            double sum = 0.0, cnt = 0.0;
+            for (int i = lane; i < d.K; i += 64)
+            {
+                const double c = pc[i];
+                if (c < 1e-8) continue;
+                sum += c;
+                cnt += 1.0;
+            }
+            sum = wsum(sum);
+            cnt = wsum(cnt);
+            const double mu = sum / cnt;
+            double var = 0.0;
+            for (int i = lane; i < d.K; i += 64)
+            {
+                const double c = pc[i];
+                if (c < 1e-8) continue;
+                var += (c - mu) * (c - mu);
+            }
+            var = wsum(var) / cnt;
+            const double bound = o.chi * (double)sqrtf((float)var);
+            double nbad = 0.0;
+            for (int i = lane; i < d.K; i += 64)
+                if (fabs(pc[i] - mu) > bound) { flags[i] = 1; nbad += 1.0; }
+            s.num_bad = (int)wsum(nbad);
+            const long long num_residuals = (long long)(d.K - s.num_bad) * d.F * d.P;
+            // accept: the candidate becomes the current point, the next pass re-evaluates H/g there
+            double *Ct = cur_t + (size_t)b * 3 * o.max_N, *CR = cur_R + (size_t)b * 4 * o.max_N;
+            for (int i = lane; i < 3 * d.N; i += 64) Ct[i] = d.knots_t[i];
+            for (int i = lane; i < 4 * d.N; i += 64) CR[i] = d.knots_R[i];
+            s.fresh = 1;
+            s.pending_accept = 1;
+            if (lane == 0)
+            {
+                inv[b] = num_residuals > 0 ? 1.0 / (double)num_residuals : 0.0;
+                active[b] = 2;
+                states[b] = s;
+            }
+            return;
+        }
+        lm_rejected(s); // handleUnsuccessfulStep
+        trace_push(s, tr, o.trace_cap, lane, 2, s.cand_cost, s.model, s.quality);
+        ++s.n_reject;
+        if (lane == 0) { active[b] = 0; states[b] = s; }
+    }
+
+    __global__ void k_lm_init(const ProblemDesc *__restrict__ descs, int B, LmState *__restrict__ states, LmOpts o,
+                              double *__restrict__ cur_t, double *__restrict__ cur_R)
+    {
+        const int b = blockIdx.x, lane = threadIdx.x;
+        if (b >= B) return;
+        const ProblemDesc &d = descs[b];
+        double *Ct = cur_t + (size_t)b * 3 * o.max_N, *CR = cur_R + (size_t)b * 4 * o.max_N;
+        for (int i = lane; i < 3 * d.N; i += 64) Ct[i] = d.knots_t[i];
+        for (int i = lane; i < 4 * d.N; i += 64) CR[i] = d.knots_R[i];
+        if (lane == 0)
+        {
+            LmState s;
+            memset(&s, 0, sizeof(s));
+            s.radius = 1e4; s.decrease_factor = 2.0; s.abs_dec = 1e10; s.fresh = 1;
+            states[b] = s;
+        }
+    }
+
+#define LM_HIP(expr)                                                                        \
+    do                                                                                      \
+    {                                                                                       \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+        {                                                                                   \
+            fprintf(stderr, "mbavo lm_batch: %s failed: %s\n", #expr, hipGetErrorString(e_)); \
+            rc = (int)e_;                                                                   \
+            goto done;                                                                      \
+        }                                                                                   \
+    } while (0)
+
+    int lm_batch(Engine &eng, int B, const mbavo_problem *probs, const mbavo_lm_batch_opts &opt, mbavo_lm_batch_result *results,
+                 mbavo_trace_rec *trace, int trace_cap)
+    {
+        const int k = opt.spline_deg_k;
+        if (B < 1 || !probs || (k != 2 && k != 4) || (opt.solver_type != 0 && opt.solver_type != 1) || opt.max_num_iterations < 0)
+            return MBAVO_E_ARG;
+        int rc = 0;
+        hipStream_t st = eng.stream();
+        const int E = (6 * k + 1) * (6 * k + 2) / 2;
+        int max_N = 0, nbf = 0;
+        long long total_K = 0, total_patches = 0;
+        for (int b = 0; b < B; ++b)
+        {
+            if (probs[b].N < k || probs[b].N > 16 || !probs[b].h_start_idx || probs[b].F < 1) return MBAVO_E_ARG;
+            max_N = probs[b].N > max_N ? probs[b].N : max_N;
+            nbf += probs[b].F;
+            total_K += probs[b].K > 0 ? probs[b].K : 1;
+            total_patches += (long long)probs[b].F * probs[b].K;
+        }
+        const int max_n = 6 * max_N;
+        LmOpts o;
+        o.max_it = opt.max_num_iterations; o.max_nonmono = opt.max_consecutive_nonmonotonic_steps; o.solver = opt.solver_type;
+        o.trace_cap = trace ? trace_cap : 0; o.max_n = max_n; o.max_N = max_N;
+        o.min_q = opt.min_step_quality; o.min_dec = opt.min_abs_cost_decrease; o.chi = opt.max_chi_square_error;
+        const size_t lds = ((size_t)3 * max_n * max_n + 7 * max_n) * sizeof(double) + (size_t)max_n * sizeof(int);
+        if (lds > 160 * 1024) return MBAVO_E_ARG;
+
+        // one allocation for all LM state (freed at the end: this is a per-level call, not a per-iteration one)
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+        const size_t o_state = take(sizeof(LmState) * B), o_H = take(sizeof(double) * (size_t)B * max_n * max_n),
+                     o_g = take(sizeof(double) * (size_t)B * max_n), o_ct = take(sizeof(double) * (size_t)B * 3 * max_N),
+                     o_cR = take(sizeof(double) * (size_t)B * 4 * max_N), o_inv = take(sizeof(double) * B),
+                     o_act = take(sizeof(int) * B), o_done = take(sizeof(int)), o_start = take(sizeof(int) * nbf),
+                     o_flags = take((size_t)total_K), o_fb = take(sizeof(double) * (size_t)nbf * E),
+                     o_pc = take(sizeof(double) * (size_t)(total_patches + 1)),
+                     o_trace = take(sizeof(mbavo_trace_rec) * (size_t)B * (trace ? trace_cap : 0));
+        char *base = nullptr;
+        std::vector<mbavo_problem> work(probs, probs + B);
+        std::vector<int> h_start(nbf);
+        std::vector<LmState> h_states(B);
+        std::vector<double> h_inv(B);
+        std::vector<int> h_act(B);
+        int h_done = 0;
+        LM_HIP(hipSetDevice(eng.device()));
+        LM_HIP(hipMalloc((void **)&base, off));
+        LM_HIP(hipMemsetAsync(base, 0, off, st));
+        {
+            LmState *states = (LmState *)(base + o_state);
+            double *Hst = (double *)(base + o_H), *gst = (double *)(base + o_g), *ct = (double *)(base + o_ct), *cR = (double *)(base + o_cR);
+            double *inv = (double *)(base + o_inv), *fb = (double *)(base + o_fb), *pc = (double *)(base + o_pc);
+            int *act = (int *)(base + o_act), *num_done = (int *)(base + o_done), *d_start = (int *)(base + o_start);
+            unsigned char *flags = (unsigned char *)(base + o_flags);
+            mbavo_trace_rec *d_trace = trace ? (mbavo_trace_rec *)(base + o_trace) : nullptr;
+            size_t fo = 0;
+            int bf = 0;
+            for (int b = 0; b < B; ++b)
+            { // per-level reset of the outlier flags and count (:600-601): the engine owns them here
+                work[b].d_outlier = flags + fo;
+                work[b].num_bad = 0;
+                fo += work[b].K > 0 ? work[b].K : 1;
+                for (int f = 0; f < work[b].F; ++f) h_start[bf++] = work[b].h_start_idx[f];
+            }
+            LM_HIP(hipMemcpyAsync(d_start, h_start.data(), sizeof(int) * nbf, hipMemcpyHostToDevice, st));
+            for (int b = 0; b < B; ++b)
+            { // num_bad = 0 at the start of a level (:600); every problem takes part in the first H/g pass
+                const long long num_residuals = (long long)work[b].K * work[b].F * work[b].P;
+                h_inv[b] = num_residuals > 0 ? 1.0 / (double)num_residuals : 0.0;
+                h_act[b] = 2;
+            }
+            LM_HIP(hipMemcpyAsync(inv, h_inv.data(), sizeof(double) * B, hipMemcpyHostToDevice, st));
+            LM_HIP(hipMemcpyAsync(act, h_act.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
+            // iteration 0 (:604): also builds the layout (device descriptors) the LM kernels read
+            if ((rc = eng.evaluate(B, work.data(), k, true, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
+            const ProblemDesc *descs = eng.device_descs();
+            hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(64), 0, st, descs, B, states, o, ct, cR);
+            const int sync_every = opt.sync_every > 0 ? opt.sync_every : 4;
+            bool range_checked = false;
+            if (lds > 48 * 1024)
+            { // more than 8 control knots: the three n x n areas need the large-LDS attribute
+                if (k == 4) LM_HIP(hipFuncSetAttribute((const void *)k_lm_solve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                else LM_HIP(hipFuncSetAttribute((const void *)k_lm_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
+            for (int slot = 0; slot <= o.max_it + 1; ++slot)
+            {
+                if (k == 4)
+                    hipLaunchKernelGGL((k_lm_solve<4>), dim3(B), dim3(64), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
+                else
+                    hipLaunchKernelGGL((k_lm_solve<2>), dim3(B), dim3(64), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
+                if (slot % sync_every == sync_every - 1 || slot == o.max_it + 1)
+                {
+                    LM_HIP(hipMemcpyAsync(&h_done, num_done, sizeof(int), hipMemcpyDeviceToHost, st));
+                    LM_HIP(hipStreamSynchronize(st));
+                    if (!range_checked && eng.fetch_status() != 0) { rc = MBAVO_E_RANGE; goto done; }
+                    range_checked = true;
+                    if (h_done >= B) break;
+                }
+                if ((rc = eng.evaluate(B, work.data(), k, false, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
+                if (k == 4)
+                    hipLaunchKernelGGL((k_lm_decide<4>), dim3(B), dim3(64), 0, st, descs, states, o, fb, pc, inv, ct, cR, act, d_trace);
+                else
+                    hipLaunchKernelGGL((k_lm_decide<2>), dim3(B), dim3(64), 0, st, descs, states, o, fb, pc, inv, ct, cR, act, d_trace);
+                if ((rc = eng.evaluate(B, work.data(), k, true, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
+            }
+            LM_HIP(hipGetLastError());
+            LM_HIP(hipMemcpyAsync(h_states.data(), states, sizeof(LmState) * B, hipMemcpyDeviceToHost, st));
+            if (trace) LM_HIP(hipMemcpyAsync(trace, d_trace, sizeof(mbavo_trace_rec) * (size_t)B * trace_cap, hipMemcpyDeviceToHost, st));
+            LM_HIP(hipStreamSynchronize(st));
+            if (h_done < B)
+            {
+                LM_HIP(hipMemcpy(&h_done, num_done, sizeof(int), hipMemcpyDeviceToHost));
+                if (h_done < B) { rc = MBAVO_E_RANGE; goto done; }
+            }
+            if (results)
+                for (int b = 0; b < B; ++b)
+                {
+                    const LmState &s = h_states[b];
+                    mbavo_lm_batch_result &r = results[b];
+                    r.iterations = s.iter; r.accepted = s.n_accept; r.rejected = s.n_reject; r.invalid = s.n_invalid;
+                    r.num_outliers = s.num_bad; r.num_trace = s.ntrace;
+                    r.initial_cost = s.initial_cost; r.final_cost = s.eval_cost; r.radius = s.radius;
+                }
+        }
+    done:
+        if (base) (void)hipFree(base);
+        return rc > 0 ? -1000 - rc : rc;
+    }
+} // namespace mbavo

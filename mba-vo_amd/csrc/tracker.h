@@ -10,6 +10,9 @@ namespace mbavo
                             const double *h_cap, const double *h_exp, double t0, double dt, double *knots_t,
                             double *knots_R, int N, int *start_idx_out, double *final_cost, mbavo_trace_rec *trace,
                             int trace_cap);
+    // lm_batch.hip: the same loop for B one-level problems with all control state on the device
+    int lm_batch(Engine &eng, int B, const mbavo_problem *probs, const mbavo_lm_batch_opts &opt, mbavo_lm_batch_result *results,
+                 mbavo_trace_rec *trace, int trace_cap);
 }
 
 #endif

@@ -109,6 +109,7 @@ class DeviceWorkload:
             return cache[key]
 
         B = len(probs)
+        self._knots = []
         self.array = (capi.Problem * B)()
         for b, p in enumerate(probs):
             ref = up(p.ref)
@@ -136,6 +137,7 @@ class DeviceWorkload:
             q.h_start_idx = p.start_idx.ctypes.data_as(C.POINTER(C.c_int))
             q.huber_a = p.huber
             q.grad_fp16 = 1 if p.grad_fp16 else 0
+            self._knots.append((kt, kR))
         self.B = B
         self.k = probs[0].k
         self.E = synth.packed_len(self.k)
@@ -143,6 +145,10 @@ class DeviceWorkload:
         self.frame_blocks = torch.zeros(self.nbf * self.E, dtype=torch.float64, device=device)
         self.valid = torch.zeros(self.nbf, dtype=torch.float64, device=device)
         torch.cuda.synchronize()
+
+    def keep_knots(self, b):
+        """(knots_t, knots_R) device tensors of problem b (updated in place by mbavo_lm_batch)."""
+        return self._knots[b]
 
     def step(self, ctx, with_hessian=True):
         """One GN-iteration evaluation of every problem (asynchronous on the context's stream)."""

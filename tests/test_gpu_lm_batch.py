@@ -1,0 +1,142 @@
+"""Device-side batched LM against the host-driven loop (mbavo_optimize_trajectory, one level,
+one problem at a time) and the oracle: the accept / reject / invalid sequence, iteration and outlier counts are
+exact; costs, radii and knots agree to rounding amplified by the conditioning of the normal equations (the wave
+reduces dot products as a butterfly, the host sums sequentially; on these plane scenes cond(H) ~ 1e8-1e10).
+Stated tolerances: costs 1e-5 relative, radius 1e-4 relative, knots 1e-4 absolute (the same as the host-loop
+tracker against the oracle, tests/test_gpu_tracker.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mba_vo_amd import synth, workloads
+
+pytestmark = pytest.mark.gpu
+
+OPTS = dict(max_it=25, max_nonmono=5, min_q=0.5, min_dec=1e-3, chi=3.0)
+
+
+def _scene(B, k, N, F, seed, H=96, W=128, S=4):
+    """B independent pairs with their own splines; F frames per pair at different knot segments."""
+    rng = np.random.default_rng(seed)
+    probs = []
+    ref0 = synth.texture_image(H, W, seed=seed, octaves=(32, 16, 8, 4))
+    grad0 = synth.image_gradients(ref0)
+    xy, z = synth.semi_dense_keypoints(ref0, cell=10, thresh=2.0, margin=8, seed=seed + 1)
+    intr = np.array([W / 2.0, W / 2.0, W / 2.0, H / 2.0])
+    t0, dt = 0.0, 0.5
+    cap = [0.25 + 0.5 * f for f in range(F)]
+    exp = [0.1] * F
+    assert int((cap[-1] + exp[-1]) / dt) + k <= N
+    for b in range(B):
+        kt, kR = synth.harness_spline(0.004, 0.05, N)
+        kt = kt + rng.normal(0, 2e-3, kt.shape)
+        curs = [workloads._current_image(ref0, rng, shift=(1 + (b + f) % 2, -(1 + b % 2)), noise=3) for f in range(F)]
+        probs.append(workloads.Prob(ref0, curs, xy, z, synth.PATTERN8, intr, S, k, N, cap, exp, t0, dt, kt, kR, 10.0, grad=grad0))
+    return probs
+
+
+def _host_lm(mbavo, ctx, dw, b, p, solver, trace_cap=64):
+    capi = mbavo.capi
+    lv = (capi.Level * 1)()
+    q, a = lv[0], dw.array[b]
+    q.H, q.W, q.K, q.P, q.S = p.H, p.W, p.K, p.P, p.S
+    q.d_ref_img, q.d_ref_dIxy, q.d_cur_imgs = a.d_ref_img, a.d_ref_dIxy, a.d_cur_imgs
+    q.d_kp_xy, q.d_kp_z, q.d_pattern = a.d_kp_xy, a.d_kp_z, a.d_pattern
+    o = capi.TrackOpts()
+    o.num_levels, o.spline_deg_k, o.max_num_iterations = 1, p.k, OPTS["max_it"]
+    o.max_consecutive_nonmonotonic_steps, o.solver_type = OPTS["max_nonmono"], solver
+    for i in range(4):
+        o.intrinsics[i] = float(p.intr[i])
+    o.huber_k, o.min_step_quality = p.huber, OPTS["min_q"]
+    o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_dec"], OPTS["chi"]
+    kt, kR = p.knots_t.copy(), p.knots_R.copy()
+    start, cost = np.zeros(p.F, np.int32), np.zeros(1)
+    trace = (capi.TraceRec * trace_cap)()
+    n = ctx.lib.mbavo_optimize_trajectory(ctx.handle, C.byref(o), lv, p.F, capi.dp(p.cap), capi.dp(p.exp), p.t0, p.dt,
+                                          capi.dp(kt), capi.dp(kR), p.N, capi.ip(start), capi.dp(cost), trace, trace_cap)
+    assert 0 < n <= trace_cap, n
+    return kt, kR, float(cost[0]), [(r.iter, r.kind, r.num_outliers, r.radius, r.eval_cost, r.candidate_cost, r.model_change, r.quality)
+                                     for r in trace[:n]]
+
+
+@pytest.mark.parametrize("k,N,F,solver", [(4, 4, 1, 0), (4, 6, 2, 0), (2, 3, 2, 1), (4, 4, 1, 1), (2, 2, 1, 0)])
+def test_lm_batch_matches_host_loop(mbavo, gpu_ctx, k, N, F, solver):
+    import torch
+    capi = mbavo.capi
+    B = 6
+    probs = _scene(B, k, N, F, seed=11 + k + N)
+    dw = workloads.DeviceWorkload(probs)
+    host = [_host_lm(mbavo, gpu_ctx, dw, b, p, solver) for b, p in enumerate(probs)]  # does not touch the device knots
+    o = capi.LmBatchOpts()
+    o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, OPTS["max_it"], OPTS["max_nonmono"]
+    o.solver_type, o.sync_every = solver, 3
+    o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
+    cap = 64
+    res = (capi.LmBatchResult * B)()
+    trace = (capi.TraceRec * (B * cap))()
+    rc = gpu_ctx.lib.mbavo_lm_batch(gpu_ctx.handle, B, dw.array, C.byref(o), res, trace, cap)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    kinds_seen = set()
+    for b, p in enumerate(probs):
+        kt_h, kR_h, cost_h, tr_h = host[b]
+        r = res[b]
+        tr_d = [(t.iter, t.kind, t.num_outliers, t.radius, t.eval_cost, t.candidate_cost, t.model_change, t.quality)
+                for t in trace[b * cap:b * cap + r.num_trace]]
+        assert [(t[0], t[1], t[2]) for t in tr_d] == [(t[0], t[1], t[2]) for t in tr_h], (b, tr_d, tr_h)
+        kinds_seen |= {t[1] for t in tr_d}
+        for td, th in zip(tr_d, tr_h):
+            assert abs(td[3] - th[3]) <= 1e-4 * th[3]                      # radius
+            for i in (4, 5, 6):                                            # costs, model change
+                assert abs(td[i] - th[i]) <= 1e-5 * max(1.0, abs(th[i])), (b, i, td, th)
+            assert abs(td[7] - th[7]) <= 1e-3 * max(1.0, abs(th[7]))       # quality (ratio of small differences)
+        assert r.accepted == sum(1 for t in tr_h if t[1] == 1) and r.rejected == sum(1 for t in tr_h if t[1] == 2)
+        assert r.invalid == sum(1 for t in tr_h if t[1] == 3)
+        assert abs(r.final_cost - cost_h) <= 1e-5 * max(1.0, cost_h) and abs(r.initial_cost - tr_h[0][4]) <= 1e-12 * tr_h[0][4]
+        kt_d = dw.keep_knots(b)[0].cpu().numpy()
+        kR_d = dw.keep_knots(b)[1].cpu().numpy()
+        assert np.abs(kt_d - kt_h).max() < 1e-4 and np.abs(kR_d - kR_h).max() < 1e-4
+        if r.accepted > 0:
+            assert np.abs(kt_d - p.knots_t).max() > 1e-9  # the knots really moved
+    assert 1 in kinds_seen and (2 in kinds_seen or 3 in kinds_seen)
+
+
+def test_lm_batch_against_oracle(orc, mbavo, gpu_ctx):
+    """The same loop on the CPU oracle (orc_optimize_trajectory, one level) for a few problems."""
+    import torch
+    import tracking
+    capi = mbavo.capi
+    k, N, F, B = 4, 4, 1, 3
+    probs = _scene(B, k, N, F, seed=5)
+    dw = workloads.DeviceWorkload(probs)
+    o = capi.LmBatchOpts()
+    o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, OPTS["max_it"], OPTS["max_nonmono"]
+    o.solver_type, o.sync_every = 0, 4
+    o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
+    res = (capi.LmBatchResult * B)()
+    cap = 64
+    trace = (capi.TraceRec * (B * cap))()
+    assert gpu_ctx.lib.mbavo_lm_batch(gpu_ctx.handle, B, dw.array, C.byref(o), res, trace, cap) == 0
+    torch.cuda.synchronize()
+    for b, p in enumerate(probs):
+        sc = dict(levels=[dict(H=p.H, W=p.W, ref=p.ref, grad=p.grad, cur=p.cur, kp_xy=p.kp_xy, kp_z=p.kp_z, pattern=p.pattern, S=p.S)],
+                  k=k, N=N, F=F, cap=p.cap, exp=p.exp, t0=p.t0, dt=p.dt, intr=p.intr, kt0=p.knots_t.reshape(-1, 3), kR0=p.knots_R.reshape(-1, 4))
+        want = tracking.run_oracle_tracker(orc, sc, dict(max_num_iterations=OPTS["max_it"], max_nonmono=OPTS["max_nonmono"], solver_type=0,
+                                                         huber_k=p.huber, min_step_quality=OPTS["min_q"],
+                                                         min_abs_cost_decrease=OPTS["min_dec"], max_chi_square_error=OPTS["chi"]))
+        got = [(t.iter, t.kind, t.num_outliers) for t in trace[b * cap:b * cap + res[b].num_trace]]
+        assert got == [(t[1], t[2], t[3]) for t in want["trace"]]
+        assert abs(res[b].final_cost - want["cost"]) <= 1e-5 * max(1.0, want["cost"])
+        assert np.abs(dw.keep_knots(b)[0].cpu().numpy() - want["kt"].ravel()).max() < 1e-4
+
+
+def test_lm_batch_argument_errors(mbavo, gpu_ctx):
+    capi = mbavo.capi
+    probs = _scene(1, 4, 4, 1, seed=2)
+    dw = workloads.DeviceWorkload(probs)
+    o = capi.LmBatchOpts()
+    o.spline_deg_k, o.max_num_iterations, o.solver_type = 3, 5, 0
+    assert gpu_ctx.lib.mbavo_lm_batch(gpu_ctx.handle, 1, dw.array, C.byref(o), None, None, 0) == -1
+    o.spline_deg_k, o.solver_type = 4, 7
+    assert gpu_ctx.lib.mbavo_lm_batch(gpu_ctx.handle, 1, dw.array, C.byref(o), None, None, 0) == -1
