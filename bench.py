@@ -213,10 +213,10 @@ def main():
                              "note": "compulsory bytes only; compute-bound kernel, low by construction; traffic = "
                                      "(2*FETCH_SIZE + WRITE_SIZE) KiB from profiles/r01_hbm_counters.json"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             cb, fb_cpu = cpu_baseline(probs, args.cpu_seconds)
             scale = np.abs(fb_cpu).max(axis=1, keepdims=True)
-            cb["gpu_vs_cpu_max_rel_diff"] = float((np.abs(fb_gpu - fb_cpu) / scale).max()) if world == 1 else None
+            cb["gpu_vs_cpu_max_rel_diff"] = float((np.abs(fb_gpu - fb_cpu) / scale).max())
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:

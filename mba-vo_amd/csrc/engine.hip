@@ -353,7 +353,7 @@ namespace mbavo
             const int g = base + (int)threadIdx.x;
             double res = 0.0, w = 0.0, rho = 0.0;
             bool keep = false;
-            double Jrow[WITH_J ? 6 * KD : 1];
+            double Jrow[WITH_J ? 6 * KD : 1] = {}; // lanes past the end of the tile park 0 * Jrow: must be finite
             if (g < npx)
             {
                 const int kpl = g / P, pp = g - kpl * P;
@@ -386,9 +386,12 @@ namespace mbavo
                     if (ROUNDS == 1 || (lane / OuterAcc<ND>::ROWS) == rd)
                     {
                         double *mine = slab + (lane % OuterAcc<ND>::ROWS) * RS;
-                        mine[0] = keep ? w * res : 0.0;
+                        // dropped pixels park zero rows: res and Jrow are finite (A9 zeroes them when a sample is out
+                        // of bounds), so a zero weight does it without a select per entry
+                        const double wk = keep ? w : 0.0;
+                        mine[0] = wk * res;
 #pragma unroll
-                        for (int i = 0; i < 6 * KD; ++i) mine[1 + i] = keep ? w * Jrow[i] : 0.0;
+                        for (int i = 0; i < 6 * KD; ++i) mine[1 + i] = wk * Jrow[i];
 #pragma unroll
                         for (int i = ND; i < RS; ++i) mine[i] = 0.0;
                     }
@@ -470,7 +473,16 @@ namespace mbavo
         const int t0 = bf_tile_begin[bf], t1 = bf_tile_begin[bf + 1];
         double s = 0.0;
         if (e <= E && (WITH_J || e == 0 || e == E))
-            for (int t = t0 + tl; t < t1; t += 16) s += partials[(size_t)t * PS + e];
+        { // same order as a plain loop; four loads in flight (the partials come from other XCDs: every load misses L2)
+            int t = t0 + tl;
+            for (; t + 48 < t1; t += 64)
+            {
+                const double a = partials[(size_t)t * PS + e], b = partials[(size_t)(t + 16) * PS + e];
+                const double c = partials[(size_t)(t + 32) * PS + e], d = partials[(size_t)(t + 48) * PS + e];
+                s += a; s += b; s += c; s += d;
+            }
+            for (; t < t1; t += 16) s += partials[(size_t)t * PS + e];
+        }
         sm[tl][el] = s;
         __syncthreads();
         for (int h = 8; h >= 1; h >>= 1)

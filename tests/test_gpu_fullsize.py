@@ -45,9 +45,11 @@ def test_c2_dense_full_size_properties(orc, mbavo, gpu_ctx):
     parts = a[0] * (cut * p0.P) + b[0] * ((p0.K - cut) * p0.P)
     assert np.abs(whole - parts).max() <= 1e-11 * np.abs(whole).max()
     assert va[0] + vb[0] == valid[0]
-    # cost-only mode
+    # cost-only mode: a separate kernel instantiation, whose fp64 warp may be contracted differently -- a tap
+    # coordinate that moves by 1e-16 can change an fp32 bilinear weight by one ulp (6e-8 on that pixel's intensity),
+    # i.e. ~1e-12 of the summed cost.  Stated tolerance 1e-11.
     fc, _ = _run(gpu_ctx, probs, with_h=False)
-    assert np.abs(fc[:, 0] - fb[:, 0]).max() <= 1e-12 * np.abs(fb[:, 0]).max()
+    assert np.abs(fc[:, 0] - fb[:, 0]).max() <= 1e-11 * np.abs(fb[:, 0]).max()
     # the oracle once, multi-threaded, on the whole headline workload (fp64 blocks, 1e-9 relative)
     for i, p in enumerate(probs):
         op, keep = orc.make_problem(p.S, p.F, p.K, p.P, p.k, p.N, p.H, p.W, p.ref, p.grad, p.cur, p.kp_xy, p.kp_z,
