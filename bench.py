@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--workload", default="c2_dense",
                     choices=["c2_dense", "c2_semidense", "c1_dense", "c3_batch64", "c4_batch512", "c5_1080p"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="HIP-event pair around the dominant kernel on every n-th timed step (events cost launch gaps)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the bounded CPU baseline sample")
     return ap.parse_args()
 
@@ -151,7 +153,7 @@ def main():
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
-    ctx.lib.mbavo_profile(ctx.handle, 1)
+    ctx.lib.mbavo_profile(ctx.handle, args.time_every)  # HIP-event pair around the fused kernel of every n-th step
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

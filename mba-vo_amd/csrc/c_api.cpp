@@ -404,7 +404,7 @@ extern "C"
     int mbavo_profile(mbavo_ctx *ctx, int enable)
     {
         if (!ctx) return MBAVO_E_ARG;
-        ctx->engine->profile_enable(enable != 0);
+        ctx->engine->profile_enable(enable);
         return 0;
     }
 

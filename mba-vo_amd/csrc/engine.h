@@ -77,7 +77,7 @@ namespace mbavo
 
         // optional per-launch timing of the dominant kernel (k_fused) with HIP events on the
         // engine's stream; read back after a stream sync (bench.py roofline leg)
-        void profile_enable(bool on);
+        void profile_enable(int every); // 0 = off, n > 0 = time every n-th launch
         int profile_read(double *fused_ms_sum, int *launches);
 
         // named device scratch that persists across calls (grown on demand, freed with the engine): the LM loop
@@ -122,7 +122,8 @@ namespace mbavo
         void *slots_[kSlots] = {};
         size_t slot_cap_[kSlots] = {};
 
-        bool prof_on_ = false;
+        int prof_every_ = 0, prof_seen_ = 0;
+        bool prof_open_ = false;
         std::vector<hipEvent_t> prof_ev_; // pairs (start, stop)
         int prof_used_ = 0;
 

@@ -83,14 +83,37 @@ namespace mbavo
     }
 
     // ------------------------------------------------------------------ pose table
-    // grid = (ceil(entries / 64), WITH_J ? KD : 1): one lane per (problem, frame, blur sample) and, with
-    // Jacobians, one WAVE per knot (blockIdx.y): the four 4x3 Jacobian blocks of a sample are independent given
-    // the shared logs / exps, so they run side by side instead of back to back on one latency-bound lane.
+    // grid = (ceil(entries * NCOL / 64), WITH_J ? KD : 1).  Latency-bound (one serial fp64 log / exp / product chain
+    // per sample, a few thousand dependent instructions), so the independent pieces of a sample are spread out
+    // instead of run back to back on one lane: one WAVE per knot (blockIdx.y; compile-time knot index, so each
+    // knot only differentiates the segments it touches) and one LANE per column of that knot's 4x3 Jacobian block
+    // (NCOL = 3 lanes per sample).  The pose itself is written by knot 0 / column 0.
+    template <int KD, int KNOT>
+    __device__ __forceinline__ Quat pose_table_entry(const double *kR, double u, int col, PoseEntry<KD> &pe)
+    {
+        JacC<1> blk;
+        const Quat q = spline_rotation_knot<KD, 1, KNOT>(kR, u, col, blk);
+        // tangent form of this column: A[a][3*knot + col] = 2 * L3(q)^T[a] . blk      (pixel_math.h)
+        const double L3[4][3] = {{q.w, -q.z, q.y}, {q.z, q.w, -q.x}, {-q.y, q.x, q.w}, {-q.x, -q.y, -q.z}};
+        const Quat &v = blk.c[0];
+        for (int a = 0; a < 3; ++a)
+        {
+            double r = L3[0][a] * v.x;
+            r += L3[1][a] * v.y;
+            r += L3[2][a] * v.z;
+            r += L3[3][a] * v.w;
+            pe.A[a * 3 * KD + 3 * KNOT + col] = 2.0 * r;
+        }
+        return q;
+    }
+
     template <int KD, bool WITH_J>
     __global__ __launch_bounds__(64) void k_pose_table(const ProblemDesc *__restrict__ descs, int B, int total_entries,
                                                        PoseEntry<KD> *__restrict__ table, int *__restrict__ status)
     {
-        const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+        constexpr int NCOL = WITH_J ? 3 : 1;
+        const int lane_id = blockIdx.x * blockDim.x + threadIdx.x;
+        const int gid = lane_id / NCOL, col = lane_id - gid * NCOL;
         const int knot = blockIdx.y;
         if (gid >= total_entries) return;
         int lo = 0, hi = B - 1; // last problem with pose_base <= gid
@@ -110,34 +133,31 @@ namespace mbavo
         spline_segment(t, d.t0, d.dt, idx, u);
         if (idx < 0 || idx + KD > d.N)
         { // the reference reads out of bounds here; clamp for memory safety and report
-            if (knot == 0) atomicAdd(status, 1);
+            if (knot == 0 && col == 0) atomicAdd(status, 1);
             idx = idx < 0 ? 0 : d.N - KD;
         }
         PoseEntry<KD> &pe = table[gid];
+        const double *kR = d.knots_R + 4 * idx;
         Quat q;
         if (WITH_J)
         {
-            Jac43 blk;
-            q = spline_rotation_knot<KD>(d.knots_R + 4 * idx, u, knot, blk);
-            // tangent form of this knot's block: A[a][3*knot + c] = 2 * L3(q)^T[a] . blk.c[c]   (pixel_math.h)
-            const double L3[4][3] = {{q.w, -q.z, q.y}, {q.z, q.w, -q.x}, {-q.y, q.x, q.w}, {-q.x, -q.y, -q.z}};
-            for (int a = 0; a < 3; ++a)
-                for (int c = 0; c < 3; ++c)
+            if (KD == 2)
+                q = knot == 0 ? pose_table_entry<KD, 0>(kR, u, col, pe) : pose_table_entry<KD, 1>(kR, u, col, pe);
+            else
+                switch (knot)
                 {
-                    const Quat &v = blk.c[c];
-                    double r = L3[0][a] * v.x;
-                    r += L3[1][a] * v.y;
-                    r += L3[2][a] * v.z;
-                    r += L3[3][a] * v.w;
-                    pe.A[a * 3 * KD + 3 * knot + c] = 2.0 * r;
+                case 0: q = pose_table_entry<KD, 0>(kR, u, col, pe); break;
+                case 1: q = pose_table_entry<KD, 1>(kR, u, col, pe); break;
+                case 2: q = pose_table_entry<KD, KD == 4 ? 2 : 0>(kR, u, col, pe); break;
+                default: q = pose_table_entry<KD, KD == 4 ? 3 : 1>(kR, u, col, pe); break;
                 }
         }
         else
         {
-            q = spline_rotation<KD, false>(d.knots_R + 4 * idx, u, nullptr);
+            q = spline_rotation<KD, false>(kR, u, nullptr);
             for (int i = 0; i < 9 * KD; ++i) pe.A[i] = 0.0;
         }
-        if (knot == 0)
+        if (knot == 0 && col == 0)
         {
             double c[KD], p[3], qv[4] = {q.x, q.y, q.z, q.w}, R[9];
             trans_coeffs<KD>(u, c);
@@ -683,7 +703,7 @@ namespace mbavo
                           double *frame_blocks, double *valid)
     {
         PoseEntry<KD> *table = (PoseEntry<KD> *)poses;
-        hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries + 63) / 64, WITH_J ? KD : 1), dim3(64), 0, st, descs, B, entries, table, status);
+        hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries * (WITH_J ? 3 : 1) + 63) / 64, WITH_J ? KD : 1), dim3(64), 0, st, descs, B, entries, table, status);
         if (ntiles > 0)
         {
             const size_t lds = (WITH_J ? (size_t)kWavesPerGroup * OuterAcc<Pack<KD>::ND>::SLAB : 0) * sizeof(double) +
@@ -745,26 +765,39 @@ namespace mbavo
         return rc;
     }
 
-    void Engine::profile_enable(bool on)
+    void Engine::profile_enable(int every)
     {
-        prof_on_ = on;
+        prof_every_ = every > 0 ? every : 0;
         prof_used_ = 0;
+        prof_seen_ = 0;
+        prof_open_ = false;
     }
 
+    // An event pair around the fused kernel of every prof_every_-th launch.  A recorded event is a barrier packet on
+    // the queue and costs a few us of launch gap per pair, so timing EVERY launch slows the timed region itself
+    // (measured 67 -> 60 us per step on configs[1]); a sample of the launches gives the same average.
     void Engine::prof_mark(bool start)
     {
-        if (!prof_on_) return;
-        const int idx = prof_used_ * 2 + (start ? 0 : 1);
-        if (idx >= (int)prof_ev_.size())
+        if (prof_every_ == 0) return;
+        if (start)
         {
-            if (prof_ev_.size() >= 2 * 8192) { if (!start) ++prof_used_; return; } // cap; later launches are not timed
-            hipEvent_t e0, e1;
-            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
-            prof_ev_.push_back(e0);
-            prof_ev_.push_back(e1);
+            prof_open_ = (prof_seen_++ % prof_every_) == 0;
+            if (!prof_open_) return;
+            if (prof_used_ * 2 + 1 >= (int)prof_ev_.size())
+            {
+                if (prof_ev_.size() >= 2 * 8192) { prof_open_ = false; return; } // cap; later launches are not timed
+                hipEvent_t e0, e1;
+                if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { prof_open_ = false; return; }
+                prof_ev_.push_back(e0);
+                prof_ev_.push_back(e1);
+            }
+            (void)hipEventRecord(prof_ev_[prof_used_ * 2], stream_);
+            return;
         }
-        (void)hipEventRecord(prof_ev_[idx], stream_);
-        if (!start) ++prof_used_;
+        if (!prof_open_) return;
+        (void)hipEventRecord(prof_ev_[prof_used_ * 2 + 1], stream_);
+        ++prof_used_;
+        prof_open_ = false;
     }
 
     int Engine::profile_read(double *ms_sum, int *launches)

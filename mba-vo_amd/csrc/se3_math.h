@@ -43,11 +43,15 @@ namespace mbavo
         o[0] = v.x; o[1] = v.y; o[2] = v.z;
     }
 
-    // A 4x3 Jacobian block d(quaternion)/d(3-vector), stored as its 3 columns.
-    struct Jac43
+    // A 4x3 Jacobian block d(quaternion)/d(3-vector), stored as its columns.  Every operation below acts on the
+    // columns independently, so a block can also be processed one column at a time (NC = 1: the pose-table kernel
+    // gives each column of a block its own lane).
+    template <int NC>
+    struct JacC
     {
-        Quat c[3];
+        Quat c[NC];
     };
+    typedef JacC<3> Jac43;
     // 3x4 (log) and 4x3 (exp) Jacobians, row-major as in the reference.
     struct LogJac { double m[12]; };
     struct ExpJac { double m[12]; };
@@ -145,39 +149,47 @@ namespace mbavo
         return Quat{im * tg[0], im * tg[1], im * tg[2], re};
     }
 
-    // d(R * exp(w))/dw at w = 0: columns R * (e_i/2, 0)      (L(R) * [I/2; 0])
-    MBAVO_HD Jac43 local_param_jac(const Quat &R)
+    // d(R * exp(w))/dw at w = 0: columns R * (e_i/2, 0)      (L(R) * [I/2; 0]); columns first .. first + NC - 1
+    template <int NC>
+    MBAVO_HD JacC<NC> local_param_jac_cols(const Quat &R, int first)
     {
-        Jac43 o;
-        o.c[0] = qmul(R, Quat{0.5, 0, 0, 0});
-        o.c[1] = qmul(R, Quat{0, 0.5, 0, 0});
-        o.c[2] = qmul(R, Quat{0, 0, 0.5, 0});
+        JacC<NC> o;
+        for (int i = 0; i < NC; ++i)
+        {
+            const int a = first + i;
+            o.c[i] = qmul(R, Quat{a == 0 ? 0.5 : 0.0, a == 1 ? 0.5 : 0.0, a == 2 ? 0.5 : 0.0, 0.0});
+        }
         return o;
     }
-    MBAVO_HD Jac43 lmul(const Quat &q, const Jac43 &M) // L(q) * M : q (x) column
+    MBAVO_HD Jac43 local_param_jac(const Quat &R) { return local_param_jac_cols<3>(R, 0); }
+    template <int NC>
+    MBAVO_HD JacC<NC> lmul(const Quat &q, const JacC<NC> &M) // L(q) * M : q (x) column
     {
-        Jac43 o;
-        for (int i = 0; i < 3; ++i) o.c[i] = qmul(q, M.c[i]);
+        JacC<NC> o;
+        for (int i = 0; i < NC; ++i) o.c[i] = qmul(q, M.c[i]);
         return o;
     }
-    MBAVO_HD Jac43 rmul(const Jac43 &M, const Quat &q) // Rhat(q) * M : column (x) q
+    template <int NC>
+    MBAVO_HD JacC<NC> rmul(const JacC<NC> &M, const Quat &q) // Rhat(q) * M : column (x) q
     {
-        Jac43 o;
-        for (int i = 0; i < 3; ++i) o.c[i] = qmul(M.c[i], q);
+        JacC<NC> o;
+        for (int i = 0; i < NC; ++i) o.c[i] = qmul(M.c[i], q);
         return o;
     }
-    MBAVO_HD Jac43 conj_cols(const Jac43 &M) // K * M, K = diag(-1,-1,-1,1)
+    template <int NC>
+    MBAVO_HD JacC<NC> conj_cols(const JacC<NC> &M) // K * M, K = diag(-1,-1,-1,1)
     {
-        Jac43 o;
-        for (int i = 0; i < 3; ++i) o.c[i] = qconj(M.c[i]);
+        JacC<NC> o;
+        for (int i = 0; i < NC; ++i) o.c[i] = qconj(M.c[i]);
         return o;
     }
-    // dexp(4x3) * (scale * dlog(3x4) * M(4x3))
-    MBAVO_HD Jac43 through_log_exp(const ExpJac &de, double scale, const LogJac &dl, const Jac43 &M)
+    // dexp(4x3) * (scale * dlog(3x4) * M(4xNC))
+    template <int NC>
+    MBAVO_HD JacC<NC> through_log_exp(const ExpJac &de, double scale, const LogJac &dl, const JacC<NC> &M)
     {
-        double t[3][3];
+        double t[3][NC];
         for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < NC; ++c)
             {
                 const Quat &v = M.c[c];
                 double a = 0.0;
@@ -187,8 +199,8 @@ namespace mbavo
                 a += dl.m[r * 4 + 3] * v.w;
                 t[r][c] = a * scale;
             }
-        Jac43 o;
-        for (int c = 0; c < 3; ++c)
+        JacC<NC> o;
+        for (int c = 0; c < NC; ++c)
         {
             double v[4];
             for (int r = 0; r < 4; ++r)
@@ -203,10 +215,11 @@ namespace mbavo
         }
         return o;
     }
-    MBAVO_HD Jac43 jadd(const Jac43 &a, const Jac43 &b)
+    template <int NC>
+    MBAVO_HD JacC<NC> jadd(const JacC<NC> &a, const JacC<NC> &b)
     {
-        Jac43 o;
-        for (int i = 0; i < 3; ++i)
+        JacC<NC> o;
+        for (int i = 0; i < NC; ++i)
             o.c[i] = Quat{a.c[i].x + b.c[i].x, a.c[i].y + b.c[i].y, a.c[i].z + b.c[i].z, a.c[i].w + b.c[i].w};
         return o;
     }
@@ -347,11 +360,13 @@ namespace mbavo
         }
     }
 
-    // Same spline sample as spline_rotation, but only the 4x3 Jacobian block of ONE knot j (0 <= j < KDEG):
-    // the pose-table kernel spreads the knots of a sample over separate waves (the blocks are independent
-    // given the shared logs / exps), which cuts its latency-bound critical path.
-    template <int KDEG>
-    MBAVO_HD Quat spline_rotation_knot(const double *kR, double u, int j, Jac43 &block)
+    // Same spline sample as spline_rotation, but only columns col0 .. col0 + NC - 1 of the 4x3 Jacobian block of ONE
+    // knot J (0 <= J < KDEG).  The pose-table kernel spreads the knots of a sample over separate waves and the
+    // columns of a block over lanes (blocks and columns are independent given the shared logs / exps); with J a
+    // compile-time constant only the log / exp Jacobians that knot needs are computed.  Per column the arithmetic is
+    // the one of spline_rotation.
+    template <int KDEG, int NC, int J>
+    MBAVO_HD Quat spline_rotation_knot(const double *kR, double u, int col0, JacC<NC> &block)
     {
         if constexpr (KDEG == 2)
         {
@@ -362,13 +377,13 @@ namespace mbavo
             qlog<true>(qmul(R0c, R1), om, &dl);
             om[0] *= u; om[1] *= u; om[2] *= u;
             const Quat A0 = qexp<true>(om, &de);
-            if (j == 0)
+            if constexpr (J == 0)
             {
-                const Jac43 E0 = local_param_jac(R0);
+                const JacC<NC> E0 = local_param_jac_cols<NC>(R0, col0);
                 block = jadd(rmul(E0, A0), lmul(R0, through_log_exp(de, u, dl, rmul(conj_cols(E0), R1))));
             }
             else
-                block = lmul(R0, through_log_exp(de, u, dl, lmul(R0c, local_param_jac(R1))));
+                block = lmul(R0, through_log_exp(de, u, dl, lmul(R0c, local_param_jac_cols<NC>(R1, col0))));
             return qmul(R0, A0);
         }
         else
@@ -379,50 +394,44 @@ namespace mbavo
             const double c3 = s * uuu;
             const Quat R0 = load_quat(kR), R1 = load_quat(kR + 4), R2 = load_quat(kR + 8), R3 = load_quat(kR + 12);
             const Quat R0c = qconj(R0), R1c = qconj(R1), R2c = qconj(R2);
+            constexpr bool J01 = J <= 1, J12 = J == 1 || J == 2, J23 = J >= 2; // which segments this knot differentiates
             LogJac dl01, dl12, dl23; ExpJac de0, de1, de2;
             double o01[3], o12[3], o23[3];
-            qlog<true>(qmul(R0c, R1), o01, &dl01);
-            qlog<true>(qmul(R1c, R2), o12, &dl12);
-            qlog<true>(qmul(R2c, R3), o23, &dl23);
+            qlog<J01>(qmul(R0c, R1), o01, &dl01);
+            qlog<J12>(qmul(R1c, R2), o12, &dl12);
+            qlog<J23>(qmul(R2c, R3), o23, &dl23);
             for (int a = 0; a < 3; ++a) { o01[a] *= c1; o12[a] *= c2; o23[a] *= c3; }
-            const Quat A0 = qexp<true>(o01, &de0);
-            const Quat A1 = qexp<true>(o12, &de1);
-            const Quat A2 = qexp<true>(o23, &de2);
+            const Quat A0 = qexp<J01>(o01, &de0);
+            const Quat A1 = qexp<J12>(o12, &de1);
+            const Quat A2 = qexp<J23>(o23, &de2);
             const Quat R0A0 = qmul(R0, A0);
             const Quat R0A0A1 = qmul(R0A0, A1);
             const Quat A12 = qmul(A1, A2);
-            switch (j)
+            if constexpr (J == 0)
             {
-            case 0:
-            {
-                const Jac43 E0 = local_param_jac(R0);
+                const JacC<NC> E0 = local_param_jac_cols<NC>(R0, col0);
                 const Quat A012 = qmul(qmul(A0, A1), A2);
-                const Jac43 dA0 = through_log_exp(de0, c1, dl01, rmul(conj_cols(E0), R1));
+                const JacC<NC> dA0 = through_log_exp(de0, c1, dl01, rmul(conj_cols(E0), R1));
                 block = jadd(rmul(E0, A012), lmul(R0, rmul(dA0, A12)));
-                break;
             }
-            case 1:
+            else if constexpr (J == 1)
             {
-                const Jac43 E1 = local_param_jac(R1);
-                const Jac43 dA0 = through_log_exp(de0, c1, dl01, lmul(R0c, E1));
-                const Jac43 dA1 = through_log_exp(de1, c2, dl12, rmul(conj_cols(E1), R2));
+                const JacC<NC> E1 = local_param_jac_cols<NC>(R1, col0);
+                const JacC<NC> dA0 = through_log_exp(de0, c1, dl01, lmul(R0c, E1));
+                const JacC<NC> dA1 = through_log_exp(de1, c2, dl12, rmul(conj_cols(E1), R2));
                 block = jadd(lmul(R0, rmul(dA0, A12)), lmul(R0A0, rmul(dA1, A2)));
-                break;
             }
-            case 2:
+            else if constexpr (J == 2)
             {
-                const Jac43 E2 = local_param_jac(R2);
-                const Jac43 dA1 = through_log_exp(de1, c2, dl12, lmul(R1c, E2));
-                const Jac43 dA2 = through_log_exp(de2, c3, dl23, rmul(conj_cols(E2), R3));
+                const JacC<NC> E2 = local_param_jac_cols<NC>(R2, col0);
+                const JacC<NC> dA1 = through_log_exp(de1, c2, dl12, lmul(R1c, E2));
+                const JacC<NC> dA2 = through_log_exp(de2, c3, dl23, rmul(conj_cols(E2), R3));
                 block = jadd(lmul(R0A0, rmul(dA1, A2)), lmul(R0A0A1, dA2));
-                break;
             }
-            default:
+            else
             {
-                const Jac43 dA2 = through_log_exp(de2, c3, dl23, lmul(R2c, local_param_jac(R3)));
+                const JacC<NC> dA2 = through_log_exp(de2, c3, dl23, lmul(R2c, local_param_jac_cols<NC>(R3, col0)));
                 block = lmul(R0A0A1, dA2);
-                break;
-            }
             }
             return qmul(R0A0A1, A2);
         }
