@@ -41,15 +41,17 @@ namespace mbavo
 #ifndef MBAVO_WAVES_PER_GROUP
 #define MBAVO_WAVES_PER_GROUP 12
 #endif
-    constexpr int kWavesPerGroup = MBAVO_WAVES_PER_GROUP;
-    constexpr int kThreads = kWavesPerGroup * 64;
+    // Waves per workgroup of the fused kernel, per instantiation: one workgroup is resident per CU, so this is the
+    // occupancy.  k = 4 with Jacobians needs 153 VGPRs -> 3 waves per SIMD (12 per CU; 16 spill); k = 2 (117 VGPRs)
+    // and the cost-only kernels (62) take the 16 waves a workgroup can have.
+    template <int KD, bool WITH_J>
+    constexpr int waves_of() { return WITH_J && KD == 4 ? MBAVO_WAVES_PER_GROUP : 16; }
 
     template <int KD>
     struct Pack
     {
         static constexpr int ND = 6 * KD + 1;
         static constexpr int E = ND * (ND + 1) / 2;
-        static constexpr int EPW = (E + kWavesPerGroup - 1) / kWavesPerGroup; // entries per wave
         static constexpr int PSTRIDE = E + 2; // partial: [nvalid | g,H sums (1..E-1) | cost | spare]
     };
 
@@ -222,12 +224,12 @@ namespace mbavo
             }
         }
         // sum of element (i, j), i <= j, over the waves' parked tiles
-        static __device__ __forceinline__ double gather(const double *rows, int i, int j)
+        static __device__ __forceinline__ double gather(const double *rows, int i, int j, int nwaves)
         {
             const int t = (i >= 16 ? 2 : (j >= 16 ? 1 : 0));
             const int off = t * 256 + (i & 15) * 16 + (j & 15);
             double s = 0.0;
-            for (int wv = 0; wv < kWavesPerGroup; ++wv) s += rows[wv * SLAB + off];
+            for (int wv = 0; wv < nwaves; ++wv) s += rows[wv * SLAB + off];
             return s;
         }
     };
@@ -298,13 +300,13 @@ namespace mbavo
         }
 
         // sum of element (i, j), i <= j, over waves and pixel groups, in a fixed order
-        static __device__ __forceinline__ double gather(const double *rows, int i, int j)
+        static __device__ __forceinline__ double gather(const double *rows, int i, int j, int nwaves)
         {
             const int bi = i / BS, bj = j / BS;
             const int bp = bi * NB - bi * (bi - 1) / 2 + (bj - bi);
             const int off = bp * (BS * BS) + (i - bi * BS) * BS + (j - bj * BS);
             double s = 0.0;
-            for (int wv = 0; wv < kWavesPerGroup; ++wv)
+            for (int wv = 0; wv < nwaves; ++wv)
                 for (int g = 0; g < G; ++g) s += rows[wv * SLAB + g * NBP * (BS * BS) + off];
             return s;
         }
@@ -319,7 +321,7 @@ namespace mbavo
     }
 
     template <int KD, bool WITH_J, bool HALF_GRAD>
-    __global__ __launch_bounds__(kThreads) void k_fused(const ProblemDesc *__restrict__ descs,
+    __global__ __launch_bounds__((waves_of<KD, WITH_J>() * 64)) void k_fused(const ProblemDesc *__restrict__ descs,
                                                         const TileDesc *__restrict__ tiles,
                                                         const PoseEntry<KD> *__restrict__ table,
                                                         double *__restrict__ rho_out,
@@ -328,6 +330,7 @@ namespace mbavo
                                                         double *__restrict__ partials)
     {
         constexpr int ND = Pack<KD>::ND, E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
+        constexpr int kWavesPerGroup = waves_of<KD, WITH_J>(), kThreads = kWavesPerGroup * 64;
         constexpr int SLAB = OuterAcc<ND>::SLAB;     // doubles per wave: rows, and the parked accumulators at the end
         constexpr int RS = OuterAcc<ND>::STRIDE;     // row stride (>= ND, zero padded)
         extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -465,7 +468,7 @@ namespace mbavo
             for (int e = 1 + threadIdx.x; e < E; e += kThreads)
             {
                 const int i = tri_row_rt(e, ND), j = tri_col_rt(e, ND);
-                out[e] = OuterAcc<ND>::gather(rows, i, j);
+                out[e] = OuterAcc<ND>::gather(rows, i, j, kWavesPerGroup);
             }
         }
     }
@@ -706,6 +709,7 @@ namespace mbavo
         hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries * (WITH_J ? 3 : 1) + 63) / 64, WITH_J ? KD : 1), dim3(64), 0, st, descs, B, entries, table, status);
         if (ntiles > 0)
         {
+            constexpr int kWavesPerGroup = waves_of<KD, WITH_J>(), kThreads = kWavesPerGroup * 64;
             const size_t lds = (WITH_J ? (size_t)kWavesPerGroup * OuterAcc<Pack<KD>::ND>::SLAB : 0) * sizeof(double) +
                                2 * kWavesPerGroup * sizeof(double)
 #if defined(MBAVO_EXP_LDS_TABLE)
