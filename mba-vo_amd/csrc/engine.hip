@@ -360,6 +360,16 @@ namespace mbavo
         const PoseEntry<KD> *__restrict__ ftab = ltab;
 #else
         const PoseEntry<KD> *__restrict__ ftab = table + d.pose_base + frame * S;
+        {
+            // Warm the scalar cache: the frame's S entries were written by the pose kernel (cold here, often in another
+            // XCD's L2), and the sample loop reads them in ~11 dependent scalar-load groups per sample pair -- each a
+            // miss on the first pass.  One 8-byte read per 64-byte line, spread over the waves, all in flight together.
+            const double *tb = (const double *)ftab;
+            const int nlines = S * (int)(sizeof(PoseEntry<KD>) / 64);
+            double warm = 0.0;
+            for (int l = wave; l < nlines; l += kWavesPerGroup) warm += tb[l * 8];
+            if (warm == 1.2345678e301) red[0] = warm; // never true: keeps the loads alive
+        }
 #endif
         const PoseEntry<KD> &mid = ftab[S / 2]; // patch centres use sample S/2 (compute_local_patches_xy.cu:26)
         const unsigned char *__restrict__ I_cur = d.cur_imgs[frame];
