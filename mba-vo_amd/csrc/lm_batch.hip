@@ -127,58 +127,83 @@ namespace mbavo
         // wave-wide reductions measured 2.2 us per rotation, 4.9 ms per 24 x 24 solve; this order 37x less).
         // G holds A on entry, column-major with leading dimension ld = n + 1 (odd in doubles: the lanes of a round
         // read different columns at the same row, a stride of n doubles would put them on 4 LDS banks); V the same.
-        __device__ void svd_solve(double *G, double *V, const double *b, double *x, double *tmp, int n, int ld, int lane)
+        // One sweep structure for SUB lanes per column pair: the N six-row groups of a column are dealt out to the SUB
+        // lanes of a pair, partial dot products meet by xor-shuffles inside the (adjacent) lane group.
+        template <int SUB>
+        __device__ bool svd_sweeps(double *G, double *V, int n, int ld, int lane)
         {
-            for (int i = lane; i < n * n; i += 64) V[(i / n) * ld + i % n] = (i / n == i % n) ? 1.0 : 0.0;
-            __syncthreads();
             const double eps = DBL_EPSILON;
-            const int half = n / 2, m1 = n - 1; // n = 6N is even
+            const int half = n / 2, m1 = n - 1, N6 = n / 6; // n = 6N is even
+            const int pair = lane / SUB, sub = lane % SUB;
             for (int sweep = 0; sweep < 60; ++sweep)
             {
                 bool rotated = false;
                 for (int r = 0; r < m1; ++r)
                 {
-                    if (lane < half)
+                    // every lane takes part in the shuffles; lanes past the last pair work on pair 0's columns
+                    // without writing (their results are discarded)
+                    const bool live = pair < half;
+                    const int pr = live ? pair : 0;
+                    int p = pr == 0 ? m1 : (r + pr) % m1, q = pr == 0 ? r : (r - pr + m1) % m1;
+                    if (p > q) { const int t = p; p = q; q = t; }
+                    double *gp = G + p * ld, *gq = G + q * ld;
+                    double a = 0, c = 0, d = 0;
+                    for (int g6 = sub; g6 < N6; g6 += SUB)
+                    { // six rows at a time, all loads issued before the (in-order) accumulation
+                        const int i0 = 6 * g6;
+                        double u[6], w[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) { u[j] = gp[i0 + j]; w[j] = gq[i0 + j]; }
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) { a += u[j] * u[j]; c += w[j] * w[j]; d += u[j] * w[j]; }
+                    }
+#pragma unroll
+                    for (int o = 1; o < SUB; o <<= 1)
                     {
-                        int p = lane == 0 ? m1 : (r + lane) % m1, q = lane == 0 ? r : (r - lane + m1) % m1;
-                        if (p > q) { const int t = p; p = q; q = t; }
-                        double *gp = G + p * ld, *gq = G + q * ld;
-                        double a = 0, c = 0, d = 0;
-                        for (int i0 = 0; i0 < n; i0 += 6)
-                        { // n = 6N: six rows at a time, all loads issued before the (in-order) accumulation
-                            double u[6], w[6];
-#pragma unroll
-                            for (int j = 0; j < 6; ++j) { u[j] = gp[i0 + j]; w[j] = gq[i0 + j]; }
-#pragma unroll
-                            for (int j = 0; j < 6; ++j) { a += u[j] * u[j]; c += w[j] * w[j]; d += u[j] * w[j]; }
-                        }
-                        if (!(d == 0.0 || fabs(d) <= eps * sqrt(a * c)))
+                        a += __shfl_xor(a, o, 64);
+                        c += __shfl_xor(c, o, 64);
+                        d += __shfl_xor(d, o, 64);
+                    }
+                    if (live && !(d == 0.0 || fabs(d) <= eps * sqrt(a * c)))
+                    {
+                        rotated = true;
+                        const double zeta = (c - a) / (2.0 * d);
+                        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                        double *vp = V + p * ld, *vq = V + q * ld;
+                        for (int g6 = sub; g6 < N6; g6 += SUB)
                         {
-                            rotated = true;
-                            const double zeta = (c - a) / (2.0 * d);
-                            const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                            const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-                            double *vp = V + p * ld, *vq = V + q * ld;
-                            for (int i0 = 0; i0 < n; i0 += 6)
+                            const int i0 = 6 * g6;
+                            double u[6], w[6], y[6], z[6];
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) { u[j] = gp[i0 + j]; w[j] = gq[i0 + j]; y[j] = vp[i0 + j]; z[j] = vq[i0 + j]; }
+#pragma unroll
+                            for (int j = 0; j < 6; ++j)
                             {
-                                double u[6], w[6], y[6], z[6];
-#pragma unroll
-                                for (int j = 0; j < 6; ++j) { u[j] = gp[i0 + j]; w[j] = gq[i0 + j]; y[j] = vp[i0 + j]; z[j] = vq[i0 + j]; }
-#pragma unroll
-                                for (int j = 0; j < 6; ++j)
-                                {
-                                    gp[i0 + j] = cs * u[j] - sn * w[j];
-                                    gq[i0 + j] = sn * u[j] + cs * w[j];
-                                    vp[i0 + j] = cs * y[j] - sn * z[j];
-                                    vq[i0 + j] = sn * y[j] + cs * z[j];
-                                }
+                                gp[i0 + j] = cs * u[j] - sn * w[j];
+                                gq[i0 + j] = sn * u[j] + cs * w[j];
+                                vp[i0 + j] = cs * y[j] - sn * z[j];
+                                vq[i0 + j] = sn * y[j] + cs * z[j];
                             }
                         }
                     }
                     __syncthreads();
                 }
-                if (__ballot(rotated) == 0ull) break;
+                if (__ballot(rotated) == 0ull) return true;
             }
+            return false;
+        }
+
+        __device__ void svd_solve(double *G, double *V, const double *b, double *x, double *tmp, int n, int ld, int lane)
+        {
+            for (int i = lane; i < n * n; i += 64) V[(i / n) * ld + i % n] = (i / n == i % n) ? 1.0 : 0.0;
+            __syncthreads();
+            const double eps = DBL_EPSILON;
+            // lanes per column pair: as many as fit the wave and have a six-row group to work on
+            const int half = n / 2, N6 = n / 6;
+            if (half * 4 <= 64 && N6 >= 4) svd_sweeps<4>(G, V, n, ld, lane);
+            else if (half * 2 <= 64 && N6 >= 2) svd_sweeps<2>(G, V, n, ld, lane);
+            else svd_sweeps<1>(G, V, n, ld, lane);
             // squared singular values, one column per lane
             double smax2 = 0.0;
             for (int j = lane; j < n; j += 64)
