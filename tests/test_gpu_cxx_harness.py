@@ -17,3 +17,14 @@ def test_cxx_module_harness(mbavo):
     print(r.stdout[-4000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-2000:]
     assert "HARNESS PASSED" in r.stdout
+
+
+def test_device_solvers_against_host(mbavo):
+    """One-wave Jacobi SVD / LDL^T of the device-side LM (lm_solvers.h) against host_math.cpp on random systems,
+    n = 12 ... 78, full rank and rank deficient; tolerance 1e-8 relative on the solution."""
+    exe = os.path.join(HERE, "harness", "solver_check_bin")
+    if not os.path.exists(exe):
+        subprocess.run(["bash", os.path.join(HERE, "harness", "build.sh")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-4000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "SOLVER CHECK PASSED" in r.stdout, r.stdout[-2000:]
