@@ -82,6 +82,7 @@ namespace mbavo
         for (int l = 0; l < o.num_levels; ++l) maxK = levels[l].K > maxK ? levels[l].K : maxK;
         double *d_cap = nullptr, *d_exp = nullptr, *d_kt = nullptr, *d_kR = nullptr, *d_fb = nullptr, *d_pc = nullptr;
         unsigned char *d_flags = nullptr;
+        double *h_pin = nullptr;
         std::vector<double> h_pc(maxK > 0 ? maxK : 1);
         std::vector<unsigned char> flags;
 
@@ -89,12 +90,13 @@ namespace mbavo
         // engine-owned scratch, reused by every call (no hipMalloc / hipFree in the tracking loop)
         d_cap = (double *)eng.named_scratch(0, sizeof(double) * F);
         d_exp = (double *)eng.named_scratch(1, sizeof(double) * F);
-        d_kt = (double *)eng.named_scratch(2, sizeof(double) * 3 * N);
-        d_kR = (double *)eng.named_scratch(3, sizeof(double) * 4 * N);
+        d_kt = (double *)eng.named_scratch(2, sizeof(double) * 7 * N); // [t (3N) | R (4N)]: one upload per evaluation
+        d_kR = d_kt ? d_kt + 3 * N : nullptr;
         d_fb = (double *)eng.named_scratch(4, sizeof(double) * (size_t)F * E);
         d_pc = (double *)eng.named_scratch(5, sizeof(double) * (size_t)F * (maxK > 0 ? maxK : 1));
         d_flags = (unsigned char *)eng.named_scratch(6, maxK > 0 ? maxK : 1);
-        if (!d_cap || !d_exp || !d_kt || !d_kR || !d_fb || !d_pc || !d_flags) { rc_ = (int)hipErrorOutOfMemory; goto done; }
+        h_pin = eng.host_frame_blocks((size_t)7 * N + (size_t)F * E);
+        if (!d_cap || !d_exp || !d_kt || !d_kR || !d_fb || !d_pc || !d_flags || !h_pin) { rc_ = (int)hipErrorOutOfMemory; goto done; }
         TRK_HIP(hipMemcpyAsync(d_cap, h_cap, sizeof(double) * F, hipMemcpyHostToDevice, st)); // :701-719
         TRK_HIP(hipMemcpyAsync(d_exp, h_exp, sizeof(double) * F, hipMemcpyHostToDevice, st));
         TRK_HIP(hipMemsetAsync(d_fb, 0, sizeof(double) * (size_t)F * E, st));
@@ -120,12 +122,16 @@ namespace mbavo
             // one evaluation at the given knots: H2D knots, fused pass, D2H F*E doubles, host scatter
             auto evaluate = [&](const double *kt, const double *kR, bool with_h, double *cost) -> int {
                 hipError_t e;
-                if ((e = hipMemcpyAsync(d_kt, kt, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st)) != hipSuccess) return (int)e;
-                if ((e = hipMemcpyAsync(d_kR, kR, sizeof(double) * 4 * N, hipMemcpyHostToDevice, st)) != hipSuccess) return (int)e;
+                // pinned staging: [knots (7N) | frame blocks (F*E)]; pageable copies are staged by the runtime and cost
+                // a synchronisation each
+                memcpy(h_pin, kt, sizeof(double) * 3 * N);
+                memcpy(h_pin + 3 * N, kR, sizeof(double) * 4 * N);
+                if ((e = hipMemcpyAsync(d_kt, h_pin, sizeof(double) * 7 * N, hipMemcpyHostToDevice, st)) != hipSuccess) return (int)e;
                 int r = eng.evaluate(1, &p, k, with_h, d_fb, d_pc, nullptr, nullptr);
                 if (r) return r;
-                if ((e = hipMemcpyAsync(fb.data(), d_fb, sizeof(double) * (size_t)F * E, hipMemcpyDeviceToHost, st)) != hipSuccess) return (int)e;
+                if ((e = hipMemcpyAsync(h_pin + 7 * N, d_fb, sizeof(double) * (size_t)F * E, hipMemcpyDeviceToHost, st)) != hipSuccess) return (int)e;
                 if ((e = hipStreamSynchronize(st)) != hipSuccess) return (int)e;
+                memcpy(fb.data(), h_pin + 7 * N, sizeof(double) * (size_t)F * E);
                 if (check_range) // depends on the times only, not on the knot values: once per level
                 {
                     check_range = false;
