@@ -16,6 +16,11 @@
  * Eigen::JacobiSVD / LDLT and Sophus::SO3d::exp are third-party code absent
  * from /root/reference (versions unpinned by the repo): restated from their
  * published algorithms, "parity unpinned", checked by closed-form properties.
+ * Part 2 (mbavo_oracle_vo.c: the callers either side of the path): the
+ * semi-dense detector needs cv::KeyPoint (OpenCV absent) and Transformation
+ * exp/log is Sophus::SE3d (absent): both "parity unpinned" -- checked by a
+ * brute-force restatement of the selection rule and against scipy's matrix
+ * exponential; trackFrame composes them with the pinned pieces.
  *
  * All arrays are host memory, row-major unless stated, doubles unless stated.
  * Build: gcc -O2 -ffp-contract=off (no FMA contraction, no fast-math).
