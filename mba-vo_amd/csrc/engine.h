@@ -47,6 +47,14 @@ namespace mbavo
         const double *inv_ptr;
     };
 
+    // Control knots handed to the pose kernel BY VALUE (kernel arguments) instead of through device memory: a
+    // host-driven LM loop then needs no H2D copy per evaluation (single problem, n = number of knots, 0 = unused)
+    struct InlineKnots
+    {
+        double t[3 * 16], R[4 * 16];
+        int n;
+    };
+
     // a tile = a contiguous keypoint range of one (problem, frame), handled by one workgroup
     struct TileDesc
     {
@@ -66,7 +74,8 @@ namespace mbavo
         int evaluate(int B, const mbavo_problem *probs, int kdeg, bool with_hessian,
                      double *d_frame_blocks, double *d_patch_cost, double *d_valid,
                      double *d_patch_blocks_strided /* B == 1 only, stride E, may be null */,
-                     const int *d_active_mask = nullptr /* [B] */, const double *d_inv = nullptr /* [B] */);
+                     const int *d_active_mask = nullptr /* [B] */, const double *d_inv = nullptr /* [B] */,
+                     const double *h_knots_t = nullptr, const double *h_knots_R = nullptr /* B == 1: knots by value */);
         const ProblemDesc *device_descs() const { return (const ProblemDesc *)d_descs_; }
 
         // range status since the previous fetch (call after a stream sync): non-zero if a blur

@@ -111,7 +111,8 @@ namespace mbavo
 
     template <int KD, bool WITH_J>
     __global__ __launch_bounds__(64) void k_pose_table(const ProblemDesc *__restrict__ descs, int B, int total_entries,
-                                                       PoseEntry<KD> *__restrict__ table, int *__restrict__ status)
+                                                       PoseEntry<KD> *__restrict__ table, int *__restrict__ status,
+                                                       const InlineKnots ik)
     {
         constexpr int NCOL = WITH_J ? 3 : 1;
         const int lane_id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -139,7 +140,18 @@ namespace mbavo
             idx = idx < 0 ? 0 : d.N - KD;
         }
         PoseEntry<KD> &pe = table[gid];
-        const double *kR = d.knots_R + 4 * idx;
+        // this sample's KD knots, from the kernel arguments (host-driven LM loop) or from device memory
+        double kR[4 * KD], kt[3 * KD];
+        if (ik.n > 0)
+        {
+            for (int i = 0; i < 4 * KD; ++i) kR[i] = ik.R[4 * idx + i];
+            for (int i = 0; i < 3 * KD; ++i) kt[i] = ik.t[3 * idx + i];
+        }
+        else
+        {
+            for (int i = 0; i < 4 * KD; ++i) kR[i] = d.knots_R[4 * idx + i];
+            for (int i = 0; i < 3 * KD; ++i) kt[i] = d.knots_t[3 * idx + i];
+        }
         Quat q;
         if (WITH_J)
         {
@@ -163,7 +175,7 @@ namespace mbavo
         {
             double c[KD], p[3], qv[4] = {q.x, q.y, q.z, q.w}, R[9];
             trans_coeffs<KD>(u, c);
-            spline_translation<KD>(d.knots_t + 3 * idx, c, p);
+            spline_translation<KD>(kt, c, p);
             rotation_entries(qv, R);
             for (int i = 0; i < 3; ++i) pe.t[i] = p[i];
             for (int i = 0; i < 4; ++i) pe.q[i] = qv[i];
@@ -713,10 +725,10 @@ namespace mbavo
     static int launch_all(Engine *eng, hipStream_t st, int max_S, bool half_grad, const ProblemDesc *descs, int B, int entries, const TileDesc *tiles, int ntiles,
                           const int *bf_prob, const int *bf_tile_begin, int nbf, void *poses, double *rho,
                           double *patch_cost, double *patch_blocks_strided, double *partials, int *status,
-                          double *frame_blocks, double *valid)
+                          double *frame_blocks, double *valid, const InlineKnots &ik)
     {
         PoseEntry<KD> *table = (PoseEntry<KD> *)poses;
-        hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries * (WITH_J ? 3 : 1) + 63) / 64, WITH_J ? KD : 1), dim3(64), 0, st, descs, B, entries, table, status);
+        hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries * (WITH_J ? 3 : 1) + 63) / 64, WITH_J ? KD : 1), dim3(64), 0, st, descs, B, entries, table, status, ik);
         if (ntiles > 0)
         {
             constexpr int kWavesPerGroup = waves_of<KD, WITH_J>(), kThreads = kWavesPerGroup * 64;
@@ -753,9 +765,18 @@ namespace mbavo
 
     int Engine::evaluate(int B, const mbavo_problem *probs, int kdeg, bool with_hessian, double *d_frame_blocks,
                          double *d_patch_cost, double *d_valid, double *d_patch_blocks_strided, const int *d_active,
-                         const double *d_inv)
+                         const double *d_inv, const double *h_knots_t, const double *h_knots_R)
     {
         if (B < 1 || !probs || !d_frame_blocks || (kdeg != 2 && kdeg != 4)) return MBAVO_E_ARG;
+        InlineKnots ik;
+        ik.n = 0;
+        if (h_knots_t || h_knots_R)
+        {
+            if (B != 1 || !h_knots_t || !h_knots_R || probs[0].N > 16) return MBAVO_E_ARG;
+            ik.n = probs[0].N;
+            memcpy(ik.t, h_knots_t, sizeof(double) * 3 * ik.n);
+            memcpy(ik.R, h_knots_R, sizeof(double) * 4 * ik.n);
+        }
         if (d_patch_blocks_strided && B != 1) return MBAVO_E_ARG;
         HIP_TRY(hipSetDevice(device_));
         int rc = rebuild_layout(B, probs, kdeg, d_active, d_inv);
@@ -772,7 +793,7 @@ namespace mbavo
 #define MBAVO_LAUNCH(KD, WJ)                                                                                      \
     launch_all<KD, WJ>(this, stream_, max_S, half_grad, descs, B, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
                        (const int *)d_bf_tile_begin_, total_bf_, d_poses_, (double *)d_rho_, d_patch_cost,        \
-                       d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid)
+                       d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid, ik)
         if (kdeg == 4) rc = with_hessian ? MBAVO_LAUNCH(4, true) : MBAVO_LAUNCH(4, false);
         else rc = with_hessian ? MBAVO_LAUNCH(2, true) : MBAVO_LAUNCH(2, false);
 #undef MBAVO_LAUNCH

@@ -95,7 +95,8 @@ namespace mbavo
         d_fb = (double *)eng.named_scratch(4, sizeof(double) * (size_t)F * E);
         d_pc = (double *)eng.named_scratch(5, sizeof(double) * (size_t)F * (maxK > 0 ? maxK : 1));
         d_flags = (unsigned char *)eng.named_scratch(6, maxK > 0 ? maxK : 1);
-        h_pin = eng.host_frame_blocks((size_t)7 * N + (size_t)F * E);
+        h_pin = eng.host_frame_blocks((size_t)F * E); // device-visible pinned host memory
+        if (h_pin) memset(h_pin, 0, sizeof(double) * (size_t)F * E);
         if (!d_cap || !d_exp || !d_kt || !d_kR || !d_fb || !d_pc || !d_flags || !h_pin) { rc_ = (int)hipErrorOutOfMemory; goto done; }
         TRK_HIP(hipMemcpyAsync(d_cap, h_cap, sizeof(double) * F, hipMemcpyHostToDevice, st)); // :701-719
         TRK_HIP(hipMemcpyAsync(d_exp, h_exp, sizeof(double) * F, hipMemcpyHostToDevice, st));
@@ -122,16 +123,12 @@ namespace mbavo
             // one evaluation at the given knots: H2D knots, fused pass, D2H F*E doubles, host scatter
             auto evaluate = [&](const double *kt, const double *kR, bool with_h, double *cost) -> int {
                 hipError_t e;
-                // pinned staging: [knots (7N) | frame blocks (F*E)]; pageable copies are staged by the runtime and cost
-                // a synchronisation each
-                memcpy(h_pin, kt, sizeof(double) * 3 * N);
-                memcpy(h_pin + 3 * N, kR, sizeof(double) * 4 * N);
-                if ((e = hipMemcpyAsync(d_kt, h_pin, sizeof(double) * 7 * N, hipMemcpyHostToDevice, st)) != hipSuccess) return (int)e;
-                int r = eng.evaluate(1, &p, k, with_h, d_fb, d_pc, nullptr, nullptr);
+                // no copies: the knots travel as kernel arguments of the pose kernel and the finalize kernel writes the
+                // F*E doubles straight into pinned host memory (h_pin); one stream synchronisation per evaluation
+                int r = eng.evaluate(1, &p, k, with_h, h_pin, d_pc, nullptr, nullptr, nullptr, nullptr, kt, kR);
                 if (r) return r;
-                if ((e = hipMemcpyAsync(h_pin + 7 * N, d_fb, sizeof(double) * (size_t)F * E, hipMemcpyDeviceToHost, st)) != hipSuccess) return (int)e;
                 if ((e = hipStreamSynchronize(st)) != hipSuccess) return (int)e;
-                memcpy(fb.data(), h_pin + 7 * N, sizeof(double) * (size_t)F * E);
+                memcpy(fb.data(), h_pin, sizeof(double) * (size_t)F * E);
                 if (check_range) // depends on the times only, not on the knot values: once per level
                 {
                     check_range = false;
