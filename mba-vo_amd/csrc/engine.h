@@ -114,6 +114,7 @@ namespace mbavo
         int total_bf_ = 0, total_entries_ = 0;
         long long total_pixels_ = 0, total_patches_ = 0;
         bool layout_uploaded_ = false;
+        int sp_logs_ = 0; // > 0: the cached layout is tiled for the sample-parallel kernel with S = 2^sp_logs_
 
         void *d_descs_ = nullptr; size_t cap_descs_ = 0;
         void *d_tiles_ = nullptr; size_t cap_tiles_ = 0;

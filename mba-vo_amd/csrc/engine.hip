@@ -206,12 +206,12 @@ namespace mbavo
         static constexpr int SLAB = ROWS * ND > 768 ? ROWS * ND : 768;
         f64x4 t00, t01, t11;
         __device__ __forceinline__ void init(int) { t00 = f64x4{0, 0, 0, 0}; t01 = t00; t11 = t00; }
-        __device__ __forceinline__ void accumulate(const double *slab, int lane)
+        __device__ __forceinline__ void accumulate(const double *slab, int lane, int nsteps = ROWS / 4)
         {
             const int col = lane & 15, kq = lane >> 4;
             const bool has1 = HALVES == 2 && (16 + col) < ND;
 #pragma unroll 4
-            for (int step = 0; step < ROWS / 4; ++step)
+            for (int step = 0; step < nsteps; ++step)
             {
                 const double *r = slab + (4 * step + kq) * ND;
                 const double a0 = col < ND ? r[col] : 0.0;
@@ -495,6 +495,189 @@ namespace mbavo
         }
     }
 
+    // ------------------------------------------------------------------ fused kernel, sample-parallel variant
+    // For SMALL problems (semi-dense keypoints: a few thousand pixels in all) the lane-per-pixel kernel above leaves
+    // the machine empty and each lone wave walks its S samples one after the other at dependent-issue speed (one
+    // instruction per ~6 cycles): 20 us for a few hundred pixels.  Here a pixel takes S = 2^LOGS adjacent lanes, one
+    // per blur sample, so the sample loop is ONE iteration; the per-sample Jacobian contributions meet through the
+    // wave's LDS slab and are summed in sample order (the order of the lane-per-pixel kernel), the intensities by
+    // shuffles in sample order (bit-identical residuals and Huber costs), and the 64 / S finished rows of a wave go
+    // through the same MFMA outer product.  The pose entry of a lane is per lane now (vector loads, L1-resident).
+    constexpr int kSpWaves = 12;
+    template <int KD, bool WITH_J, bool HALF_GRAD, int LOGS>
+    __global__ __launch_bounds__((kSpWaves * 64)) void k_fused_sp(const ProblemDesc *__restrict__ descs,
+                                                        const TileDesc *__restrict__ tiles,
+                                                        const PoseEntry<KD> *__restrict__ table,
+                                                        double *__restrict__ rho_out,
+                                                        double *__restrict__ patch_cost,
+                                                        double *__restrict__ patch_blocks_strided,
+                                                        double *__restrict__ partials)
+    {
+        constexpr int ND = Pack<KD>::ND, E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
+        constexpr int kWavesPerGroup = kSpWaves, kThreads = kWavesPerGroup * 64;
+        constexpr int SS = 1 << LOGS, PXW = 64 >> LOGS, PXG = kWavesPerGroup * PXW; // lanes per pixel, pixels per wave / per round
+        constexpr int SLAB = OuterAcc<ND>::SLAB;     // doubles per wave: rows, and the parked accumulators at the end
+        constexpr int RS = OuterAcc<ND>::STRIDE;     // row stride (>= ND, zero padded)
+        extern __shared__ __attribute__((aligned(16))) double lds[];
+        double *rows = lds;                                               // [8 waves][64 pixels][ND] (WITH_J only)
+        double *red = lds + (WITH_J ? kWavesPerGroup * SLAB : 0);         // [2][8]
+
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const TileDesc tile = tiles[blockIdx.x];
+        const ProblemDesc &d = descs[tile.prob];
+        if (d.active != nullptr && (*d.active & (WITH_J ? 2 : 1)) == 0) return; // device-side LM: problem sits this pass out
+        const int S = d.S, K = d.K, P = d.P, frame = tile.frame;
+        Camera cam;
+        cam.fx = d.fx; cam.fy = d.fy; cam.cx = d.cx; cam.cy = d.cy; cam.H = d.H; cam.W = d.W;
+        const PoseEntry<KD> *__restrict__ ftab = table + d.pose_base + frame * S; // S == SS (checked by the host)
+        const PoseEntry<KD> &mid = ftab[S / 2]; // patch centres use sample S/2 (compute_local_patches_xy.cu:26)
+        const unsigned char *__restrict__ I_cur = d.cur_imgs[frame];
+        const long long pix0 = d.pixel_base + ((long long)frame * K + tile.kp_begin) * P;
+        const int npx = tile.kp_count * P;
+
+        OuterAcc<ND> acc;
+        acc.init(lane);
+        double *slab = rows + wave * SLAB;
+        int nvalid = 0;
+
+        const int pw = lane >> LOGS, sidx = lane & (SS - 1), lane0 = lane & ~(SS - 1);
+        const unsigned long long gmask = (SS == 64 ? ~0ull : ((1ull << SS) - 1ull)) << lane0;
+        const double fS = (double)(float)SS; // A8
+        for (int base = 0; base < npx; base += PXG)
+        {
+            const int g = base + wave * PXW + pw;
+            const bool in = g < npx;
+            double res = 0.0, w = 0.0, rho = 0.0, cur = 0.0, val = 0.0;
+            bool ok_l = false, flagged = false;
+            double Jc[WITH_J ? 6 * KD : 1] = {};
+            if (in)
+            {
+                const int kpl = g / P, pp = g - kpl * P;
+                const int kp = tile.kp_begin + kpl;
+                flagged = d.outlier != nullptr && d.outlier[kp] == 1;
+                const double kx = d.kp_xy[(size_t)kp * d.kp_stride], ky = d.kp_xy[(size_t)kp * d.kp_stride + 1];
+                const double kz = d.kp_z[kp];
+                double pcx, pcy;
+                patch_centre(mid.t, mid.q, kx, ky, kz, cam, pcx, pcy);
+                const int px = (int)(pcx + d.pattern[2 * pp]); // truncation, A3 (pixel_row)
+                const int py = (int)(pcy + d.pattern[2 * pp + 1]);
+                if (!(px < 0 || px > cam.W - 1 || py < 0 || py > cam.H - 1))
+                {
+                    cur = (double)((const MBAVO_GLOBAL unsigned char *)I_cur)[py * cam.W + px];
+                    double ray[3];
+                    unit_ray(cam, (double)px, (double)py, ray);
+                    const double iz = 1. / (kz + 1e-8);
+                    SampleInFlight f;
+                    const PoseEntry<KD> &pe = ftab[sidx];
+                    sample_issue<KD, WITH_J, HALF_GRAD>(pe, ray, kz, iz, cam, d.ref_img, d.ref_dIxy, f);
+                    ok_l = f.taps.ok;
+                    sample_retire<KD, WITH_J>(pe, f, ray, iz, cam, val, Jc);
+                }
+            }
+            // the pixel is valid iff all its samples are (A9); intensities summed in sample order
+            const bool valid = in && (__ballot(ok_l) & gmask) == gmask;
+            double isum = 0.0;
+#pragma unroll
+            for (int j = 0; j < SS; ++j) isum += __shfl(val, lane0 + j, 64);
+            if (valid) res = isum / fS - cur;
+            huber_weight(res, d.huber_a, w, rho);
+            if (in && sidx == 0)
+            {
+                rho_out[pix0 + g] = rho;
+                nvalid += valid ? 1 : 0;
+            }
+            const bool keep = valid && !flagged;
+            if (WITH_J)
+            {
+                // 1. every lane parks its sample's contribution; 2. lane (pixel, j) sums entries j, j + S, ... over the
+                // samples in order; 3. the pixel's weighted row replaces row `pw` of the slab; 4. MFMA over the rows
+                double *mine = slab + lane * RS;
+#pragma unroll
+                for (int i = 0; i < 6 * KD; ++i) mine[i] = Jc[i];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                constexpr int NOUT = (6 * KD + SS - 1) / SS;
+                const double wk = keep ? w : 0.0, inv = 1.0 / fS;
+                double outv[NOUT];
+#pragma unroll
+                for (int t = 0; t < NOUT; ++t)
+                {
+                    const int i = sidx + t * SS;
+                    double a = 0.0;
+                    if (i < 6 * KD)
+                    {
+#pragma unroll
+                        for (int j = 0; j < SS; ++j) a += slab[(lane0 + j) * RS + i];
+                    }
+                    outv[t] = wk * (a * inv);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                double *row = slab + pw * RS;
+                if (sidx == 0) row[0] = wk * res;
+#pragma unroll
+                for (int t = 0; t < NOUT; ++t)
+                {
+                    const int i = sidx + t * SS;
+                    if (i < 6 * KD) row[1 + i] = outv[t];
+                }
+                if (PXW < 4) // pad to the 4 rows of one MFMA step
+                    for (int z = lane; z < (4 - PXW) * RS; z += 64) slab[PXW * RS + z] = 0.0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                acc.accumulate(slab, lane, (PXW < 4 ? 4 : PXW) / 4);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+
+        // per-patch cost = slot 0 of the reference's patch block (:232-238), and the
+        // tile's share of the frame cost (outlier patches skipped, :265-272)
+        __syncthreads();
+        double cost_local = 0.0;
+        const double inv = d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals;
+        for (int kpl = threadIdx.x; kpl < tile.kp_count; kpl += kThreads)
+        {
+            const double *r = rho_out + pix0 + (long long)kpl * P;
+            double sum = 0.0;
+            for (int p = 0; p < P; ++p) sum += r[p];
+            const double c = sum * inv;
+            const int kp = tile.kp_begin + kpl;
+            const long long patch = (long long)frame * K + kp;
+            if (patch_cost) patch_cost[d.patch_base + patch] = c;
+            if (patch_blocks_strided) patch_blocks_strided[patch * E] = c;
+            if (!(d.outlier != nullptr && d.outlier[kp] == 1)) cost_local += c;
+        }
+        const double wc = wave_sum(cost_local);
+        const double wv = wave_sum((double)nvalid);
+        if (lane == 0) { red[wave] = wc; red[kWavesPerGroup + wave] = wv; }
+        __syncthreads();
+        double *out = partials + (size_t)blockIdx.x * PS;
+        if (threadIdx.x == 0)
+        {
+            double c = 0.0, v = 0.0;
+            for (int i = 0; i < kWavesPerGroup; ++i) { c += red[i]; v += red[kWavesPerGroup + i]; }
+            out[0] = v;
+            out[E] = c;
+        }
+        if (WITH_J)
+        {
+            // every wave parks its accumulators in its slab; entry e = (i, j) of the packed block is then the sum
+            // over waves (and pixel groups) in a fixed order
+            acc.store(slab, lane);
+            __syncthreads();
+            for (int e = 1 + threadIdx.x; e < E; e += kThreads)
+            {
+                const int i = tri_row_rt(e, ND), j = tri_col_rt(e, ND);
+                out[e] = OuterAcc<ND>::gather(rows, i, j, kWavesPerGroup);
+            }
+        }
+    }
+
     // ------------------------------------------------------------------ finalize
     // Sum of the tile partials of one (problem, frame) in a fixed order: 16 tile-lanes each add
     // every 16th tile, then a fixed tree over the tile-lanes.  grid = (nBF, ceil((E+1)/16)),
@@ -657,7 +840,21 @@ namespace mbavo
             }
             return n;
         };
-        long long lo = env_int("MBAVO_MIN_TILE_PX", 256), hi = pixels > lo ? pixels : lo;
+        // small problems take the sample-parallel kernel (k_fused_sp): same S = 4 .. 32 everywhere, fp32 gradients, and
+        // no more pixels than two of its rounds on every CU
+        int sp_logs = 0;
+        {
+            const int S0 = descs[0].S;
+            int lg = 0;
+            while ((1 << lg) < S0) ++lg;
+            bool ok = (1 << lg) == S0 && lg >= 2 && lg <= 5;
+            for (int b = 0; b < B && ok; ++b) ok = descs[b].S == S0 && descs[b].grad_fp16 == 0;
+            const long long round_px = (long long)kSpWaves * (64 >> lg);
+            const int force = env_int("MBAVO_SP", -1);
+            if (ok && force != 0 && (force == 1 || pixels <= 2 * round_px * num_cus_)) sp_logs = lg;
+        }
+        sp_logs_ = sp_logs;
+        long long lo = sp_logs ? (long long)kSpWaves * (64 >> sp_logs) : env_int("MBAVO_MIN_TILE_PX", 256), hi = pixels > lo ? pixels : lo;
         if (count_tiles(lo) > target_tiles)
         {
             while (lo < hi)
@@ -722,7 +919,7 @@ namespace mbavo
     }
 
     template <int KD, bool WITH_J>
-    static int launch_all(Engine *eng, hipStream_t st, int max_S, bool half_grad, const ProblemDesc *descs, int B, int entries, const TileDesc *tiles, int ntiles,
+    static int launch_all(Engine *eng, hipStream_t st, int max_S, bool half_grad, int sp_logs, const ProblemDesc *descs, int B, int entries, const TileDesc *tiles, int ntiles,
                           const int *bf_prob, const int *bf_tile_begin, int nbf, void *poses, double *rho,
                           double *patch_cost, double *patch_blocks_strided, double *partials, int *status,
                           double *frame_blocks, double *valid, const InlineKnots &ik)
@@ -749,7 +946,31 @@ namespace mbavo
                 attr_lds[half_grad ? 1 : 0] = lds;
             }
             eng->prof_mark(true);
-            if (half_grad)
+            if (sp_logs > 0)
+            {
+                const size_t lds_sp = (WITH_J ? (size_t)kSpWaves * OuterAcc<Pack<KD>::ND>::SLAB : 0) * sizeof(double) + 2 * kSpWaves * sizeof(double);
+                static size_t attr_sp[6] = {0, 0, 0, 0, 0, 0};
+#define MBAVO_SP_LAUNCH(LG)                                                                                                    \
+    do                                                                                                                         \
+    {                                                                                                                          \
+        if (lds_sp > attr_sp[LG])                                                                                              \
+        {                                                                                                                      \
+            HIP_TRY(hipFuncSetAttribute((const void *)k_fused_sp<KD, WITH_J, false, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp)); \
+            attr_sp[LG] = lds_sp;                                                                                              \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((k_fused_sp<KD, WITH_J, false, LG>), dim3(ntiles), dim3(kSpWaves * 64), lds_sp, st, descs, tiles, table, rho, \
+                           patch_cost, patch_blocks_strided, partials);                                                        \
+    } while (0)
+                switch (sp_logs)
+                {
+                case 2: MBAVO_SP_LAUNCH(2); break;
+                case 3: MBAVO_SP_LAUNCH(3); break;
+                case 4: MBAVO_SP_LAUNCH(4); break;
+                default: MBAVO_SP_LAUNCH(5); break;
+                }
+#undef MBAVO_SP_LAUNCH
+            }
+            else if (half_grad)
                 hipLaunchKernelGGL((k_fused<KD, WITH_J, true>), dim3(ntiles), dim3(kThreads), lds, st, descs, tiles, table, rho,
                                    patch_cost, patch_blocks_strided, partials);
             else
@@ -791,7 +1012,7 @@ namespace mbavo
         for (const ProblemDesc &pd : h_descs_)
             if ((pd.grad_fp16 != 0) != half_grad) return MBAVO_E_ARG;
 #define MBAVO_LAUNCH(KD, WJ)                                                                                      \
-    launch_all<KD, WJ>(this, stream_, max_S, half_grad, descs, B, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
+    launch_all<KD, WJ>(this, stream_, max_S, half_grad, sp_logs_, descs, B, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
                        (const int *)d_bf_tile_begin_, total_bf_, d_poses_, (double *)d_rho_, d_patch_cost,        \
                        d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid, ik)
         if (kdeg == 4) rc = with_hessian ? MBAVO_LAUNCH(4, true) : MBAVO_LAUNCH(4, false);
