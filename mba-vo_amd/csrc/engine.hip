@@ -398,7 +398,7 @@ namespace mbavo
             const int g = base + (int)threadIdx.x;
             double res = 0.0, w = 0.0, rho = 0.0;
             bool keep = false;
-            double Jrow[WITH_J ? 6 * KD : 1] = {}; // lanes past the end of the tile park 0 * Jrow: must be finite
+            double Jrow[WITH_J ? 6 * KD : 1];
             if (g < npx)
             {
                 const int kpl = g / P, pp = g - kpl * P;
@@ -418,6 +418,11 @@ namespace mbavo
                 rho_out[pix0 + g] = rho;
                 nvalid += valid ? 1 : 0;
                 keep = valid && !flagged;
+            }
+            else if (WITH_J)
+            { // lanes past the end of the tile park 0 * Jrow: it must be finite (pixel_row zeroes it for the others)
+#pragma unroll
+                for (int i = 0; i < 6 * KD; ++i) Jrow[i] = 0.0;
             }
             if (WITH_J)
             {
