@@ -332,6 +332,105 @@ namespace mbavo
         return v;
     }
 
+    // One round of the tile in SAMPLE-PARALLEL form (see k_fused_sp below), with S = 2^logs a run-time value: used
+    // by k_fused for the pixels of a tile beyond its last full round when all their (pixel, sample) pairs fit the
+    // workgroup.  On configs[1] a tile is 1 600 pixels = 25 chunks of 64 on 12 waves: the 25th chunk used to be one
+    // more chunk for one wave, i.e. 7 chunks on its SIMD against 6 on the others (+5 us measured against a tile of
+    // exactly two rounds).
+    template <int KD, bool WITH_J, bool HALF_GRAD, int NWAVES>
+    __device__ __forceinline__ void sp_round_rt(const ProblemDesc &d, const TileDesc &tile, const Camera &cam,
+                                                const PoseEntry<KD> *__restrict__ ftab, const PoseEntry<KD> &mid,
+                                                const unsigned char *__restrict__ I_cur, int logs, int base, int npx,
+                                                long long pix0, int lane, int wave, double *slab,
+                                                OuterAcc<6 * KD + 1> &acc, double *__restrict__ rho_out, int &nvalid)
+    {
+        constexpr int ND = 6 * KD + 1, RS = OuterAcc<ND>::STRIDE;
+        const int SS = 1 << logs, PXW = 64 >> logs, P = d.P;
+        const int pw = lane >> logs, sidx = lane & (SS - 1), lane0 = lane & ~(SS - 1);
+        const unsigned long long gmask = (SS == 64 ? ~0ull : ((1ull << SS) - 1ull)) << lane0;
+        const double fS = (double)(float)SS; // A8
+        const int g = base + wave * PXW + pw;
+        const bool in = g < npx;
+        double res = 0.0, w = 0.0, rho = 0.0, cur = 0.0, val = 0.0;
+        bool ok_l = false, flagged = false;
+        double Jc[WITH_J ? 6 * KD : 1] = {};
+        if (in)
+        {
+            const int kpl = g / P, pp = g - kpl * P;
+            const int kp = tile.kp_begin + kpl;
+            flagged = d.outlier != nullptr && d.outlier[kp] == 1;
+            const double kx = d.kp_xy[(size_t)kp * d.kp_stride], ky = d.kp_xy[(size_t)kp * d.kp_stride + 1];
+            const double kz = d.kp_z[kp];
+            double pcx, pcy;
+            patch_centre(mid.t, mid.q, kx, ky, kz, cam, pcx, pcy);
+            const int px = (int)(pcx + d.pattern[2 * pp]); // truncation, A3 (pixel_row)
+            const int py = (int)(pcy + d.pattern[2 * pp + 1]);
+            if (!(px < 0 || px > cam.W - 1 || py < 0 || py > cam.H - 1))
+            {
+                cur = (double)((const MBAVO_GLOBAL unsigned char *)I_cur)[py * cam.W + px];
+                double ray[3];
+                unit_ray(cam, (double)px, (double)py, ray);
+                const double iz = 1. / (kz + 1e-8);
+                SampleInFlight f;
+                const PoseEntry<KD> &pe = ftab[sidx];
+                sample_issue<KD, WITH_J, HALF_GRAD>(pe, ray, kz, iz, cam, d.ref_img, d.ref_dIxy, f);
+                ok_l = f.taps.ok;
+                sample_retire<KD, WITH_J>(pe, f, ray, iz, cam, val, Jc);
+            }
+        }
+        const bool valid = in && (__ballot(ok_l) & gmask) == gmask;
+        double isum = 0.0;
+        for (int j = 0; j < SS; ++j) isum += __shfl(val, lane0 + j, 64); // sample order, as the sequential loop
+        if (valid) res = isum / fS - cur;
+        huber_weight(res, d.huber_a, w, rho);
+        if (in && sidx == 0)
+        {
+            rho_out[pix0 + g] = rho;
+            nvalid += valid ? 1 : 0;
+        }
+        const bool keep = valid && !flagged;
+        if (WITH_J)
+        {
+            double *mine = slab + lane * RS;
+#pragma unroll
+            for (int i = 0; i < 6 * KD; ++i) mine[i] = Jc[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            constexpr int NOUT = (6 * KD + 3) / 4; // S >= 4 lanes share the 6k entries of a pixel
+            const double wk = keep ? w : 0.0, inv = 1.0 / fS;
+            double outv[NOUT];
+#pragma unroll
+            for (int t = 0; t < NOUT; ++t)
+            {
+                const int i = sidx + t * SS;
+                double a = 0.0;
+                if (i < 6 * KD)
+                    for (int j = 0; j < SS; ++j) a += slab[(lane0 + j) * RS + i];
+                outv[t] = wk * (a * inv);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double *row = slab + pw * RS;
+            if (sidx == 0) row[0] = wk * res;
+#pragma unroll
+            for (int t = 0; t < NOUT; ++t)
+            {
+                const int i = sidx + t * SS;
+                if (i < 6 * KD) row[1 + i] = outv[t];
+            }
+            if (PXW < 4)
+                for (int z = lane; z < (4 - PXW) * RS; z += 64) slab[PXW * RS + z] = 0.0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            acc.accumulate(slab, lane, (PXW < 4 ? 4 : PXW) / 4);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
     template <int KD, bool WITH_J, bool HALF_GRAD>
     __global__ __launch_bounds__((waves_of<KD, WITH_J>() * 64)) void k_fused(const ProblemDesc *__restrict__ descs,
                                                         const TileDesc *__restrict__ tiles,
@@ -393,7 +492,26 @@ namespace mbavo
         double *slab = rows + wave * SLAB;
         int nvalid = 0;
 
-        for (int base = 0; base < npx; base += kThreads)
+        // S = 2^sp_logs in 4 .. 64: the last round may go sample-parallel (sp_round_rt)
+        int sp_logs = 0;
+        while ((1 << sp_logs) < S) ++sp_logs;
+        const bool sp_ok = (1 << sp_logs) == S && sp_logs >= 2 && sp_logs <= 6;
+        // The pixels beyond the last full round go FIRST and sample-parallel: spread over the waves of all four SIMDs
+        // and overlapped with the other waves' first round, instead of one more chunk for one wave (and so for one
+        // SIMD: 7 chunks against 6 on the others) at the end.
+        int main_end = npx;
+        if (sp_ok)
+        {
+            const int rem = npx % kThreads;
+            if (rem > 0 && (long long)rem * S <= kThreads)
+            {
+                main_end = npx - rem;
+                if (main_end + wave * (64 >> sp_logs) < npx)
+                    sp_round_rt<KD, WITH_J, HALF_GRAD, kWavesPerGroup>(d, tile, cam, ftab, mid, I_cur, sp_logs, main_end, npx, pix0,
+                                                                        lane, wave, slab, acc, rho_out, nvalid);
+            }
+        }
+        for (int base = 0; base < main_end; base += kThreads)
         {
             const int g = base + (int)threadIdx.x;
             double res = 0.0, w = 0.0, rho = 0.0;
