@@ -342,9 +342,11 @@ namespace mbavo
                                                 const PoseEntry<KD> *__restrict__ ftab, const PoseEntry<KD> &mid,
                                                 const unsigned char *__restrict__ I_cur, int logs, int base, int npx,
                                                 long long pix0, int lane, int wave, double *slab,
-                                                OuterAcc<6 * KD + 1> &acc, double *__restrict__ rho_out, int &nvalid)
+                                                OuterAcc<6 * KD + 1> &acc, double *__restrict__ rho_out, int &nvalid,
+                                                double inv, double *__restrict__ patch_cost,
+                                                double *__restrict__ patch_blocks_strided, int frame, double &cost_local)
     {
-        constexpr int ND = 6 * KD + 1, RS = OuterAcc<ND>::STRIDE;
+        constexpr int ND = 6 * KD + 1, RS = OuterAcc<ND>::STRIDE, E = ND * (ND + 1) / 2;
         const int SS = 1 << logs, PXW = 64 >> logs, P = d.P;
         const int pw = lane >> logs, sidx = lane & (SS - 1), lane0 = lane & ~(SS - 1);
         const unsigned long long gmask = (SS == 64 ? ~0ull : ((1ull << SS) - 1ull)) << lane0;
@@ -385,7 +387,16 @@ namespace mbavo
         huber_weight(res, d.huber_a, w, rho);
         if (in && sidx == 0)
         {
-            rho_out[pix0 + g] = rho;
+            if (P == 1)
+            { // one-pixel patches: the patch cost is this pixel's (see k_fused)
+                const double c = rho * inv;
+                const long long patch = (long long)frame * d.K + tile.kp_begin + g;
+                if (patch_cost) patch_cost[d.patch_base + patch] = c;
+                if (patch_blocks_strided) patch_blocks_strided[patch * E] = c;
+                if (!flagged) cost_local += c;
+            }
+            else
+                rho_out[pix0 + g] = rho;
             nvalid += valid ? 1 : 0;
         }
         const bool keep = valid && !flagged;
@@ -499,6 +510,10 @@ namespace mbavo
         // The pixels beyond the last full round go FIRST and sample-parallel: spread over the waves of all four SIMDs
         // and overlapped with the other waves' first round, instead of one more chunk for one wave (and so for one
         // SIMD: 7 chunks against 6 on the others) at the end.
+        // One-pixel patches (dense mode): the patch cost is the pixel's own, taken where rho is computed; the
+        // per-pixel rho scratch (8 B per pixel written and read back at the end of the tile) is not touched.
+        const double inv = d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals;
+        double cost_local = 0.0;
         int main_end = npx;
         if (sp_ok)
         {
@@ -508,9 +523,13 @@ namespace mbavo
                 main_end = npx - rem;
                 if (main_end + wave * (64 >> sp_logs) < npx)
                     sp_round_rt<KD, WITH_J, HALF_GRAD, kWavesPerGroup>(d, tile, cam, ftab, mid, I_cur, sp_logs, main_end, npx, pix0,
-                                                                        lane, wave, slab, acc, rho_out, nvalid);
+                                                                        lane, wave, slab, acc, rho_out, nvalid, inv, patch_cost,
+                                                                        patch_blocks_strided, frame, cost_local);
             }
         }
+#if defined(MBAVO_EXP_NO_ROUNDS) // timing experiment: launch + prologue + end-of-tile work only
+        main_end = 0;
+#endif
         for (int base = 0; base < main_end; base += kThreads)
         {
             const int g = base + (int)threadIdx.x;
@@ -533,7 +552,16 @@ namespace mbavo
                 const bool valid = pixel_row<KD, WITH_J, HALF_GRAD>(ftab, S, cam, d.ref_img, d.ref_dIxy, I_cur, pcx, pcy, kz,
                                                          d.pattern[2 * pp], d.pattern[2 * pp + 1], res, Jrow);
                 huber_weight(res, d.huber_a, w, rho);
-                rho_out[pix0 + g] = rho;
+                if (P == 1)
+                {
+                    const double c = rho * inv;
+                    const long long patch = (long long)frame * K + kp;
+                    if (patch_cost) patch_cost[d.patch_base + patch] = c;
+                    if (patch_blocks_strided) patch_blocks_strided[patch * E] = c;
+                    if (!flagged) cost_local += c;
+                }
+                else
+                    rho_out[pix0 + g] = rho;
                 nvalid += valid ? 1 : 0;
                 keep = valid && !flagged;
             }
@@ -575,12 +603,13 @@ namespace mbavo
             }
         }
 
+#if defined(MBAVO_EXP_NO_TAIL) // timing experiment: no end-of-tile work
+        if (npx >= 0) return;
+#endif
         // per-patch cost = slot 0 of the reference's patch block (:232-238), and the
         // tile's share of the frame cost (outlier patches skipped, :265-272)
         __syncthreads();
-        double cost_local = 0.0;
-        const double inv = d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals;
-        for (int kpl = threadIdx.x; kpl < tile.kp_count; kpl += kThreads)
+        for (int kpl = threadIdx.x; P != 1 && kpl < tile.kp_count; kpl += kThreads)
         {
             const double *r = rho_out + pix0 + (long long)kpl * P;
             double sum = 0.0;

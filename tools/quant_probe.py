@@ -17,5 +17,7 @@ def run(H, W):
     ctx.lib.mbavo_profile_read(ctx.handle, M.capi.dp(ms), M.capi.ip(n)); ctx.lib.mbavo_profile(ctx.handle, 0)
     px = H * W
     print("%4dx%4d px %7d  px/256CU %.1f  chunks/wave %.3f  step %.1f us  fused %.1f us  -> %.0f px/us" % (H, W, px, px / 256, px / 256 / 768, el, ms[0] / n[0] * 1e3, px / (ms[0] / n[0] * 1e3)))
-for H, W in ((480, 816), (480, 850), (480, 800), (480, 410), (480, 1228), (480, 1640), (480, 640)):
+import os
+sizes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(480, 816), (480, 850), (480, 800), (480, 410), (480, 1228), (480, 1640), (480, 640)]
+for H, W in sizes:
     run(H, W)
