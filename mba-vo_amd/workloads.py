@@ -150,10 +150,12 @@ class DeviceWorkload:
         """(knots_t, knots_R) device tensors of problem b (updated in place by mbavo_lm_batch)."""
         return self._knots[b]
 
-    def step(self, ctx, with_hessian=True):
-        """One GN-iteration evaluation of every problem (asynchronous on the context's stream)."""
+    def step(self, ctx, with_hessian=True, out=None):
+        """One GN-iteration evaluation of every problem (asynchronous on the context's stream); `out` replaces the
+        default output tensor (double buffering under an asynchronous all-reduce)."""
+        fb = self.frame_blocks if out is None else out
         rc = ctx.lib.mbavo_eval_batch(ctx.handle, self.B, self.array, self.k, 1 if with_hessian else 0,
-                                      self.frame_blocks.data_ptr(), None, self.valid.data_ptr())
+                                      fb.data_ptr(), None, self.valid.data_ptr())
         if rc != 0:
             raise RuntimeError("mbavo_eval_batch failed: %d" % rc)
 
