@@ -144,13 +144,22 @@ def main():
     probs, desc = build_workload(args.workload, rank, world)
     dw = wl.DeviceWorkload(probs, device=dev)
 
-    # N > 1: the final sum of the packed normal equations over xGMI (RCCL) runs on the collective's own stream and
-    # overlaps the next step's kernels; two output buffers, a buffer is reused only after its all-reduce completed
+    # N > 1: the final sum of the packed normal equations over xGMI (RCCL), one all-reduce per step.  Default: in place,
+    # ordered after the finalize kernel (+8 us per step measured with a 1-rank group).  MBAVO_BENCH_ALLREDUCE=async runs
+    # it on the collective's own stream, overlapped with the next step through two output buffers (the stream
+    # hand-offs then cost +23 us per step on one GPU, so it only pays when the collective itself is slower than that)
     bufs = [dw.frame_blocks, torch.zeros_like(dw.frame_blocks)]
     pending = [None, None]
     count = [0]
 
+    sync_allreduce = os.environ.get("MBAVO_BENCH_ALLREDUCE", "sync") == "sync"
+
     def step():
+        if sync_allreduce:  # in place on the default buffer, ordered by the collective's own stream semantics
+            dw.step(ctx, True)
+            if use_dist:
+                dist.all_reduce(dw.frame_blocks, op=dist.ReduceOp.SUM)
+            return
         b = count[0] & 1
         count[0] += 1
         if pending[b] is not None:
@@ -222,7 +231,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "name": args.workload, "problems_per_rank": len(probs),
                        "pixel_samples_per_step_per_rank": ps_rank, "pixel_samples_launched": ps_launched,
-                       "parallelism": "independent pairs per GPU + asynchronous all-reduce of the packed J^T J blocks (RCCL, overlapped with the next step)" if world > 1 else "1 GPU"},
+                       "parallelism": "independent pairs per GPU + one RCCL all-reduce of the packed J^T J blocks per step" if world > 1 else "1 GPU"},
             "roofline": {"bound": "mfma", "achieved": round(ach_tf, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach_tf / FP64_PEAK_TFLOPS, 5), "traffic": measured_hbm_traffic(args.workload),
                          "kernel": "k_fused<4,true>", "kernel_ms": round(k_ms, 6), "launches_timed": int(nlaunch[0]),
