@@ -7,10 +7,12 @@
 
 #include <cfloat>
 #include <hip/hip_runtime.h>
-// Several lanes per column pair (svd_sweeps<2>, <4>) pass the standalone solver check (tests/harness/solver_check.hip) but
-// fault inside k_lm_solve on this toolchain (HSA aperture violation, not yet understood): off by default.
+// Several lanes per column pair (svd_sweeps<2>, <4>).  All solver functions are force-inlined: as real (called)
+// device functions the multi-lane variant faulted inside k_lm_solve on this toolchain -- rocgdb showed the `lane`
+// argument of svd_solve corrupted after the sweeps (HSA aperture violation on the next LDS access through a
+// generic pointer) -- while the same code passed the standalone check; inlined it is correct in both.
 #ifndef MBAVO_SVD_MULTILANE
-#define MBAVO_SVD_MULTILANE 0
+#define MBAVO_SVD_MULTILANE 1
 #endif
 
 namespace mbavo
@@ -40,7 +42,7 @@ namespace mbavo
         // One sweep structure for SUB lanes per column pair: the N six-row groups of a column are dealt out to the SUB
         // lanes of a pair, partial dot products meet by xor-shuffles inside the (adjacent) lane group.
         template <int SUB>
-        __device__ bool svd_sweeps(double *G, double *V, int n, int ld, int lane)
+        __device__ __forceinline__ bool svd_sweeps(double *G, double *V, int n, int ld, int lane)
         {
             const double eps = DBL_EPSILON;
             const int half = n / 2, m1 = n - 1, N6 = n / 6; // n = 6N is even
@@ -104,7 +106,7 @@ namespace mbavo
             return false;
         }
 
-        __device__ void svd_solve(double *G, double *V, const double *b, double *x, double *tmp, int n, int ld, int lane)
+        __device__ __forceinline__ void svd_solve(double *G, double *V, const double *b, double *x, double *tmp, int n, int ld, int lane)
         {
             for (int i = lane; i < n * n; i += 64) V[(i / n) * ld + i % n] = (i / n == i % n) ? 1.0 : 0.0;
             __syncthreads();
@@ -148,7 +150,7 @@ namespace mbavo
         }
 
         // x = A^-1 b by LDL^T with diagonal pivoting (host_math.cpp:solve_ldlt); M holds A on entry
-        __device__ void ldlt_solve(double *M, const double *b, double *x, double *y, int *order, int n, int lane)
+        __device__ __forceinline__ void ldlt_solve(double *M, const double *b, double *x, double *y, int *order, int n, int lane)
         {
             for (int i = lane; i < n; i += 64) order[i] = i;
             __syncthreads();
