@@ -96,13 +96,11 @@ extern "C"
         mbavo::Engine &eng = *ctx->engine;
         const int E = packed_len(k);
         const size_t n = (size_t)p->F * E;
-        double *d_fb = eng.scratch_frame_blocks(n);
-        double *h_fb = eng.host_frame_blocks(n);
-        if (!d_fb || !h_fb) return (int)hipErrorOutOfMemory;
-        int rc = eng.evaluate(1, p, k, h_H != nullptr, d_fb, nullptr, nullptr, d_patch_blocks);
+        double *h_fb = eng.host_frame_blocks(n); // pinned, device-visible: the finalize kernel writes it directly
+        if (!h_fb) return (int)hipErrorOutOfMemory;
+        int rc = eng.evaluate(1, p, k, h_H != nullptr, h_fb, nullptr, nullptr, d_patch_blocks);
         if (rc) return rc;
-        hipError_t e = hipMemcpyAsync(h_fb, d_fb, n * sizeof(double), hipMemcpyDeviceToHost, eng.stream());
-        if (e == hipSuccess) e = hipStreamSynchronize(eng.stream());
+        hipError_t e = hipStreamSynchronize(eng.stream());
         if (e != hipSuccess) return (int)e;
         if (eng.fetch_status() != 0) return MBAVO_E_RANGE;
         mbavo::merge_blocks_host(p->F, k, h_fb, p->h_start_idx, p->N, h_cost, h_H, h_g);
