@@ -186,3 +186,28 @@ def test_empty_and_ragged_batches(orc, mbavo, gpu_ctx):
         assert _rel(fb[rows], ro["frame_blocks"]) < RTOL
     alone, _, _ = scenes.gpu_eval_batch(gpu_ctx, [ds[1]], 4)
     assert np.all(alone == 0.0)
+
+
+def test_non_finite_and_wild_knots_do_not_fault(mbavo, gpu_ctx):
+    """A diverging LM step can hand the path NaN / huge control knots: every tap coordinate is then out of bounds or
+    NaN, the pixels are invalid (zero residual, zero row, A9) and nothing is read outside the images."""
+    import torch
+    for mode in ("nan", "huge", "inf"):
+        sc = scenes.Scene(S=8, F=1, k=4, P=8, K=200, seed=9)
+        if mode == "nan":
+            sc.knots_t[4] = np.nan
+            sc.knots_R[5] = np.nan
+        elif mode == "huge":
+            sc.knots_t[:] = 1e300
+        else:
+            sc.knots_t[2] = np.inf
+        d = scenes.DeviceScene(sc)
+        fb, pc, valid = scenes.gpu_eval_batch(gpu_ctx, [d], 4)
+        torch.cuda.synchronize()
+        assert valid.sum() == 0 or mode == "nan"  # NaN in one knot may leave samples of other segments valid
+        finite = np.isfinite(fb)
+        assert finite.all() or mode != "huge"
+    # the context is still usable afterwards
+    ok = scenes.Scene(S=4, F=1, k=4, P=8, K=50, seed=2)
+    fb, _, valid = scenes.gpu_eval_batch(gpu_ctx, [scenes.DeviceScene(ok)], 4)
+    assert np.isfinite(fb).all() and valid.sum() > 0
