@@ -332,6 +332,17 @@ namespace mbavo
         return v;
     }
 
+    // Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and every XCD has its own L2:
+    // give each XCD a CONTIGUOUS range of tiles (= a band of the keyframe and of the current image), so that the
+    // rows neighbouring tiles share are fetched into one L2 instead of eight.  Bijection for any tile count.
+    __device__ __forceinline__ int xcd_tile_of_block(int b, int ntiles)
+    {
+        constexpr int kXcds = 8;
+        const int q = ntiles / kXcds, r = ntiles % kXcds;
+        const int x = b % kXcds, j = b / kXcds;
+        return x * q + (x < r ? x : r) + j;
+    }
+
     // One round of the tile in SAMPLE-PARALLEL form (see k_fused_sp below), with S = 2^logs a run-time value: used
     // by k_fused for the pixels of a tile beyond its last full round when all their (pixel, sample) pairs fit the
     // workgroup.  On configs[1] a tile is 1 600 pixels = 25 chunks of 64 on 12 waves: the 25th chunk used to be one
@@ -461,7 +472,8 @@ namespace mbavo
 
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const TileDesc tile = tiles[blockIdx.x];
+        const int tile_id = xcd_tile_of_block((int)blockIdx.x, (int)gridDim.x);
+        const TileDesc tile = tiles[tile_id];
         const ProblemDesc &d = descs[tile.prob];
         if (d.active != nullptr && (*d.active & (WITH_J ? 2 : 1)) == 0) return; // device-side LM: problem sits this pass out
         const int S = d.S, K = d.K, P = d.P, frame = tile.frame;
@@ -625,7 +637,7 @@ namespace mbavo
         const double wv = wave_sum((double)nvalid);
         if (lane == 0) { red[wave] = wc; red[kWavesPerGroup + wave] = wv; }
         __syncthreads();
-        double *out = partials + (size_t)blockIdx.x * PS;
+        double *out = partials + (size_t)tile_id * PS;
         if (threadIdx.x == 0)
         {
             double c = 0.0, v = 0.0;
@@ -676,7 +688,8 @@ namespace mbavo
 
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const TileDesc tile = tiles[blockIdx.x];
+        const int tile_id = xcd_tile_of_block((int)blockIdx.x, (int)gridDim.x);
+        const TileDesc tile = tiles[tile_id];
         const ProblemDesc &d = descs[tile.prob];
         if (d.active != nullptr && (*d.active & (WITH_J ? 2 : 1)) == 0) return; // device-side LM: problem sits this pass out
         const int S = d.S, K = d.K, P = d.P, frame = tile.frame;
@@ -808,7 +821,7 @@ namespace mbavo
         const double wv = wave_sum((double)nvalid);
         if (lane == 0) { red[wave] = wc; red[kWavesPerGroup + wave] = wv; }
         __syncthreads();
-        double *out = partials + (size_t)blockIdx.x * PS;
+        double *out = partials + (size_t)tile_id * PS;
         if (threadIdx.x == 0)
         {
             double c = 0.0, v = 0.0;
