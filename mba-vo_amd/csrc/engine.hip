@@ -109,10 +109,17 @@ namespace mbavo
         return q;
     }
 
-    template <int KD, bool WITH_J>
+    // KnotsArg = InlineKnots (knots by value, host-driven LM loop) or NoKnots (knots in device memory): a separate
+    // instantiation, so that the batch path does not carry 900 bytes of kernel arguments
+    struct NoKnots
+    {
+        static constexpr int n = 0;
+        double t[1], R[1];
+    };
+    template <int KD, bool WITH_J, class KnotsArg>
     __global__ __launch_bounds__(64) void k_pose_table(const ProblemDesc *__restrict__ descs, int B, int total_entries,
                                                        PoseEntry<KD> *__restrict__ table, int *__restrict__ status,
-                                                       const InlineKnots ik)
+                                                       const KnotsArg ik)
     {
         constexpr int NCOL = WITH_J ? 3 : 1;
         const int lane_id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1090,7 +1097,11 @@ namespace mbavo
                           double *frame_blocks, double *valid, const InlineKnots &ik)
     {
         PoseEntry<KD> *table = (PoseEntry<KD> *)poses;
-        hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries * (WITH_J ? 3 : 1) + 63) / 64, WITH_J ? KD : 1), dim3(64), 0, st, descs, B, entries, table, status, ik);
+        const dim3 pose_grid((entries * (WITH_J ? 3 : 1) + 63) / 64, WITH_J ? KD : 1);
+        if (ik.n > 0)
+            hipLaunchKernelGGL((k_pose_table<KD, WITH_J, InlineKnots>), pose_grid, dim3(64), 0, st, descs, B, entries, table, status, ik);
+        else
+            hipLaunchKernelGGL((k_pose_table<KD, WITH_J, NoKnots>), pose_grid, dim3(64), 0, st, descs, B, entries, table, status, NoKnots());
         if (ntiles > 0)
         {
             constexpr int kWavesPerGroup = waves_of<KD, WITH_J>(), kThreads = kWavesPerGroup * 64;
