@@ -32,6 +32,10 @@ CASES = {
     "k4_6knots_C5shape": dict(H=135, W=240, S=16, F=2, k=4, P=1, kp="dense", margin=2, N=6),
     "k4_S64_F16_max_sizes": dict(S=64, F=16, k=4, P=8, K=25, trans_scale=0.002, rot_scale=0.02, exp=0.3),   # reference maxima: 64 samples, 16 frames
     "k2_S64_F16_max_sizes": dict(S=64, F=16, k=2, P=8, K=25, trans_scale=0.002, rot_scale=0.02, exp=0.3),
+    # small problems with S = 4 .. 32 take the sample-parallel kernel (one lane per blur sample)
+    "k4_S32_P8_sample_parallel": dict(S=32, F=2, k=4, P=8, K=60, trans_scale=0.002, rot_scale=0.02),
+    "k2_S32_P8_sample_parallel": dict(S=32, F=1, k=2, P=8, K=60, trans_scale=0.002, rot_scale=0.02),
+    "k4_S4_P3_sample_parallel": dict(S=4, F=2, k=4, P=3, K=77),
 }
 
 
