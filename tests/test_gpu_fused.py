@@ -36,6 +36,9 @@ CASES = {
     "k4_S32_P8_sample_parallel": dict(S=32, F=2, k=4, P=8, K=60, trans_scale=0.002, rot_scale=0.02),
     "k2_S32_P8_sample_parallel": dict(S=32, F=1, k=2, P=8, K=60, trans_scale=0.002, rot_scale=0.02),
     "k4_S4_P3_sample_parallel": dict(S=4, F=2, k=4, P=3, K=77),
+    # S = 64: lane-per-pixel kernel whose whole (tiny) tile is the sample-parallel remainder round, one pixel per wave
+    "k4_S64_K1_remainder_round": dict(S=64, F=1, k=4, P=8, K=1, trans_scale=0.002, rot_scale=0.02, exp=0.3),
+    "k2_S64_K1_remainder_round": dict(S=64, F=2, k=2, P=5, K=2, trans_scale=0.002, rot_scale=0.02, exp=0.3),
 }
 
 
