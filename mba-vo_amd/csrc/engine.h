@@ -94,7 +94,6 @@ namespace mbavo
         void *named_scratch(int slot, size_t bytes);
 
         // persistent staging owned by the context (used by mbavo_eval / tracker)
-        double *scratch_frame_blocks(size_t n_doubles);
         double *host_frame_blocks(size_t n_doubles);
 
     private:
@@ -125,7 +124,6 @@ namespace mbavo
         void *d_partials_ = nullptr; size_t cap_partials_ = 0;
         void *d_status_ = nullptr;
         int status_seen_ = 0;
-        void *d_fb_ = nullptr; size_t cap_fb_ = 0;
         void *h_fb_ = nullptr; size_t cap_hfb_ = 0;
 
         static constexpr int kSlots = 12; // 0-6 LM loop (tracker.cpp), 8-10 keyframe detection (keyframe_ops.hip)

@@ -910,7 +910,7 @@ namespace mbavo
     Engine::~Engine()
     {
         void *bufs[] = {d_descs_, d_tiles_, d_bf_tile_begin_, d_bf_prob_, d_poses_, d_rho_, d_partials_,
-                        d_status_, d_fb_};
+                        d_status_};
         for (void *p : bufs)
             if (p) (void)hipFree(p);
         if (h_fb_) (void)hipHostFree(h_fb_);
@@ -935,12 +935,6 @@ namespace mbavo
         if (slot < 0 || slot >= kSlots) return nullptr;
         if (ensure(&slots_[slot], &slot_cap_[slot], bytes ? bytes : 1) != 0) return nullptr;
         return slots_[slot];
-    }
-
-    double *Engine::scratch_frame_blocks(size_t n)
-    {
-        if (ensure(&d_fb_, &cap_fb_, n * sizeof(double)) != 0) return nullptr;
-        return (double *)d_fb_;
     }
 
     double *Engine::host_frame_blocks(size_t n)

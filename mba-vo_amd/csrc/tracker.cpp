@@ -80,7 +80,7 @@ namespace mbavo
 
         int maxK = 0;
         for (int l = 0; l < o.num_levels; ++l) maxK = levels[l].K > maxK ? levels[l].K : maxK;
-        double *d_cap = nullptr, *d_exp = nullptr, *d_kt = nullptr, *d_kR = nullptr, *d_fb = nullptr, *d_pc = nullptr;
+        double *d_cap = nullptr, *d_exp = nullptr, *d_kt = nullptr, *d_kR = nullptr, *d_pc = nullptr;
         unsigned char *d_flags = nullptr;
         double *h_pin = nullptr;
         std::vector<double> h_pc(maxK > 0 ? maxK : 1);
@@ -92,15 +92,13 @@ namespace mbavo
         d_exp = (double *)eng.named_scratch(1, sizeof(double) * F);
         d_kt = (double *)eng.named_scratch(2, sizeof(double) * 7 * N); // [t (3N) | R (4N)]: one upload per evaluation
         d_kR = d_kt ? d_kt + 3 * N : nullptr;
-        d_fb = (double *)eng.named_scratch(4, sizeof(double) * (size_t)F * E);
         d_pc = (double *)eng.named_scratch(5, sizeof(double) * (size_t)F * (maxK > 0 ? maxK : 1));
         d_flags = (unsigned char *)eng.named_scratch(6, maxK > 0 ? maxK : 1);
         h_pin = eng.host_frame_blocks((size_t)F * E); // device-visible pinned host memory
         if (h_pin) memset(h_pin, 0, sizeof(double) * (size_t)F * E);
-        if (!d_cap || !d_exp || !d_kt || !d_kR || !d_fb || !d_pc || !d_flags || !h_pin) { rc_ = (int)hipErrorOutOfMemory; goto done; }
+        if (!d_cap || !d_exp || !d_kt || !d_kR || !d_pc || !d_flags || !h_pin) { rc_ = (int)hipErrorOutOfMemory; goto done; }
         TRK_HIP(hipMemcpyAsync(d_cap, h_cap, sizeof(double) * F, hipMemcpyHostToDevice, st)); // :701-719
         TRK_HIP(hipMemcpyAsync(d_exp, h_exp, sizeof(double) * F, hipMemcpyHostToDevice, st));
-        TRK_HIP(hipMemsetAsync(d_fb, 0, sizeof(double) * (size_t)F * E, st));
 
         for (int li = 0; li < o.num_levels; ++li)
         {
