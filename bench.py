@@ -103,6 +103,26 @@ def cpu_baseline(probs, budget_s):
         plist.append(op)
         keeps.append(keep)
     ps = sum(p.pixel_samples for p in probs)
+    R = B.ref()
+    if R is not None and hasattr(R, "ref_compute_pixel_jacobian_residual") and os.environ.get("MBAVO_CPU_BASELINE", "reference") == "reference":
+        # kind "reference": the per-sample arithmetic is the reference's own code (spline functors,
+        # compute_pixel_intensity<double>, Core::MatrixMatrixMultiply) compiled from its sources into oracle/_ref;
+        # the kernels' launch geometry and block reductions cannot be compiled and are the oracle's restatement
+        args = [dict(S=p.S, F=p.F, K=p.K, P=p.P, k=p.k, N=p.N, H=p.H, W=p.W, ref_img=p.ref, ref_dIxy=p.grad, cur_imgs=p.cur,
+                     kp_xy=p.kp_xy, kp_z=p.kp_z, pattern=p.pattern, intr=p.intr, cap=p.cap, exp_t=p.exp, t0=p.t0, dt=p.dt,
+                     knots_t=p.knots_t, knots_R=p.knots_R, huber_a=p.huber) for p in probs]
+        t_all, reps, blocks = 0.0, 0, None
+        while reps < 1 or (t_all + t_all / reps < budget_s and reps < 20):
+            t0 = time.perf_counter()
+            blocks = [B.evaluate_with_reference(a) for a in args]
+            t_all += time.perf_counter() - t0
+            reps += 1
+        return dict(value=round(ps * reps / t_all / 1e6, 3), unit="Mpixel-samples/s", cores=1, kind="reference",
+                    sample="%d full H/g evaluation(s) of the same workload (%d pixel-samples each) on ONE host core: "
+                           "per-sample code = the reference's compute_pixel_intensity<double>, C2/C4 spline functors and "
+                           "Core::MatrixMatrixMultiply compiled from its sources (oracle/_ref, g++ -O2 -ffp-contract=off); "
+                           "kernel launch geometry, Huber and block reductions = oracle restatement; %.1f s"
+                           % (reps, ps, t_all)), np.concatenate(blocks, 0)
     t_all, reps, blocks = 0.0, 0, None
     while reps < 1 or (t_all + t_all / reps < budget_s and reps < 20):
         t0 = time.perf_counter()

@@ -202,6 +202,12 @@ def ref():
             getattr(R, n).argtypes = [c_dp, C.c_double, c_dp, c_dp]
         R.ref_pyramid_u8.argtypes = [c_u8p, C.c_int, C.c_int, C.c_int, C.POINTER(c_u8p)]
         R.ref_image_gradients_u8.argtypes = [c_u8p, C.c_int, C.c_int, c_fp, c_fp]
+        if hasattr(R, "ref_compute_pixel_jacobian_residual"):
+            R.ref_compute_virtual_camera_poses.argtypes = [C.c_int, C.c_int, c_dp, c_dp, C.c_int, C.c_double, C.c_double,
+                                                           c_dp, c_dp, c_dp, c_dp, c_dp]
+            R.ref_compute_pixel_jacobian_residual.argtypes = [
+                c_u8p, c_fp, C.POINTER(c_u8p), C.c_int, C.c_int, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp, C.c_int,
+                c_ip, C.c_int, c_dp, C.c_int, C.c_int, c_dp, c_dp]
         R.ref_lm_new.restype = C.c_void_p
         R.ref_tr_new.restype = C.c_void_p
         R.ref_tr_new.argtypes = [C.c_int]
@@ -283,3 +289,51 @@ def evaluate_fast(prob, num_threads=1, with_hessian=True):
     L.orc_evaluate_fast(C.byref(prob), int(num_threads), dp(frame_blocks), dp(cost), dp(H), dp(g))
     return dict(cost=float(cost[0]), H=None if H is None else H.reshape(n, n).T.copy(), g=g,
                 frame_blocks=frame_blocks.reshape(prob.F, E))
+
+
+def stages_with_reference(prob_args, with_jacobians=True):
+    """One evaluation with the REFERENCE's own per-sample code for the two dominant stages (oracle/_ref:
+    ref_compute_virtual_camera_poses, ref_compute_pixel_jacobian_residual) and the oracle's restated reductions for the
+    rest (patch / frame blocks, merge).  prob_args: dict with the make_problem() arguments.  Returns dict with
+    poses, J_t, J_R, centres, residuals, jacobians, frame_blocks, cost."""
+    R, L = ref(), lib()
+    assert R is not None and hasattr(R, "ref_compute_pixel_jacobian_residual"), "oracle/_ref with the stage drivers is not built"
+    a = prob_args
+    S, F, K, P, k, N, H, W = a["S"], a["F"], a["K"], a["P"], a["k"], a["N"], a["H"], a["W"]
+    E = packed_len(k)
+    poses, Jt, JR = np.zeros(F * S * 7), np.zeros(F * S * 9 * k), np.zeros(F * S * 12 * k)
+    R.ref_compute_virtual_camera_poses(S, F, dp(a["cap"]), dp(a["exp_t"]), k, a["t0"], a["dt"], dp(a["knots_t"]),
+                                       dp(a["knots_R"]), dp(poses), dp(Jt), dp(JR))
+    centres = np.zeros(F * K * 2)
+    L.orc_compute_local_patches_xy(S, F, dp(poses), dp(a["kp_xy"]), dp(a["kp_z"]), K, dp(a["intr"]), dp(centres))
+    res = np.zeros(F * K * P)
+    jac = np.zeros(F * K * P * 6 * k) if with_jacobians else None
+    cur_arr = (c_u8p * F)(*[u8p(c) for c in a["cur_imgs"]])
+    R.ref_compute_pixel_jacobian_residual(u8p(a["ref_img"]), fp(a["ref_dIxy"]), cur_arr, S, F, dp(poses), k, dp(Jt), dp(JR),
+                                          dp(centres), dp(a["kp_z"]), K, ip(a["pattern"]), P, dp(a["intr"]), H, W, dp(res),
+                                          dp(jac))
+    inv = 1.0 / (K * F * P) if K * F * P > 0 else 0.0
+    pb = np.zeros(F * K * E)
+    L.orc_compute_patch_cost_gradient_hessian(F, K, P, k, dp(res), dp(jac), a["huber_a"], inv, dp(pb))
+    fb = np.zeros(F * E)
+    L.orc_compute_frame_cost_gradient_hessian(F, K, k, dp(pb), 1 if with_jacobians else 0, None, dp(fb))
+    return dict(poses=poses, J_t=Jt, J_R=JR, centres=centres, residuals=res, jacobians=jac,
+                frame_blocks=fb.reshape(F, E), cost=float(fb.reshape(F, E)[:, 0].sum()))
+
+
+def evaluate_with_reference(prob_args, chunk=4096):
+    """Whole evaluation (frame blocks [F, E]) with the reference's per-sample code, keypoints in chunks so that the
+    per-pixel Jacobians and per-patch blocks the reference pipeline materialises stay small (dense problems: 800 MB of
+    patch blocks otherwise).  The chunks' frame sums are added in keypoint order."""
+    a = dict(prob_args)
+    K, F, P, k = a["K"], a["F"], a["P"], a["k"]
+    E = packed_len(k)
+    total = np.zeros((F, E))
+    for k0 in range(0, max(K, 1), chunk):
+        k1 = min(K, k0 + chunk)
+        if k1 <= k0:
+            break
+        sub = dict(a, K=k1 - k0, kp_xy=np.ascontiguousarray(a["kp_xy"][k0:k1]), kp_z=np.ascontiguousarray(a["kp_z"][k0:k1]))
+        r = stages_with_reference(sub)
+        total += r["frame_blocks"] * ((k1 - k0) * F * P)  # un-normalise the chunk (inv = 1 / (K_chunk F P))
+    return total / (K * F * P) if K * F * P > 0 else total

@@ -13,6 +13,11 @@
 //   core/measurements/ImagePyramid.h    ref_pyramid_u8
 //   core/image_proc/Gradient.h          ref_image_gradients_u8
 //   ba_tracker/levenberg_marquardt_strategy.cpp, trust_region_step_evaluator.cpp  ref_lm_*, ref_tr_*
+//   stage drivers over whole problems, with the REFERENCE's per-sample code inside and only the kernels' launch
+//   geometry / block reductions restated (the .cu files cannot be compiled):
+//     ref_compute_virtual_camera_poses      kernel body of compute_virtual_camera_poses.cu:26-109 (spline functors)
+//     ref_compute_pixel_jacobian_residual   kernel body of compute_hessian_gradients_cost.cu:51-153
+//                                           (compute_pixel_intensity<double>, Core::MatrixMatrixMultiply)
 // The CUDA kernels (.cu), merge (Eigen), Spline.h (Sophus) cannot be built here.
 #include <cmath>
 #include <cstring>
@@ -21,6 +26,7 @@
 #include "ba_tracker/compute_pixel_intensity.h"
 #include "ba_tracker/levenberg_marquardt_strategy.h"
 #include "ba_tracker/trust_region_step_evaluator.h"
+#include "core/common/SmallBlas.h"
 #include "core/common/SplineFunctor.h"
 #include "core/image_proc/Gradient.h"
 #include "core/measurements/ImagePyramid.h"
@@ -152,4 +158,109 @@ void ref_tr_reset(void *p, double c) { ((VO::TrustRegionStepEvaluator *)p)->rese
 double ref_tr_quality(void *p, double c, double m) { return ((VO::TrustRegionStepEvaluator *)p)->StepQuality(c, m); }
 void ref_tr_accepted(void *p, double c, double m) { ((VO::TrustRegionStepEvaluator *)p)->StepAccepted(c, m); }
 
+
+// ---- stage drivers (whole problems) ----------------------------------------------------------------------------
+// block reduction of reduction.h:13-55 as the kernels use it: pairwise tree for power-of-two sizes; other sizes are
+// racy in the reference and DEFINED here as the plain sum
+static double ref_tree_sum(double *buf, int n)
+{
+    if (n <= 0) return 0.0;
+    if ((n & (n - 1)) == 0)
+    {
+        for (int s = n / 2; s >= 1; s /= 2)
+            for (int i = 0; i < s; ++i) buf[i] = buf[i] + buf[i + s];
+        return buf[0];
+    }
+    double acc = 0.0;
+    for (int i = 0; i < n; ++i) acc += buf[i];
+    return acc;
+}
+
+void ref_compute_virtual_camera_poses(int S, int F, const double *cap, const double *exp_t, int k, double t0, double dt,
+                                      const double *knots_t, const double *knots_R, double *poses, double *J_t,
+                                      double *J_R)
+{
+    double le[72], X[16], Y[16], Z[16];
+    for (int f = 0; f < F; ++f)
+        for (int i = 0; i < S; ++i)
+        {
+            const int v = f * S + i;
+            const double t_cap = cap[f], t_mu = exp_t[f];
+            const double t = t_cap - t_mu * 0.5 + i * t_mu / (S - 1 + 1e-8); // compute_virtual_camera_poses.cu:33
+            int idx;
+            double u;
+            SplineSegmentStartKnotIdxAndNormalizedU(t, t0, dt, idx, u);
+            double *jt = J_t ? J_t + (size_t)v * 9 * k : nullptr;
+            double *jr = J_R ? J_R + (size_t)v * 12 * k : nullptr;
+            Vector3d p;
+            Quaterniond q;
+            if (k == 2)
+            {
+                p = C2SplineVec3Functor(knots_t + idx * 3, u, jt);
+                q = jr ? C2SplineRot3Functor(knots_R + idx * 4, u, jr, le, X, Y, Z) : C2SplineRot3Functor(knots_R + idx * 4, u);
+            }
+            else
+            {
+                p = C4SplineVec3Functor(knots_t + idx * 3, u, jt);
+                q = jr ? C4SplineRot3Functor(knots_R + idx * 4, u, jr, le, X, Y, Z) : C4SplineRot3Functor(knots_R + idx * 4, u);
+            }
+            double *o = poses + (size_t)v * 7;
+            o[0] = p(0); o[1] = p(1); o[2] = p(2);
+            o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
+        }
+}
+
+// jacobians may be null (cost-only).  A pixel whose location or any of whose S samples is out of bounds gets
+// residual 0 and a zero row (the reference leaves stale values there).
+void ref_compute_pixel_jacobian_residual(const unsigned char *I_ref, const float *dIxy_ref, const unsigned char *const *I_cur,
+                                         int S, int F, const double *poses, int k, const double *J_t, const double *J_R,
+                                         const double *centres, const double *kp_z, int K, const int *pattern, int P,
+                                         const double intr[4], int H, int W, double *residuals, double *jacobians)
+{
+    const int n6k = 6 * k;
+    double *ints = new double[S];
+    double *chain = new double[(size_t)S * n6k];
+    for (int f = 0; f < F; ++f)
+        for (int i = 0; i < K; ++i)
+            for (int pp = 0; pp < P; ++pp)
+            {
+                const size_t g = ((size_t)f * K + i) * P + pp;
+                residuals[g] = 0.0;
+                if (jacobians) std::memset(jacobians + g * n6k, 0, sizeof(double) * n6k);
+                const int px = centres[((size_t)f * K + i) * 2] + pattern[2 * pp];     // :69-70, int truncation
+                const int py = centres[((size_t)f * K + i) * 2 + 1] + pattern[2 * pp + 1];
+                if (px < 0 || px > W - 1 || py < 0 || py > H - 1) continue;
+                const Vector2d cur(px, py);
+                bool ok = true;
+                for (int s = 0; s < S && ok; ++s)
+                {
+                    const double *t_c2r = poses + ((size_t)f * S + s) * 7, *R_c2r = t_c2r + 3;
+                    double val, j7[7];
+                    ok = VO::compute_pixel_intensity<double>(I_ref, dIxy_ref, H, W, R_c2r, t_c2r, kp_z[i], intr[0], intr[1],
+                                                             intr[2], intr[3], cur, &val, jacobians ? j7 : nullptr);
+                    if (!ok) break;
+                    ints[s] = val;
+                    if (jacobians)
+                    { // :136-142
+                        double *c = chain + (size_t)s * n6k;
+                        MatrixMatrixMultiply<double, double, double, 0>(j7, 1, 3, J_t + ((size_t)f * S + s) * 9 * k, 3, 3 * k, c, 0, 0, 1,
+                                                                         3 * k);
+                        MatrixMatrixMultiply<double, double, double, 0>(j7 + 3, 1, 4, J_R + ((size_t)f * S + s) * 12 * k, 4, 3 * k, c, 0,
+                                                                         3 * k, 1, 3 * k);
+                    }
+                }
+                if (!ok) continue;
+                const double sum = ref_tree_sum(ints, S);
+                const double intensity_cur = *(I_cur[f] + py * W + px);
+                residuals[g] = sum / float(S) - intensity_cur; // :120
+                if (jacobians)
+                    for (int c = 0; c < n6k; ++c)
+                    {
+                        for (int s = 0; s < S; ++s) ints[s] = chain[(size_t)s * n6k + c];
+                        jacobians[g * n6k + c] = ref_tree_sum(ints, S) / float(S); // :145-153
+                    }
+            }
+    delete[] ints;
+    delete[] chain;
+}
 } // extern "C"

@@ -141,3 +141,57 @@ def test_oracle_matches_live_reference_when_present(orc):
         L.orc_c4_rot3(orc.dp(kR[idx * 4:]), u, orc.dp(a), orc.dp(ja))
         R.ref_c4_rot3(orc.dp(kR[idx * 4:]), u, orc.dp(b), orc.dp(jb))
         assert np.array_equal(a, b) and np.array_equal(ja, jb)
+
+
+GS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_stage_vectors.npz"))
+
+
+@pytest.mark.parametrize("name", ["k4", "k2", "k4_S3"])
+def test_oracle_stages_reproduce_reference_on_whole_problems(orc, name):
+    """Stage a3 (virtual poses + pose-to-knot Jacobians) and stage a5 (per-pixel residual + 1 x 6k Jacobian) of the
+    oracle against the REFERENCE's own per-sample code run over whole problems (tests/golden/make_stage_golden.py:
+    spline functors, compute_pixel_intensity<double>, Core::MatrixMatrixMultiply compiled from /root/reference).
+    Exact equality, including which pixels are invalid."""
+    L = orc.lib()
+    g = lambda k: GS["%s_%s" % (name, k)]
+    S, F, K, P, k, N, H, W = (int(v) for v in g("in_scalars")[:8])
+    t0, dt = float(g("in_scalars")[8]), float(g("in_scalars")[9])
+    ref_img = np.ascontiguousarray(g("in_ref_img"))
+    grad = np.zeros((H, W, 2), np.float32)
+    L.orc_image_gradients_u8(orc.u8p(ref_img), H, W, orc.fp(grad), None)
+    cur = [np.ascontiguousarray(c) for c in g("in_cur")]
+    c64 = lambda a: np.ascontiguousarray(a, np.float64)
+    kp_xy, kp_z, intr, cap, exp_t = c64(g("in_kp_xy")), c64(g("in_kp_z")), c64(g("in_intr")), c64(g("in_cap")), c64(g("in_exp_t"))
+    kt, kR, pattern = c64(g("in_knots_t")), c64(g("in_knots_R")), np.ascontiguousarray(g("in_pattern"), np.int32)
+    poses, Jt, JR = np.zeros(F * S * 7), np.zeros(F * S * 9 * k), np.zeros(F * S * 12 * k)
+    L.orc_compute_virtual_camera_poses(S, F, orc.dp(cap), orc.dp(exp_t), k, t0, dt, orc.dp(kt), orc.dp(kR), orc.dp(poses),
+                                       orc.dp(Jt), orc.dp(JR), None)
+    assert np.array_equal(poses, g("out_poses")) and np.array_equal(Jt, g("out_J_t")) and np.array_equal(JR, g("out_J_R"))
+    centres = np.zeros(F * K * 2)
+    L.orc_compute_local_patches_xy(S, F, orc.dp(poses), orc.dp(kp_xy), orc.dp(kp_z), K, orc.dp(intr), orc.dp(centres))
+    res, jac = np.zeros(F * K * P), np.zeros(F * K * P * 6 * k)
+    cur_arr = (orc.c_u8p * F)(*[orc.u8p(c) for c in cur])
+    L.orc_compute_pixel_jacobian_residual(orc.u8p(ref_img), orc.fp(grad), cur_arr, S, F, orc.dp(poses), k, orc.dp(Jt), orc.dp(JR),
+                                          orc.dp(centres), orc.dp(kp_z), K, orc.ip(pattern), P, orc.dp(intr), H, W, orc.dp(res),
+                                          orc.dp(jac))
+    assert np.array_equal(res, g("out_residuals")) and np.array_equal(jac, g("out_jacobians"))
+    assert np.count_nonzero(res) > 0.7 * res.size
+
+
+def test_oracle_evaluation_matches_live_reference_stages_when_present(orc):
+    """Larger random problems through oracle/_ref's stage drivers (only where it has been built): the whole
+    evaluation of the oracle -- frame blocks included -- equals the one composed with the reference's per-sample code."""
+    R = orc.ref()
+    if R is None or not hasattr(R, "ref_compute_pixel_jacobian_residual"):
+        pytest.skip("oracle/_ref (with stage drivers) not built on this machine")
+    import scenes
+    for kw in (dict(S=8, F=2, k=4, P=8, K=145), dict(S=4, F=1, k=2, P=8, K=145, huber=0.1),
+               dict(H=96, W=128, S=16, F=1, k=4, P=1, kp="dense", margin=0)):
+        sc = scenes.Scene(**kw)
+        p, keep = sc.oracle_problem(orc)
+        ro = orc.evaluate(p)
+        rr = orc.stages_with_reference(dict(S=sc.S, F=sc.F, K=sc.K, P=sc.P, k=sc.k, N=sc.N, H=sc.H, W=sc.W, ref_img=sc.ref,
+                                            ref_dIxy=sc.grad, cur_imgs=sc.cur, kp_xy=sc.kp_xy, kp_z=sc.kp_z, pattern=sc.pattern,
+                                            intr=sc.intr, cap=sc.cap, exp_t=sc.exp, t0=sc.t0, dt=sc.dt, knots_t=sc.knots_t,
+                                            knots_R=sc.knots_R, huber_a=sc.huber))
+        assert np.array_equal(ro["frame_blocks"], rr["frame_blocks"])
