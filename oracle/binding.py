@@ -205,6 +205,8 @@ def ref():
         if hasattr(R, "ref_compute_pixel_jacobian_residual"):
             R.ref_compute_virtual_camera_poses.argtypes = [C.c_int, C.c_int, c_dp, c_dp, C.c_int, C.c_double, C.c_double,
                                                            c_dp, c_dp, c_dp, c_dp, c_dp]
+            if hasattr(R, "ref_compute_local_patches_xy"):
+                R.ref_compute_local_patches_xy.argtypes = [C.c_int, C.c_int, c_dp, c_dp, c_dp, C.c_int, c_dp, c_dp]
             R.ref_compute_pixel_jacobian_residual.argtypes = [
                 c_u8p, c_fp, C.POINTER(c_u8p), C.c_int, C.c_int, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp, C.c_int,
                 c_ip, C.c_int, c_dp, C.c_int, C.c_int, c_dp, c_dp]
@@ -305,7 +307,8 @@ def stages_with_reference(prob_args, with_jacobians=True):
     R.ref_compute_virtual_camera_poses(S, F, dp(a["cap"]), dp(a["exp_t"]), k, a["t0"], a["dt"], dp(a["knots_t"]),
                                        dp(a["knots_R"]), dp(poses), dp(Jt), dp(JR))
     centres = np.zeros(F * K * 2)
-    L.orc_compute_local_patches_xy(S, F, dp(poses), dp(a["kp_xy"]), dp(a["kp_z"]), K, dp(a["intr"]), dp(centres))
+    (R.ref_compute_local_patches_xy if hasattr(R, "ref_compute_local_patches_xy") else L.orc_compute_local_patches_xy)(
+        S, F, dp(poses), dp(a["kp_xy"]), dp(a["kp_z"]), K, dp(a["intr"]), dp(centres))
     res = np.zeros(F * K * P)
     jac = np.zeros(F * K * P * 6 * k) if with_jacobians else None
     cur_arr = (c_u8p * F)(*[u8p(c) for c in a["cur_imgs"]])

@@ -9,7 +9,10 @@
  *
  * Parity pinning: the per-sample math, spline functors, LM / trust-region
  * classes, pyramid and gradient are pinned bit-for-bit against the reference's
- * own headers compiled in oracle/_ref (see oracle/Makefile, tests/golden).
+ * own headers compiled in oracle/_ref (see oracle/Makefile, tests/golden);
+ * stages a3, a4, a5 (poses + Jacobians, patch centres, per-pixel residual and
+ * Jacobian) also over whole problems, with the reference's per-sample code
+ * driven through the restated kernel geometry (tests/golden/ref_stage_vectors.npz).
  * The kernel orchestration (reductions, packing, merge) cannot be compiled
  * from the reference (.cu) and is pinned by the harness' analytic checks
  * (test/test_blur_aware_tracker_modules.cpp:958-982,1039-1050,1130-1153).

@@ -16,6 +16,7 @@
 //   stage drivers over whole problems, with the REFERENCE's per-sample code inside and only the kernels' launch
 //   geometry / block reductions restated (the .cu files cannot be compiled):
 //     ref_compute_virtual_camera_poses      kernel body of compute_virtual_camera_poses.cu:26-109 (spline functors)
+//     ref_compute_local_patches_xy          kernel body of compute_local_patches_xy.cu:19-49 (Vector3d, Quaterniond)
 //     ref_compute_pixel_jacobian_residual   kernel body of compute_hessian_gradients_cost.cu:51-153
 //                                           (compute_pixel_intensity<double>, Core::MatrixMatrixMultiply)
 // The CUDA kernels (.cu), merge (Eigen), Spline.h (Sophus) cannot be built here.
@@ -262,5 +263,28 @@ void ref_compute_pixel_jacobian_residual(const unsigned char *I_ref, const float
             }
     delete[] ints;
     delete[] chain;
+}
+
+// kernel body of compute_local_patches_xy.cu:19-49 with the reference's Vector3d / Quaterniond classes
+void ref_compute_local_patches_xy(int S, int F, const double *poses, const double *kp_xy, const double *kp_z, int K,
+                                  const double intr[4], double *centres)
+{
+    for (int f = 0; f < F; ++f)
+        for (int i = 0; i < K; ++i)
+        {
+            const int pose_idx = f * S + S / 2;
+            Vector3d P3dr;
+            P3dr(0) = kp_z[i] * (kp_xy[2 * i] - intr[2]) / intr[0];
+            P3dr(1) = kp_z[i] * (kp_xy[2 * i + 1] - intr[3]) / intr[1];
+            P3dr(2) = kp_z[i];
+            const double *cam_pose = poses + (size_t)pose_idx * 7;
+            const Vector3d t_c2r(cam_pose[0], cam_pose[1], cam_pose[2]);
+            const Quaterniond R_c2r(cam_pose[3], cam_pose[4], cam_pose[5], cam_pose[6]);
+            const Quaterniond R_r2c = R_c2r.conjugate();
+            const Vector3d t_r2c = -(R_r2c * t_c2r);
+            const Vector3d P3dc = R_r2c * P3dr + t_r2c;
+            centres[((size_t)f * K + i) * 2] = P3dc(0) / P3dc(2) * intr[0] + intr[2];
+            centres[((size_t)f * K + i) * 2 + 1] = P3dc(1) / P3dc(2) * intr[1] + intr[3];
+        }
 }
 } // extern "C"

@@ -1,5 +1,6 @@
 """Generates tests/golden/ref_stage_vectors.npz by EXECUTING THE REFERENCE's own per-sample code over whole (small)
-problems: oracle/_ref's ref_compute_virtual_camera_poses (spline functors) and ref_compute_pixel_jacobian_residual
+problems: oracle/_ref's ref_compute_virtual_camera_poses (spline functors), ref_compute_local_patches_xy (Vector3d /
+Quaterniond classes) and ref_compute_pixel_jacobian_residual
 (compute_pixel_intensity<double> + Core::MatrixMatrixMultiply inside the restated kernel geometry of
 compute_hessian_gradients_cost.cu:51-153).  Runs only in the build container (needs /root/reference); the file holds
 inputs and outputs, no reference source.  tests/test_oracle_golden.py requires the oracle's stages to reproduce it
@@ -35,7 +36,7 @@ for name, kw in CASES.items():
         out["%s_in_%s" % (name, key)] = np.asarray(args[key])
     out[name + "_in_cur"] = np.stack(sc.cur)
     out[name + "_in_scalars"] = np.array([sc.S, sc.F, sc.K, sc.P, sc.k, sc.N, sc.H, sc.W, sc.t0, sc.dt, sc.huber])
-    for key in ("poses", "J_t", "J_R", "residuals", "jacobians", "frame_blocks"):
+    for key in ("poses", "J_t", "J_R", "centres", "residuals", "jacobians", "frame_blocks"):
         out["%s_out_%s" % (name, key)] = r[key]
     print(name, "pixels", sc.F * sc.K * sc.P, "valid residuals", int(np.count_nonzero(r["residuals"])), "cost", r["cost"])
 np.savez_compressed(os.path.join(HERE, "ref_stage_vectors.npz"), **out)

@@ -148,7 +148,7 @@ GS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", 
 
 @pytest.mark.parametrize("name", ["k4", "k2", "k4_S3"])
 def test_oracle_stages_reproduce_reference_on_whole_problems(orc, name):
-    """Stage a3 (virtual poses + pose-to-knot Jacobians) and stage a5 (per-pixel residual + 1 x 6k Jacobian) of the
+    """Stage a3 (virtual poses + pose-to-knot Jacobians), stage a4 (patch centres) and stage a5 (per-pixel residual + 1 x 6k Jacobian) of the
     oracle against the REFERENCE's own per-sample code run over whole problems (tests/golden/make_stage_golden.py:
     spline functors, compute_pixel_intensity<double>, Core::MatrixMatrixMultiply compiled from /root/reference).
     Exact equality, including which pixels are invalid."""
@@ -169,6 +169,7 @@ def test_oracle_stages_reproduce_reference_on_whole_problems(orc, name):
     assert np.array_equal(poses, g("out_poses")) and np.array_equal(Jt, g("out_J_t")) and np.array_equal(JR, g("out_J_R"))
     centres = np.zeros(F * K * 2)
     L.orc_compute_local_patches_xy(S, F, orc.dp(poses), orc.dp(kp_xy), orc.dp(kp_z), K, orc.dp(intr), orc.dp(centres))
+    assert np.array_equal(centres, g("out_centres"))
     res, jac = np.zeros(F * K * P), np.zeros(F * K * P * 6 * k)
     cur_arr = (orc.c_u8p * F)(*[orc.u8p(c) for c in cur])
     L.orc_compute_pixel_jacobian_residual(orc.u8p(ref_img), orc.fp(grad), cur_arr, S, F, orc.dp(poses), k, orc.dp(Jt), orc.dp(JR),
