@@ -1,11 +1,12 @@
 // harness.cpp -- module tests of the ba_tracker C++ API on the GPU, with real pass/fail.
 //
 // Counterpart of the reference's test/test_blur_aware_tracker_modules.cpp (which only prints):
-// the same eight module tests driven through the same free functions (namespace SLAM::VO) with
-// hipMalloc'd buffers, checked against host-side analytic formulas, plus one test the reference
+// the same eight module tests driven through the same free functions (namespace SLAM::VO, and the host-callable
+// helpers of ba_tracker_compat.h under the reference's names) with hipMalloc'd buffers, checked against host-side analytic formulas, plus one test the reference
 // lacks: evaluate_cost_hessian_gradient (fused engine) against the five launchers run one by one.
 // Build: hipcc --offload-arch=gfx950 -I mba-vo_amd/csrc harness.cpp -L mba-vo_amd -lmbavo
 #include "ba_tracker.h"
+#include "ba_tracker_compat.h"
 #include "host_math.h"
 #include "pixel_math.h"
 #include "se3_math.h"
@@ -15,6 +16,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 
@@ -416,11 +418,144 @@ static void test_evaluate_cost_hessian_gradient(Fixture &fx)
     CHECK(st.cuda_frame_cost_gradient_hessian_tR == nullptr, "storages reset");
 }
 
+
+// test_compute_pixel_intensity (test/test_blur_aware_tracker_modules.cpp:83-181) through the reference's own host-callable
+// names (ba_tracker_compat.h): the warp of the pixel that sees keyframe pixel (20.5, 20.5) must return the bilinear value
+// there (1e-4), and the analytic 1 x 7 Jacobian must agree with forward differences (the reference only prints these).
+static void test_compute_pixel_intensity()
+{
+    printf("-- test_compute_pixel_intensity\n");
+    const int H = 480, W = 640;
+    const double fx = 320, fy = 320, cx = 320, cy = 240;
+    Image<unsigned char> I_ref(H, W, 1);
+    for (int r = 0; r < H; ++r)
+        for (int c = 0; c < W; ++c) I_ref.getData()[(size_t)r * W + c] = (unsigned char)((c + r) % 255); // create_uniform_image (:69-81)
+    Image<float> I_gradXY(H, W, 2);
+    for (int r = 1; r < H - 1; ++r)
+        for (int c = 1; c < W - 1; ++c)
+        {
+            const size_t i = (size_t)r * W + c;
+            I_gradXY.getData()[2 * i] = 0.5f * ((float)I_ref.getData()[i + 1] - (float)I_ref.getData()[i - 1]);
+            I_gradXY.getData()[2 * i + 1] = 0.5f * ((float)I_ref.getData()[i + W] - (float)I_ref.getData()[i - W]);
+        }
+    std::mt19937 rng(11);
+    std::uniform_real_distribution<double> ud(-1.0, 1.0), uz(5.0, 10.0);
+    int done = 0;
+    for (int attempt = 0; attempt < 200 && done < 8; ++attempt)
+    {
+        VectorX<double, 2> ref_xy;
+        ref_xy.nDim = 2; ref_xy.values[0] = 20.5; ref_xy.values[1] = 20.5;
+        const double plane_depth = uz(rng);
+        double q[4] = {0.2 * ud(rng), 0.2 * ud(rng), 0.2 * ud(rng), 1.0}, t[3] = {0.3 * ud(rng), 0.3 * ud(rng), 0.3 * ud(rng)};
+        const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        for (double &v : q) v /= n;
+        // the current-frame pixel that sees keyframe point P3dr: P3dc = R^-1 (P3dr - t)
+        const double P3dr[3] = {(ref_xy.values[0] - cx) / fx * plane_depth, (ref_xy.values[1] - cy) / fy * plane_depth, plane_depth};
+        const double d[3] = {P3dr[0] - t[0], P3dr[1] - t[1], P3dr[2] - t[2]}, qc[4] = {-q[0], -q[1], -q[2], q[3]};
+        double P3dc[3];
+        mbavo::qrotate(mbavo::load_quat(qc), d, P3dc);
+        if (P3dc[2] < 0.5) continue;
+        Vector2d cur_xy(fx * P3dc[0] / P3dc[2] + cx, fy * P3dc[1] / P3dc[2] + cy);
+        Vector3d I_dI(0, 0, 0);
+        CHECK(bilinear_interpolation<double>(I_ref.getData(), I_gradXY.getData(), H, W, ref_xy, I_dI), "reference pixel in bounds");
+        double intensity = 0, Ja[7], Jn[7];
+        if (!compute_pixel_intensity<double>(I_ref.getData(), I_gradXY.getData(), H, W, q, t, plane_depth, fx, fy, cx, cy, cur_xy,
+                                             &intensity, Ja))
+            continue; // the fronto-parallel patch of this pixel does not hit the image: try another pose
+        // the patch is fronto-parallel in the CURRENT frame (compute_pixel_intensity.h:113-132), so the hit point is the
+        // keyframe point only up to the plane model: compare against the bilinear value at the pixel it really hits
+        ++done;
+        // the reference uses eps = 1e-6 and only prints: the intensity goes through an fp32 blend (A5), so a forward
+        // difference is noisy by ~6e-8 * I / eps; 1e-4 keeps that below 0.1 while the ramp image has no curvature
+        const double eps = 1e-4;
+        for (int i = 0; i < 3; ++i)
+        {
+            double t2[3] = {t[0], t[1], t[2]}, v2 = 0;
+            t2[i] += eps;
+            CHECK(compute_pixel_intensity<double>(I_ref.getData(), I_gradXY.getData(), H, W, q, t2, plane_depth, fx, fy, cx, cy, cur_xy, &v2), "perturbed t");
+            Jn[i] = (v2 - intensity) / eps;
+        }
+        for (int i = 0; i < 4; ++i)
+        { // raw quaternion coefficient, NOT re-normalised: the 1 x 7 Jacobian is with respect to the four coefficients
+            double q2[4] = {q[0], q[1], q[2], q[3]}, v2 = 0;
+            q2[i] += eps;
+            CHECK(compute_pixel_intensity<double>(I_ref.getData(), I_gradXY.getData(), H, W, q2, t, plane_depth, fx, fy, cx, cy, cur_xy, &v2), "perturbed q");
+            Jn[3 + i] = (v2 - intensity) / eps;
+        }
+        double amax = 0;
+        for (int i = 0; i < 7; ++i) amax = fmax(amax, fabs(Ja[i]));
+        for (int i = 0; i < 7; ++i) CHECK(fabs(Ja[i] - Jn[i]) <= 5e-3 * amax + 0.2, "1x7 Jacobian entry %d: analytic %g numeric %g", i, Ja[i], Jn[i]);
+        CHECK(intensity >= 0 && intensity <= 255, "intensity %g", intensity);
+    }
+    CHECK(done >= 4, "only %d usable poses", done);
+    // on the ramp image (c + r) % 255 the interpolated value at a non-wrapping position is x + y exactly
+    {
+        VectorX<double, 2> p;
+        p.nDim = 2; p.values[0] = 20.5; p.values[1] = 20.5;
+        Vector3d v(0, 0, 0);
+        CHECK(bilinear_interpolation<double>(I_ref.getData(), I_gradXY.getData(), H, W, p, v), "in bounds");
+        CHECK(fabs(v(0) - 41.0) < 1e-4 && fabs(v(1) - 1.0) < 1e-6 && fabs(v(2) - 1.0) < 1e-6, "ramp value %g grad %g %g", v(0), v(1), v(2));
+        p.values[0] = -0.5;
+        CHECK(!bilinear_interpolation<double>(I_ref.getData(), I_gradXY.getData(), H, W, p, v), "out of bounds rejected");
+    }
+    // Image<T>::uploadToGpu / getGpuData (Image.h:125-136)
+    I_ref.uploadToGpu();
+    CHECK(I_ref.getGpuData() != nullptr, "device copy");
+    auto back = to_host(I_ref.getGpuData(), (size_t)H * W);
+    CHECK(memcmp(back.data(), I_ref.getData(), (size_t)H * W) == 0, "device copy content");
+    unsigned char *first = I_ref.getGpuData();
+    I_ref.uploadToGpu();
+    CHECK(I_ref.getGpuData() == first, "second upload is a no-op");
+}
+
+// the spline functors under the reference's names against SplineSE3::GetPose (as :287-321 does for the kernel) and
+// forward differences on the knots
+static void test_spline_functors(Fixture &fx)
+{
+    printf("-- test_spline_functors\n");
+    const double *kt = fx.spline->get_knot_data_t(), *kR = fx.spline->get_knot_data_R();
+    for (double t : {0.26, 0.8, 1.33})
+    {
+        int idx;
+        double u;
+        SplineSegmentStartKnotIdxAndNormalizedU(t, 0.0, 0.5, idx, u);
+        double jt[36], jR[48], q0[4], p0[3], jR0[48], jt0[36];
+        const Vector3d p = C4SplineVec3Functor(kt + 3 * idx, u, jt);
+        const Quaterniond q = C4SplineRot3Functor(kR + 4 * idx, u, jR);
+        CHECK(fx.spline->GetPose(t, q0, p0, jR0, jt0), "GetPose range");
+        CHECK(fabs(p(0) - p0[0]) + fabs(p(1) - p0[1]) + fabs(p(2) - p0[2]) < 1e-12, "translation");
+        CHECK(fabs(q.x - q0[0]) + fabs(q.y - q0[1]) + fabs(q.z - q0[2]) + fabs(q.w - q0[3]) < 1e-12, "rotation");
+        CHECK(maxdiff(jt, jt0, 36) < 1e-12 && maxdiff(jR, jR0, 48) < 1e-12, "Jacobians");
+        // d q / d (local rotation of knot j) by forward differences: R_j <- R_j * exp(eps e_a)
+        const double eps = 1e-6;
+        for (int j = 0; j < 4; ++j)
+            for (int a = 0; a < 3; ++a)
+            {
+                double k2[16];
+                memcpy(k2, kR + 4 * idx, sizeof(k2));
+                double w[3] = {0, 0, 0};
+                w[a] = eps;
+                const mbavo::Quat r = mbavo::qmul(mbavo::load_quat(k2 + 4 * j), mbavo::so3_exp(w));
+                k2[4 * j] = r.x; k2[4 * j + 1] = r.y; k2[4 * j + 2] = r.z; k2[4 * j + 3] = r.w;
+                const Quaterniond q2 = C4SplineRot3Functor(k2, u);
+                const double num[4] = {(q2.x - q.x) / eps, (q2.y - q.y) / eps, (q2.z - q.z) / eps, (q2.w - q.w) / eps};
+                for (int r4 = 0; r4 < 4; ++r4) CHECK(fabs(num[r4] - jR[r4 * 12 + 3 * j + a]) < 1e-4, "dq/dw knot %d axis %d row %d", j, a, r4);
+            }
+        const Vector3d p2 = C2SplineVec3Functor(kt + 3 * idx, u);
+        CHECK(fabs(p2(0) - ((1 - u) * kt[3 * idx] + u * kt[3 * idx + 3])) < 1e-14, "linear spline");
+        const Quaterniond qa = C2SplineRot3Functor(kR + 4 * idx, 0.0), qb = C2SplineRot3Functor(kR + 4 * idx, 1.0);
+        CHECK(fabs(qa.x - kR[4 * idx]) + fabs(qa.w - kR[4 * idx + 3]) < 1e-12 && fabs(qb.x - kR[4 * idx + 4]) + fabs(qb.w - kR[4 * idx + 7]) < 1e-12,
+              "C2 rotation spline interpolates its knots");
+    }
+}
+
 int main()
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { printf("no HIP device\n"); return 3; }
     Fixture fx;
+    test_compute_pixel_intensity();
+    test_spline_functors(fx);
     test_compute_virtual_camera_poses(fx);
     test_compute_local_patches(fx);
     test_compute_pixel_jacobian_residual(fx);
