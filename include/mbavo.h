@@ -178,8 +178,8 @@ int mbavo_optimize_trajectory(mbavo_ctx *ctx, const mbavo_track_opts *opts, cons
  * statistics all on the device; the host only polls a done-counter every `sync_every` iterations.
  * Each problem's knots (d_knots_t / d_knots_R, device) are updated in place; d_outlier / num_bad of the input are
  * ignored (flags start cleared, as at the start of a level).  Trace records as mbavo_optimize_trajectory writes
- * them (level = 0), `trace_cap` per problem.  At most 13 control knots per problem (three 6N x 6N areas in the
- * 160 KB of LDS); more returns MBAVO_E_ARG.  Returns 0 or an error. */
+ * them (level = 0), `trace_cap` per problem.  At most 16 control knots per problem (the reference's
+ * max_num_ctrl_knots: two 6N x 6N work areas in the 160 KB of LDS); more returns MBAVO_E_ARG.  Returns 0 or an error. */
 typedef struct mbavo_lm_batch_opts {
     int spline_deg_k, max_num_iterations, max_consecutive_nonmonotonic_steps, solver_type, sync_every;
     double min_step_quality, min_abs_cost_decrease, max_chi_square_error;

@@ -126,9 +126,12 @@ namespace mbavo
         const int N = d.N, n = 6 * N, F = d.F;
         LmState s = states[b];
         if (s.done) return;
-        double *H = lds, *V = H + n * n, *g = V + n * (n + 1), *x = g + n, *tmp = x + n;
+        // LDS: V and G (n x (n + 1) each) + vectors; the damped system H itself lives in global memory (it persists
+        // across iterations anyway), which leaves room for the reference's maximum of 16 control knots (n = 96)
+        double *V = lds, *g = V + n * (n + 1), *x = g + n, *tmp = x + n;
         int *order = (int *)(tmp + n);
         double *Hg = Hst + (size_t)b * o.max_n * o.max_n, *gg = gst + (size_t)b * o.max_n;
+        double *H = Hg;
         double *Ct = cur_t + (size_t)b * 3 * o.max_N, *CR = cur_R + (size_t)b * 4 * o.max_N;
         mbavo_trace_rec *tr = trace ? trace + (size_t)b * o.trace_cap : nullptr;
 
@@ -177,14 +180,12 @@ namespace mbavo
                 }
                 __syncthreads();
             }
-            for (int i = lane; i < n * n; i += 64) Hg[i] = H[i];
             for (int i = lane; i < n; i += 64) gg[i] = g[i];
             s.fresh = 0;
             s.pending_accept = 0;
         }
         else
         {
-            for (int i = lane; i < n * n; i += 64) H[i] = Hg[i];
             for (int i = lane; i < n; i += 64) g[i] = gg[i];
         }
         __syncthreads();
@@ -214,7 +215,6 @@ namespace mbavo
         {
             const double v = H[i * n + i] + H[i * n + i] * iradius;
             H[i * n + i] = v;
-            Hg[i * n + i] = v;
         }
         __syncthreads();
         // the solvers destroy their matrix: work on a copy in V's place (LDLT) or keep H in V and rotate a copy (SVD)
@@ -386,7 +386,7 @@ namespace mbavo
         o.max_it = opt.max_num_iterations; o.max_nonmono = opt.max_consecutive_nonmonotonic_steps; o.solver = opt.solver_type;
         o.trace_cap = trace ? trace_cap : 0; o.max_n = max_n; o.max_N = max_N;
         o.min_q = opt.min_step_quality; o.min_dec = opt.min_abs_cost_decrease; o.chi = opt.max_chi_square_error;
-        const size_t lds = ((size_t)3 * max_n * max_n + 7 * max_n) * sizeof(double) + (size_t)max_n * sizeof(int);
+        const size_t lds = ((size_t)2 * max_n * (max_n + 1) + 6 * max_n) * sizeof(double) + (size_t)max_n * sizeof(int);
         if (lds > 160 * 1024) return MBAVO_E_ARG;
 
         // one allocation for all LM state (freed at the end: this is a per-level call, not a per-iteration one)

@@ -12,21 +12,21 @@ __global__ __launch_bounds__(64) void k_solve(const double *A, const double *b, 
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x, ld = n + 1;
-    double *H = lds, *V = H + n * n, *g = V + n * ld, *xx = g + n, *tmp = xx + n;
+    // the LDS layout of k_lm_solve: V and G (n x (n + 1) each) + vectors; the system itself stays in global memory
+    double *V = lds, *g = V + n * ld, *xx = g + n, *tmp = xx + n;
     int *order = (int *)(tmp + n);
     double *G = tmp + 2 * n;
-    for (int i = lane; i < n * n; i += 64) H[i] = A[i];
     for (int i = lane; i < n; i += 64) g[i] = b[i];
     __syncthreads();
     if (solver == 1)
     {
-        for (int i = lane; i < n * n; i += 64) V[i] = H[i];
+        for (int i = lane; i < n * n; i += 64) V[i] = A[i];
         __syncthreads();
         mbavo::ldlt_solve(V, g, xx, tmp, order, n, lane);
     }
     else
     {
-        for (int i = lane; i < n * n; i += 64) G[(i / n) * ld + i % n] = H[i];
+        for (int i = lane; i < n * n; i += 64) G[(i / n) * ld + i % n] = A[i];
         __syncthreads();
         mbavo::svd_solve(G, V, g, xx, tmp, n, ld, lane);
     }
@@ -37,7 +37,7 @@ int main()
 {
     int bad = 0;
     srand(3);
-    for (int N = 2; N <= 13; N += (N < 8 ? 1 : (N < 12 ? 4 : 1))) // 3 n^2 doubles of LDS: n = 6N <= 78
+    for (int N = 2; N <= 16; N += (N < 8 ? 1 : 4)) // up to the reference's max_num_ctrl_knots = 16 (n = 96)
         for (int solver = 0; solver < 2; ++solver)
             for (int rankdef = 0; rankdef < 2; ++rankdef)
             {
@@ -58,7 +58,7 @@ int main()
                 hipMalloc(&dA, A.size() * 8); hipMalloc(&db, n * 8); hipMalloc(&dx, n * 8);
                 hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
                 hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice);
-                const size_t lds = ((size_t)3 * n * n + 7 * n) * 8 + n * 4;
+                const size_t lds = ((size_t)2 * n * (n + 1) + 6 * n) * 8 + n * 4;
                 hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), lds, 0, dA, db, dx, n, solver);
                 hipError_t e = hipDeviceSynchronize();
