@@ -60,7 +60,7 @@ def _host_lm(mbavo, ctx, dw, b, p, solver, trace_cap=64):
                                      for r in trace[:n]]
 
 
-@pytest.mark.parametrize("k,N,F,solver", [(4, 4, 1, 0), (4, 6, 2, 0), (2, 3, 2, 1), (4, 4, 1, 1), (2, 2, 1, 0)])
+@pytest.mark.parametrize("k,N,F,solver", [(4, 4, 1, 0), (4, 6, 2, 0), (2, 3, 2, 1), (4, 4, 1, 1), (2, 2, 1, 0), (4, 16, 2, 0)])
 def test_lm_batch_matches_host_loop(mbavo, gpu_ctx, k, N, F, solver):
     import torch
     capi = mbavo.capi
