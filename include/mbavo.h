@@ -262,8 +262,9 @@ int mbavo_vo_track_frame(mbavo_vo *vo, const unsigned char *h_sharp, const float
 int mbavo_allreduce_blocks(mbavo_ctx *ctx, void *rccl_comm, double *d_blocks, long long count);
 
 /* ---- measurement: HIP-event timing of the dominant kernel (the fused residual/Jacobian/JtJ
- * kernel) on the context's stream.  enable = n > 0 starts a fresh collection that times every n-th launch (an
- * event pair costs a few us of launch gap, so timing every launch would slow the measured region itself);
+ * kernel) on the context's stream, attached to the kernel's own dispatch (hipExtLaunchKernelGGL: begin / end
+ * timestamps of the kernel).  enable = n > 0 starts a fresh collection that times every n-th launch (a timed
+ * launch costs a few us of launch gap, so timing every launch would slow the measured region itself);
  * 0 stops.  read returns the summed duration in ms and the number of timed launches (blocks until the recorded
  * events completed). */
 int mbavo_profile(mbavo_ctx *ctx, int enable);

@@ -131,13 +131,12 @@ namespace mbavo
         size_t slot_cap_[kSlots] = {};
 
         int prof_every_ = 0, prof_seen_ = 0;
-        bool prof_open_ = false;
         std::vector<hipEvent_t> prof_ev_; // pairs (start, stop)
         int prof_used_ = 0;
 
     public:
-        // called by the launch helper around k_fused
-        void prof_mark(bool start);
+        // called by the launch helper of k_fused
+        bool prof_events(hipEvent_t *e0, hipEvent_t *e1);
     };
 } // namespace mbavo
 

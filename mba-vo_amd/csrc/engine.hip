@@ -16,6 +16,7 @@
 //   * accumulators live across the whole tile loop and are reduced once per
 //     workgroup in a fixed order -- no atomics.
 #include "engine.h"
+#include <hip/hip_ext.h>
 #include "pixel_math.h"
 #include "se3_math.h"
 
@@ -1084,6 +1085,19 @@ namespace mbavo
         return 0;
     }
 
+    // Launch with the kernel's own begin / end timestamps attached to an event pair (hipExtLaunchKernelGGL) when this
+    // launch is one of the timed ones: the duration is the kernel's, as rocprofv3 reports it, and no barrier packet is
+    // added to the queue (an event RECORDED around the launch brackets the dispatch too, +3-4 us, and costs a launch gap)
+#define MBAVO_LAUNCH_TIMED(kernel, grid, block, lds_bytes, ...)                                              \
+    do                                                                                                      \
+    {                                                                                                       \
+        hipEvent_t ev0_, ev1_;                                                                              \
+        if (eng->prof_events(&ev0_, &ev1_))                                                                 \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds_bytes, st, ev0_, ev1_, 0, __VA_ARGS__);          \
+        else                                                                                                \
+            hipLaunchKernelGGL(kernel, grid, block, lds_bytes, st, __VA_ARGS__);                            \
+    } while (0)
+
     template <int KD, bool WITH_J>
     static int launch_all(Engine *eng, hipStream_t st, int max_S, bool half_grad, int sp_logs, const ProblemDesc *descs, int B, int entries, const TileDesc *tiles, int ntiles,
                           const int *bf_prob, const int *bf_tile_begin, int nbf, void *poses, double *rho,
@@ -1115,7 +1129,6 @@ namespace mbavo
                     HIP_TRY(hipFuncSetAttribute((const void *)k_fused<KD, WITH_J, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 attr_lds[half_grad ? 1 : 0] = lds;
             }
-            eng->prof_mark(true);
             if (sp_logs > 0)
             {
                 const size_t lds_sp = (WITH_J ? (size_t)kSpWaves * OuterAcc<Pack<KD>::ND>::SLAB : 0) * sizeof(double) + 2 * kSpWaves * sizeof(double);
@@ -1128,7 +1141,7 @@ namespace mbavo
             HIP_TRY(hipFuncSetAttribute((const void *)k_fused_sp<KD, WITH_J, false, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp)); \
             attr_sp[LG] = lds_sp;                                                                                              \
         }                                                                                                                      \
-        hipLaunchKernelGGL((k_fused_sp<KD, WITH_J, false, LG>), dim3(ntiles), dim3(kSpWaves * 64), lds_sp, st, descs, tiles, table, rho, \
+        MBAVO_LAUNCH_TIMED((k_fused_sp<KD, WITH_J, false, LG>), dim3(ntiles), dim3(kSpWaves * 64), lds_sp, descs, tiles, table, rho, \
                            patch_cost, patch_blocks_strided, partials);                                                        \
     } while (0)
                 switch (sp_logs)
@@ -1141,12 +1154,11 @@ namespace mbavo
 #undef MBAVO_SP_LAUNCH
             }
             else if (half_grad)
-                hipLaunchKernelGGL((k_fused<KD, WITH_J, true>), dim3(ntiles), dim3(kThreads), lds, st, descs, tiles, table, rho,
-                                   patch_cost, patch_blocks_strided, partials);
+                MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, true>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho, patch_cost,
+                                   patch_blocks_strided, partials);
             else
-                hipLaunchKernelGGL((k_fused<KD, WITH_J, false>), dim3(ntiles), dim3(kThreads), lds, st, descs, tiles, table, rho,
-                                   patch_cost, patch_blocks_strided, partials);
-            eng->prof_mark(false);
+                MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, false>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho, patch_cost,
+                                   patch_blocks_strided, partials);
         }
         hipLaunchKernelGGL((k_finalize<KD, WITH_J>), dim3(nbf, (Pack<KD>::E + 1 + 15) / 16), dim3(256), 0, st, descs, bf_prob,
                            bf_tile_begin, partials, frame_blocks, valid);
@@ -1196,34 +1208,25 @@ namespace mbavo
         prof_every_ = every > 0 ? every : 0;
         prof_used_ = 0;
         prof_seen_ = 0;
-        prof_open_ = false;
     }
 
-    // An event pair around the fused kernel of every prof_every_-th launch.  A recorded event is a barrier packet on
-    // the queue and costs a few us of launch gap per pair, so timing EVERY launch slows the timed region itself
-    // (measured 67 -> 60 us per step on configs[1]); a sample of the launches gives the same average.
-    void Engine::prof_mark(bool start)
+    // Event pair for the fused kernel of every prof_every_-th launch (see MBAVO_LAUNCH_TIMED); false = not this one.
+    bool Engine::prof_events(hipEvent_t *e0, hipEvent_t *e1)
     {
-        if (prof_every_ == 0) return;
-        if (start)
+        if (prof_every_ == 0) return false;
+        if ((prof_seen_++ % prof_every_) != 0) return false;
+        if (prof_used_ * 2 + 1 >= (int)prof_ev_.size())
         {
-            prof_open_ = (prof_seen_++ % prof_every_) == 0;
-            if (!prof_open_) return;
-            if (prof_used_ * 2 + 1 >= (int)prof_ev_.size())
-            {
-                if (prof_ev_.size() >= 2 * 8192) { prof_open_ = false; return; } // cap; later launches are not timed
-                hipEvent_t e0, e1;
-                if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { prof_open_ = false; return; }
-                prof_ev_.push_back(e0);
-                prof_ev_.push_back(e1);
-            }
-            (void)hipEventRecord(prof_ev_[prof_used_ * 2], stream_);
-            return;
+            if (prof_ev_.size() >= 2 * 8192) return false; // cap; later launches are not timed
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
+            prof_ev_.push_back(a);
+            prof_ev_.push_back(b);
         }
-        if (!prof_open_) return;
-        (void)hipEventRecord(prof_ev_[prof_used_ * 2 + 1], stream_);
+        *e0 = prof_ev_[prof_used_ * 2];
+        *e1 = prof_ev_[prof_used_ * 2 + 1];
         ++prof_used_;
-        prof_open_ = false;
+        return true;
     }
 
     int Engine::profile_read(double *ms_sum, int *launches)
