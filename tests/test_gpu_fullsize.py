@@ -103,3 +103,21 @@ def test_c5_fp16_gradient_pyramid(orc, mbavo, gpu_ctx):
     assert gpu_ctx.lib.mbavo_image_gradients_u8_half(src.data_ptr(), H, W, g.data_ptr(), None) == 0
     torch.cuda.synchronize()
     assert np.array_equal(g.cpu().numpy().reshape(H, W, 2), big[0].grad.astype(np.float16))
+
+
+def test_fp16_gradient_sample_parallel_remainder(orc, mbavo, gpu_ctx):
+    """fp16 gradient image on a tile of 800 pixels = one round + 32: the remainder goes through the sample-parallel
+    round of the fp16 instantiation (S = 8 and S = 16); same tolerance as above against the fp32 image, and 1e-9
+    against the oracle."""
+    for S in (8, 16):
+        probs = wl.pyramid_pair(20, 40, 1, S=S, k=4, N=4, mode="dense", seed=4)
+        fb32, v32 = _run(gpu_ctx, probs)
+        p = probs[0]
+        op, keep = orc.make_problem(p.S, p.F, p.K, p.P, p.k, p.N, p.H, p.W, p.ref, p.grad, p.cur, p.kp_xy, p.kp_z,
+                                    p.pattern, p.intr, p.cap, p.exp, p.t0, p.dt, p.knots_t, p.knots_R, p.start_idx, p.huber)
+        ro = orc.evaluate(op)
+        assert np.abs(ro["frame_blocks"][0] - fb32[0]).max() <= 1e-9 * np.abs(fb32[0]).max()
+        for q in probs:
+            q.grad_fp16 = True
+        fb16, v16 = _run(gpu_ctx, probs)
+        assert np.abs(fb16 - fb32).max() <= 1e-13 * np.abs(fb32).max() and np.array_equal(v16, v32) and v32.sum() > 0
