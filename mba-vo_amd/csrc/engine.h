@@ -16,6 +16,7 @@
 
 #include "../../include/mbavo.h"
 #include <hip/hip_runtime.h>
+#include <map>
 #include <vector>
 
 namespace mbavo
@@ -131,12 +132,15 @@ namespace mbavo
         size_t slot_cap_[kSlots] = {};
 
         int prof_every_ = 0, prof_seen_ = 0;
+        std::map<const void *, size_t> lds_attr_;
         std::vector<hipEvent_t> prof_ev_; // pairs (start, stop)
         int prof_used_ = 0;
 
     public:
         // called by the launch helper of k_fused
         bool prof_events(hipEvent_t *e0, hipEvent_t *e1);
+        // hipFuncAttributeMaxDynamicSharedMemorySize, set once per kernel on this engine's device
+        hipError_t ensure_lds(const void *kernel, size_t bytes);
     };
 } // namespace mbavo
 

@@ -1120,27 +1120,18 @@ namespace mbavo
 #endif
                 ;
             (void)max_S;
-            static size_t attr_lds[2] = {0, 0};
-            if (lds > attr_lds[half_grad ? 1 : 0])
-            {
-                if (half_grad)
-                    HIP_TRY(hipFuncSetAttribute((const void *)k_fused<KD, WITH_J, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                else
-                    HIP_TRY(hipFuncSetAttribute((const void *)k_fused<KD, WITH_J, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_lds[half_grad ? 1 : 0] = lds;
-            }
+            // the large-LDS attribute is per device and per kernel: remembered per engine (= per device)
+            if (half_grad)
+                HIP_TRY(eng->ensure_lds((const void *)k_fused<KD, WITH_J, true>, lds));
+            else
+                HIP_TRY(eng->ensure_lds((const void *)k_fused<KD, WITH_J, false>, lds));
             if (sp_logs > 0)
             {
                 const size_t lds_sp = (WITH_J ? (size_t)kSpWaves * OuterAcc<Pack<KD>::ND>::SLAB : 0) * sizeof(double) + 2 * kSpWaves * sizeof(double);
-                static size_t attr_sp[6] = {0, 0, 0, 0, 0, 0};
 #define MBAVO_SP_LAUNCH(LG)                                                                                                    \
     do                                                                                                                         \
     {                                                                                                                          \
-        if (lds_sp > attr_sp[LG])                                                                                              \
-        {                                                                                                                      \
-            HIP_TRY(hipFuncSetAttribute((const void *)k_fused_sp<KD, WITH_J, false, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sp)); \
-            attr_sp[LG] = lds_sp;                                                                                              \
-        }                                                                                                                      \
+        HIP_TRY(eng->ensure_lds((const void *)k_fused_sp<KD, WITH_J, false, LG>, lds_sp));                                      \
         MBAVO_LAUNCH_TIMED((k_fused_sp<KD, WITH_J, false, LG>), dim3(ntiles), dim3(kSpWaves * 64), lds_sp, descs, tiles, table, rho, \
                            patch_cost, patch_blocks_strided, partials);                                                        \
     } while (0)
@@ -1208,6 +1199,15 @@ namespace mbavo
         prof_every_ = every > 0 ? every : 0;
         prof_used_ = 0;
         prof_seen_ = 0;
+    }
+
+    hipError_t Engine::ensure_lds(const void *kernel, size_t bytes)
+    {
+        size_t &have = lds_attr_[kernel];
+        if (bytes <= have) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) have = bytes;
+        return e;
     }
 
     // Event pair for the fused kernel of every prof_every_-th launch (see MBAVO_LAUNCH_TIMED); false = not this one.
