@@ -110,6 +110,7 @@ namespace mbavo
         std::vector<TileDesc> h_tiles_;
         std::vector<int> h_bf_tile_begin_; // nBF + 1
         std::vector<int> h_bf_prob_;       // nBF
+        std::vector<int> h_entry_prob_;    // problem of every pose-table entry (saves the pose kernel a search)
         int cached_kdeg_ = 0;
         int total_bf_ = 0, total_entries_ = 0;
         long long total_pixels_ = 0, total_patches_ = 0;
@@ -120,6 +121,7 @@ namespace mbavo
         void *d_tiles_ = nullptr; size_t cap_tiles_ = 0;
         void *d_bf_tile_begin_ = nullptr; size_t cap_bf_ = 0;
         void *d_bf_prob_ = nullptr; size_t cap_bfp_ = 0;
+        void *d_entry_prob_ = nullptr; size_t cap_ep_ = 0;
         void *d_poses_ = nullptr; size_t cap_poses_ = 0;
         void *d_rho_ = nullptr; size_t cap_rho_ = 0;
         void *d_partials_ = nullptr; size_t cap_partials_ = 0;

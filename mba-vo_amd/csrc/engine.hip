@@ -118,22 +118,16 @@ namespace mbavo
         double t[1], R[1];
     };
     template <int KD, bool WITH_J, class KnotsArg>
-    __global__ __launch_bounds__(64) void k_pose_table(const ProblemDesc *__restrict__ descs, int B, int total_entries,
-                                                       PoseEntry<KD> *__restrict__ table, int *__restrict__ status,
-                                                       const KnotsArg ik)
+    __global__ __launch_bounds__(64) void k_pose_table(const ProblemDesc *__restrict__ descs, const int *__restrict__ entry_prob,
+                                                       int total_entries, PoseEntry<KD> *__restrict__ table,
+                                                       int *__restrict__ status, const KnotsArg ik)
     {
         constexpr int NCOL = WITH_J ? 3 : 1;
         const int lane_id = blockIdx.x * blockDim.x + threadIdx.x;
         const int gid = lane_id / NCOL, col = lane_id - gid * NCOL;
         const int knot = blockIdx.y;
         if (gid >= total_entries) return;
-        int lo = 0, hi = B - 1; // last problem with pose_base <= gid
-        while (lo < hi)
-        {
-            const int mid = (lo + hi + 1) >> 1;
-            if (descs[mid].pose_base <= gid) lo = mid; else hi = mid - 1;
-        }
-        const ProblemDesc &d = descs[lo];
+        const ProblemDesc &d = descs[entry_prob[gid]]; // one load instead of a search over the problems' pose_base
         const int local = gid - d.pose_base;
         const int f = local / d.S, s = local - f * d.S;
         const double t_cap = d.cap[f], t_mu = d.exp_t[f];
@@ -910,7 +904,7 @@ namespace mbavo
 
     Engine::~Engine()
     {
-        void *bufs[] = {d_descs_, d_tiles_, d_bf_tile_begin_, d_bf_prob_, d_poses_, d_rho_, d_partials_,
+        void *bufs[] = {d_descs_, d_tiles_, d_bf_tile_begin_, d_bf_prob_, d_entry_prob_, d_poses_, d_rho_, d_partials_,
                         d_status_};
         for (void *p : bufs)
             if (p) (void)hipFree(p);
@@ -1057,6 +1051,9 @@ namespace mbavo
         h_tiles_.swap(tiles);
         h_bf_tile_begin_.swap(bf_tile_begin);
         h_bf_prob_.swap(bf_prob);
+        h_entry_prob_.resize(entries > 0 ? entries : 1);
+        for (int b = 0; b < B; ++b)
+            for (int e = 0; e < h_descs_[b].F * h_descs_[b].S; ++e) h_entry_prob_[h_descs_[b].pose_base + e] = b;
         cached_kdeg_ = kdeg;
         total_bf_ = bf; total_entries_ = entries; total_pixels_ = pixels; total_patches_ = patches;
 
@@ -1067,6 +1064,7 @@ namespace mbavo
         if ((rc = ensure(&d_tiles_, &cap_tiles_, (h_tiles_.size() + 1) * sizeof(TileDesc)))) return rc;
         if ((rc = ensure(&d_bf_tile_begin_, &cap_bf_, h_bf_tile_begin_.size() * sizeof(int)))) return rc;
         if ((rc = ensure(&d_bf_prob_, &cap_bfp_, (h_bf_prob_.size() + 1) * sizeof(int)))) return rc;
+        if ((rc = ensure(&d_entry_prob_, &cap_ep_, h_entry_prob_.size() * sizeof(int)))) return rc;
         if ((rc = ensure(&d_poses_, &cap_poses_, pose_bytes))) return rc;
         if ((rc = ensure(&d_rho_, &cap_rho_, (size_t)(pixels + 1) * sizeof(double)))) return rc;
         if ((rc = ensure(&d_partials_, &cap_partials_, (h_tiles_.size() + 1) * pstride * sizeof(double)))) return rc;
@@ -1081,6 +1079,7 @@ namespace mbavo
             HIP_TRY(hipMemcpyAsync(d_tiles_, h_tiles_.data(), h_tiles_.size() * sizeof(TileDesc), hipMemcpyHostToDevice, stream_));
         HIP_TRY(hipMemcpyAsync(d_bf_tile_begin_, h_bf_tile_begin_.data(), h_bf_tile_begin_.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
         HIP_TRY(hipMemcpyAsync(d_bf_prob_, h_bf_prob_.data(), h_bf_prob_.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipMemcpyAsync(d_entry_prob_, h_entry_prob_.data(), h_entry_prob_.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
         layout_uploaded_ = true;
         return 0;
     }
@@ -1099,7 +1098,7 @@ namespace mbavo
     } while (0)
 
     template <int KD, bool WITH_J>
-    static int launch_all(Engine *eng, hipStream_t st, int max_S, bool half_grad, int sp_logs, const ProblemDesc *descs, int B, int entries, const TileDesc *tiles, int ntiles,
+    static int launch_all(Engine *eng, hipStream_t st, int max_S, bool half_grad, int sp_logs, const ProblemDesc *descs, const int *entry_prob, int entries, const TileDesc *tiles, int ntiles,
                           const int *bf_prob, const int *bf_tile_begin, int nbf, void *poses, double *rho,
                           double *patch_cost, double *patch_blocks_strided, double *partials, int *status,
                           double *frame_blocks, double *valid, const InlineKnots &ik)
@@ -1107,9 +1106,9 @@ namespace mbavo
         PoseEntry<KD> *table = (PoseEntry<KD> *)poses;
         const dim3 pose_grid((entries * (WITH_J ? 3 : 1) + 63) / 64, WITH_J ? KD : 1);
         if (ik.n > 0)
-            hipLaunchKernelGGL((k_pose_table<KD, WITH_J, InlineKnots>), pose_grid, dim3(64), 0, st, descs, B, entries, table, status, ik);
+            hipLaunchKernelGGL((k_pose_table<KD, WITH_J, InlineKnots>), pose_grid, dim3(64), 0, st, descs, entry_prob, entries, table, status, ik);
         else
-            hipLaunchKernelGGL((k_pose_table<KD, WITH_J, NoKnots>), pose_grid, dim3(64), 0, st, descs, B, entries, table, status, NoKnots());
+            hipLaunchKernelGGL((k_pose_table<KD, WITH_J, NoKnots>), pose_grid, dim3(64), 0, st, descs, entry_prob, entries, table, status, NoKnots());
         if (ntiles > 0)
         {
             constexpr int kWavesPerGroup = waves_of<KD, WITH_J>(), kThreads = kWavesPerGroup * 64;
@@ -1185,7 +1184,7 @@ namespace mbavo
         for (const ProblemDesc &pd : h_descs_)
             if ((pd.grad_fp16 != 0) != half_grad) return MBAVO_E_ARG;
 #define MBAVO_LAUNCH(KD, WJ)                                                                                      \
-    launch_all<KD, WJ>(this, stream_, max_S, half_grad, sp_logs_, descs, B, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
+    launch_all<KD, WJ>(this, stream_, max_S, half_grad, sp_logs_, descs, (const int *)d_entry_prob_, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
                        (const int *)d_bf_tile_begin_, total_bf_, d_poses_, (double *)d_rho_, d_patch_cost,        \
                        d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid, ik)
         if (kdeg == 4) rc = with_hessian ? MBAVO_LAUNCH(4, true) : MBAVO_LAUNCH(4, false);
