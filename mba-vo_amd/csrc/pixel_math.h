@@ -292,6 +292,7 @@ namespace mbavo
     // the reference's fp32 square roots are kept (A11).
     MBAVO_HD void huber_weight(double r, double a, double &w, double &rho)
     {
+#pragma clang fp contract(off) // rho = 2 a sqrt(x) - a^2 as written: per-pixel costs equal the oracle's bit for bit
         const double aa = a * a;
         const double x = 0.5 * r * r;
         w = 1.;
