@@ -233,6 +233,19 @@ namespace SLAM
         }
 
         // ---------------------------------------------------------------- stage 4
+        // products of two entries of the patch's weighted rows, indexed by pixel (rounded products, summed in the
+        // reference's reduce() order by patch_rho_sum)
+        struct RowProducts
+        {
+            const double *rows;
+            int stride, i, j;
+            __device__ double operator[](int p) const
+            {
+#pragma clang fp contract(off)
+                return rows[p * stride + i] * rows[p * stride + j];
+            }
+        };
+
         // compute_hessian_gradients_cost.cu:165-239: one wave per patch, the weighted rows
         // of its P pixels in LDS, lane e owns packed entries e, e+64, ...
         __global__ void k_api_patch(int P, int k, const double *__restrict__ residuals, const double *__restrict__ jac,
@@ -263,16 +276,12 @@ namespace SLAM
                     int i = 0, rem = e;
                     while (rem >= ndim - i) { rem -= ndim - i; ++i; }
                     const int j = i + rem;
-                    double s = 0.0;
-                    for (int p = 0; p < P; ++p) s += rows[p * stride + i] * rows[p * stride + j];
-                    out[e] = s * inv;
+                    out[e] = patch_rho_sum(RowProducts{rows, stride, i, j}, P) * inv; // reduction.h order
                 }
             }
             if (threadIdx.x == 0)
             { // slot 0 := sum(rho) * inv, overwriting sum((w r)^2) (:232-238)
-                double s = 0.0;
-                for (int p = 0; p < P; ++p) s += rho[p];
-                out[0] = s * inv;
+                out[0] = patch_rho_sum((const double *)rho, P) * inv;
             }
         }
 

@@ -626,9 +626,7 @@ namespace mbavo
         for (int kpl = threadIdx.x; P != 1 && kpl < tile.kp_count; kpl += kThreads)
         {
             const double *r = rho_out + pix0 + (long long)kpl * P;
-            double sum = 0.0;
-            for (int p = 0; p < P; ++p) sum += r[p];
-            const double c = sum * inv;
+            const double c = patch_rho_sum(r, P) * inv; // reduction.h order
             const int kp = tile.kp_begin + kpl;
             const long long patch = (long long)frame * K + kp;
             if (patch_cost) patch_cost[d.patch_base + patch] = c;
@@ -810,9 +808,7 @@ namespace mbavo
         for (int kpl = threadIdx.x; kpl < tile.kp_count; kpl += kThreads)
         {
             const double *r = rho_out + pix0 + (long long)kpl * P;
-            double sum = 0.0;
-            for (int p = 0; p < P; ++p) sum += r[p];
-            const double c = sum * inv;
+            const double c = patch_rho_sum(r, P) * inv; // reduction.h order
             const int kp = tile.kp_begin + kpl;
             const long long patch = (long long)frame * K + kp;
             if (patch_cost) patch_cost[d.patch_base + patch] = c;

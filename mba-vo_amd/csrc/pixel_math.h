@@ -305,6 +305,70 @@ namespace mbavo
         }
     }
 
+    // Sum of a patch's P Huber costs in the order of the reference's shared-memory reduce() (reduction.h:13-55):
+    // power-of-two P -> the stride-halving tree b[i] += b[i + s], s = P/2 .. 1; any other P -> ascending (A10: the
+    // reference drops elements there, the oracle defines the plain sum).  b_m[i] = b_2m[i] + b_2m[i + m] with
+    // b_P[i] = r[i], so the total is val(0, 1) of the recursion below: per-patch costs equal the oracle's bit for bit.
+    template <int N, int M = 1, class PtrT = const double *>
+    MBAVO_HD double patch_tree(PtrT r, int i)
+    {
+        if constexpr (M == N)
+            return r[i];
+        else
+            return patch_tree<N, 2 * M, PtrT>(r, i) + patch_tree<N, 2 * M, PtrT>(r, i + M);
+    }
+
+    template <class PtrT = const double *>
+    MBAVO_HD double patch_rho_sum(PtrT r, int P)
+    {
+        if ((P & (P - 1)) == 0)
+        {
+            switch (P)
+            {
+            case 1: return r[0];
+            case 2: return patch_tree<2, 1, PtrT>(r, 0);
+            case 4: return patch_tree<4, 1, PtrT>(r, 0);
+            case 8: return patch_tree<8, 1, PtrT>(r, 0);
+            case 16: return patch_tree<16, 1, PtrT>(r, 0);
+            default: break;
+            }
+            // larger power of two: the same tree is the adjacent-pairs tree over the bit-reversed index sequence;
+            // evaluated as a stream with one pending partial sum per level (a binary counter), levels in registers
+            int logp = 0;
+            while ((1 << logp) < P) ++logp;
+            constexpr int MAXL = 24;
+            double lv[MAXL];
+#pragma unroll
+            for (int l = 0; l < MAXL; ++l) lv[l] = 0.0;
+            double x = 0.0;
+            for (unsigned idx = 0; idx < (unsigned)P; ++idx)
+            {
+                unsigned rev = 0;
+                for (int b = 0; b < logp; ++b) rev |= ((idx >> b) & 1u) << (logp - 1 - b);
+                x = r[rev];
+                bool carrying = true;
+#pragma unroll
+                for (int l = 0; l < MAXL; ++l)
+                {
+                    if (carrying)
+                    {
+                        if ((idx >> l) & 1u)
+                            x = lv[l] + x; // the earlier (lower-index) half is the left operand, as b[i] + b[i + s]
+                        else
+                        {
+                            lv[l] = x;
+                            carrying = false;
+                        }
+                    }
+                }
+            }
+            return x; // idx = P - 1 is all ones: the carry ran through every level
+        }
+        double acc = 0.0;
+        for (int p = 0; p < P; ++p) acc += r[p];
+        return acc;
+    }
+
     // geometry of one sample up to the tap address, with the tap loads issued
     struct SampleInFlight
     {
