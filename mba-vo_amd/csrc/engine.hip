@@ -190,6 +190,75 @@ namespace mbavo
     typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 #if !defined(MBAVO_OUTER_VALU)
+#if !defined(MBAVO_OUTER_16X16)
+    // Per-wave outer product rows^T * rows on v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction,
+    // ~17 cycles).  The row of ND = 6k + 1 entries is cut into G groups of four (25 -> 7 groups, 13 -> 4; the padding
+    // needs no zeros: entry (i, j) of a block depends only on A's row i and B's column j, so whatever a padded lane
+    // reads -- the next row's first entries -- only reaches padded outputs, which are never gathered).
+    // Lane = 16 * pixel + 4 * d + e holds W[m] = row[4 * ((m + d) % G) + e]; instruction (delta, h) takes A = W[4h],
+    // B = W[(4h + delta) % G], so its block d is group (4h + d) % G times group (4h + d + delta) % G.  delta = 0 .. G/2
+    // and h = 0 .. ceil(G/4) - 1 cover every unordered pair of groups (a few block slots repeat a pair and are
+    // ignored): k = 4: 8 instructions (~140 cycles) per four pixels against 3 x 66 for the padded 16x16x4 tiles
+    // (MBAVO_OUTER_16X16, the previous scheme), for 7 LDS reads per step instead of 2; 16 accumulator VGPRs instead
+    // of 24.  The MFMA shares the FP64 pipe with the VALU, so instructions saved here are kernel time saved.
+    // (Layout probed in tools/micro/mfma4_probe.hip and mfma4_outer_probe.hip; the cbsz / abid broadcast controls
+    // are ignored by this instruction, which rules out a 7-instruction scheme with A broadcast from block 0.)
+    template <int ND>
+    struct OuterAcc
+    {
+        static constexpr int G = (ND + 3) / 4, ND_DELTA = G / 2 + 1, NH = (G + 3) / 4, NI = ND_DELTA * NH;
+        static constexpr int STRIDE = ND;
+        static constexpr int ROWS = 64;
+        static constexpr int SLAB = ROWS * ND > 768 ? ROWS * ND : 768;
+        static_assert(NI * 64 <= SLAB, "parked accumulators must fit the slab");
+        double acc[NI];
+        __device__ __forceinline__ void init(int)
+        {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[i] = 0.0;
+        }
+        __device__ __forceinline__ void accumulate(const double *slab, int lane, int nsteps = ROWS / 4)
+        {
+            // the lane's G read offsets are recomputed per call (a dozen integer instructions per 64 pixels): hoisted
+            // out of the caller's pixel loop they would occupy VGPRs through the sample loop, which has none to spare
+            asm volatile("" : "+v"(lane));
+            const int kq = lane >> 4, d = (lane >> 2) & 3, e = lane & 3;
+            const double *base[G];
+#pragma unroll
+            for (int m = 0; m < G; ++m) base[m] = slab + kq * ND + 4 * ((m + d) % G) + e;
+#pragma unroll 4
+            for (int step = 0; step < nsteps; ++step)
+            {
+                double W[G];
+#pragma unroll
+                for (int m = 0; m < G; ++m) W[m] = base[m][4 * step * ND];
+#pragma unroll
+                for (int dl = 0; dl < ND_DELTA; ++dl)
+#pragma unroll
+                    for (int h = 0; h < NH; ++h)
+                        acc[dl * NH + h] = __builtin_amdgcn_mfma_f64_4x4x4f64(W[(4 * h) % G], W[(4 * h + dl) % G], acc[dl * NH + h], 0, 0, 0);
+            }
+        }
+        __device__ __forceinline__ void store(double *dst, int lane) const
+        {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) dst[i * 64 + lane] = acc[i];
+        }
+        // sum of element (i, j), i <= j, over the waves' parked accumulators
+        static __device__ __forceinline__ double gather(const double *rows, int i, int j, int nwaves)
+        {
+            const int I = i >> 2, J = j >> 2, dd = J - I; // 0 .. G - 1
+            int dl, g, ri, cj;
+            if (dd <= G / 2) { dl = dd; g = I; ri = i & 3; cj = j & 3; }
+            else { dl = G - dd; g = J; ri = j & 3; cj = i & 3; } // the block holds group J x group I: transposed
+            const int h = g >> 2, d = g & 3;
+            const int off = (dl * NH + h) * 64 + 16 * ri + 4 * d + cj;
+            double s = 0.0;
+            for (int wv = 0; wv < nwaves; ++wv) s += rows[wv * SLAB + off];
+            return s;
+        }
+    };
+#else
     // Per-wave outer product on v_mfma_f64_16x16x4_f64 (rows^T * rows, 25 entries padded to 2 x 16 -> three
     // 16x16 tiles, 24 accumulator VGPRs).  On gfx950 the f64 MFMA runs at the FP64 VALU rate and competes with it
     // for the FP64 pipe, and the padded tiles do 2.4x the useful flops (~15 us of a 58 us kernel) -- it still wins
@@ -200,11 +269,7 @@ namespace mbavo
     {
         static constexpr int HALVES = ND > 16 ? 2 : 1;
         static constexpr int STRIDE = ND;
-#if defined(MBAVO_HALF_SLAB)
-        static constexpr int ROWS = 32; // rows parked per round: lanes 0-31, then lanes 32-63
-#else
         static constexpr int ROWS = 64;
-#endif
         static constexpr int SLAB = ROWS * ND > 768 ? ROWS * ND : 768;
         f64x4 t00, t01, t11;
         __device__ __forceinline__ void init(int) { t00 = f64x4{0, 0, 0, 0}; t01 = t00; t11 = t00; }
@@ -247,6 +312,8 @@ namespace mbavo
             return s;
         }
     };
+
+#endif
 #else
     // Per-wave outer-product accumulation, register-blocked on the FP64 VALU.
     //   slab: this wave's weighted rows, [64 pixels][STRIDE] doubles (zero padded), written by lane == pixel.
@@ -481,6 +548,11 @@ namespace mbavo
         const int S = d.S, K = d.K, P = d.P, frame = tile.frame;
         Camera cam;
         cam.fx = d.fx; cam.fy = d.fy; cam.cx = d.cx; cam.cy = d.cy; cam.H = d.H; cam.W = d.W;
+        // The intrinsics live in VGPRs: the sample loop streams the pose entry through ~100 SGPRs, and with four more
+        // doubles there the allocator spilled scalars into VGPR lanes inside the loop (16 v_readlane per sample pair);
+        // u = fx * x + cx also has two scalar operands otherwise (one extra move each).
+        // (k = 4 with Jacobians only: the other instantiations have SGPRs to spare and, at 4 waves per SIMD, no VGPRs.)
+        if constexpr (KD == 4 && WITH_J) asm volatile("" : "+v"(cam.fx), "+v"(cam.fy), "+v"(cam.cx), "+v"(cam.cy));
         // The frame's S table entries are read with wave-uniform addresses -> scalar loads.  (Staging the table
         // in LDS and reading it as a broadcast was measured 1.5x SLOWER on the fused kernel: one ds_read per FMA
         // operand instead of an SGPR operand.)
