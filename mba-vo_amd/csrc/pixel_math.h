@@ -128,6 +128,26 @@ namespace mbavo
 #endif
     }
 
+    // 1 / x for the per-sample depth scale: the runtime's IEEE division (v_div_scale x2, v_rcp, four FMAs, a multiply,
+    // v_div_fmas, v_div_fixup = 11 instructions) without the range scaling and the special-case fix-up -- the same
+    // Newton steps and the same final correction, so the SAME correctly rounded bits whenever x is a normal number
+    // with a normal reciprocal (x = row 3 of R times a unit ray here: |x| <= 1).  x = 0 or subnormal gives NaN
+    // instead of inf / a huge value; either way the sample's coordinates fail the bounds test.
+    MBAVO_HD double reciprocal(double x)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        double r = __builtin_amdgcn_rcp(x);
+        double e = __builtin_fma(-x, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-x, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-x, r, 1.0);
+        return __builtin_fma(e, r, r);
+#else
+        return 1. / x;
+#endif
+    }
+
     struct TapLoads
     {
         float w00, w01, w10, w11;
@@ -151,12 +171,22 @@ namespace mbavo
 #if defined(MBAVO_TAP_EARLY_RETURN)
         if (!t.ok) return;
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the conversion saturates and maps NaN to 0 (v_cvt_i32_f64), so the window is clamped on the integer side
+        // (one v_med3_i32 per axis) instead of zeroing the coordinates of a dropped sample first
+        int xi = __double2int_rz(x), yi = __double2int_rz(y);
+        xi = xi > 0 ? xi : 0; xi = xi < W - 2 ? xi : W - 2;
+        yi = yi > 0 ? yi : 0; yi = yi < H - 2 ? yi : H - 2;
+        const float dx = (float)(x - xi);
+        const float dy = (float)(y - yi);
+#else
         const double xs = t.ok ? x : 0.0, ys = t.ok ? y : 0.0;
         int xi = (int)xs, yi = (int)ys;
         xi = xi > W - 2 ? W - 2 : xi;
         yi = yi > H - 2 ? H - 2 : yi;
         const float dx = (float)(xs - xi);
         const float dy = (float)(ys - yi);
+#endif
         const float dxdy = dx * dy;
         t.w00 = 1.0f - dx - dy + dxdy;
         t.w01 = dx - dxdy;
@@ -384,10 +414,15 @@ namespace mbavo
         f.rx = R[0] * ray[0] + R[1] * ray[1] + R[2] * ray[2];
         f.ry = R[3] * ray[0] + R[4] * ray[1] + R[5] * ray[2];
         const double rz = R[6] * ray[0] + R[7] * ray[1] + R[8] * ray[2];
-        f.C1 = 1. / rz;
+        f.C1 = reciprocal(rz);
         f.sc = (D - pe.t[2]) * f.C1;
-        const double Px = f.sc * f.rx + pe.t[0];
-        const double Py = f.sc * f.ry + pe.t[1];
+        double Px, Py;
+        { // product and sum as written (as the oracle rounds them): the translation is a scalar operand of the add,
+          // where the fused form first copies it into the accumulator's VGPRs (two moves each)
+#pragma clang fp contract(off)
+            Px = f.sc * f.rx + pe.t[0];
+            Py = f.sc * f.ry + pe.t[1];
+        }
         const double u = cam.fx * (Px * iz) + cam.cx;
         const double v = cam.fy * (Py * iz) + cam.cy;
         tap_fetch<WITH_J, HALF_GRAD>(I, G, cam.H, cam.W, u, v, f.taps);

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 cp mba-vo_amd/libmbavo.so /tmp/libmbavo_good.so
 for v in "$@"; do
   defs=""; for d in $v; do case $d in FLAG:*) defs="$defs ${d#FLAG:}";; *=*) defs="$defs -DMBAVO_$d";; BASE) ;; *) defs="$defs -DMBAVO_EXP_$d";; esac; done
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $defs $EXP_FLAGS -c mba-vo_amd/csrc/engine.hip -o /tmp/engine_exp.o 2>/dev/null || { echo "compile failed: $v"; continue; }
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize $defs $EXP_FLAGS -c mba-vo_amd/csrc/engine.hip -o /tmp/engine_exp.o 2>/dev/null || { echo "compile failed: $v"; continue; }
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o mba-vo_amd/libmbavo.so /tmp/engine_exp.o $(ls mba-vo_amd/build/*.o | grep -v engine) -ldl
   if [ -n "$EXP_CMD" ]; then echo "== $v"; eval "$EXP_CMD"; continue; fi
   python bench.py --steps 100 --warmup 10 --no-cpu-baseline ${EXP_BENCH_ARGS} 2>&1 | tail -1 | python -c "
