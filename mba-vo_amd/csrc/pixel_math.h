@@ -175,8 +175,9 @@ namespace mbavo
         // the conversion saturates and maps NaN to 0 (v_cvt_i32_f64), so the window is clamped on the integer side
         // (one v_med3_i32 per axis) instead of zeroing the coordinates of a dropped sample first
         int xi = __double2int_rz(x), yi = __double2int_rz(y);
-        xi = xi > 0 ? xi : 0; xi = xi < W - 2 ? xi : W - 2;
-        yi = yi > 0 ? yi : 0; yi = yi < H - 2 ? yi : H - 2;
+        // clamp to [0, W - 2] x [0, H - 2] (W, H: wave-uniform image size; the compiler only forms med3 for constants)
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(xi) : "v"(xi), "s"(W - 2));
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(yi) : "v"(yi), "s"(H - 2));
         const float dx = (float)(x - xi);
         const float dy = (float)(y - yi);
 #else
@@ -192,28 +193,30 @@ namespace mbavo
         t.w01 = dx - dxdy;
         t.w10 = dy - dxdy;
         t.w11 = dxdy;
+        // Unsigned 32-bit byte offsets from the (wave-uniform) image bases: the loads take the base from SGPRs and a
+        // 32-bit VGPR offset, with no 64-bit address arithmetic (images of up to 2^29 pixels).
 #if defined(MBAVO_EXP_NO_TAPS) // timing experiment only: every tap hits the same address
-        const int idx = (xi + yi) & 1;
+        const unsigned idx = (unsigned)((xi + yi) & 1);
 #else
-        const int idx = yi * W + xi;
+        const unsigned idx = (unsigned)(yi * W + xi);
 #endif
+        const unsigned idx1 = idx + (unsigned)W;
         const MBAVO_GLOBAL unsigned char *Ig = (const MBAVO_GLOBAL unsigned char *)I;
         t.r0 = ((const MBAVO_GLOBAL UnalignedU16 *)(Ig + idx))->v;
-        t.r1 = ((const MBAVO_GLOBAL UnalignedU16 *)(Ig + idx + W))->v;
+        t.r1 = ((const MBAVO_GLOBAL UnalignedU16 *)(Ig + idx1))->v;
         if (WITH_GRAD)
         {
+            const MBAVO_GLOBAL unsigned char *Gb = (const MBAVO_GLOBAL unsigned char *)G;
             if (HALF_GRAD)
             { // 8 bytes per row pair instead of 16
-                const MBAVO_GLOBAL unsigned short *Gh = (const MBAVO_GLOBAL unsigned short *)G;
-                const Half4A4 a = *(const MBAVO_GLOBAL Half4A4 *)(Gh + 2 * idx);
-                const Half4A4 b = *(const MBAVO_GLOBAL Half4A4 *)(Gh + 2 * (idx + W));
+                const Half4A4 a = *(const MBAVO_GLOBAL Half4A4 *)(Gb + idx * 4u);
+                const Half4A4 b = *(const MBAVO_GLOBAL Half4A4 *)(Gb + idx1 * 4u);
                 for (int i = 0; i < 4; ++i) { t.g0[i] = half_bits_to_float(a.v[i]); t.g1[i] = half_bits_to_float(b.v[i]); }
             }
             else
             {
-                const MBAVO_GLOBAL float *Gg = (const MBAVO_GLOBAL float *)G;
-                const Float4A8 a = *(const MBAVO_GLOBAL Float4A8 *)(Gg + 2 * idx);
-                const Float4A8 b = *(const MBAVO_GLOBAL Float4A8 *)(Gg + 2 * (idx + W));
+                const Float4A8 a = *(const MBAVO_GLOBAL Float4A8 *)(Gb + idx * 8u);
+                const Float4A8 b = *(const MBAVO_GLOBAL Float4A8 *)(Gb + idx1 * 8u);
                 for (int i = 0; i < 4; ++i) { t.g0[i] = a.v[i]; t.g1[i] = b.v[i]; }
             }
         }
