@@ -43,7 +43,7 @@ namespace mbavo
 #define MBAVO_WAVES_PER_GROUP 12
 #endif
     // Waves per workgroup of the fused kernel, per instantiation: one workgroup is resident per CU, so this is the
-    // occupancy.  k = 4 with Jacobians needs 153 VGPRs -> 3 waves per SIMD (12 per CU; 16 spill); k = 2 (117 VGPRs)
+    // occupancy.  k = 4 with Jacobians needs 160 VGPRs -> 3 waves per SIMD (12 per CU; 16 spill); k = 2 (118 VGPRs)
     // and the cost-only kernels (62) take the 16 waves a workgroup can have.
     template <int KD, bool WITH_J>
     constexpr int waves_of() { return WITH_J && KD == 4 ? MBAVO_WAVES_PER_GROUP : 16; }
