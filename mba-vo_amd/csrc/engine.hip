@@ -619,12 +619,12 @@ namespace mbavo
         for (int base = 0; base < main_end; base += kThreads)
         {
             const int g = base + (int)threadIdx.x;
-            double res = 0.0, w = 0.0, rho = 0.0;
+            double res = 0.0, w = 0.0, rho = 0.0, inv_S = 0.0;
             bool keep = false;
-            double Jrow[WITH_J ? 6 * KD : 1];
+            double Jrow[WITH_J ? 6 * KD : 1]; // the SUM over the samples, defined only where keep (see pixel_row)
             if (g < npx)
             {
-                const int kpl = g / P, pp = g - kpl * P;
+                const int kpl = P == 1 ? g : g / P, pp = g - kpl * P;
                 const int kp = tile.kp_begin + kpl;
                 const bool flagged = d.outlier != nullptr && d.outlier[kp] == 1;
                 const double kx = d.kp_xy[(size_t)kp * d.kp_stride], ky = d.kp_xy[(size_t)kp * d.kp_stride + 1];
@@ -636,7 +636,7 @@ namespace mbavo
                 patch_centre(mid.t, mid.q, kx, ky, kz, cam, pcx, pcy);
 #endif
                 const bool valid = pixel_row<KD, WITH_J, HALF_GRAD>(ftab, S, cam, d.ref_img, d.ref_dIxy, I_cur, pcx, pcy, kz,
-                                                         d.pattern[2 * pp], d.pattern[2 * pp + 1], res, Jrow);
+                                                         d.pattern[2 * pp], d.pattern[2 * pp + 1], res, Jrow, inv_S);
                 huber_weight(res, d.huber_a, w, rho);
                 if (P == 1)
                 {
@@ -651,41 +651,34 @@ namespace mbavo
                 nvalid += valid ? 1 : 0;
                 keep = valid && !flagged;
             }
-            else if (WITH_J)
-            { // lanes past the end of the tile park 0 * Jrow: it must be finite (pixel_row zeroes it for the others)
-#pragma unroll
-                for (int i = 0; i < 6 * KD; ++i) Jrow[i] = 0.0;
-            }
             if (WITH_J)
             {
-                // rows of this wave's 64 pixels -> its LDS slab (zero rows for inactive / invalid / outlier pixels),
-                // ROWS at a time; the same wave reads back what it wrote: LDS executes a wave's operations in
-                // order, only the compiler has to be kept from reordering across these points
-                constexpr int ROUNDS = 64 / OuterAcc<ND>::ROWS;
-#pragma unroll
-                for (int rd = 0; rd < ROUNDS; ++rd)
+                // rows of this wave's 64 pixels -> its LDS slab; the same wave reads back what it wrote: LDS executes a
+                // wave's operations in order, only the compiler has to be kept from reordering across these points.
+                // Inactive / invalid / outlier pixels park ZERO rows by a branch, not by a zero weight: their Jrow is
+                // undefined (an out-of-bounds sample may have left NaNs in it).
+                static_assert(OuterAcc<ND>::ROWS == 64, "one row per lane");
+                double *mine = slab + lane * RS;
+                if (keep)
                 {
-                    if (ROUNDS == 1 || (lane / OuterAcc<ND>::ROWS) == rd)
-                    {
-                        double *mine = slab + (lane % OuterAcc<ND>::ROWS) * RS;
-                        // dropped pixels park zero rows: res and Jrow are finite (A9 zeroes them when a sample is out
-                        // of bounds), so a zero weight does it without a select per entry
-                        const double wk = keep ? w : 0.0;
-                        mine[0] = wk * res;
+                    const double wj = w * inv_S; // Huber weight times the 1/S of the mean over the samples
+                    mine[0] = w * res;
 #pragma unroll
-                        for (int i = 0; i < 6 * KD; ++i) mine[1 + i] = wk * Jrow[i];
-#pragma unroll
-                        for (int i = ND; i < RS; ++i) mine[i] = 0.0;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#if !defined(MBAVO_EXP_NO_MFMA) // timing experiment switch
-                    acc.accumulate(slab, lane);
-#endif
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
+                    for (int i = 0; i < 6 * KD; ++i) mine[1 + i] = wj * Jrow[i];
                 }
+                else
+                {
+#pragma unroll
+                    for (int i = 0; i < ND; ++i) mine[i] = 0.0;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if !defined(MBAVO_EXP_NO_MFMA) // timing experiment switch
+                acc.accumulate(slab, lane);
+#endif
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         }
 

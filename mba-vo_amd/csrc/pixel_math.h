@@ -431,13 +431,15 @@ namespace mbavo
         tap_fetch<WITH_J, HALF_GRAD>(I, G, cam.H, cam.W, u, v, f.taps);
     }
 
-    template <int KDEG, bool WITH_J>
+    // FIRST: the pixel's first sample SETS isum and Jrow instead of adding to them (no zero-initialisation of the 6k
+    // accumulators per pixel).
+    template <int KDEG, bool WITH_J, bool FIRST = false>
     MBAVO_HD void sample_retire(const PoseEntry<KDEG> &pe, const SampleInFlight &f, const double ray[3], double iz,
                                 const Camera &cam, double &isum, double *Jrow)
     {
         double val, gx = 0, gy = 0;
         tap_blend<WITH_J>(f.taps, val, gx, gy);
-        isum += val;
+        isum = FIRST ? val : isum + val;
         if (WITH_J)
         {
             const double *R = pe.R;
@@ -456,18 +458,16 @@ namespace mbavo
 #pragma unroll
             for (int j = 0; j < KDEG; ++j)
             {
-                Jrow[3 * j + 0] += pe.c[j] * jt[0];
-                Jrow[3 * j + 1] += pe.c[j] * jt[1];
-                Jrow[3 * j + 2] += pe.c[j] * jt[2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Jrow[3 * j + c] = FIRST ? pe.c[j] * jt[c] : Jrow[3 * j + c] + pe.c[j] * jt[c];
             }
 #if defined(MBAVO_EXP_NO_CHAIN) // timing experiment only
-            Jrow[3 * KDEG] += phi[0] + phi[1] + phi[2];
+            Jrow[3 * KDEG] = (FIRST ? 0.0 : Jrow[3 * KDEG]) + phi[0] + phi[1] + phi[2];
 #else
 #pragma unroll
             for (int cidx = 0; cidx < 3 * KDEG; ++cidx)
             { // three FMAs into the accumulator (one instruction less per entry than forming the sample's term first)
-                double a = Jrow[3 * KDEG + cidx];
-                a += phi[0] * pe.A[cidx];
+                double a = FIRST ? phi[0] * pe.A[cidx] : Jrow[3 * KDEG + cidx] + phi[0] * pe.A[cidx];
                 a += phi[1] * pe.A[3 * KDEG + cidx];
                 a += phi[2] * pe.A[6 * KDEG + cidx];
                 Jrow[3 * KDEG + cidx] = a;
@@ -476,23 +476,20 @@ namespace mbavo
         }
     }
 
-    // Residual and mean 1 x 6k Jacobian of one pixel over its S blur samples.
-    // A pixel is valid iff its integer location and all S warps are in bounds
-    // (SURVEY A9); otherwise residual = 0, Jrow = 0 and false is returned.
-    // `table` points at the S entries of this pixel's frame.  The sample loop is software
-    // pipelined: the tap loads of sample s+1 are issued before sample s is consumed.
+    // Residual and 1 x 6k Jacobian of one pixel over its S blur samples.
+    // A pixel is valid iff its integer location and all S warps are in bounds.  Returns true for a valid
+    // pixel, with the residual, Jrow = the SUM of the samples' Jacobian rows and inv_S = 1 / float(S) (the mean is
+    // inv_S * Jrow: the caller folds the factor into the Huber weight it scales the row with anyway).  For an invalid
+    // pixel: false, residual = 0, and Jrow UNDEFINED (possibly non-finite: it must not be used, not even times zero).
+    // `table` points at the S entries of this pixel's frame.  The sample loop is software pipelined: the tap loads
+    // of sample s+1 are issued before sample s is consumed.
     template <int KDEG, bool WITH_J, bool HALF_GRAD = false>
     MBAVO_HD bool pixel_row(const PoseEntry<KDEG> *__restrict__ table, int S, const Camera &cam,
                             const unsigned char *__restrict__ I_ref, const float *__restrict__ G_ref,
                             const unsigned char *__restrict__ I_cur, double centre_x, double centre_y,
-                            double depth, int dx, int dy, double &residual, double *Jrow)
+                            double depth, int dx, int dy, double &residual, double *Jrow, double &inv_S)
     {
         residual = 0.0;
-        if (WITH_J)
-        {
-#pragma unroll
-            for (int i = 0; i < 6 * KDEG; ++i) Jrow[i] = 0.0;
-        }
         const int px = (int)(centre_x + dx); // truncation, A3
         const int py = (int)(centre_y + dy);
         if (px < 0 || px > cam.W - 1 || py < 0 || py > cam.H - 1) return false;
@@ -500,8 +497,8 @@ namespace mbavo
         double ray[3];
         unit_ray(cam, (double)px, (double)py, ray);
         const double iz = 1. / (depth + 1e-8); // P_z == plane depth, A7
-        double isum = 0.0;
-        bool ok = true;
+        double isum;
+        bool ok;
         // Samples are processed in pairs: both samples' tap loads are issued, then both are retired, so the loads of
         // the second overlap the arithmetic of the first and vice versa.  No load is left outstanding across the loop
         // back-edge: the compiler's s_waitcnt insertion cannot count loop-carried loads and falls back to vmcnt(0),
@@ -512,38 +509,39 @@ namespace mbavo
 #else
 #define MBAVO_TAB(i) table[i]
 #endif
-        int s = 0;
-        for (; s + 1 < S; s += 2)
-        {
-            sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s), ray, depth, iz, cam, I_ref, G_ref, fa);
-            sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s + 1), ray, depth, iz, cam, I_ref, G_ref, fb);
-            ok = ok && fa.taps.ok && fb.taps.ok;
-            sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, iz, cam, isum, Jrow);
-            sample_retire<KDEG, WITH_J>(MBAVO_TAB(s + 1), fb, ray, iz, cam, isum, Jrow);
-        }
-        if (s < S)
-        { // odd S (incl. the sharp case S = 1)
-            sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s), ray, depth, iz, cam, I_ref, G_ref, fa);
-            ok = ok && fa.taps.ok;
-            sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, iz, cam, isum, Jrow);
-        }
-        if (!ok)
-        {
-            if (WITH_J)
+        int s;
+        if (S >= 2)
+        { // the first pair sets the accumulators
+            sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(0), ray, depth, iz, cam, I_ref, G_ref, fa);
+            sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(1), ray, depth, iz, cam, I_ref, G_ref, fb);
+            ok = fa.taps.ok && fb.taps.ok;
+            sample_retire<KDEG, WITH_J, true>(MBAVO_TAB(0), fa, ray, iz, cam, isum, Jrow);
+            sample_retire<KDEG, WITH_J>(MBAVO_TAB(1), fb, ray, iz, cam, isum, Jrow);
+            for (s = 2; s + 1 < S; s += 2)
             {
-#pragma unroll
-                for (int i = 0; i < 6 * KDEG; ++i) Jrow[i] = 0.0;
+                sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s), ray, depth, iz, cam, I_ref, G_ref, fa);
+                sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s + 1), ray, depth, iz, cam, I_ref, G_ref, fb);
+                ok = ok && fa.taps.ok && fb.taps.ok;
+                sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, iz, cam, isum, Jrow);
+                sample_retire<KDEG, WITH_J>(MBAVO_TAB(s + 1), fb, ray, iz, cam, isum, Jrow);
             }
-            return false;
+            if (s < S)
+            { // odd S
+                sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s), ray, depth, iz, cam, I_ref, G_ref, fa);
+                ok = ok && fa.taps.ok;
+                sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, iz, cam, isum, Jrow);
+            }
         }
+        else
+        { // the sharp case S = 1
+            sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(0), ray, depth, iz, cam, I_ref, G_ref, fa);
+            ok = fa.taps.ok;
+            sample_retire<KDEG, WITH_J, true>(MBAVO_TAB(0), fa, ray, iz, cam, isum, Jrow);
+        }
+        if (!ok) return false;
         const double fS = (double)(float)S; // A8
         residual = isum / fS - cur;
-        if (WITH_J)
-        {
-            const double inv = 1.0 / fS;
-#pragma unroll
-            for (int i = 0; i < 6 * KDEG; ++i) Jrow[i] *= inv;
-        }
+        inv_S = 1.0 / fS;
         return true;
     }
 } // namespace mbavo
