@@ -189,7 +189,6 @@ namespace mbavo
     // ------------------------------------------------------------------ fused kernel
     typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-#if !defined(MBAVO_OUTER_VALU)
 #if !defined(MBAVO_OUTER_16X16)
     // Per-wave outer product rows^T * rows on v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction,
     // ~17 cycles).  The row of ND = 6k + 1 entries is cut into G groups of four (25 -> 7 groups, 13 -> 4; the padding
@@ -259,11 +258,8 @@ namespace mbavo
         }
     };
 #else
-    // Per-wave outer product on v_mfma_f64_16x16x4_f64 (rows^T * rows, 25 entries padded to 2 x 16 -> three
-    // 16x16 tiles, 24 accumulator VGPRs).  On gfx950 the f64 MFMA runs at the FP64 VALU rate and competes with it
-    // for the FP64 pipe, and the padded tiles do 2.4x the useful flops (~15 us of a 58 us kernel) -- it still wins
-    // over the register-blocked VALU variant below because that one needs 50 accumulator VGPRs and spills at 3
-    // waves/SIMD (measured 57.6 us vs 75.1 us at 12 waves, 61.6 us at 8 waves).
+    // The previous scheme, kept for A/B runs: v_mfma_f64_16x16x4_f64 (25 entries padded to 2 x 16 -> three 16x16
+    // tiles, 24 accumulator VGPRs; the padded tiles do 2.4x the useful flops on the FP64 pipe the VALU shares).
     template <int ND>
     struct OuterAcc
     {
@@ -313,85 +309,6 @@ namespace mbavo
         }
     };
 
-#endif
-#else
-    // Per-wave outer-product accumulation, register-blocked on the FP64 VALU.
-    //   slab: this wave's weighted rows, [64 pixels][STRIDE] doubles (zero padded), written by lane == pixel.
-    //   The (6k+1) row entries are cut into NB blocks of 5; lane l owns ONE 5x5 block pair (bi <= bj) of the
-    //   upper triangle for ONE group of pixels (k = 4: 15 block pairs x 4 groups of 16 pixels = 60 lanes).  Per
-    //   pixel it reads 5 + 5 row entries from LDS (lanes of one group/block share addresses -> broadcast, the
-    //   rest fall on distinct banks) and issues 25 FMAs: 400 FMA issues per 64 pixels instead of 325 for the
-    //   bare packed triangle, with no cross-wave exchange and 25 accumulators per lane.  (The same product on
-    //   v_mfma_f64_16x16x4_f64 needs three padded 16x16 tiles = 768 FMA-equivalents per 64 pixels on the SAME
-    //   FP64 pipe: measured slower, see MBAVO_OUTER_MFMA.)
-    template <int ND>
-    struct OuterAcc
-    {
-        static constexpr int BS = 5;
-        static constexpr int NB = (ND + BS - 1) / BS;
-        static constexpr int NBP = NB * (NB + 1) / 2;
-        static constexpr int G = 64 / NBP;             // pixel groups
-        static constexpr int PPG = (64 + G - 1) / G;   // pixels per group
-        static constexpr int STRIDE = NB * BS;
-        static constexpr int ROWS = 64;
-        static constexpr int SLAB = 64 * STRIDE > G * NBP * BS * BS ? 64 * STRIDE : G * NBP * BS * BS;
-        double a[BS * BS];
-        int off_i, off_j, px0;
-        bool live;
-
-        __device__ __forceinline__ void init(int lane)
-        {
-#pragma unroll
-            for (int i = 0; i < BS * BS; ++i) a[i] = 0.0;
-            const int bp = lane % NBP, grp = lane / NBP;
-            int bi = 0, rem = bp;
-            while (rem >= NB - bi) { rem -= NB - bi; ++bi; }
-            off_i = bi * BS;
-            off_j = (bi + rem) * BS;
-            px0 = grp * PPG;
-            live = grp < G;
-        }
-
-        __device__ __forceinline__ void accumulate(const double *slab, int)
-        {
-            if (!live) return;
-#pragma unroll 2
-            for (int p = 0; p < PPG; ++p)
-            {
-                const int px = px0 + p;
-                if (px >= 64) break;
-                const double *r = slab + px * STRIDE;
-                double u[BS], v[BS];
-#pragma unroll
-                for (int i = 0; i < BS; ++i) { u[i] = r[off_i + i]; v[i] = r[off_j + i]; }
-#pragma unroll
-                for (int i = 0; i < BS; ++i)
-#pragma unroll
-                    for (int j = 0; j < BS; ++j) a[i * BS + j] = fma(u[i], v[j], a[i * BS + j]);
-            }
-        }
-
-        // park the block in LDS as [group][block pair][5][5]
-        __device__ __forceinline__ void store(double *dst, int lane) const
-        {
-            if (!live) return;
-            double *o = dst + lane * (BS * BS); // lane == grp * NBP + bp
-#pragma unroll
-            for (int i = 0; i < BS * BS; ++i) o[i] = a[i];
-        }
-
-        // sum of element (i, j), i <= j, over waves and pixel groups, in a fixed order
-        static __device__ __forceinline__ double gather(const double *rows, int i, int j, int nwaves)
-        {
-            const int bi = i / BS, bj = j / BS;
-            const int bp = bi * NB - bi * (bi - 1) / 2 + (bj - bi);
-            const int off = bp * (BS * BS) + (i - bi * BS) * BS + (j - bj * BS);
-            double s = 0.0;
-            for (int wv = 0; wv < nwaves; ++wv)
-                for (int g = 0; g < G; ++g) s += rows[wv * SLAB + g * NBP * (BS * BS) + off];
-            return s;
-        }
-    };
 #endif
 
     __device__ __forceinline__ double wave_sum(double v)
