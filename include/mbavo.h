@@ -34,7 +34,7 @@ typedef struct mbavo_problem {
     int K;                                /* num_keypoints */
     int P;                                /* patch_size */
     int N;                                /* num_ctrl_knots */
-    int H, W;                             /* im_size_HW */
+    int H, W;                             /* im_size_HW; H*W <= 2^29 (32-bit tap offsets), else MBAVO_E_ARG */
     const unsigned char *d_ref_img;       /* cuda_ref_img, H*W u8 */
     const float *d_ref_dIxy;              /* cuda_dIxy_ref, H*W*2 interleaved [dx,dy] */
     const unsigned char *const *d_cur_imgs; /* storages.cuda_cur_images: device array of F device pointers */

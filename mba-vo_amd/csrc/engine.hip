@@ -938,7 +938,8 @@ namespace mbavo
             const mbavo_problem &p = probs[b];
             if (p.S < 1 || p.F < 1 || p.K < 0 || p.P < 1 || p.N < kdeg || !p.d_ref_img || !p.d_cur_imgs ||
                 !p.d_kp_xy || !p.d_kp_z || !p.d_pattern || !p.d_cap_time || !p.d_exp_time || !p.d_knots_t ||
-                !p.d_knots_R || (p.kp_stride != 2 && p.kp_stride != 3) || p.H < 2 || p.W < 2)
+                !p.d_knots_R || (p.kp_stride != 2 && p.kp_stride != 3) || p.H < 2 || p.W < 2 ||
+                (long long)p.H * p.W > (1ll << 29)) // the tap loads use 32-bit byte offsets (8 B per gradient pixel)
                 return MBAVO_E_ARG;
             ProblemDesc &d = descs[b];
             memset(&d, 0, sizeof(d));

@@ -134,6 +134,9 @@ def test_bad_arguments_rejected(mbavo, gpu_ctx):
     assert gpu_ctx.lib.mbavo_eval(gpu_ctx.handle, C.byref(p), 3, mbavo.capi.dp(cost), None, None, None) == -1
     p.d_ref_img = None
     assert gpu_ctx.lib.mbavo_eval(gpu_ctx.handle, C.byref(p), 4, mbavo.capi.dp(cost), None, None, None) == -1
+    p = d.problem()
+    p.H, p.W = 1 << 15, 1 << 15  # 2^30 pixels: beyond the 32-bit tap offsets (rejected before anything is launched)
+    assert gpu_ctx.lib.mbavo_eval(gpu_ctx.handle, C.byref(p), 4, mbavo.capi.dp(cost), None, None, None) == -1
 
 
 def test_zero_motion_dense_integer_centres(orc, mbavo, gpu_ctx):
