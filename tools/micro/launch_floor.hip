@@ -12,6 +12,13 @@
 #include <vector>
 __global__ void k_other(double *p) { p[blockIdx.x * blockDim.x + threadIdx.x] += 1.0; }
 __global__ __launch_bounds__(768) void k_empty(double *out) {}
+// every wave spins for `ticks` of the 100 MHz real-time counter: a kernel of known GPU-side duration
+__global__ __launch_bounds__(768) void k_spin(double *out, long long ticks)
+{
+    const long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(1);
+    if (ticks < 0) out[0] = 1.0;
+}
 __global__ __launch_bounds__(768) void k_lds(double *out)
 {
     extern __shared__ double lds[];
@@ -87,6 +94,18 @@ int main()
         float ms; hipEventElapsedTime(&ms, a, b);
         return ms / N * 1e3;
     };
+    // GPU-side gap between dependent kernels: back-to-back kernels that each spin for 10 us (1000 ticks)
+    {
+        (void)hipDeviceSynchronize();
+        hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+        const int N = 1000;
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_spin, dim3(G), dim3(T), 0, 0, out, 1000LL);
+        (void)hipEventRecord(a);
+        for (int i = 0; i < N; ++i) hipLaunchKernelGGL(k_spin, dim3(G), dim3(T), 0, 0, out, 1000LL);
+        (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+        float ms; (void)hipEventElapsedTime(&ms, a, b);
+        printf("back-to-back 10 us spin kernels: %.2f us per launch -> %.2f us between kernels\n", ms / N * 1e3, ms / N * 1e3 - 10.0);
+    }
     printf("back-to-back empty 1x64      %.2f us per launch\n", wall(1, 64, 0, 0));
     printf("back-to-back empty 255x768   %.2f us per launch\n", wall(G, T, 0, 0));
     printf("back-to-back lds 255x768     %.2f us per launch\n", wall(G, T, LDS, 1));
