@@ -96,6 +96,10 @@ namespace mbavo
 
         // persistent staging owned by the context (used by mbavo_eval / tracker)
         double *host_frame_blocks(size_t n_doubles);
+        // further pinned, device-visible host buffers (grown on demand, freed with the engine): the LM loop has the
+        // fused kernel write the per-patch costs straight into one (no D2H copy for the outlier statistics) and stages
+        // the outlier flags in another (an H2D copy from pinned memory is asynchronous, from pageable memory it is not)
+        void *pinned_scratch(int slot, size_t bytes);
 
     private:
         int ensure(void **ptr, size_t *cap, size_t bytes);
@@ -128,6 +132,9 @@ namespace mbavo
         void *d_status_ = nullptr;
         int status_seen_ = 0;
         void *h_fb_ = nullptr; size_t cap_hfb_ = 0;
+        static constexpr int kPinnedSlots = 4;
+        void *pinned_[kPinnedSlots] = {};
+        size_t pinned_cap_[kPinnedSlots] = {};
 
         static constexpr int kSlots = 12; // 0-6 LM loop (tracker.cpp), 8-10 keyframe detection (keyframe_ops.hip)
         void *slots_[kSlots] = {};

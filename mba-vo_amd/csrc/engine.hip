@@ -887,6 +887,8 @@ namespace mbavo
         for (void *p : bufs)
             if (p) (void)hipFree(p);
         if (h_fb_) (void)hipHostFree(h_fb_);
+        for (void *q : pinned_)
+            if (q) (void)hipHostFree(q);
         for (void *p : slots_)
             if (p) (void)hipFree(p);
         for (hipEvent_t e : prof_ev_) (void)hipEventDestroy(e);
@@ -920,6 +922,19 @@ namespace mbavo
             if (hipHostMalloc(&h_fb_, cap_hfb_, hipHostMallocDefault) != hipSuccess) { h_fb_ = nullptr; cap_hfb_ = 0; }
         }
         return (double *)h_fb_;
+    }
+
+    void *Engine::pinned_scratch(int slot, size_t bytes)
+    {
+        if (slot < 0 || slot >= kPinnedSlots) return nullptr;
+        if (bytes > pinned_cap_[slot] || !pinned_[slot])
+        {
+            if (pinned_[slot]) (void)hipHostFree(pinned_[slot]);
+            pinned_[slot] = nullptr;
+            pinned_cap_[slot] = bytes + 4096;
+            if (hipHostMalloc(&pinned_[slot], pinned_cap_[slot], hipHostMallocDefault) != hipSuccess) { pinned_[slot] = nullptr; pinned_cap_[slot] = 0; }
+        }
+        return pinned_[slot];
     }
 
     static int env_int(const char *name, int dflt)

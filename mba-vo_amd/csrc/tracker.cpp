@@ -31,7 +31,7 @@ namespace mbavo
         }                                                                                \
     } while (0)
 
-    static int detect_outliers(const double *patch_cost, int K, double chi, std::vector<unsigned char> &flags)
+    static int detect_outliers(const double *patch_cost, int K, double chi, unsigned char *flags)
     { // :639-699
         double sum = 0.0;
         std::vector<double> kept;
@@ -83,8 +83,7 @@ namespace mbavo
         double *d_cap = nullptr, *d_exp = nullptr, *d_kt = nullptr, *d_kR = nullptr, *d_pc = nullptr;
         unsigned char *d_flags = nullptr;
         double *h_pin = nullptr;
-        std::vector<double> h_pc(maxK > 0 ? maxK : 1);
-        std::vector<unsigned char> flags;
+        unsigned char *flags = nullptr; // pinned host staging of the outlier flags
 
         TRK_HIP(hipSetDevice(eng.device()));
         // engine-owned scratch, reused by every call (no hipMalloc / hipFree in the tracking loop)
@@ -92,11 +91,15 @@ namespace mbavo
         d_exp = (double *)eng.named_scratch(1, sizeof(double) * F);
         d_kt = (double *)eng.named_scratch(2, sizeof(double) * 7 * N); // [t (3N) | R (4N)]: one upload per evaluation
         d_kR = d_kt ? d_kt + 3 * N : nullptr;
-        d_pc = (double *)eng.named_scratch(5, sizeof(double) * (size_t)F * (maxK > 0 ? maxK : 1));
+        // the per-patch costs land in pinned host memory (written by the fused kernel, read by detect_outliers after the
+        // evaluation's synchronisation: no D2H copy); the flags are staged in pinned memory so that their upload is a
+        // truly asynchronous copy
+        d_pc = (double *)eng.pinned_scratch(0, sizeof(double) * (size_t)F * (maxK > 0 ? maxK : 1));
+        flags = (unsigned char *)eng.pinned_scratch(1, maxK > 0 ? maxK : 1);
         d_flags = (unsigned char *)eng.named_scratch(6, maxK > 0 ? maxK : 1);
         h_pin = eng.host_frame_blocks((size_t)F * E); // device-visible pinned host memory
         if (h_pin) memset(h_pin, 0, sizeof(double) * (size_t)F * E);
-        if (!d_cap || !d_exp || !d_kt || !d_kR || !d_pc || !d_flags || !h_pin) { rc_ = (int)hipErrorOutOfMemory; goto done; }
+        if (!d_cap || !d_exp || !d_kt || !d_kR || !d_pc || !d_flags || !flags || !h_pin) { rc_ = (int)hipErrorOutOfMemory; goto done; }
         TRK_HIP(hipMemcpyAsync(d_cap, h_cap, sizeof(double) * F, hipMemcpyHostToDevice, st)); // :701-719
         TRK_HIP(hipMemcpyAsync(d_exp, h_exp, sizeof(double) * F, hipMemcpyHostToDevice, st));
 
@@ -105,7 +108,7 @@ namespace mbavo
             const int lv = o.num_levels - li - 1; // coarse to fine (:571-575)
             const mbavo_level &L = levels[lv];
             const int scale = 1 << lv;
-            flags.assign(L.K > 0 ? L.K : 1, 0);
+            memset(flags, 0, L.K > 0 ? L.K : 1);
             TRK_HIP(hipMemsetAsync(d_flags, 0, L.K > 0 ? L.K : 1, st)); // :601
             mbavo_problem p;
             memset(&p, 0, sizeof(p));
@@ -185,9 +188,8 @@ namespace mbavo
                 const double quality = evaluator.StepQuality(cand_cost, model);
                 if (quality > o.min_step_quality && cand_cost < eval_cost)
                 { // isStepSuccessful (:890-894) -> detectOutliers + handleSuccessfulStep (:896-903)
-                    TRK_HIP(hipMemcpy(h_pc.data(), d_pc, sizeof(double) * L.K, hipMemcpyDeviceToHost));
-                    p.num_bad = detect_outliers(h_pc.data(), L.K, o.max_chi_square_error, flags);
-                    TRK_HIP(hipMemcpyAsync(d_flags, flags.data(), L.K, hipMemcpyHostToDevice, st));
+                    p.num_bad = detect_outliers(d_pc, L.K, o.max_chi_square_error, flags); // frame 0's costs, just written
+                    TRK_HIP(hipMemcpyAsync(d_flags, flags, L.K, hipMemcpyHostToDevice, st));
                     spline.InvalidParameter(cand_t.data(), cand_R.data());
                     if ((rc_ = evaluate(spline.get_knot_data_t(), spline.get_knot_data_R(), true, &eval_cost))) goto done;
                     lm.step_accepted(quality);
