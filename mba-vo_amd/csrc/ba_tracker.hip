@@ -273,9 +273,8 @@ namespace SLAM
             {
                 for (int e = 1 + threadIdx.x; e < E; e += blockDim.x)
                 {
-                    int i = 0, rem = e;
-                    while (rem >= ndim - i) { rem -= ndim - i; ++i; }
-                    const int j = i + rem;
+                    int i, j;
+                    tri_decode(e, ndim, i, j);
                     out[e] = patch_rho_sum(RowProducts{rows, stride, i, j}, P) * inv; // reduction.h order
                 }
             }

@@ -56,35 +56,6 @@ namespace mbavo
         static constexpr int PSTRIDE = E + 2; // partial: [nvalid | g,H sums (1..E-1) | cost | spare]
     };
 
-    // packed index e -> (i, j), i <= j, row-major upper triangle (compute_hessian_gradients_cost.cu:217-229)
-    template <int ND>
-    __host__ __device__ constexpr int tri_row(int e)
-    {
-        int i = 0;
-        while (e >= ND - i) { e -= ND - i; ++i; }
-        return i;
-    }
-    template <int ND>
-    __host__ __device__ constexpr int tri_col(int e)
-    {
-        int i = 0;
-        while (e >= ND - i) { e -= ND - i; ++i; }
-        return i + e;
-    }
-
-    __device__ __forceinline__ int tri_row_rt(int e, int nd)
-    {
-        int i = 0;
-        while (e >= nd - i) { e -= nd - i; ++i; }
-        return i;
-    }
-    __device__ __forceinline__ int tri_col_rt(int e, int nd)
-    {
-        int i = 0;
-        while (e >= nd - i) { e -= nd - i; ++i; }
-        return i + e;
-    }
-
     // ------------------------------------------------------------------ pose table
     // grid = (ceil(entries * NCOL / 64), WITH_J ? KD : 1).  Latency-bound (one serial fp64 log / exp / product chain
     // per sample, a few thousand dependent instructions), so the independent pieces of a sample are spread out
@@ -635,7 +606,8 @@ namespace mbavo
             __syncthreads();
             for (int e = 1 + threadIdx.x; e < E; e += kThreads)
             {
-                const int i = tri_row_rt(e, ND), j = tri_col_rt(e, ND);
+                int i, j;
+                tri_decode(e, ND, i, j);
                 out[e] = OuterAcc<ND>::gather(rows, i, j, kWavesPerGroup);
             }
         }
@@ -817,7 +789,8 @@ namespace mbavo
             __syncthreads();
             for (int e = 1 + threadIdx.x; e < E; e += kThreads)
             {
-                const int i = tri_row_rt(e, ND), j = tri_col_rt(e, ND);
+                int i, j;
+                tri_decode(e, ND, i, j);
                 out[e] = OuterAcc<ND>::gather(rows, i, j, kWavesPerGroup);
             }
         }

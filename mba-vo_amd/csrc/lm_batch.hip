@@ -17,6 +17,7 @@
 // Problems that are finished, took an invalid step or rejected their step sit the passes out (ProblemDesc::active).
 #include "../../include/mbavo.h"
 #include "engine.h"
+#include "pixel_math.h"
 #include "se3_math.h"
 #include "lm_solvers.h"
 
@@ -169,9 +170,8 @@ namespace mbavo
                 }
                 for (int e = lane; e < M6 * (M6 + 1) / 2; e += 64)
                 {
-                    int r = 0, rem = e;
-                    while (rem >= M6 - r) { rem -= M6 - r; ++r; }
-                    const int c = r + rem;
+                    int r, c;
+                    tri_decode(e, M6, r, c);
                     const int R = r < 3 * KD ? 3 * st + r : 3 * (N + st) + (r - 3 * KD);
                     const int C = c < 3 * KD ? 3 * st + c : 3 * (N + st) + (c - 3 * KD);
                     const double v = blk[ND + e];

@@ -35,6 +35,30 @@
 
 namespace mbavo
 {
+    // Packed index e -> (i, j), i <= j, of the row-major upper triangle of an nd x nd matrix
+    // (compute_hessian_gradients_cost.cu:217-229), in closed form: row = floor((2nd + 1 - sqrt((2nd + 1)^2 - 8e)) / 2)
+    // in fp32, then one step of correction either way.  (A row-by-row search costs up to nd divergent iterations per
+    // lane: 1.3 us of every workgroup's end-of-tile work in the fused kernel, measured.)  Checked against the search for
+    // every e at nd = 12, 13, 24, 25, 37, 49, 96 (tests/test_host_logic.py restates it).
+    MBAVO_HD void tri_decode(int e, int nd, int &i, int &j)
+    {
+        const float b = 2.0f * (float)nd + 1.0f;
+        int r = (int)((b - sqrtf(b * b - 8.0f * (float)e)) * 0.5f);
+        int start = r * nd - r * (r - 1) / 2;
+        if (start > e)
+        {
+            --r;
+            start = r * nd - r * (r - 1) / 2;
+        }
+        else if (e - start >= nd - r)
+        {
+            start += nd - r;
+            ++r;
+        }
+        i = r;
+        j = r + (e - start);
+    }
+
     // One entry per (problem, frame, blur sample), written by the pose kernel.
     template <int KDEG>
     struct PoseEntry

@@ -152,3 +152,31 @@ def test_transformation_and_spline_frame_change_match_oracle(mbavo, orc):
         L.orc_spline_transform_to(k, 0.0, 0.5, orc.dp(kt2), orc.dp(kR2), N, 0.2, orc.dp(tgt[3:]), orc.dp(tgt))
         assert np.abs(kt - kt2).max() < 1e-13 and np.abs(kR - kR2).max() < 1e-14
         assert lib.mbavo_spline_transform_to(k, 0.0, 0.5, dp(kt), dp(kR), N, 99.0, dp(tgt[3:]), dp(tgt)) == -2  # MBAVO_E_RANGE
+
+
+def test_triangular_index_decode_closed_form():
+    """pixel_math.h:tri_decode (packed upper-triangle index -> (row, col) through an fp32 square root and one correction
+    step) restated in numpy float32 and compared with the row-by-row search of the reference's packing
+    (compute_hessian_gradients_cost.cu:217-229) for every entry of every size the kernels use and some beyond."""
+    def search(e, nd):
+        i = 0
+        while e >= nd - i:
+            e -= nd - i
+            i += 1
+        return i, i + e
+
+    def closed(e, nd):
+        b = np.float32(2 * nd + 1)
+        r = int((b - np.sqrt(np.float32(b * b - np.float32(8.0) * np.float32(e)), dtype=np.float32)) * np.float32(0.5))
+        start = r * nd - r * (r - 1) // 2
+        if start > e:
+            r -= 1
+            start = r * nd - r * (r - 1) // 2
+        elif e - start >= nd - r:
+            start += nd - r
+            r += 1
+        return r, r + (e - start)
+
+    for nd in (1, 2, 12, 13, 24, 25, 36, 37, 49, 96, 97, 200):
+        for e in range(nd * (nd + 1) // 2):
+            assert closed(e, nd) == search(e, nd), (nd, e)
