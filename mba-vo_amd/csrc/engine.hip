@@ -340,7 +340,7 @@ namespace mbavo
                 cur = (double)((const MBAVO_GLOBAL unsigned char *)I_cur)[py * cam.W + px];
                 double ray[3];
                 unit_ray(cam, (double)px, (double)py, ray);
-                const double iz = 1. / (kz + 1e-8);
+                const double iz = reciprocal(kz + 1e-8);
                 SampleInFlight f;
                 const PoseEntry<KD> &pe = ftab[sidx];
                 sample_issue<KD, WITH_J, HALF_GRAD>(pe, ray, kz, iz, cam, d.ref_img, d.ref_dIxy, f);
@@ -351,7 +351,7 @@ namespace mbavo
         const bool valid = in && (__ballot(ok_l) & gmask) == gmask;
         double isum = 0.0;
         for (int j = 0; j < SS; ++j) isum += __shfl(val, lane0 + j, 64); // sample order, as the sequential loop
-        if (valid) res = isum / fS - cur;
+        if (valid) res = quotient(isum, fS) - cur;
         huber_weight(res, d.huber_a, w, rho);
         if (in && sidx == 0)
         {
@@ -686,7 +686,7 @@ namespace mbavo
                     cur = (double)((const MBAVO_GLOBAL unsigned char *)I_cur)[py * cam.W + px];
                     double ray[3];
                     unit_ray(cam, (double)px, (double)py, ray);
-                    const double iz = 1. / (kz + 1e-8);
+                    const double iz = reciprocal(kz + 1e-8);
                     SampleInFlight f;
                     const PoseEntry<KD> &pe = ftab[sidx];
                     sample_issue<KD, WITH_J, HALF_GRAD>(pe, ray, kz, iz, cam, d.ref_img, d.ref_dIxy, f);
@@ -699,7 +699,7 @@ namespace mbavo
             double isum = 0.0;
 #pragma unroll
             for (int j = 0; j < SS; ++j) isum += __shfl(val, lane0 + j, 64);
-            if (valid) res = isum / fS - cur;
+            if (valid) res = quotient(isum, fS) - cur;
             huber_weight(res, d.huber_a, w, rho);
             if (in && sidx == 0)
             {
