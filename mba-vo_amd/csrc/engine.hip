@@ -150,7 +150,9 @@ namespace mbavo
             trans_coeffs<KD>(u, c);
             spline_translation<KD>(kt, c, p);
             rotation_entries(qv, R);
-            for (int i = 0; i < 3; ++i) pe.t[i] = p[i];
+            double rt[3];
+            rotated_translation(p, qv, rt);
+            for (int i = 0; i < 3; ++i) { pe.t[i] = p[i]; pe.rt[i] = rt[i]; }
             for (int i = 0; i < 4; ++i) pe.q[i] = qv[i];
             for (int i = 0; i < 9; ++i) pe.R[i] = R[i];
             for (int i = 0; i < KD; ++i) pe.c[i] = c[i];
@@ -332,7 +334,7 @@ namespace mbavo
             const double kx = d.kp_xy[(size_t)kp * d.kp_stride], ky = d.kp_xy[(size_t)kp * d.kp_stride + 1];
             const double kz = d.kp_z[kp];
             double pcx, pcy;
-            patch_centre(mid.t, mid.q, kx, ky, kz, cam, pcx, pcy);
+            patch_centre_rt(mid.rt, mid.q, kx, ky, kz, cam, pcx, pcy);
             const int px = (int)(pcx + d.pattern[2 * pp]); // truncation, A3 (pixel_row)
             const int py = (int)(pcy + d.pattern[2 * pp + 1]);
             if (!(px < 0 || px > cam.W - 1 || py < 0 || py > cam.H - 1))
@@ -461,7 +463,7 @@ namespace mbavo
             // XCD's L2), and the sample loop reads them in ~11 dependent scalar-load groups per sample pair -- each a
             // miss on the first pass.  One 8-byte read per 64-byte line, spread over the waves, all in flight together.
             const double *tb = (const double *)ftab;
-            const int nlines = S * (int)(sizeof(PoseEntry<KD>) / 64);
+            const int nlines = (S * (int)sizeof(PoseEntry<KD>) + 63) / 64;
             double warm = 0.0;
             for (int l = wave; l < nlines; l += kWavesPerGroup) warm += tb[l * 8];
             if (warm == 1.2345678e301) red[0] = warm; // never true: keeps the loads alive
@@ -521,7 +523,7 @@ namespace mbavo
 #if defined(MBAVO_EXP_NO_CENTRE) // timing experiment switch
                 pcx = kx + mid.t[0]; pcy = ky + mid.t[1];
 #else
-                patch_centre(mid.t, mid.q, kx, ky, kz, cam, pcx, pcy);
+                patch_centre_rt(mid.rt, mid.q, kx, ky, kz, cam, pcx, pcy);
 #endif
                 const bool valid = pixel_row<KD, WITH_J, HALF_GRAD>(ftab, S, cam, d.ref_img, d.ref_dIxy, I_cur, pcx, pcy, kz,
                                                          d.pattern[2 * pp], d.pattern[2 * pp + 1], res, Jrow, inv_S);
@@ -678,7 +680,7 @@ namespace mbavo
                 const double kx = d.kp_xy[(size_t)kp * d.kp_stride], ky = d.kp_xy[(size_t)kp * d.kp_stride + 1];
                 const double kz = d.kp_z[kp];
                 double pcx, pcy;
-                patch_centre(mid.t, mid.q, kx, ky, kz, cam, pcx, pcy);
+                patch_centre_rt(mid.rt, mid.q, kx, ky, kz, cam, pcx, pcy);
                 const int px = (int)(pcx + d.pattern[2 * pp]); // truncation, A3 (pixel_row)
                 const int py = (int)(pcy + d.pattern[2 * pp + 1]);
                 if (!(px < 0 || px > cam.W - 1 || py < 0 || py > cam.H - 1))
@@ -1032,7 +1034,7 @@ namespace mbavo
         if ((rc = ensure(&d_bf_tile_begin_, &cap_bf_, h_bf_tile_begin_.size() * sizeof(int)))) return rc;
         if ((rc = ensure(&d_bf_prob_, &cap_bfp_, (h_bf_prob_.size() + 1) * sizeof(int)))) return rc;
         if ((rc = ensure(&d_entry_prob_, &cap_ep_, h_entry_prob_.size() * sizeof(int)))) return rc;
-        if ((rc = ensure(&d_poses_, &cap_poses_, pose_bytes))) return rc;
+        if ((rc = ensure(&d_poses_, &cap_poses_, pose_bytes + 64))) return rc; // + one cache line: the scalar-cache warm-up reads whole lines
         if ((rc = ensure(&d_rho_, &cap_rho_, (size_t)(pixels + 1) * sizeof(double)))) return rc;
         if ((rc = ensure(&d_partials_, &cap_partials_, (h_tiles_.size() + 1) * pstride * sizeof(double)))) return rc;
         if (!d_status_)

@@ -64,6 +64,7 @@ namespace mbavo
     struct PoseEntry
     {
         double t[3];          // t_c2r
+        double rt[3];         // conj(q) applied to t: the pixel-independent half of patch_centre (read from sample S/2)
         double q[4];          // R_c2r xyzw
         double R[9];          // rotation matrix of q, row-major, reference term order
         double c[KDEG];       // translation spline weights (J_t = kron(c, I3))
@@ -348,19 +349,35 @@ namespace mbavo
 
     // patch centre of a keypoint in the current frame at the mid-exposure pose
     // (compute_local_patches_xy.cu:19-49)
-    MBAVO_HD void patch_centre(const double t_c2r[3], const double q_c2r[4], double kx, double ky, double kz,
-                               const Camera &cam, double &ox, double &oy)
+    // R_r2c * t_c2r with R_r2c = conj(R_c2r): the part of patch_centre that does not depend on the keypoint (the pose
+    // kernel stores it in the table entry; 56 of patch_centre's ~130 instructions)
+    MBAVO_HD void rotated_translation(const double t_c2r[3], const double q_c2r[4], double rt[3])
+    {
+#pragma clang fp contract(off)
+        const Quat r2c = qconj(Quat{q_c2r[0], q_c2r[1], q_c2r[2], q_c2r[3]});
+        qrotate(r2c, t_c2r, rt);
+    }
+
+    MBAVO_HD void patch_centre_rt(const double rt[3], const double q_c2r[4], double kx, double ky, double kz,
+                                  const Camera &cam, double &ox, double &oy)
     {
 #pragma clang fp contract(off)
         const double P[3] = {kz * (kx - cam.cx) / cam.fx, kz * (ky - cam.cy) / cam.fy, kz};
         // R_r2c = conj(R_c2r); t_r2c = -(R_r2c * t_c2r); P_c = R_r2c * P + t_r2c
         const Quat r2c = qconj(Quat{q_c2r[0], q_c2r[1], q_c2r[2], q_c2r[3]});
-        double rt[3], rp[3];
-        qrotate(r2c, t_c2r, rt);
+        double rp[3];
         qrotate(r2c, P, rp);
         const double X = rp[0] - rt[0], Y = rp[1] - rt[1], Z = rp[2] - rt[2];
         ox = X / Z * cam.fx + cam.cx;
         oy = Y / Z * cam.fy + cam.cy;
+    }
+
+    MBAVO_HD void patch_centre(const double t_c2r[3], const double q_c2r[4], double kx, double ky, double kz,
+                               const Camera &cam, double &ox, double &oy)
+    {
+        double rt[3];
+        rotated_translation(t_c2r, q_c2r, rt);
+        patch_centre_rt(rt, q_c2r, kx, ky, kz, cam, ox, oy);
     }
 
     // Huber weight sqrt(rho') and rho for residual r (compute_hessian_gradients_cost.cu:189-199);
