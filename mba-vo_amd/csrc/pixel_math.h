@@ -362,7 +362,7 @@ namespace mbavo
                                   const Camera &cam, double &ox, double &oy)
     {
 #pragma clang fp contract(off)
-        const double P[3] = {kz * (kx - cam.cx) / cam.fx, kz * (ky - cam.cy) / cam.fy, kz};
+        const double P[3] = {quotient(kz * (kx - cam.cx), cam.fx), quotient(kz * (ky - cam.cy), cam.fy), kz};
         // R_r2c = conj(R_c2r); t_r2c = -(R_r2c * t_c2r); P_c = R_r2c * P + t_r2c
         const Quat r2c = qconj(Quat{q_c2r[0], q_c2r[1], q_c2r[2], q_c2r[3]});
         double rp[3];
