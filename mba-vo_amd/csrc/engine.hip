@@ -307,16 +307,18 @@ namespace mbavo
     // workgroup.  On configs[1] a tile is 1 600 pixels = 25 chunks of 64 on 12 waves: the 25th chunk used to be one
     // more chunk for one wave, i.e. 7 chunks on its SIMD against 6 on the others (+5 us measured against a tile of
     // exactly two rounds).
-    template <int KD, bool WITH_J, bool HALF_GRAD, int NWAVES>
+    // LOGS_CT >= 0: S is the compile-time 2^LOGS_CT (the exchange loops over the samples unroll); -1: run-time `logs_rt`.
+    template <int KD, bool WITH_J, bool HALF_GRAD, int NWAVES, int LOGS_CT = -1>
     __device__ __forceinline__ void sp_round_rt(const ProblemDesc &d, const TileDesc &tile, const Camera &cam,
                                                 const PoseEntry<KD> *__restrict__ ftab, const PoseEntry<KD> &mid,
-                                                const unsigned char *__restrict__ I_cur, int logs, int base, int npx,
+                                                const unsigned char *__restrict__ I_cur, int logs_rt, int base, int npx,
                                                 long long pix0, int lane, int wave, double *slab,
                                                 OuterAcc<6 * KD + 1> &acc, double *__restrict__ rho_out, int &nvalid,
                                                 double inv, double *__restrict__ patch_cost,
                                                 double *__restrict__ patch_blocks_strided, int frame, double &cost_local)
     {
         constexpr int ND = 6 * KD + 1, RS = OuterAcc<ND>::STRIDE, E = ND * (ND + 1) / 2;
+        const int logs = LOGS_CT >= 0 ? LOGS_CT : logs_rt;
         const int SS = 1 << logs, PXW = 64 >> logs, P = d.P;
         const int pw = lane >> logs, sidx = lane & (SS - 1), lane0 = lane & ~(SS - 1);
         const unsigned long long gmask = (SS == 64 ? ~0ull : ((1ull << SS) - 1ull)) << lane0;
@@ -498,9 +500,22 @@ namespace mbavo
             {
                 main_end = npx - rem;
                 if (main_end + wave * (64 >> sp_logs) < npx)
-                    sp_round_rt<KD, WITH_J, HALF_GRAD, kWavesPerGroup>(d, tile, cam, ftab, mid, I_cur, sp_logs, main_end, npx, pix0,
-                                                                        lane, wave, slab, acc, rho_out, nvalid, inv, patch_cost,
-                                                                        patch_blocks_strided, frame, cost_local);
+                {
+#define MBAVO_SP_ROUND(L)                                                                                              \
+    sp_round_rt<KD, WITH_J, HALF_GRAD, kWavesPerGroup, L>(d, tile, cam, ftab, mid, I_cur, sp_logs, main_end, npx, pix0, lane, \
+                                                          wave, slab, acc, rho_out, nvalid, inv, patch_cost,                 \
+                                                          patch_blocks_strided, frame, cost_local)
+                    // S = 4, 8, 16 as compile-time cases (the exchange loops over the samples unroll: -1 us of the
+                    // remainder round's 4.4 us on configs[1]); other powers of two take the run-time form
+                    switch (sp_logs)
+                    {
+                    case 2: MBAVO_SP_ROUND(2); break;
+                    case 3: MBAVO_SP_ROUND(3); break;
+                    case 4: MBAVO_SP_ROUND(4); break;
+                    default: MBAVO_SP_ROUND(-1); break;
+                    }
+#undef MBAVO_SP_ROUND
+                }
             }
         }
 #if defined(MBAVO_EXP_NO_ROUNDS) // timing experiment: launch + prologue + end-of-tile work only
