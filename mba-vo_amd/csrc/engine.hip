@@ -328,6 +328,20 @@ namespace mbavo
         double res = 0.0, w = 0.0, rho = 0.0, cur = 0.0, val = 0.0;
         bool ok_l = false, flagged = false;
         double Jc[WITH_J ? 6 * KD : 1] = {};
+        // A lane's pose entry is its SAMPLE's: 59 doubles per lane that no longer arrive as scalar operands.  Read from
+        // global memory they come in four or five dependent pieces (the registers cannot hold an entry), each an L2
+        // round trip: 1.7 us of the round's 5.3 us.  So the wave first copies the frame's S entries into its own slab
+        // (free until the samples are done and the rows are exchanged) and every lane reads its entry from LDS.
+        constexpr int EW = (int)(sizeof(PoseEntry<KD>) / sizeof(double));
+        const bool staged = WITH_J && SS * EW <= OuterAcc<ND>::SLAB; // the cost-only kernels have no slabs (and need 15 of the 59 doubles)
+        if (staged)
+        {
+            const MBAVO_GLOBAL double *src = (const MBAVO_GLOBAL double *)ftab;
+            for (int z = lane; z < SS * EW; z += 64) slab[z] = src[z];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         if (in)
         {
             const int kpl = g / P, pp = g - kpl * P;
@@ -345,12 +359,22 @@ namespace mbavo
                 double ray[3];
                 unit_ray(cam, (double)px, (double)py, ray);
                 const double iz = reciprocal(kz + 1e-8);
-                SampleInFlight f;
-                const PoseEntry<KD> &pe = ftab[sidx];
-                sample_issue<KD, WITH_J, HALF_GRAD>(pe, ray, kz, iz, cam, d.ref_img, d.ref_dIxy, f);
-                ok_l = f.taps.ok;
-                sample_retire<KD, WITH_J>(pe, f, ray, iz, cam, val, Jc);
+                auto one_sample = [&](const PoseEntry<KD> &pe) {
+                    SampleInFlight f;
+                    sample_issue<KD, WITH_J, HALF_GRAD>(pe, ray, kz, iz, cam, d.ref_img, d.ref_dIxy, f);
+                    ok_l = f.taps.ok;
+                    sample_retire<KD, WITH_J>(pe, f, ray, iz, cam, val, Jc);
+                };
+                if (staged)
+                    one_sample(((const PoseEntry<KD> *)slab)[sidx]); // LDS
+                else
+                    one_sample(ftab[sidx]);
             }
+        }
+        if (staged)
+        { // every lane is done with the staged entries before the rows overwrite them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         const bool valid = in && (__ballot(ok_l) & gmask) == gmask;
         double isum = 0.0;
