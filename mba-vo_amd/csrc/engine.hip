@@ -663,6 +663,17 @@ namespace mbavo
     // shuffles in sample order (bit-identical residuals and Huber costs), and the 64 / S finished rows of a wave go
     // through the same MFMA outer product.  The pose entry of a lane is per lane now (vector loads, L1-resident).
     constexpr int kSpWaves = 12;
+    // LDS of k_fused_sp: the slabs, the cost / valid-count scratch, and -- when it fits the 160 KB -- the frame's S pose
+    // entries, staged once per workgroup (a lane's entry is its SAMPLE's; read from global memory it arrives in four
+    // or five dependent pieces, each an L2 round trip)
+    template <int KD, bool WITH_J, int LOGS>
+    struct SpLds
+    {
+        static constexpr size_t kBase = ((WITH_J ? (size_t)kSpWaves * OuterAcc<6 * KD + 1>::SLAB : 0) + 2 * kSpWaves) * sizeof(double);
+        static constexpr size_t kEntries = ((size_t)1 << LOGS) * sizeof(PoseEntry<KD>);
+        static constexpr bool kStage = WITH_J && kBase + kEntries <= 160 * 1024;
+        static constexpr size_t kBytes = kBase + (kStage ? kEntries : 0);
+    };
     template <int KD, bool WITH_J, bool HALF_GRAD, int LOGS>
     __global__ __launch_bounds__((kSpWaves * 64)) void k_fused_sp(const ProblemDesc *__restrict__ descs,
                                                         const TileDesc *__restrict__ tiles,
@@ -695,6 +706,15 @@ namespace mbavo
         const unsigned char *__restrict__ I_cur = d.cur_imgs[frame];
         const long long pix0 = d.pixel_base + ((long long)frame * K + tile.kp_begin) * P;
         const int npx = tile.kp_count * P;
+        constexpr bool STAGE = SpLds<KD, WITH_J, LOGS>::kStage;
+        double *stage = red + 2 * kSpWaves;
+        if (STAGE)
+        {
+            constexpr int EW = (int)(sizeof(PoseEntry<KD>) / sizeof(double));
+            const MBAVO_GLOBAL double *src = (const MBAVO_GLOBAL double *)ftab;
+            for (int z = threadIdx.x; z < SS * EW; z += kSpWaves * 64) stage[z] = src[z];
+            __syncthreads();
+        }
 
         OuterAcc<ND> acc;
         acc.init(lane);
@@ -728,11 +748,16 @@ namespace mbavo
                     double ray[3];
                     unit_ray(cam, (double)px, (double)py, ray);
                     const double iz = reciprocal(kz + 1e-8);
-                    SampleInFlight f;
-                    const PoseEntry<KD> &pe = ftab[sidx];
-                    sample_issue<KD, WITH_J, HALF_GRAD>(pe, ray, kz, iz, cam, d.ref_img, d.ref_dIxy, f);
-                    ok_l = f.taps.ok;
-                    sample_retire<KD, WITH_J>(pe, f, ray, iz, cam, val, Jc);
+                    auto one_sample = [&](const PoseEntry<KD> &pe) {
+                        SampleInFlight f;
+                        sample_issue<KD, WITH_J, HALF_GRAD>(pe, ray, kz, iz, cam, d.ref_img, d.ref_dIxy, f);
+                        ok_l = f.taps.ok;
+                        sample_retire<KD, WITH_J>(pe, f, ray, iz, cam, val, Jc);
+                    };
+                    if (STAGE)
+                        one_sample(((const PoseEntry<KD> *)stage)[sidx]); // LDS
+                    else
+                        one_sample(ftab[sidx]);
                 }
             }
             // the pixel is valid iff all its samples are (A9); intensities summed in sample order
@@ -1134,10 +1159,10 @@ namespace mbavo
                 HIP_TRY(eng->ensure_lds((const void *)k_fused<KD, WITH_J, false>, lds));
             if (sp_logs > 0)
             {
-                const size_t lds_sp = (WITH_J ? (size_t)kSpWaves * OuterAcc<Pack<KD>::ND>::SLAB : 0) * sizeof(double) + 2 * kSpWaves * sizeof(double);
 #define MBAVO_SP_LAUNCH(LG)                                                                                                    \
     do                                                                                                                         \
     {                                                                                                                          \
+        const size_t lds_sp = SpLds<KD, WITH_J, LG>::kBytes;                                                                    \
         HIP_TRY(eng->ensure_lds((const void *)k_fused_sp<KD, WITH_J, false, LG>, lds_sp));                                      \
         MBAVO_LAUNCH_TIMED((k_fused_sp<KD, WITH_J, false, LG>), dim3(ntiles), dim3(kSpWaves * 64), lds_sp, descs, tiles, table, rho, \
                            patch_cost, patch_blocks_strided, partials);                                                        \
