@@ -616,20 +616,27 @@ namespace mbavo
 #endif
         // per-patch cost = slot 0 of the reference's patch block (:232-238), and the
         // tile's share of the frame cost (outlier patches skipped, :265-272)
-        __syncthreads();
-        for (int kpl = threadIdx.x; P != 1 && kpl < tile.kp_count; kpl += kThreads)
-        {
-            const double *r = rho_out + pix0 + (long long)kpl * P;
-            const double c = patch_rho_sum(r, P) * inv; // reduction.h order
-            const int kp = tile.kp_begin + kpl;
-            const long long patch = (long long)frame * K + kp;
-            if (patch_cost) patch_cost[d.patch_base + patch] = c;
-            if (patch_blocks_strided) patch_blocks_strided[patch * E] = c;
-            if (!(d.outlier != nullptr && d.outlier[kp] == 1)) cost_local += c;
+        if (P != 1)
+        { // the patches' pixels were handled by other waves: their rho values are read back (one-pixel patches took
+          // their cost in the round loop)
+            __syncthreads();
+            for (int kpl = threadIdx.x; kpl < tile.kp_count; kpl += kThreads)
+            {
+                const double *r = rho_out + pix0 + (long long)kpl * P;
+                const double c = patch_rho_sum(r, P) * inv; // reduction.h order
+                const int kp = tile.kp_begin + kpl;
+                const long long patch = (long long)frame * K + kp;
+                if (patch_cost) patch_cost[d.patch_base + patch] = c;
+                if (patch_blocks_strided) patch_blocks_strided[patch * E] = c;
+                if (!(d.outlier != nullptr && d.outlier[kp] == 1)) cost_local += c;
+            }
         }
         const double wc = wave_sum(cost_local);
         const double wv = wave_sum((double)nvalid);
         if (lane == 0) { red[wave] = wc; red[kWavesPerGroup + wave] = wv; }
+        // every wave parks its accumulators in its slab; entry e = (i, j) of the packed block is then the sum
+        // over waves (and pixel groups) in a fixed order.  One barrier for the scratch and the slabs.
+        if (WITH_J) acc.store(slab, lane);
         __syncthreads();
         double *out = partials + (size_t)tile_id * PS;
         if (threadIdx.x == 0)
@@ -641,10 +648,6 @@ namespace mbavo
         }
         if (WITH_J)
         {
-            // every wave parks its accumulators in its slab; entry e = (i, j) of the packed block is then the sum
-            // over waves (and pixel groups) in a fixed order
-            acc.store(slab, lane);
-            __syncthreads();
             for (int e = 1 + threadIdx.x; e < E; e += kThreads)
             {
                 int i, j;
@@ -838,6 +841,9 @@ namespace mbavo
         const double wc = wave_sum(cost_local);
         const double wv = wave_sum((double)nvalid);
         if (lane == 0) { red[wave] = wc; red[kWavesPerGroup + wave] = wv; }
+        // every wave parks its accumulators in its slab; entry e = (i, j) of the packed block is then the sum
+        // over waves (and pixel groups) in a fixed order.  One barrier for the scratch and the slabs.
+        if (WITH_J) acc.store(slab, lane);
         __syncthreads();
         double *out = partials + (size_t)tile_id * PS;
         if (threadIdx.x == 0)
@@ -849,10 +855,6 @@ namespace mbavo
         }
         if (WITH_J)
         {
-            // every wave parks its accumulators in its slab; entry e = (i, j) of the packed block is then the sum
-            // over waves (and pixel groups) in a fixed order
-            acc.store(slab, lane);
-            __syncthreads();
             for (int e = 1 + threadIdx.x; e < E; e += kThreads)
             {
                 int i, j;
