@@ -120,6 +120,7 @@ namespace mbavo
         long long total_pixels_ = 0, total_patches_ = 0;
         bool layout_uploaded_ = false;
         int sp_logs_ = 0; // > 0: the cached layout is tiled for the sample-parallel kernel with S = 2^sp_logs_
+        bool flat_finalize_ = false; // many (problem, frame) slots of <= 4 tiles each: k_finalize_flat
 
         void *d_descs_ = nullptr; size_t cap_descs_ = 0;
         void *d_tiles_ = nullptr; size_t cap_tiles_ = 0;
