@@ -8,7 +8,7 @@ mkdir -p tools/_ab; rm -f tools/_ab/*.so
 bash mba-vo_amd/build.sh > /dev/null
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize $flags -c mba-vo_amd/csrc/engine.hip -o tools/_ab/engine_$name.o 2>/dev/null \
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -fPIC -fno-slp-vectorize ${OPT:--O3} $flags -c mba-vo_amd/csrc/engine.hip -o tools/_ab/engine_$name.o 2>/dev/null \
     && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/_ab/libmbavo_$name.so tools/_ab/engine_$name.o $(ls mba-vo_amd/build/*.o | grep -v engine) -ldl \
     && rm tools/_ab/engine_$name.o && echo "built $name ($flags)" || echo "FAILED $name" ) &
 done
