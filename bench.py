@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--workload", default="c2_dense",
                     choices=["c2_dense", "c2_semidense", "c1_dense", "c3_batch64", "c4_batch512", "c5_1080p"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--grad-fp16", action="store_true",
+                    help="gradient pyramid stored as IEEE half pairs (BASELINE configs[4]: lossless for 8-bit images)")
     ap.add_argument("--time-every", type=int, default=8,
                     help="HIP-event pair around the dominant kernel on every n-th timed step (events cost launch gaps)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the bounded CPU baseline sample")
@@ -162,6 +164,10 @@ def main():
     ctx = M.capi.Context(local_rank, stream=stream.cuda_stream)
 
     probs, desc = build_workload(args.workload, rank, world)
+    if args.grad_fp16:
+        for p in probs:
+            p.grad_fp16 = True
+        desc += ", fp16 gradient pyramid"
     dw = wl.DeviceWorkload(probs, device=dev)
 
     # N > 1: the final sum of the packed normal equations over xGMI (RCCL), one all-reduce per step.  Default: in place,
