@@ -75,8 +75,8 @@ def measured_hbm_traffic(workload):
     profiles/r01_hbm_counters.json; the counters need rocprofv3, so they are collected outside this process).
     FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE under-counts 2x on gfx950 (calibrated in the same file on a
     256 MiB copy: 131084 KiB read), WRITE_SIZE is exact."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_counters.json")
-    if workload != "c2_dense" or not os.path.exists(path):
+    path = os.path.join(ROOT, "profiles", "r01_hbm_counters.json" if workload == "c2_dense" else "r01_hbm_counters_%s.json" % workload)
+    if not os.path.exists(path):
         return None
     try:
         h = json.load(open(path))
@@ -269,7 +269,7 @@ def main():
                              "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": nbytes,
                              "traffic": measured_hbm_traffic(args.workload),
                              "note": "compulsory bytes only; compute-bound kernel, low by construction; traffic = "
-                                     "(2*FETCH_SIZE + WRITE_SIZE) KiB from profiles/r01_hbm_counters.json"},
+                                     "(2*FETCH_SIZE + WRITE_SIZE) KiB from profiles/r01_hbm_counters*.json"},
         }
         if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
             cb, fb_cpu = cpu_baseline(probs, args.cpu_seconds)
