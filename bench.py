@@ -140,6 +140,12 @@ def cpu_baseline(probs, budget_s):
 
 def main():
     args = parse()
+    # The one JSON line goes to the REAL stdout; everything else written to file descriptor 1 by this process or by the
+    # libraries it loads goes to stderr.  RCCL prints a version banner to C stdout when the first communicator is
+    # created, block-buffered when stdout is a pipe and flushed only at exit -- i.e. AFTER the JSON line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -276,7 +282,8 @@ def main():
             scale = np.abs(fb_cpu).max(axis=1, keepdims=True)
             cb["gpu_vs_cpu_max_rel_diff"] = float((np.abs(fb_gpu - fb_cpu) / scale).max())
             out["cpu_baseline"] = cb
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
