@@ -7,12 +7,13 @@
 //   * the per-sample pose table is read with wave-uniform addresses (scalar loads);
 //   * each wave parks the weighted rows [r | J] of its own 64 pixels in a private LDS
 //     slab ([pixel][entry]) and feeds them back to the matrix core as BOTH operands of
-//     v_mfma_f64_16x16x4_f64: rows^T * rows, 4 pixels per instruction, the 25 row
-//     entries padded to 2 x 16 -> three 16x16 accumulator tiles (00, 01, 11) per wave
-//     (24 VGPRs).  The FP64 matrix pipe runs beside the FP64 VALU pipe that the other
-//     wave of the SIMD is using for its sample loop, so the 325-entry outer product
-//     costs no VALU issue slots, needs no cross-wave barrier and frees ~60 VGPRs
-//     compared with per-lane VALU accumulators (measured: see DESIGN.md).
+//     v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction): the row is
+//     cut into groups of four entries and every unordered pair of groups is one block slot
+//     (OuterAcc below; 8 instructions per four pixels for k = 4, 16 accumulator VGPRs).
+//     On gfx950 the f64 MFMA issues at the FP64 VALU rate and SHARES that pipe
+//     (tools/micro/mfma_valu_overlap.hip), so it is not a free second engine: what it buys
+//     over per-lane VALU accumulators is registers and instruction count (no cross-wave
+//     barrier, ~95 fewer VGPRs).  -DMBAVO_OUTER_16X16 keeps the earlier padded 16x16x4 tiles.
 //   * accumulators live across the whole tile loop and are reduced once per
 //     workgroup in a fixed order -- no atomics.
 #include "engine.h"
@@ -44,8 +45,10 @@ namespace mbavo
 #define MBAVO_WAVES_PER_GROUP 12
 #endif
     // Waves per workgroup of the fused kernel, per instantiation: one workgroup is resident per CU, so this is the
-    // occupancy.  k = 4 with Jacobians needs 160 VGPRs -> 3 waves per SIMD (12 per CU; 16 spill); k = 2 (118 VGPRs)
-    // and the cost-only kernels (62) take the 16 waves a workgroup can have.
+    // occupancy.  k = 4 with Jacobians: 168 VGPRs (the budget of 3 waves per SIMD = 12 per CU is 170; 16 waves spill
+    // vectors) and 53 scalar spills into VGPR lanes, none of them inside the sample-pair loop; k = 2 (126 VGPRs) and
+    // the cost-only kernels (64) take the 16 waves a workgroup can have.  Figures: profiles/r02_kernel_resources.txt
+    // (tools/kernel_resources.py, from the code-object metadata).
     template <int KD, bool WITH_J>
     constexpr int waves_of() { return WITH_J && KD == 4 ? MBAVO_WAVES_PER_GROUP : 16; }
 
@@ -410,7 +413,10 @@ namespace mbavo
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             constexpr int NOUT = (6 * KD + 3) / 4; // S >= 4 lanes share the 6k entries of a pixel
-            const double wk = keep ? w : 0.0, inv = 1.0 / fS;
+            // a dropped pixel (invalid, out of the image, outlier) parks a ZERO row by a select, not by a zero weight: its
+            // samples' contributions may be non-finite (a NaN / inf keypoint depth passes the detector's `!(z < 1e-2)`
+            // test as in the reference; an out-of-bounds warp) and 0 * NaN would poison the frame's H and g
+            const double inv = 1.0 / fS;
             double outv[NOUT];
 #pragma unroll
             for (int t = 0; t < NOUT; ++t)
@@ -419,13 +425,13 @@ namespace mbavo
                 double a = 0.0;
                 if (i < 6 * KD)
                     for (int j = 0; j < SS; ++j) a += slab[(lane0 + j) * RS + i];
-                outv[t] = wk * (a * inv);
+                outv[t] = keep ? w * (a * inv) : 0.0;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             double *row = slab + pw * RS;
-            if (sidx == 0) row[0] = wk * res;
+            if (sidx == 0) row[0] = keep ? w * res : 0.0;
 #pragma unroll
             for (int t = 0; t < NOUT; ++t)
             {
@@ -792,7 +798,8 @@ namespace mbavo
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 constexpr int NOUT = (6 * KD + SS - 1) / SS;
-                const double wk = keep ? w : 0.0, inv = 1.0 / fS;
+                // dropped pixels park ZERO rows by a select (their contributions may be non-finite, see sp_round_rt)
+                const double inv = 1.0 / fS;
                 double outv[NOUT];
 #pragma unroll
                 for (int t = 0; t < NOUT; ++t)
@@ -804,13 +811,13 @@ namespace mbavo
 #pragma unroll
                         for (int j = 0; j < SS; ++j) a += slab[(lane0 + j) * RS + i];
                     }
-                    outv[t] = wk * (a * inv);
+                    outv[t] = keep ? w * (a * inv) : 0.0;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 double *row = slab + pw * RS;
-                if (sidx == 0) row[0] = wk * res;
+                if (sidx == 0) row[0] = keep ? w * res : 0.0;
 #pragma unroll
                 for (int t = 0; t < NOUT; ++t)
                 {

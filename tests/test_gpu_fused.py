@@ -242,3 +242,28 @@ def test_many_small_problems_flat_finalize(orc, mbavo, gpu_ctx):
     one, _, _ = scenes.gpu_eval_batch(gpu_ctx, [ds[3]], 4)
     r3 = sum(s.F for s in scs[:3])
     assert np.array_equal(one, fb[r3:r3 + scs[3].F])
+
+
+@pytest.mark.parametrize("sp", ["0", "1"])
+def test_non_finite_depth_is_dropped_in_both_kernels(orc, mbavo, sp, monkeypatch):
+    """A keypoint with inf / NaN depth passes the detector's `!(z < 1e-2)` test (blur_aware_direct_tracker.cpp:403-405)
+    and reaches the path: its pixels must be dropped (invalid: zero residual, zero row), not weighted by zero --
+    0 * NaN would turn the frame's H and g into NaN.  Both the lane-per-pixel kernel (MBAVO_SP=0) and the
+    sample-parallel kernel (MBAVO_SP=1) against the oracle."""
+    import torch
+    monkeypatch.setenv("MBAVO_SP", sp)
+    ctx = mbavo.capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)  # the switch is read per layout
+    try:
+        for k in (4, 2):
+            sc = scenes.Scene(S=8, F=2, k=k, P=8, K=90, seed=21)
+            sc.kp_z[3], sc.kp_z[40], sc.kp_z[77] = np.inf, np.nan, -np.inf
+            p, keep = sc.oracle_problem(orc)
+            ro = orc.evaluate(p)
+            assert np.isfinite(ro["frame_blocks"]).all()
+            fb, pc, valid = scenes.gpu_eval_batch(ctx, [scenes.DeviceScene(sc)], k)
+            assert np.isfinite(fb).all() and np.isfinite(pc).all()
+            assert _rel(fb, ro["frame_blocks"]) < RTOL
+            assert np.array_equal(valid, _oracle_valid_counts(orc, sc)) and valid.max() <= (sc.K - 3) * sc.P
+            assert (pc.reshape(sc.F, sc.K)[:, [3, 40, 77]] == 0.0).all()
+    finally:
+        ctx.close()
