@@ -57,6 +57,11 @@ typedef struct mbavo_problem {
                                              Central differences of an 8-bit image are multiples of 0.5 in [-127.5, 127.5],
                                              exactly representable in fp16, so both formats see identical tap values (results agree to rounding).
                                              All problems of one mbavo_eval_batch call must use the same format. */
+    long long num_residuals;              /* 0: the blocks are scaled by 1/((K - num_bad)*F*P) of THIS problem
+                                             (inv_num_residuals, spline_update_step.cpp:116-117).  > 0: by 1/num_residuals --
+                                             the residual count of the WHOLE problem a keypoint / frame shard belongs to, so
+                                             that the shards' packed blocks simply add up to the whole problem's (multi-GPU:
+                                             mbavo_shard_keypoints / mbavo_shard_frames fill it in) */
 } mbavo_problem;
 
 /* ---- context: owns all device scratch (replaces initialize/free_shared_cuda_storages,
@@ -257,8 +262,37 @@ int mbavo_vo_track_frame(mbavo_vo *vo, const unsigned char *h_sharp, const float
                          const unsigned char *h_blur, double blur_cap_time, double blur_exp_time,
                          double h_T_out[7], mbavo_vo_info *info_or_null);
 
-/* ---- multi-GPU: in-place sum of the packed blocks over all ranks (RCCL over xGMI).
- * `rccl_comm` is an ncclComm_t created by the caller; count in doubles. */
+/* ---- multi-GPU: one process per GPU; the path shards with no exchange except the final sum of the normal equations
+ * (the reference's reduction point: merge_hessian_gradient_cost, ba_tracker/merge_hessian_gradient_cost.cpp:39-86, called
+ * at spline_update_step.cpp:232-239).  RCCL is resolved at run time (dlopen), so the library loads on hosts without it. */
+/* Shards of one problem (host-side pointer arithmetic on the DEVICE pointers of `whole`; nothing is copied): contiguous
+ * keypoint range [K*rank/world, K*(rank+1)/world) -- a band of the keyframe, since the detector emits keypoints row-major --
+ * or contiguous frame range [F*rank/world, F*(rank+1)/world).  `shard->num_residuals` is set to the whole problem's count,
+ * so the packed blocks of all shards ADD UP to the blocks of the whole problem (keypoint shards: every frame block is a
+ * partial sum; frame shards: every rank owns its frames' blocks).  A frame shard may come out empty (F == 0 when
+ * world > F): the caller skips its evaluation.  *h_first = first keypoint / frame of the shard (may be NULL). */
+int mbavo_shard_keypoints(const mbavo_problem *h_whole, int rank, int world, mbavo_problem *h_shard, int *h_first);
+int mbavo_shard_frames(const mbavo_problem *h_whole, int rank, int world, mbavo_problem *h_shard, int *h_first);
+/* merge_hessian_gradient_cost (merge_hessian_gradient_cost.cpp:39-86) ON THE DEVICE for B problems: the F_b packed frame
+ * blocks of problem b (d_frame_blocks, the layout mbavo_eval_batch writes; h_problems[b] supplies F, N, h_start_idx) are
+ * scattered into its normal-equation system [cost | g (6N) | H (6N x 6N, column-major, symmetric)] = mbavo_system_len(N)
+ * doubles, systems back to back in problem order.  Frames are added in ascending order (bit-reproducible).  For a
+ * keypoint / frame shard (mbavo_shard_*) the result is that shard's PARTIAL system; the sum over ranks
+ * (mbavo_allreduce_blocks) is the whole problem's system.  Asynchronous on the context's stream. */
+int mbavo_system_len(int N); /* 1 + 6N + 36N^2 */
+int mbavo_merge_device(mbavo_ctx *ctx, int B, const mbavo_problem *h_problems, int spline_deg_k,
+                       const double *d_frame_blocks, double *d_systems);
+/* The context's own RCCL communicator: rank 0 calls mbavo_comm_unique_id (ncclGetUniqueId) and hands the bytes to the
+ * other ranks through any side channel (bench.py: a torch.distributed broadcast); every rank then calls mbavo_comm_init
+ * (ncclCommInitRank on the context's device; collective).  mbavo_comm_ranks = ncclCommCount (0: no communicator). */
+#define MBAVO_COMM_ID_BYTES 128
+int mbavo_comm_unique_id(unsigned char h_id[MBAVO_COMM_ID_BYTES]);
+int mbavo_comm_init(mbavo_ctx *ctx, const unsigned char h_id[MBAVO_COMM_ID_BYTES], int rank, int world);
+int mbavo_comm_ranks(mbavo_ctx *ctx);
+int mbavo_comm_destroy(mbavo_ctx *ctx);
+/* In-place sum over all ranks of `count` doubles (packed blocks or merged systems) with ONE ncclAllReduce on the context's
+ * stream, ordered after the kernels that wrote them (RCCL over xGMI).  `rccl_comm` = a caller-owned ncclComm_t, or NULL
+ * for the context's own communicator (mbavo_comm_init); with neither: MBAVO_E_ARG. */
 int mbavo_allreduce_blocks(mbavo_ctx *ctx, void *rccl_comm, double *d_blocks, long long count);
 
 /* ---- measurement: HIP-event timing of the dominant kernel (the fused residual/Jacobian/JtJ
@@ -269,6 +303,8 @@ int mbavo_allreduce_blocks(mbavo_ctx *ctx, void *rccl_comm, double *d_blocks, lo
  * events completed). */
 int mbavo_profile(mbavo_ctx *ctx, int enable);
 int mbavo_profile_read(mbavo_ctx *ctx, double *h_fused_ms_sum, int *h_launches);
+/* name of the dominant kernel the context's last evaluation dispatched, e.g. "k_fused<4,true,false>" (labels the timing) */
+const char *mbavo_last_kernel(mbavo_ctx *ctx);
 
 const char *mbavo_version(void);
 

@@ -23,7 +23,7 @@ class Problem(C.Structure):
         ("d_outlier", vp), ("num_bad", C.c_int), ("intrinsics", C.c_double * 4),
         ("d_cap_time", vp), ("d_exp_time", vp), ("t0", C.c_double), ("dt", C.c_double),
         ("d_knots_t", vp), ("d_knots_R", vp), ("h_start_idx", c_ip), ("huber_a", C.c_double),
-        ("grad_fp16", C.c_int),
+        ("grad_fp16", C.c_int), ("num_residuals", C.c_longlong),
     ]
 
 
@@ -104,6 +104,8 @@ SYMBOLS = [
     "mbavo_gradient_magnitude_u8", "mbavo_detect_semidense", "mbavo_se3_exp", "mbavo_se3_log", "mbavo_transform_mul",
     "mbavo_transform_inverse", "mbavo_spline_transform_to", "mbavo_vo_create", "mbavo_vo_destroy", "mbavo_vo_set_spline",
     "mbavo_vo_get_spline", "mbavo_vo_num_keypoints", "mbavo_vo_get_keypoints", "mbavo_vo_track_frame", "mbavo_lm_batch",
+    "mbavo_shard_keypoints", "mbavo_shard_frames", "mbavo_system_len", "mbavo_merge_device", "mbavo_comm_unique_id",
+    "mbavo_comm_init", "mbavo_comm_ranks", "mbavo_comm_destroy", "mbavo_last_kernel",
 ]
 
 
@@ -178,6 +180,16 @@ def load():
     L.mbavo_synthesize_blur.argtypes = [vp, C.c_int, C.c_int, C.c_double, c_dp, C.c_int, C.c_double, C.c_double, c_dp,
                                         c_dp, C.c_int, C.c_double, C.c_double, C.c_int, vp, vp]
     L.mbavo_allreduce_blocks.argtypes = [vp, vp, vp, C.c_longlong]
+    L.mbavo_shard_keypoints.argtypes = [C.POINTER(Problem), C.c_int, C.c_int, C.POINTER(Problem), c_ip]
+    L.mbavo_shard_frames.argtypes = [C.POINTER(Problem), C.c_int, C.c_int, C.POINTER(Problem), c_ip]
+    L.mbavo_system_len.argtypes = [C.c_int]
+    L.mbavo_merge_device.argtypes = [vp, C.c_int, C.POINTER(Problem), C.c_int, vp, vp]
+    L.mbavo_comm_unique_id.argtypes = [C.c_char_p]
+    L.mbavo_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    L.mbavo_comm_ranks.argtypes = [vp]
+    L.mbavo_comm_destroy.argtypes = [vp]
+    L.mbavo_last_kernel.argtypes = [vp]
+    L.mbavo_last_kernel.restype = C.c_char_p
     L.mbavo_gradient_magnitude_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.mbavo_detect_semidense.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                          vp, vp, vp, C.c_int, c_ip]

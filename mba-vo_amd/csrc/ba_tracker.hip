@@ -8,6 +8,7 @@
 #include "se3_math.h"
 
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -457,7 +458,7 @@ namespace SLAM
                 abort();
             }
             mbavo_problem p;
-            p.grad_fp16 = 0;
+            memset(&p, 0, sizeof(p));
             p.S = S; p.F = F; p.K = K; p.P = P; p.N = N;
             p.H = im_size_HW.values[0]; p.W = im_size_HW.values[1];
             p.d_ref_img = cuda_ref_img; p.d_ref_dIxy = cuda_dIxy_ref;

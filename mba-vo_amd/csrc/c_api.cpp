@@ -11,7 +11,6 @@
 
 #include <cstdio>
 #include <cstring>
-#include <dlfcn.h>
 #include <new>
 #include <vector>
 
@@ -412,24 +411,42 @@ extern "C"
         return ctx->engine->profile_read(ms, n);
     }
 
-    // ---- RCCL: resolved at run time so that the library loads on hosts without RCCL
+    const char *mbavo_last_kernel(mbavo_ctx *ctx) { return ctx ? ctx->engine->last_kernel() : ""; }
+
+    // ---- multi-GPU (multi_gpu.hip)
+    int mbavo_shard_keypoints(const mbavo_problem *whole, int rank, int world, mbavo_problem *shard, int *first)
+    {
+        return mbavo::shard_keypoints(whole, rank, world, shard, first);
+    }
+
+    int mbavo_shard_frames(const mbavo_problem *whole, int rank, int world, mbavo_problem *shard, int *first)
+    {
+        return mbavo::shard_frames(whole, rank, world, shard, first);
+    }
+
+    int mbavo_system_len(int N) { return 1 + 6 * N + 36 * N * N; }
+
+    int mbavo_merge_device(mbavo_ctx *ctx, int B, const mbavo_problem *probs, int k, const double *d_fb, double *d_systems)
+    {
+        if (!ctx) return MBAVO_E_ARG;
+        return ctx->engine->merge_device(B, probs, k, d_fb, d_systems);
+    }
+
+    int mbavo_comm_unique_id(unsigned char *id) { return id ? mbavo::comm_unique_id(id) : MBAVO_E_ARG; }
+
+    int mbavo_comm_init(mbavo_ctx *ctx, const unsigned char *id, int rank, int world)
+    {
+        if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return MBAVO_E_ARG;
+        return ctx->engine->comm_init(id, rank, world);
+    }
+
+    int mbavo_comm_ranks(mbavo_ctx *ctx) { return ctx ? ctx->engine->comm_ranks() : 0; }
+
+    int mbavo_comm_destroy(mbavo_ctx *ctx) { return ctx ? ctx->engine->comm_destroy() : MBAVO_E_ARG; }
+
     int mbavo_allreduce_blocks(mbavo_ctx *ctx, void *comm, double *d_blocks, long long count)
     {
-        if (!ctx || !comm || !d_blocks || count < 0) return MBAVO_E_ARG;
-        typedef int (*allreduce_fn)(const void *, void *, size_t, int, int, void *, hipStream_t);
-        static allreduce_fn fn = nullptr;
-        if (!fn)
-        {
-            // the SONAME first: binds to the RCCL instance the process already uses (e.g. the one PyTorch ships),
-            // which is the instance the caller's ncclComm_t belongs to
-            void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-            if (!h) { fprintf(stderr, "mbavo: cannot load librccl.so: %s\n", dlerror()); return MBAVO_E_NODEVICE; }
-            fn = (allreduce_fn)dlsym(h, "ncclAllReduce");
-            if (!fn) return MBAVO_E_NODEVICE;
-        }
-        // ncclDouble = 8, ncclSum = 0 (rccl.h); one fused in-place all-reduce of the packed blocks
-        const int rc = fn(d_blocks, d_blocks, (size_t)count, 8, 0, comm, ctx->engine->stream());
-        return rc == 0 ? 0 : -2000 - rc;
+        if (!ctx || !d_blocks || count < 0) return MBAVO_E_ARG;
+        return ctx->engine->allreduce(comm, d_blocks, count);
     }
 }

@@ -84,6 +84,8 @@ namespace mbavo
         int fetch_status();
 
         int total_bf() const { return total_bf_; }
+        // name of the dominant kernel the last evaluate() dispatched, e.g. "k_fused<4,true,false>" (bench labels)
+        const char *last_kernel() const { return last_kernel_; }
 
         // optional per-launch timing of the dominant kernel (k_fused) with HIP events on the
         // engine's stream; read back after a stream sync (bench.py roofline leg)
@@ -100,6 +102,14 @@ namespace mbavo
         // fused kernel write the per-patch costs straight into one (no D2H copy for the outlier statistics) and stages
         // the outlier flags in another (an H2D copy from pinned memory is asynchronous, from pageable memory it is not)
         void *pinned_scratch(int slot, size_t bytes);
+
+        // multi-GPU (multi_gpu.hip): the context's own RCCL communicator, the in-place sum over ranks on this engine's
+        // stream, and merge_hessian_gradient_cost on the device (packed frame blocks -> [cost | g | H] systems)
+        int comm_init(const unsigned char *unique_id, int rank, int world);
+        int comm_ranks() const;
+        int comm_destroy();
+        int allreduce(void *caller_comm_or_null, double *d, long long count);
+        int merge_device(int B, const mbavo_problem *probs, int kdeg, const double *d_frame_blocks, double *d_systems);
 
     private:
         int ensure(void **ptr, size_t *cap, size_t bytes);
@@ -137,9 +147,16 @@ namespace mbavo
         void *pinned_[kPinnedSlots] = {};
         size_t pinned_cap_[kPinnedSlots] = {};
 
-        static constexpr int kSlots = 12; // 0-6 LM loop (tracker.cpp), 8-10 keyframe detection (keyframe_ops.hip)
+        static constexpr int kSlots = 12; // 0-6 LM loop (tracker.cpp), 8-10 keyframe detection (keyframe_ops.hip), 7 / 11 merge_device
         void *slots_[kSlots] = {};
         size_t slot_cap_[kSlots] = {};
+
+        char last_kernel_[64] = "";
+        void *comm_ = nullptr;          // ncclComm_t owned by this context (comm_init)
+        std::vector<char> merge_descs_; // what merge_device last uploaded (re-uploaded only when it changes)
+        std::vector<int> merge_start_;
+        int merge_kdeg_ = 0;
+        void *merge_dev_[2] = {nullptr, nullptr};
 
         int prof_every_ = 0, prof_seen_ = 0;
         std::map<const void *, size_t> lds_attr_;
@@ -152,6 +169,11 @@ namespace mbavo
         // hipFuncAttributeMaxDynamicSharedMemorySize, set once per kernel on this engine's device
         hipError_t ensure_lds(const void *kernel, size_t bytes);
     };
+
+    // multi_gpu.hip
+    int comm_unique_id(unsigned char *id);
+    int shard_keypoints(const mbavo_problem *whole, int rank, int world, mbavo_problem *out, int *first);
+    int shard_frames(const mbavo_problem *whole, int rank, int world, mbavo_problem *out, int *first);
 } // namespace mbavo
 
 #endif

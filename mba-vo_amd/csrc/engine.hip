@@ -962,6 +962,7 @@ namespace mbavo
 
     Engine::~Engine()
     {
+        (void)comm_destroy();
         void *bufs[] = {d_descs_, d_tiles_, d_bf_tile_begin_, d_bf_prob_, d_entry_prob_, d_poses_, d_rho_, d_partials_,
                         d_status_};
         for (void *p : bufs)
@@ -1044,7 +1045,8 @@ namespace mbavo
             d.fx = p.intrinsics[0]; d.fy = p.intrinsics[1]; d.cx = p.intrinsics[2]; d.cy = p.intrinsics[3];
             d.t0 = p.t0; d.dt = p.dt; d.huber_a = p.huber_a;
             // 1/((K - num_bad)*F*P), counting out-of-bounds pixels (spline_update_step.cpp:116-117)
-            const long long num_residuals = (long long)(p.K - p.num_bad) * p.F * p.P;
+            // (a shard of a larger problem carries the whole problem's count, so that the shards' blocks add up)
+            const long long num_residuals = p.num_residuals > 0 ? p.num_residuals : (long long)(p.K - p.num_bad) * p.F * p.P;
             d.inv_num_residuals = num_residuals > 0 ? 1.0 / (double)num_residuals : 0.0; // empty problem: all-zero blocks
             d.S = p.S; d.F = p.F; d.K = p.K; d.P = p.P; d.N = p.N; d.H = p.H; d.W = p.W; d.kp_stride = p.kp_stride;
             d.grad_fp16 = p.grad_fp16 ? 1 : 0;
@@ -1274,6 +1276,10 @@ namespace mbavo
         if (kdeg == 4) rc = with_hessian ? MBAVO_LAUNCH(4, true) : MBAVO_LAUNCH(4, false);
         else rc = with_hessian ? MBAVO_LAUNCH(2, true) : MBAVO_LAUNCH(2, false);
 #undef MBAVO_LAUNCH
+        if (sp_logs_ > 0)
+            snprintf(last_kernel_, sizeof(last_kernel_), "k_fused_sp<%d,%s,false,%d>", kdeg, with_hessian ? "true" : "false", sp_logs_);
+        else
+            snprintf(last_kernel_, sizeof(last_kernel_), "k_fused<%d,%s,%s>", kdeg, with_hessian ? "true" : "false", half_grad ? "true" : "false");
         return rc;
     }
 

@@ -44,18 +44,20 @@ def _current_image(ref, rng, shift=(1, -2), noise=6):
 
 
 def pyramid_pair(H=480, W=640, levels=4, S=8, k=4, N=4, mode="dense", seed=1, huber=10.0, margin=0,
-                 trans_scale=0.004, rot_scale=0.05):
+                 trans_scale=0.004, rot_scale=0.05, frames=1):
     """Config 1/2 of BASELINE.json: one keyframe pair, `levels` pyramid levels, `S` blur samples,
     `N` control poses.  mode 'dense': every pixel a P=1 patch with its own depth;
-    'semidense': grid-selected keypoints (30-px cells) with the harness' 8-pixel pattern."""
+    'semidense': grid-selected keypoints (30-px cells) with the harness' 8-pixel pattern.
+    frames > 1: a joint problem of `frames` blurred frames against the same keyframe on one spline segment (the
+    multi-GPU workload: one frame per rank); frame 0 is exactly the frames == 1 problem."""
     rng = np.random.default_rng(seed)
     ref0 = synth.noise_image(H, W, seed=seed)
-    cur0 = _current_image(ref0, rng)
-    refs, curs = synth.pyramid(ref0, levels), synth.pyramid(cur0, levels)
+    refs = synth.pyramid(ref0, levels)
+    curs = [synth.pyramid(_current_image(ref0, rng, shift=(1 + f % 3, -2 - f % 2)), levels) for f in range(frames)]
     kt, kR = synth.harness_spline(trans_scale, rot_scale, N)
     t0, dt = 0.0, 0.5
-    cap, exp = [0.25], [0.1]
-    assert synth.segment_start_index(cap[0] + exp[0], t0, dt) + k <= N
+    cap, exp = [0.25 + 0.01 * f for f in range(frames)], [0.1] * frames
+    assert all(synth.segment_start_index(c - 0.05, t0, dt) == 0 and synth.segment_start_index(c + 0.05, t0, dt) + k <= N for c in cap)
     probs = []
     for l in range(levels):
         sc = 2 ** l
@@ -67,7 +69,7 @@ def pyramid_pair(H=480, W=640, levels=4, S=8, k=4, N=4, mode="dense", seed=1, hu
         else:
             xy, z = synth.semi_dense_keypoints(refs[l], cell=30, thresh=4.0, margin=max(4, 20 // sc), seed=seed + 10 + l)
             pat = synth.PATTERN8
-        probs.append(Prob(refs[l], [curs[l]], xy, z, pat, intr, S, k, N, cap, exp, t0, dt, kt, kR, huber))
+        probs.append(Prob(refs[l], [c[l] for c in curs], xy, z, pat, intr, S, k, N, cap, exp, t0, dt, kt, kR, huber))
     return probs
 
 
@@ -171,17 +173,22 @@ def algorithmic_flops(probs, valid_pixels=None):
     return total
 
 
-def algorithmic_bytes(probs):
+def algorithmic_bytes(probs, shard=None):
     """compulsory HBM bytes: images once (ref u8 + gradient 2 x f32 + current u8 per frame),
-    keypoints (xy, z), pose tables, packed output blocks."""
+    keypoints (xy, z), pose tables, packed output blocks.  shard = (mode, rank, world): the bytes of that rank's share
+    of the workload -- 'frames': keyframe images and keypoints in full, its own frames' current images; 'keypoints': a
+    1/world band of every image and of the keypoints."""
     total = 0.0
     seen = set()
+    mode, rank, world = shard if shard is not None else ("none", 0, 1)
     for p in probs:
         E = synth.packed_len(p.k)
-        for a, per_px in [(p.ref, 1), (p.grad, 1)] + [(c, 1) for c in p.cur]:
+        f0, f1 = ((p.F * rank) // world, (p.F * (rank + 1)) // world) if mode == "frames" else (0, p.F)
+        band = 1.0 / world if mode == "keypoints" else 1.0
+        for a in [p.ref, p.grad] + list(p.cur[f0:f1]):
             key = a.__array_interface__["data"][0]
             if key not in seen:
                 seen.add(key)
-                total += a.nbytes
-        total += p.K * 24 + p.F * p.S * (7 + 21 * p.k) * 8 + p.F * E * 8
+                total += a.nbytes * band
+        total += p.K * band * 24 + (f1 - f0) * p.S * (7 + 21 * p.k) * 8 + (f1 - f0) * E * 8
     return total

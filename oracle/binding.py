@@ -324,19 +324,28 @@ def stages_with_reference(prob_args, with_jacobians=True):
                 frame_blocks=fb.reshape(F, E), cost=float(fb.reshape(F, E)[:, 0].sum()))
 
 
-def evaluate_with_reference(prob_args, chunk=4096):
+def evaluate_with_reference(prob_args, chunk=4096, threads=1):
     """Whole evaluation (frame blocks [F, E]) with the reference's per-sample code, keypoints in chunks so that the
     per-pixel Jacobians and per-patch blocks the reference pipeline materialises stay small (dense problems: 800 MB of
-    patch blocks otherwise).  The chunks' frame sums are added in keypoint order."""
+    patch blocks otherwise).  The chunks' frame sums are added in keypoint order.  threads > 1: the chunks are
+    independent and run on a thread pool (the C calls release the GIL); the sum order stays the keypoint order."""
     a = dict(prob_args)
     K, F, P, k = a["K"], a["F"], a["P"], a["k"]
     E = packed_len(k)
     total = np.zeros((F, E))
-    for k0 in range(0, max(K, 1), chunk):
-        k1 = min(K, k0 + chunk)
-        if k1 <= k0:
-            break
+    spans = [(k0, min(K, k0 + chunk)) for k0 in range(0, max(K, 1), chunk) if min(K, k0 + chunk) > k0]
+
+    def one(span):
+        k0, k1 = span
         sub = dict(a, K=k1 - k0, kp_xy=np.ascontiguousarray(a["kp_xy"][k0:k1]), kp_z=np.ascontiguousarray(a["kp_z"][k0:k1]))
-        r = stages_with_reference(sub)
-        total += r["frame_blocks"] * ((k1 - k0) * F * P)  # un-normalise the chunk (inv = 1 / (K_chunk F P))
+        return stages_with_reference(sub)["frame_blocks"] * ((k1 - k0) * F * P)  # un-normalise (inv = 1 / (K_chunk F P))
+
+    if threads > 1 and len(spans) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            parts = list(ex.map(one, spans))
+    else:
+        parts = [one(sp) for sp in spans]
+    for part in parts:
+        total += part
     return total / (K * F * P) if K * F * P > 0 else total

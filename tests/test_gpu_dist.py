@@ -1,0 +1,140 @@
+"""-m gpu: the multi-GPU path on the HIP engine + RCCL: shards of ONE joint problem (mbavo_shard_frames /
+mbavo_shard_keypoints) evaluated by the fused engine on every rank, merged on the device (mbavo_merge_device) and summed
+with mbavo_allreduce_blocks on the context's own RCCL communicator (mbavo_comm_init), against (a) a single-GPU
+evaluation of the whole problem (1e-12: only the summation order differs), (b) the product's host merge (bit-exact) and
+(c) the oracle (1e-9).  The reference's reduction point: merge_hessian_gradient_cost.cpp:39-86.
+
+world = 1 runs on the one-GPU box (every code path, a 1-rank communicator); world = 2 needs two GPUs and is skipped
+otherwise.  The same body runs under torchrun:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 tests/test_gpu_dist.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def rank_body(rank, world, local_rank, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(port))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    import mba_vo_amd as M
+    from mba_vo_amd import shard, workloads as wl
+    from oracle import binding as B
+    B.build()
+    ctx = M.capi.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    assert ctx.lib.mbavo_comm_ranks(ctx.handle) == 0
+    assert ctx.lib.mbavo_allreduce_blocks(ctx.handle, None, 8, 1) == -1  # no communicator yet: MBAVO_E_ARG
+    assert shard.comm_init(ctx, rank, world, shard.torch_bcast(dev)) == world
+    res = {"world": world, "rccl_ranks": ctx.lib.mbavo_comm_ranks(ctx.handle)}
+
+    def rel(a, b):
+        return float((a - b).abs().max() / b.abs().max())
+
+    # ---- frames mode: max(world, 2) + 1 blurred frames on one spline, 2 pyramid levels, dense
+    F = max(world, 2) + 1
+    probs = wl.pyramid_pair(120, 160, 2, S=8, k=4, N=4, mode="dense", seed=7, frames=F)
+    dw = wl.DeviceWorkload(probs, device=dev)
+    se = shard.ShardedEvaluation(ctx, dw.array, 4, rank, world, "frames", dev)
+    for _ in range(3):  # repeated steps reuse the cached merge descriptors
+        se.step(True)
+    torch.cuda.synchronize()
+    got, ref = se.reduced.clone(), se.reference()
+    res["frames_vs_single_gpu"] = rel(got, ref)
+    # (b) the device merge of the whole problem against the product's host merge of the same blocks: identical bits
+    fb = se._ref_fb.cpu().numpy().reshape(-1, se.E)
+    off, row, exact = 0, 0, True
+    sys_ref = ref.cpu().numpy()
+    worst_oracle = 0.0
+    for p in probs:
+        n = 6 * p.N
+        cost, H, g = np.zeros(1), np.zeros(n * n), np.zeros(n)
+        blk = np.ascontiguousarray(fb[row:row + p.F])
+        assert ctx.lib.mbavo_merge_host(p.F, p.k, M.capi.dp(blk), M.capi.ip(p.start_idx), p.N, M.capi.dp(cost), M.capi.dp(H),
+                                        M.capi.dp(g)) == 0
+        host = np.concatenate([cost, g, H])
+        exact = exact and np.array_equal(host, sys_ref[off:off + host.size])
+        # (c) the oracle on the whole F-frame problem
+        op, keep = B.make_problem(p.S, p.F, p.K, p.P, p.k, p.N, p.H, p.W, p.ref, p.grad, p.cur, p.kp_xy, p.kp_z, p.pattern,
+                                  p.intr, p.cap, p.exp, p.t0, p.dt, p.knots_t, p.knots_R, p.start_idx, p.huber)
+        ro = B.evaluate(op)
+        orc_sys = np.concatenate([[ro["cost"]], ro["g"], ro["H"].T.ravel()])
+        mine = got.cpu().numpy()[off:off + host.size]
+        worst_oracle = max(worst_oracle, float(np.abs(mine - orc_sys).max() / np.abs(orc_sys).max()))
+        off += host.size
+        row += p.F
+    res["device_merge_equals_host_merge"] = bool(exact)
+    res["frames_vs_oracle"] = worst_oracle
+
+    # ---- keypoints mode: 5 semi-dense pairs, every pair's keypoints sharded, packed blocks summed
+    pb = wl.pair_batch(5, H=240, W=320, S=8, k=4, N=4, mode="semidense", seed=3)
+    dw2 = wl.DeviceWorkload(pb, device=dev)
+    se2 = shard.ShardedEvaluation(ctx, dw2.array, 4, rank, world, "keypoints", dev)
+    se2.step(True)
+    torch.cuda.synchronize()
+    got2, ref2 = se2.reduced.clone(), se2.reference()
+    res["keypoints_vs_single_gpu"] = rel(got2, ref2)
+    res["nonzero"] = bool(float(ref.abs().max()) > 0 and float(ref2.abs().max()) > 0)
+    # every rank holds the same reduced object
+    chk = got2.clone()
+    dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+    res["ranks_agree"] = bool(torch.equal(chk, got2))
+    dist.barrier()
+    assert ctx.lib.mbavo_comm_destroy(ctx.handle) == 0 and ctx.lib.mbavo_comm_ranks(ctx.handle) == 0
+    ctx.close()
+    dist.destroy_process_group()
+    if rank == 0 and out_path:
+        json.dump(res, open(out_path, "w"))
+    return res
+
+
+def check(res, world):
+    assert res["world"] == world and res["rccl_ranks"] == world
+    assert res["nonzero"] and res["ranks_agree"] and res["device_merge_equals_host_merge"]
+    assert res["frames_vs_single_gpu"] <= 1e-12 and res["keypoints_vs_single_gpu"] <= 1e-12
+    assert res["frames_vs_oracle"] <= 1e-9
+
+
+def _spawned(rank, world, port, out_path):
+    rank_body(rank, world, rank, port, out_path)
+
+
+def _run(world, tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "res.json")
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_spawned, args=(world, port, out), nprocs=world, join=True)
+    check(json.load(open(out)), world)
+
+
+def test_sharded_evaluation_one_rank(mbavo, tmp_path):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _run(1, tmp_path)
+
+
+def test_sharded_evaluation_two_ranks(mbavo, tmp_path):
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run(2, tmp_path)
+
+
+if __name__ == "__main__":  # under torchrun
+    w, r, lr = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    out = rank_body(r, w, lr, int(os.environ.get("MASTER_PORT", "29650")), None)
+    if r == 0:
+        check(out, w)
+        print("test_gpu_dist under torchrun: OK", json.dumps(out))

@@ -121,3 +121,53 @@ def test_fp16_gradient_sample_parallel_remainder(orc, mbavo, gpu_ctx):
             q.grad_fp16 = True
         fb16, v16 = _run(gpu_ctx, probs)
         assert np.abs(fb16 - fb32).max() <= 1e-13 * np.abs(fb32).max() and np.array_equal(v16, v32) and v32.sum() > 0
+
+
+def test_c4_batch512_full_size(orc, mbavo, gpu_ctx):
+    """configs[3] on one GPU: the whole batch of 512 semi-dense pairs in ONE evaluation.  Eight sampled pairs against
+    the oracle (1e-9 relative on the packed blocks, exact valid-pixel counts are covered by the small cases); every
+    pair against the same pair evaluated alone and inside the 64-pair batch (1e-12: only the tile partition differs);
+    permutation of the batch permutes the blocks; run-to-run bit reproducibility; keypoint shards of every pair
+    (mbavo_shard_keypoints with world = 2 and 8, as bench.py --workload c4_batch512 --gpus N does) add up to the
+    whole batch's blocks; the cost-only pass equals slot 0."""
+    import ctypes as C
+    import torch
+    probs = wl.pair_batch(512, S=8, k=4, N=4, mode="semidense", seed=1)
+    dw = wl.DeviceWorkload(probs)
+    dw.step(gpu_ctx, True)
+    torch.cuda.synchronize()
+    fb = dw.frame_blocks.cpu().numpy().reshape(512, dw.E).copy()
+    valid = dw.valid.cpu().numpy().copy()
+    dw.step(gpu_ctx, True)
+    torch.cuda.synchronize()
+    assert np.array_equal(dw.frame_blocks.cpu().numpy().reshape(512, dw.E), fb)
+    assert np.isfinite(fb).all() and (valid == probs[0].K * probs[0].P).all() and (fb[:, 0] > 0).all()
+    for i in (0, 63, 64, 129, 255, 256, 400, 511):
+        p = probs[i]
+        op, keep = orc.make_problem(p.S, p.F, p.K, p.P, p.k, p.N, p.H, p.W, p.ref, p.grad, p.cur, p.kp_xy, p.kp_z,
+                                    p.pattern, p.intr, p.cap, p.exp, p.t0, p.dt, p.knots_t, p.knots_R, p.start_idx, p.huber)
+        ro = orc.evaluate(op)
+        assert np.abs(ro["frame_blocks"][0] - fb[i]).max() <= 1e-9 * np.abs(fb[i]).max()
+        alone, _ = _run(gpu_ctx, [p])
+        assert np.abs(alone[0] - fb[i]).max() <= 1e-12 * np.abs(fb[i]).max()
+    first64, _ = _run(gpu_ctx, probs[:64])
+    assert np.abs(first64 - fb[:64]).max() <= 1e-12 * np.abs(fb[:64]).max()
+    perm = np.random.default_rng(5).permutation(512)
+    fbp, _ = _run(gpu_ctx, [probs[j] for j in perm])
+    assert np.abs(fbp - fb[perm]).max() <= 1e-12 * np.abs(fb).max()
+    fc, _ = _run(gpu_ctx, probs, with_h=False)
+    assert np.abs(fc[:, 0] - fb[:, 0]).max() <= 1e-11 * np.abs(fb[:, 0]).max()
+    # keypoint shards of every pair, evaluated one "rank" after the other on this GPU, add up to the whole
+    lib = gpu_ctx.lib
+    for world in (2, 8):
+        total = torch.zeros(512 * dw.E, dtype=torch.float64, device="cuda:0")
+        part = torch.zeros_like(total)
+        for r in range(world):
+            sh = (mbavo.capi.Problem * 512)()
+            for b in range(512):
+                assert lib.mbavo_shard_keypoints(C.byref(dw.array[b]), r, world, C.byref(sh[b]), None) == 0
+            assert lib.mbavo_eval_batch(gpu_ctx.handle, 512, sh, 4, 1, part.data_ptr(), None, None) == 0
+            torch.cuda.synchronize()
+            total += part
+        got = total.cpu().numpy().reshape(512, dw.E)
+        assert np.abs(got - fb).max() <= 1e-12 * np.abs(fb).max()
