@@ -305,6 +305,9 @@ int mbavo_profile(mbavo_ctx *ctx, int enable);
 int mbavo_profile_read(mbavo_ctx *ctx, double *h_fused_ms_sum, int *h_launches);
 /* name of the dominant kernel the context's last evaluation dispatched, e.g. "k_fused<4,true,false>" (labels the timing) */
 const char *mbavo_last_kernel(mbavo_ctx *ctx);
+/* host-side phase timers of the tracking loop (enabled by MBAVO_TIMING=1 in the environment): print the totals since
+ * the last report to stderr and reset them.  Development aid; a no-op when the timers are off. */
+void mbavo_timing_report(void);
 
 const char *mbavo_version(void);
 

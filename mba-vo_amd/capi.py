@@ -105,7 +105,7 @@ SYMBOLS = [
     "mbavo_transform_inverse", "mbavo_spline_transform_to", "mbavo_vo_create", "mbavo_vo_destroy", "mbavo_vo_set_spline",
     "mbavo_vo_get_spline", "mbavo_vo_num_keypoints", "mbavo_vo_get_keypoints", "mbavo_vo_track_frame", "mbavo_lm_batch",
     "mbavo_shard_keypoints", "mbavo_shard_frames", "mbavo_system_len", "mbavo_merge_device", "mbavo_comm_unique_id",
-    "mbavo_comm_init", "mbavo_comm_ranks", "mbavo_comm_destroy", "mbavo_last_kernel",
+    "mbavo_comm_init", "mbavo_comm_ranks", "mbavo_comm_destroy", "mbavo_last_kernel", "mbavo_timing_report",
 ]
 
 
@@ -190,6 +190,7 @@ def load():
     L.mbavo_comm_destroy.argtypes = [vp]
     L.mbavo_last_kernel.argtypes = [vp]
     L.mbavo_last_kernel.restype = C.c_char_p
+    L.mbavo_timing_report.restype = None
     L.mbavo_gradient_magnitude_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.mbavo_detect_semidense.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                          vp, vp, vp, C.c_int, c_ip]

@@ -7,6 +7,7 @@
 #include "host_math.h"
 #include "se3_math.h"
 #include "tracker.h"
+#include "timing.h"
 #include "vo_frontend.h"
 
 #include <cstdio>
@@ -410,6 +411,8 @@ extern "C"
         if (!ctx) return MBAVO_E_ARG;
         return ctx->engine->profile_read(ms, n);
     }
+
+    void mbavo_timing_report(void) { mbavo::PhaseTimers::get().report(); }
 
     const char *mbavo_last_kernel(mbavo_ctx *ctx) { return ctx ? ctx->engine->last_kernel() : ""; }
 

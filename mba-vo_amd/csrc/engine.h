@@ -1,7 +1,9 @@
 // engine.h -- fused batch evaluation engine (HIP).  Internal to the library.
 //
 // One call evaluates B independent alignment problems (pyramid levels of one
-// pair, or many keyframe pairs) with three launches on one stream:
+// pair, or many keyframe pairs); small problems in ONE launch (k_fused_sp<.., ONE>: pose
+// entries in the prologue, finalize by the last workgroup of a slot), large ones with
+// three launches on one stream:
 //   k_pose_table  : F*S blur-sample poses + pose-to-knot Jacobians per problem
 //                   (the work of compute_virtual_camera_poses.cu:9-110)
 //   k_fused       : patch centres, per-pixel residual / 1x6k Jacobian over the S
@@ -48,14 +50,6 @@ namespace mbavo
         const double *inv_ptr;
     };
 
-    // Control knots handed to the pose kernel BY VALUE (kernel arguments) instead of through device memory: a
-    // host-driven LM loop then needs no H2D copy per evaluation (single problem, n = number of knots, 0 = unused)
-    struct InlineKnots
-    {
-        double t[3 * 16], R[4 * 16];
-        int n;
-    };
-
     // a tile = a contiguous keypoint range of one (problem, frame), handled by one workgroup
     struct TileDesc
     {
@@ -76,7 +70,9 @@ namespace mbavo
                      double *d_frame_blocks, double *d_patch_cost, double *d_valid,
                      double *d_patch_blocks_strided /* B == 1 only, stride E, may be null */,
                      const int *d_active_mask = nullptr /* [B] */, const double *d_inv = nullptr /* [B] */,
-                     const double *h_knots_t = nullptr, const double *h_knots_R = nullptr /* B == 1: knots by value */);
+                     bool signal_host = false /* arm the pinned completion word (see wait_evaluation) */);
+        // blocks until the evaluation just enqueued has completed (completion word, or the stream)
+        int wait_evaluation();
         const ProblemDesc *device_descs() const { return (const ProblemDesc *)d_descs_; }
 
         // range status since the previous fetch (call after a stream sync): non-zero if a blur
@@ -85,7 +81,7 @@ namespace mbavo
 
         int total_bf() const { return total_bf_; }
         // name of the dominant kernel the last evaluate() dispatched, e.g. "k_fused<4,true,false>" (bench labels)
-        const char *last_kernel() const { return last_kernel_; }
+        const char *last_kernel();
 
         // optional per-launch timing of the dominant kernel (k_fused) with HIP events on the
         // engine's stream; read back after a stream sync (bench.py roofline leg)
@@ -141,6 +137,10 @@ namespace mbavo
         void *d_rho_ = nullptr; size_t cap_rho_ = 0;
         void *d_partials_ = nullptr; size_t cap_partials_ = 0;
         void *d_status_ = nullptr;
+        void *d_tickets_ = nullptr; size_t cap_tickets_ = 0;
+        void *h_flag_ = nullptr;            // pinned completion word of the single-launch kernels
+        unsigned long long flag_seq_ = 0;
+        bool flag_pending_ = false;
         int status_seen_ = 0;
         void *h_fb_ = nullptr; size_t cap_hfb_ = 0;
         static constexpr int kPinnedSlots = 4;
@@ -152,6 +152,8 @@ namespace mbavo
         size_t slot_cap_[kSlots] = {};
 
         char last_kernel_[64] = "";
+        int last_kernel_id_[5] = {0, 0, 0, 0, 0};
+        std::vector<ProblemDesc> scratch_descs_;
         void *comm_ = nullptr;          // ncclComm_t owned by this context (comm_init)
         std::vector<char> merge_descs_; // what merge_device last uploaded (re-uploaded only when it changes)
         std::vector<int> merge_start_;

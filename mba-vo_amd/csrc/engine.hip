@@ -85,17 +85,10 @@ namespace mbavo
         return q;
     }
 
-    // KnotsArg = InlineKnots (knots by value, host-driven LM loop) or NoKnots (knots in device memory): a separate
-    // instantiation, so that the batch path does not carry 900 bytes of kernel arguments
-    struct NoKnots
-    {
-        static constexpr int n = 0;
-        double t[1], R[1];
-    };
-    template <int KD, bool WITH_J, class KnotsArg>
+    template <int KD, bool WITH_J>
     __global__ __launch_bounds__(64) void k_pose_table(const ProblemDesc *__restrict__ descs, const int *__restrict__ entry_prob,
                                                        int total_entries, PoseEntry<KD> *__restrict__ table,
-                                                       int *__restrict__ status, const KnotsArg ik)
+                                                       int *__restrict__ status)
     {
         constexpr int NCOL = WITH_J ? 3 : 1;
         const int lane_id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,18 +110,10 @@ namespace mbavo
             idx = idx < 0 ? 0 : d.N - KD;
         }
         PoseEntry<KD> &pe = table[gid];
-        // this sample's KD knots, from the kernel arguments (host-driven LM loop) or from device memory
+        // this sample's KD knots (device memory, or pinned host memory the host-driven LM loop writes before each call)
         double kR[4 * KD], kt[3 * KD];
-        if (ik.n > 0)
-        {
-            for (int i = 0; i < 4 * KD; ++i) kR[i] = ik.R[4 * idx + i];
-            for (int i = 0; i < 3 * KD; ++i) kt[i] = ik.t[3 * idx + i];
-        }
-        else
-        {
-            for (int i = 0; i < 4 * KD; ++i) kR[i] = d.knots_R[4 * idx + i];
-            for (int i = 0; i < 3 * KD; ++i) kt[i] = d.knots_t[3 * idx + i];
-        }
+        for (int i = 0; i < 4 * KD; ++i) kR[i] = d.knots_R[4 * idx + i];
+        for (int i = 0; i < 3 * KD; ++i) kt[i] = d.knots_t[3 * idx + i];
         Quat q;
         if (WITH_J)
         {
@@ -668,6 +653,158 @@ namespace mbavo
         }
     }
 
+    // ------------------------------------------------------------------ single-launch pieces
+    // An evaluation used to be three dependent launches (pose table -> fused -> finalize): for small problems that is
+    // pure launch latency (20 us for ~2 us of arithmetic).  With these two pieces the fused kernel does all of it:
+    //  * prologue: the workgroup computes ITS frame's S pose entries itself (the pose kernel's arithmetic, same
+    //    lane layout: one wave per knot, one lane per (sample, Jacobian column)) straight into LDS;
+    //  * epilogue: the workgroup that retires the LAST tile of a (problem, frame) slot -- a ticket counter, device-scope
+    //    fences -- sums the slot's tile partials in a fixed order and writes the frame block.  No float atomics, still
+    //    bit-reproducible run to run.
+    struct OneArgs
+    {
+        const int *bf_tile_begin;                // [nBF + 1]
+        int *tickets;                            // [nBF], zero between launches (the last workgroup of a slot resets it)
+        double *frame_blocks, *valid_out;        // outputs of the finalize step
+        int *status;                             // out-of-range counter (see k_pose_table)
+        int *slots_done;                         // one counter: slots finished in this launch
+        unsigned long long *host_flag;           // pinned host word, or null: set to `seq` when every slot is done
+        unsigned long long seq;
+        int nbf;
+    };
+
+    // S pose entries of (problem d, frame) -> dst[0 .. S-1] (LDS).  Waves 0 .. KD-1 take one knot each (WITH_J), lanes
+    // (sample, column); the pose itself is written by knot 0 / column 0.  Caller synchronises the workgroup afterwards.
+    template <int KD, bool WITH_J>
+    __device__ __forceinline__ void frame_pose_entries(const ProblemDesc &d, int frame, PoseEntry<KD> *dst, int wave, int lane,
+                                                       int *status, bool report)
+    {
+        constexpr int NCOL = WITH_J ? 3 : 1, NKW = WITH_J ? KD : 1, PER = 64 / NCOL;
+        if (wave >= NKW) return;
+        const int S = d.S;
+        const double t_cap = d.cap[frame], t_mu = d.exp_t[frame];
+        for (int s0 = 0; s0 < S; s0 += PER)
+        {
+            const int sl = lane / NCOL, col = lane - sl * NCOL, smp = s0 + sl;
+            if (sl >= PER || smp >= S) continue;
+            const double t = t_cap - t_mu * 0.5 + smp * t_mu / (S - 1 + 1e-8); // compute_virtual_camera_poses.cu:33
+            int idx;
+            double u;
+            spline_segment(t, d.t0, d.dt, idx, u);
+            if (idx < 0 || idx + KD > d.N)
+            {
+                if (report && wave == 0 && col == 0) atomicAdd(status, 1);
+                idx = idx < 0 ? 0 : d.N - KD;
+            }
+            double kR[4 * KD];
+            for (int i = 0; i < 4 * KD; ++i) kR[i] = d.knots_R[4 * idx + i];
+            PoseEntry<KD> &pe = dst[smp];
+            Quat q;
+            if constexpr (WITH_J)
+            {
+                if constexpr (KD == 2)
+                    q = wave == 0 ? pose_table_entry<KD, 0>(kR, u, col, pe) : pose_table_entry<KD, 1>(kR, u, col, pe);
+                else
+                    switch (wave)
+                    {
+                    case 0: q = pose_table_entry<KD, 0>(kR, u, col, pe); break;
+                    case 1: q = pose_table_entry<KD, 1>(kR, u, col, pe); break;
+                    case 2: q = pose_table_entry<KD, KD == 4 ? 2 : 0>(kR, u, col, pe); break;
+                    default: q = pose_table_entry<KD, KD == 4 ? 3 : 1>(kR, u, col, pe); break;
+                    }
+            }
+            else
+                q = spline_rotation<KD, false>(kR, u, nullptr);
+            if (wave == 0 && col == 0)
+            {
+                double kt[3 * KD];
+                for (int i = 0; i < 3 * KD; ++i) kt[i] = d.knots_t[3 * idx + i];
+                double c[KD], p[3], qv[4] = {q.x, q.y, q.z, q.w}, R[9];
+                trans_coeffs<KD>(u, c);
+                spline_translation<KD>(kt, c, p);
+                rotation_entries(qv, R);
+                double rt[3];
+                rotated_translation(p, qv, rt);
+                for (int i = 0; i < 3; ++i) { pe.t[i] = p[i]; pe.rt[i] = rt[i]; }
+                for (int i = 0; i < 4; ++i) pe.q[i] = qv[i];
+                for (int i = 0; i < 9; ++i) pe.R[i] = R[i];
+                for (int i = 0; i < KD; ++i) pe.c[i] = c[i];
+            }
+        }
+    }
+
+    // After the workgroup wrote partials[tile_id]: take a ticket of the tile's (problem, frame) slot; the workgroup
+    // that draws the last one sums the slot's partials -- LANES tile-lanes per entry, lane l adds tiles l, l + LANES,
+    // ... in order, then the lanes are added in order (for slots of up to four tiles and LANES = 2 that is
+    // (t0 + t2) + (t1 + t3), the order of k_finalize_flat) -- and writes the frame block.  `scratch`: LANES * EPAD
+    // doubles of LDS nobody else is using any more.
+    template <int KD, bool WITH_J, int NTHREADS>
+    __device__ __forceinline__ void ticket_finalize(const ProblemDesc &d, int bf, const double *__restrict__ partials,
+                                                    const OneArgs &oa, double *scratch)
+    {
+        constexpr int E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
+        constexpr int EPAD = KD == 4 ? 384 : 128, LANES = NTHREADS / EPAD;
+        static_assert(E + 1 <= EPAD && LANES >= 1, "one thread per partial slot and tile-lane");
+        __shared__ int s_last;
+        // Release: every wave's partial stores are performed at workgroup scope before the barrier (they sit in this XCD's
+        // L2), then ONE thread makes them visible device-wide (L2 write-back) and takes the ticket.  A device-scope fence
+        // by all 768 threads costs 9 us here (measured, tools/ab_run.sh).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            __threadfence();
+            const int n = oa.bf_tile_begin[bf + 1] - oa.bf_tile_begin[bf];
+            s_last = atomicAdd(&oa.tickets[bf], 1) == n - 1 ? 1 : 0;
+            __threadfence(); // acquire side: the other workgroups' partials (other XCDs' L2s) are read from memory
+        }
+        __syncthreads();
+        if (!s_last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int t0 = oa.bf_tile_begin[bf], t1 = oa.bf_tile_begin[bf + 1];
+        const int e = threadIdx.x % EPAD, l = threadIdx.x / EPAD;
+        const bool mine = l < LANES && e <= E && (WITH_J || e == 0 || e == E);
+        double acc = 0.0;
+        if (mine)
+        {
+            const MBAVO_GLOBAL double *pp = (const MBAVO_GLOBAL double *)partials;
+            int t = t0 + l;
+            for (; t + 3 * LANES < t1; t += 4 * LANES)
+            { // four loads in flight, added in tile order
+                const double a = pp[(size_t)t * PS + e], b = pp[(size_t)(t + LANES) * PS + e];
+                const double c = pp[(size_t)(t + 2 * LANES) * PS + e], dd = pp[(size_t)(t + 3 * LANES) * PS + e];
+                acc += a; acc += b; acc += c; acc += dd;
+            }
+            for (; t < t1; t += LANES) acc += pp[(size_t)t * PS + e];
+        }
+        if (LANES > 1)
+        {
+            if (mine) scratch[l * EPAD + e] = acc;
+            __syncthreads();
+            if (mine && l == 0)
+                for (int j = 1; j < LANES; ++j) acc += scratch[j * EPAD + e];
+        }
+        const bool to_host = oa.host_flag != nullptr;
+        if (mine && l == 0)
+        {
+            if (e == 0) { if (oa.valid_out) oa.valid_out[bf] = acc; }
+            else if (e == E) oa.frame_blocks[(size_t)bf * E] = acc; // cost: patch costs are already scaled
+            else oa.frame_blocks[(size_t)bf * E + e] = acc * (d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals);
+        }
+        if (to_host) __threadfence_system(); // the frame block (pinned host memory) lands before the flag does
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            oa.tickets[bf] = 0; // ready for the next launch (stream order)
+            if (to_host && atomicAdd(oa.slots_done, 1) == oa.nbf - 1)
+            {
+                *oa.slots_done = 0;
+                __threadfence_system();
+                __hip_atomic_store(oa.host_flag, oa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+
     // ------------------------------------------------------------------ fused kernel, sample-parallel variant
     // For SMALL problems (semi-dense keypoints: a few thousand pixels in all) the lane-per-pixel kernel above leaves
     // the machine empty and each lone wave walks its S samples one after the other at dependent-issue speed (one
@@ -676,26 +813,40 @@ namespace mbavo
     // wave's LDS slab and are summed in sample order (the order of the lane-per-pixel kernel), the intensities by
     // shuffles in sample order (bit-identical residuals and Huber costs), and the 64 / S finished rows of a wave go
     // through the same MFMA outer product.  The pose entry of a lane is per lane now (vector loads, L1-resident).
-    constexpr int kSpWaves = 12;
+#ifndef MBAVO_SP_WAVES
+#define MBAVO_SP_WAVES 12
+#endif
+    constexpr int kSpWaves = MBAVO_SP_WAVES;
     // LDS of k_fused_sp: the slabs, the cost / valid-count scratch, and -- when it fits the 160 KB -- the frame's S pose
     // entries, staged once per workgroup (a lane's entry is its SAMPLE's; read from global memory it arrives in four
-    // or five dependent pieces, each an L2 round trip)
-    template <int KD, bool WITH_J, int LOGS>
+    // or five dependent pieces, each an L2 round trip).  ONE (single launch): the entries are COMPUTED into that area
+    // by the workgroup itself, cost-only kernels included.
+    template <int KD, bool WITH_J, int LOGS, bool ONE>
     struct SpLds
     {
         static constexpr size_t kBase = ((WITH_J ? (size_t)kSpWaves * OuterAcc<6 * KD + 1>::SLAB : 0) + 2 * kSpWaves) * sizeof(double);
         static constexpr size_t kEntries = ((size_t)1 << LOGS) * sizeof(PoseEntry<KD>);
-        static constexpr bool kStage = WITH_J && kBase + kEntries <= 160 * 1024;
-        static constexpr size_t kBytes = kBase + (kStage ? kEntries : 0);
+        static constexpr bool kFits = kBase + kEntries <= 160 * 1024;
+        static constexpr bool kStage = (WITH_J || ONE) && kFits;
+        // the ticket epilogue needs LANES * EPAD doubles of scratch: the slabs when there are any, else its own area
+        static constexpr size_t kEpilogue = ONE && !WITH_J ? (size_t)kSpWaves * 64 * sizeof(double) : 0;
+        static constexpr size_t kBytes = kBase + (kStage ? kEntries : 0) + kEpilogue;
     };
-    template <int KD, bool WITH_J, bool HALF_GRAD, int LOGS>
+    // can the single-launch form of the sample-parallel kernel run this (k, S)?  (k = 4, S = 32: the entries do not fit)
+    static bool sp_one_fits(int kdeg, int logs)
+    {
+        if (kdeg == 2) return logs >= 2 && logs <= 5;
+        return logs >= 2 && logs <= 4;
+    }
+
+    template <int KD, bool WITH_J, bool HALF_GRAD, int LOGS, bool ONE>
     __global__ __launch_bounds__((kSpWaves * 64)) void k_fused_sp(const ProblemDesc *__restrict__ descs,
                                                         const TileDesc *__restrict__ tiles,
                                                         const PoseEntry<KD> *__restrict__ table,
                                                         double *__restrict__ rho_out,
                                                         double *__restrict__ patch_cost,
                                                         double *__restrict__ patch_blocks_strided,
-                                                        double *__restrict__ partials)
+                                                        double *__restrict__ partials, const OneArgs oa)
     {
         constexpr int ND = Pack<KD>::ND, E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
         constexpr int kWavesPerGroup = kSpWaves, kThreads = kWavesPerGroup * 64;
@@ -703,8 +854,8 @@ namespace mbavo
         constexpr int SLAB = OuterAcc<ND>::SLAB;     // doubles per wave: rows, and the parked accumulators at the end
         constexpr int RS = OuterAcc<ND>::STRIDE;     // row stride (>= ND, zero padded)
         extern __shared__ __attribute__((aligned(16))) double lds[];
-        double *rows = lds;                                               // [8 waves][64 pixels][ND] (WITH_J only)
-        double *red = lds + (WITH_J ? kWavesPerGroup * SLAB : 0);         // [2][8]
+        double *rows = lds;                                               // [12 waves][64 pixels][ND] (WITH_J only)
+        double *red = lds + (WITH_J ? kWavesPerGroup * SLAB : 0);         // [2][12]
 
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -715,25 +866,51 @@ namespace mbavo
         const int S = d.S, K = d.K, P = d.P, frame = tile.frame;
         Camera cam;
         cam.fx = d.fx; cam.fy = d.fy; cam.cx = d.cx; cam.cy = d.cy; cam.H = d.H; cam.W = d.W;
-        const PoseEntry<KD> *__restrict__ ftab = table + d.pose_base + frame * S; // S == SS (checked by the host)
-        const PoseEntry<KD> &mid = ftab[S / 2]; // patch centres use sample S/2 (compute_local_patches_xy.cu:26)
         const unsigned char *__restrict__ I_cur = d.cur_imgs[frame];
         const long long pix0 = d.pixel_base + ((long long)frame * K + tile.kp_begin) * P;
         const int npx = tile.kp_count * P;
-        constexpr bool STAGE = SpLds<KD, WITH_J, LOGS>::kStage;
+        constexpr bool STAGE = SpLds<KD, WITH_J, LOGS, ONE>::kStage;
+        static_assert(!ONE || STAGE, "the single-launch kernel keeps its pose entries in LDS");
         double *stage = red + 2 * kSpWaves;
-        if (STAGE)
+        const PoseEntry<KD> *__restrict__ ftab = table + d.pose_base + frame * S; // S == SS (checked by the host)
+        if constexpr (ONE)
+        {
+#if !defined(MBAVO_EXP_ONE_NOPOSE) // timing experiment: entries left uninitialised
+            frame_pose_entries<KD, WITH_J>(d, frame, (PoseEntry<KD> *)stage, wave, lane, oa.status, tile.kp_begin == 0);
+#endif
+            __syncthreads();
+        }
+        else if constexpr (STAGE)
         {
             constexpr int EW = (int)(sizeof(PoseEntry<KD>) / sizeof(double));
             const MBAVO_GLOBAL double *src = (const MBAVO_GLOBAL double *)ftab;
             for (int z = threadIdx.x; z < SS * EW; z += kSpWaves * 64) stage[z] = src[z];
             __syncthreads();
         }
+        // patch centres use sample S/2 (compute_local_patches_xy.cu:26)
+        double mid_rt[3], mid_q[4];
+        if constexpr (STAGE)
+        {
+            const PoseEntry<KD> &m = ((const PoseEntry<KD> *)stage)[SS / 2];
+            for (int i = 0; i < 3; ++i) mid_rt[i] = m.rt[i];
+            for (int i = 0; i < 4; ++i) mid_q[i] = m.q[i];
+        }
+        else
+        {
+            const PoseEntry<KD> &m = ftab[S / 2];
+            for (int i = 0; i < 3; ++i) mid_rt[i] = m.rt[i];
+            for (int i = 0; i < 4; ++i) mid_q[i] = m.q[i];
+        }
 
         OuterAcc<ND> acc;
         acc.init(lane);
         double *slab = rows + wave * SLAB;
         int nvalid = 0;
+        double cost_local = 0.0;
+        const double inv = d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals;
+        // Power-of-two patches that fit the pixels of one wave round (the 8-pixel pattern at S <= 8): the patch cost is
+        // reduced across the wave in the order of the reference's reduce() -- no rho scratch, no second pass.
+        const bool wave_patches = (P & (P - 1)) == 0 && P <= PXW;
 
         const int pw = lane >> LOGS, sidx = lane & (SS - 1), lane0 = lane & ~(SS - 1);
         const unsigned long long gmask = (SS == 64 ? ~0ull : ((1ull << SS) - 1ull)) << lane0;
@@ -745,15 +922,16 @@ namespace mbavo
             double res = 0.0, w = 0.0, rho = 0.0, cur = 0.0, val = 0.0;
             bool ok_l = false, flagged = false;
             double Jc[WITH_J ? 6 * KD : 1] = {};
+            int kp = 0;
             if (in)
             {
                 const int kpl = patch_of(g, P), pp = g - kpl * P;
-                const int kp = tile.kp_begin + kpl;
+                kp = tile.kp_begin + kpl;
                 flagged = d.outlier != nullptr && d.outlier[kp] == 1;
                 const double kx = d.kp_xy[(size_t)kp * d.kp_stride], ky = d.kp_xy[(size_t)kp * d.kp_stride + 1];
                 const double kz = d.kp_z[kp];
                 double pcx, pcy;
-                patch_centre_rt(mid.rt, mid.q, kx, ky, kz, cam, pcx, pcy);
+                patch_centre_rt(mid_rt, mid_q, kx, ky, kz, cam, pcx, pcy);
                 const int px = (int)(pcx + d.pattern[2 * pp]); // truncation, A3 (pixel_row)
                 const int py = (int)(pcy + d.pattern[2 * pp + 1]);
                 if (!(px < 0 || px > cam.W - 1 || py < 0 || py > cam.H - 1))
@@ -768,7 +946,7 @@ namespace mbavo
                         ok_l = f.taps.ok;
                         sample_retire<KD, WITH_J>(pe, f, ray, iz, cam, val, Jc);
                     };
-                    if (STAGE)
+                    if constexpr (STAGE)
                         one_sample(((const PoseEntry<KD> *)stage)[sidx]); // LDS
                     else
                         one_sample(ftab[sidx]);
@@ -781,7 +959,24 @@ namespace mbavo
             for (int j = 0; j < SS; ++j) isum += __shfl(val, lane0 + j, 64);
             if (valid) res = quotient(isum, fS) - cur;
             huber_weight(res, d.huber_a, w, rho);
-            if (in && sidx == 0)
+            if (wave_patches)
+            { // b[i] += b[i + s], s = P/2 .. 1 (reduction.h:43-54): pixel pw + s sits SS * s lanes up
+                double x = rho;
+                for (int st = P >> 1; st >= 1; st >>= 1) x = x + __shfl(x, lane + st * SS, 64);
+                if (in && sidx == 0)
+                {
+                    if ((pw & (P - 1)) == 0)
+                    {
+                        const double c = x * inv;
+                        const long long patch = (long long)frame * K + kp;
+                        if (patch_cost) patch_cost[d.patch_base + patch] = c;
+                        if (patch_blocks_strided) patch_blocks_strided[patch * E] = c;
+                        if (!flagged) cost_local += c;
+                    }
+                    nvalid += valid ? 1 : 0;
+                }
+            }
+            else if (in && sidx == 0)
             {
                 rho_out[pix0 + g] = rho;
                 nvalid += valid ? 1 : 0;
@@ -799,7 +994,7 @@ namespace mbavo
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 constexpr int NOUT = (6 * KD + SS - 1) / SS;
                 // dropped pixels park ZERO rows by a select (their contributions may be non-finite, see sp_round_rt)
-                const double inv = 1.0 / fS;
+                const double invS = 1.0 / fS;
                 double outv[NOUT];
 #pragma unroll
                 for (int t = 0; t < NOUT; ++t)
@@ -811,7 +1006,7 @@ namespace mbavo
 #pragma unroll
                         for (int j = 0; j < SS; ++j) a += slab[(lane0 + j) * RS + i];
                     }
-                    outv[t] = keep ? w * (a * inv) : 0.0;
+                    outv[t] = keep ? w * (a * invS) : 0.0;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -837,18 +1032,19 @@ namespace mbavo
 
         // per-patch cost = slot 0 of the reference's patch block (:232-238), and the
         // tile's share of the frame cost (outlier patches skipped, :265-272)
-        __syncthreads();
-        double cost_local = 0.0;
-        const double inv = d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals;
-        for (int kpl = threadIdx.x; kpl < tile.kp_count; kpl += kThreads)
-        {
-            const double *r = rho_out + pix0 + (long long)kpl * P;
-            const double c = patch_rho_sum(r, P) * inv; // reduction.h order
-            const int kp = tile.kp_begin + kpl;
-            const long long patch = (long long)frame * K + kp;
-            if (patch_cost) patch_cost[d.patch_base + patch] = c;
-            if (patch_blocks_strided) patch_blocks_strided[patch * E] = c;
-            if (!(d.outlier != nullptr && d.outlier[kp] == 1)) cost_local += c;
+        if (!wave_patches)
+        { // the patches' pixels were handled by other waves: their rho values are read back
+            __syncthreads();
+            for (int kpl = threadIdx.x; kpl < tile.kp_count; kpl += kThreads)
+            {
+                const double *r = rho_out + pix0 + (long long)kpl * P;
+                const double c = patch_rho_sum(r, P) * inv; // reduction.h order
+                const int kp = tile.kp_begin + kpl;
+                const long long patch = (long long)frame * K + kp;
+                if (patch_cost) patch_cost[d.patch_base + patch] = c;
+                if (patch_blocks_strided) patch_blocks_strided[patch * E] = c;
+                if (!(d.outlier != nullptr && d.outlier[kp] == 1)) cost_local += c;
+            }
         }
         const double wc = wave_sum(cost_local);
         const double wv = wave_sum((double)nvalid);
@@ -873,6 +1069,15 @@ namespace mbavo
                 tri_decode(e, ND, i, j);
                 out[e] = OuterAcc<ND>::gather(rows, i, j, kWavesPerGroup);
             }
+        }
+        if constexpr (ONE)
+        {
+            // scratch for the tile-lane sums: the slabs (every thread is past its gather after the barrier inside),
+            // or the kernel's epilogue area when there are none
+            double *scratch = WITH_J ? rows : stage + SS * (int)(sizeof(PoseEntry<KD>) / sizeof(double));
+#if !defined(MBAVO_EXP_ONE_NOTICKET) // timing experiment: no finalize at all
+            ticket_finalize<KD, WITH_J, kThreads>(d, d.bf_base + frame, partials, oa, scratch);
+#endif
         }
     }
 
@@ -964,7 +1169,8 @@ namespace mbavo
     {
         (void)comm_destroy();
         void *bufs[] = {d_descs_, d_tiles_, d_bf_tile_begin_, d_bf_prob_, d_entry_prob_, d_poses_, d_rho_, d_partials_,
-                        d_status_};
+                        d_status_, d_tickets_};
+        if (h_flag_) (void)hipHostFree(h_flag_);
         for (void *p : bufs)
             if (p) (void)hipFree(p);
         if (h_fb_) (void)hipHostFree(h_fb_);
@@ -1026,7 +1232,8 @@ namespace mbavo
 
     int Engine::rebuild_layout(int B, const mbavo_problem *probs, int kdeg, const int *d_active, const double *d_inv)
     {
-        std::vector<ProblemDesc> descs((size_t)B);
+        std::vector<ProblemDesc> &descs = scratch_descs_; // member: no allocation per call in the LM loop
+        descs.resize((size_t)B);
         long long pixels = 0, patches = 0;
         int entries = 0, bf = 0;
         for (int b = 0; b < B; ++b)
@@ -1128,7 +1335,7 @@ namespace mbavo
             max_tiles_per_bf = std::max(max_tiles_per_bf, bf_tile_begin[i + 1] - bf_tile_begin[i]);
         flat_finalize_ = bf_prob.size() >= 64 && max_tiles_per_bf <= 4;
 
-        h_descs_.swap(descs);
+        h_descs_ = descs;
         h_tiles_.swap(tiles);
         h_bf_tile_begin_.swap(bf_tile_begin);
         h_bf_prob_.swap(bf_prob);
@@ -1149,6 +1356,12 @@ namespace mbavo
         if ((rc = ensure(&d_poses_, &cap_poses_, pose_bytes + 64))) return rc; // + one cache line: the scalar-cache warm-up reads whole lines
         if ((rc = ensure(&d_rho_, &cap_rho_, (size_t)(pixels + 1) * sizeof(double)))) return rc;
         if ((rc = ensure(&d_partials_, &cap_partials_, (h_tiles_.size() + 1) * pstride * sizeof(double)))) return rc;
+        {   // ticket counters of the single-launch kernels: one per (problem, frame) slot + the slots-done counter;
+            // zero between launches by construction, so only (re)allocation clears them
+            const size_t before = cap_tickets_;
+            if ((rc = ensure(&d_tickets_, &cap_tickets_, (size_t)(bf + 1) * sizeof(int)))) return rc;
+            if (cap_tickets_ != before) HIP_TRY(hipMemsetAsync(d_tickets_, 0, cap_tickets_, stream_));
+        }
         if (!d_status_)
         { // out-of-range counter: only ever incremented by the pose kernel; fetch_status() reports the delta
             HIP_TRY(hipMalloc(&d_status_, sizeof(int)));
@@ -1179,17 +1392,39 @@ namespace mbavo
     } while (0)
 
     template <int KD, bool WITH_J>
-    static int launch_all(Engine *eng, hipStream_t st, int max_S, bool half_grad, int sp_logs, bool flat_finalize, const ProblemDesc *descs, const int *entry_prob, int entries, const TileDesc *tiles, int ntiles,
+    static int launch_all(Engine *eng, hipStream_t st, int max_S, bool half_grad, int sp_logs, bool one, bool flat_finalize, const ProblemDesc *descs, const int *entry_prob, int entries, const TileDesc *tiles, int ntiles,
                           const int *bf_prob, const int *bf_tile_begin, int nbf, void *poses, double *rho,
                           double *patch_cost, double *patch_blocks_strided, double *partials, int *status,
-                          double *frame_blocks, double *valid, const InlineKnots &ik)
+                          double *frame_blocks, double *valid, const OneArgs &oa)
     {
         PoseEntry<KD> *table = (PoseEntry<KD> *)poses;
+        if (one)
+        { // single launch: pose entries in the prologue, finalize by the last workgroup of every slot
+            if (ntiles == 0) return 0;
+#define MBAVO_SP_ONE(LG)                                                                                                       \
+    do                                                                                                                         \
+    {                                                                                                                          \
+        if constexpr (SpLds<KD, WITH_J, LG, true>::kFits)                                                                      \
+        {                                                                                                                      \
+            const size_t lds_sp = SpLds<KD, WITH_J, LG, true>::kBytes;                                                         \
+            HIP_TRY(eng->ensure_lds((const void *)k_fused_sp<KD, WITH_J, false, LG, true>, lds_sp));                           \
+            MBAVO_LAUNCH_TIMED((k_fused_sp<KD, WITH_J, false, LG, true>), dim3(ntiles), dim3(kSpWaves * 64), lds_sp, descs, tiles, \
+                               table, rho, patch_cost, patch_blocks_strided, partials, oa);                                    \
+        }                                                                                                                      \
+    } while (0)
+            switch (sp_logs)
+            {
+            case 2: MBAVO_SP_ONE(2); break;
+            case 3: MBAVO_SP_ONE(3); break;
+            case 4: MBAVO_SP_ONE(4); break;
+            default: MBAVO_SP_ONE(5); break;
+            }
+#undef MBAVO_SP_ONE
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
         const dim3 pose_grid((entries * (WITH_J ? 3 : 1) + 63) / 64, WITH_J ? KD : 1);
-        if (ik.n > 0)
-            hipLaunchKernelGGL((k_pose_table<KD, WITH_J, InlineKnots>), pose_grid, dim3(64), 0, st, descs, entry_prob, entries, table, status, ik);
-        else
-            hipLaunchKernelGGL((k_pose_table<KD, WITH_J, NoKnots>), pose_grid, dim3(64), 0, st, descs, entry_prob, entries, table, status, NoKnots());
+        hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), pose_grid, dim3(64), 0, st, descs, entry_prob, entries, table, status);
         if (ntiles > 0)
         {
             constexpr int kWavesPerGroup = waves_of<KD, WITH_J>(), kThreads = kWavesPerGroup * 64;
@@ -1210,10 +1445,10 @@ namespace mbavo
 #define MBAVO_SP_LAUNCH(LG)                                                                                                    \
     do                                                                                                                         \
     {                                                                                                                          \
-        const size_t lds_sp = SpLds<KD, WITH_J, LG>::kBytes;                                                                    \
-        HIP_TRY(eng->ensure_lds((const void *)k_fused_sp<KD, WITH_J, false, LG>, lds_sp));                                      \
-        MBAVO_LAUNCH_TIMED((k_fused_sp<KD, WITH_J, false, LG>), dim3(ntiles), dim3(kSpWaves * 64), lds_sp, descs, tiles, table, rho, \
-                           patch_cost, patch_blocks_strided, partials);                                                        \
+        const size_t lds_sp = SpLds<KD, WITH_J, LG, false>::kBytes;                                                             \
+        HIP_TRY(eng->ensure_lds((const void *)k_fused_sp<KD, WITH_J, false, LG, false>, lds_sp));                               \
+        MBAVO_LAUNCH_TIMED((k_fused_sp<KD, WITH_J, false, LG, false>), dim3(ntiles), dim3(kSpWaves * 64), lds_sp, descs, tiles, table, rho, \
+                           patch_cost, patch_blocks_strided, partials, oa);                                                    \
     } while (0)
                 switch (sp_logs)
                 {
@@ -1244,18 +1479,9 @@ namespace mbavo
 
     int Engine::evaluate(int B, const mbavo_problem *probs, int kdeg, bool with_hessian, double *d_frame_blocks,
                          double *d_patch_cost, double *d_valid, double *d_patch_blocks_strided, const int *d_active,
-                         const double *d_inv, const double *h_knots_t, const double *h_knots_R)
+                         const double *d_inv, bool signal_host)
     {
         if (B < 1 || !probs || !d_frame_blocks || (kdeg != 2 && kdeg != 4)) return MBAVO_E_ARG;
-        InlineKnots ik;
-        ik.n = 0;
-        if (h_knots_t || h_knots_R)
-        {
-            if (B != 1 || !h_knots_t || !h_knots_R || probs[0].N > 16) return MBAVO_E_ARG;
-            ik.n = probs[0].N;
-            memcpy(ik.t, h_knots_t, sizeof(double) * 3 * ik.n);
-            memcpy(ik.R, h_knots_R, sizeof(double) * 4 * ik.n);
-        }
         if (d_patch_blocks_strided && B != 1) return MBAVO_E_ARG;
         HIP_TRY(hipSetDevice(device_));
         int rc = rebuild_layout(B, probs, kdeg, d_active, d_inv);
@@ -1269,18 +1495,74 @@ namespace mbavo
         const bool half_grad = h_descs_[0].grad_fp16 != 0;
         for (const ProblemDesc &pd : h_descs_)
             if ((pd.grad_fp16 != 0) != half_grad) return MBAVO_E_ARG;
+        // small problems: ONE launch (pose entries in the fused kernel's prologue, finalize by the last workgroup of a slot)
+        // -- where it wins: k = 2 (two knots, one log / exp segment) and the cost-only passes (no pose Jacobians): the
+        // prologue costs ~2-4 us there.  The k = 4 chain with Jacobians (three segments, four knots: ~2 600 dependent
+        // instructions per wave, and vector spills at 12 waves per workgroup) costs 6-12 us, more than the two launches it
+        // saves (profiles/r02_single_launch_ab.txt).
+        // MBAVO_ONE=0 / 2 forces it off / on for every k.
+        const int one_env = env_int("MBAVO_ONE", 1);
+        const bool one = sp_logs_ > 0 && sp_one_fits(kdeg, sp_logs_) && (one_env == 2 || (one_env == 1 && (kdeg == 2 || !with_hessian)));
+        OneArgs oa;
+        memset(&oa, 0, sizeof(oa));
+        flag_pending_ = false;
+        if (one)
+        {
+            oa.bf_tile_begin = (const int *)d_bf_tile_begin_;
+            oa.tickets = (int *)d_tickets_;
+            oa.slots_done = (int *)d_tickets_ + total_bf_;
+            oa.frame_blocks = d_frame_blocks; oa.valid_out = d_valid; oa.status = (int *)d_status_;
+            oa.nbf = total_bf_;
+            if (signal_host && !d_active && ntiles > 0)
+            { // completion word in pinned host memory: the caller spins on it instead of synchronising the stream
+                if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 64, hipHostMallocDefault) != hipSuccess) h_flag_ = nullptr;
+                if (h_flag_)
+                {
+                    oa.host_flag = (unsigned long long *)h_flag_;
+                    oa.seq = ++flag_seq_;
+                    flag_pending_ = true;
+                }
+            }
+        }
 #define MBAVO_LAUNCH(KD, WJ)                                                                                      \
-    launch_all<KD, WJ>(this, stream_, max_S, half_grad, sp_logs_, flat_finalize_, descs, (const int *)d_entry_prob_, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
+    launch_all<KD, WJ>(this, stream_, max_S, half_grad, sp_logs_, one, flat_finalize_, descs, (const int *)d_entry_prob_, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
                        (const int *)d_bf_tile_begin_, total_bf_, d_poses_, (double *)d_rho_, d_patch_cost,        \
-                       d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid, ik)
+                       d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid, oa)
         if (kdeg == 4) rc = with_hessian ? MBAVO_LAUNCH(4, true) : MBAVO_LAUNCH(4, false);
         else rc = with_hessian ? MBAVO_LAUNCH(2, true) : MBAVO_LAUNCH(2, false);
 #undef MBAVO_LAUNCH
-        if (sp_logs_ > 0)
-            snprintf(last_kernel_, sizeof(last_kernel_), "k_fused_sp<%d,%s,false,%d>", kdeg, with_hessian ? "true" : "false", sp_logs_);
-        else
-            snprintf(last_kernel_, sizeof(last_kernel_), "k_fused<%d,%s,%s>", kdeg, with_hessian ? "true" : "false", half_grad ? "true" : "false");
+        last_kernel_id_[0] = kdeg; last_kernel_id_[1] = with_hessian; last_kernel_id_[2] = half_grad; last_kernel_id_[3] = sp_logs_;
+        last_kernel_id_[4] = one;
         return rc;
+    }
+
+    // Wait for the evaluation just enqueued: spin on the completion word the last workgroup writes to pinned host memory
+    // (~1 us after the kernel's last store, against the ~10 us a stream synchronisation takes to notice), falling back
+    // to the stream when no word was armed or it does not arrive.
+    int Engine::wait_evaluation()
+    {
+        if (flag_pending_ && h_flag_)
+        {
+            volatile unsigned long long *f = (volatile unsigned long long *)h_flag_;
+            for (long spins = 0; spins < 20000000L; ++spins)
+            {
+                if (*f == flag_seq_) { flag_pending_ = false; return 0; }
+                __builtin_ia32_pause();
+            }
+        }
+        flag_pending_ = false;
+        return (int)hipStreamSynchronize(stream_);
+    }
+
+    const char *Engine::last_kernel()
+    {
+        const int *k = last_kernel_id_;
+        if (k[0] == 0) last_kernel_[0] = 0;
+        else if (k[3] > 0)
+            snprintf(last_kernel_, sizeof(last_kernel_), "k_fused_sp<%d,%s,false,%d,%s>", k[0], k[1] ? "true" : "false", k[3], k[4] ? "true" : "false");
+        else
+            snprintf(last_kernel_, sizeof(last_kernel_), "k_fused<%d,%s,%s>", k[0], k[1] ? "true" : "false", k[2] ? "true" : "false");
+        return last_kernel_;
     }
 
     void Engine::profile_enable(int every)

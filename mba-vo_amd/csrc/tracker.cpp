@@ -11,6 +11,7 @@
 // radius and outlier flags are reset per level, the spline is warm-started (:590-606).
 #include "tracker.h"
 #include "host_math.h"
+#include "timing.h"
 
 #include <cmath>
 #include <cstdio>
@@ -89,7 +90,9 @@ namespace mbavo
         // engine-owned scratch, reused by every call (no hipMalloc / hipFree in the tracking loop)
         d_cap = (double *)eng.named_scratch(0, sizeof(double) * F);
         d_exp = (double *)eng.named_scratch(1, sizeof(double) * F);
-        d_kt = (double *)eng.named_scratch(2, sizeof(double) * 7 * N); // [t (3N) | R (4N)]: one upload per evaluation
+        // the knots live in pinned, device-visible host memory [t (3N) | R (4N)]: the host writes them before an
+        // evaluation and the kernels' pose prologue reads them over the bus -- no copy, no launch
+        d_kt = (double *)eng.pinned_scratch(2, sizeof(double) * 7 * N);
         d_kR = d_kt ? d_kt + 3 * N : nullptr;
         // the per-patch costs land in pinned host memory (written by the fused kernel, read by detect_outliers after the
         // evaluation's synchronisation: no D2H copy); the flags are staged in pinned memory so that their upload is a
@@ -121,18 +124,29 @@ namespace mbavo
             p.d_knots_t = d_kt; p.d_knots_R = d_kR; p.h_start_idx = start_idx.data(); p.huber_a = o.huber_k;
 
             bool check_range = true;
-            // one evaluation at the given knots: H2D knots, fused pass, D2H F*E doubles, host scatter
+            // one evaluation at the given knots: knots into the pinned buffer, ONE launch for these problem sizes (pose
+            // prologue + fused + last-workgroup finalize) whose frame blocks land in pinned host memory (h_pin), then a
+            // spin on the kernel's completion word: no copies, no stream synchronisation
             auto evaluate = [&](const double *kt, const double *kR, bool with_h, double *cost) -> int {
-                hipError_t e;
-                // no copies: the knots travel as kernel arguments of the pose kernel and the finalize kernel writes the
-                // F*E doubles straight into pinned host memory (h_pin); one stream synchronisation per evaluation
-                int r = eng.evaluate(1, &p, k, with_h, h_pin, d_pc, nullptr, nullptr, nullptr, nullptr, kt, kR);
+                int r;
+                {
+                    PhaseScope ps(PhaseTimers::kEnqueue);
+                    memcpy(d_kt, kt, sizeof(double) * 3 * N);
+                    memcpy(d_kR, kR, sizeof(double) * 4 * N);
+                    r = eng.evaluate(1, &p, k, with_h, h_pin, d_pc, nullptr, nullptr, nullptr, nullptr, true);
+                }
                 if (r) return r;
-                if ((e = hipStreamSynchronize(st)) != hipSuccess) return (int)e;
+                {
+                    PhaseScope ps(PhaseTimers::kWait);
+                    r = eng.wait_evaluation();
+                }
+                if (r) return r;
+                PhaseScope ps(PhaseTimers::kMerge);
                 memcpy(fb.data(), h_pin, sizeof(double) * (size_t)F * E);
                 if (check_range) // depends on the times only, not on the knot values: once per level
                 {
                     check_range = false;
+                    if ((r = (int)hipStreamSynchronize(st)) != 0) return r;
                     if (eng.fetch_status() != 0) return MBAVO_E_RANGE;
                 }
                 merge_blocks_host(F, k, fb.data(), start_idx.data(), N, cost, with_h ? H.data() : nullptr,
@@ -164,6 +178,7 @@ namespace mbavo
                 if (abs_dec < o.min_abs_cost_decrease) break;
 
                 // computeTrustRegionStep (:799-831)
+                PhaseScope ps_solve(PhaseTimers::kSolve);
                 const double iradius = 1. / lm.get_radius();
                 for (int i = 0; i < n; ++i) H[(size_t)i * n + i] += H[(size_t)i * n + i] * iradius;
                 if (solve_normal_equation_host(H.data(), g.data(), n, o.solver_type, step.data()) < 0) { rc_ = MBAVO_E_ARG; goto done; }
@@ -176,6 +191,8 @@ namespace mbavo
                     xHx += step[r] * a;
                 }
                 const double model = -(gx + 0.5 * xHx);
+                ps_solve.~PhaseScope();
+                ps_solve.on = false;
                 if (model < 0) { lm.step_rejected(); record(iter, 3, 0.0, model, 0.0); continue; } // handleInvalidStep
 
                 // computeCandidatePointAndEvaluateCost (:833-883)
@@ -188,8 +205,11 @@ namespace mbavo
                 const double quality = evaluator.StepQuality(cand_cost, model);
                 if (quality > o.min_step_quality && cand_cost < eval_cost)
                 { // isStepSuccessful (:890-894) -> detectOutliers + handleSuccessfulStep (:896-903)
-                    p.num_bad = detect_outliers(d_pc, L.K, o.max_chi_square_error, flags); // frame 0's costs, just written
-                    TRK_HIP(hipMemcpyAsync(d_flags, flags, L.K, hipMemcpyHostToDevice, st));
+                    {
+                        PhaseScope ps(PhaseTimers::kOutliers);
+                        p.num_bad = detect_outliers(d_pc, L.K, o.max_chi_square_error, flags); // frame 0's costs, just written
+                        TRK_HIP(hipMemcpyAsync(d_flags, flags, L.K, hipMemcpyHostToDevice, st));
+                    }
                     spline.InvalidParameter(cand_t.data(), cand_R.data());
                     if ((rc_ = evaluate(spline.get_knot_data_t(), spline.get_knot_data_R(), true, &eval_cost))) goto done;
                     lm.step_accepted(quality);

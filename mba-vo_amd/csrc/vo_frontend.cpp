@@ -1,6 +1,7 @@
 // vo_frontend.cpp -- BlurAwareDirectTracker::trackFrame and its helpers on device-resident pyramids
 // (ba_tracker/blur_aware_direct_tracker.cpp:14-415); see vo_frontend.h.
 #include "vo_frontend.h"
+#include "timing.h"
 #include "../../include/mbavo.h"
 #include "se3_math.h"
 #include "tracker.h"
@@ -206,6 +207,7 @@ namespace SLAM
 
         int BlurAwareDirectTracker::tmpProcessKeyframe(const FrameView &kf, const float *depth_z)
         { // blur_aware_direct_tracker.cpp:342-415: pyramid, gradients, semi-dense keypoints with depth -- all on device
+            mbavo::PhaseScope ps(mbavo::PhaseTimers::kKeyframe);
             const int H = mOptions.im_size_HW[0], W = mOptions.im_size_HW[1], L = mOptions.num_pyramid_levels;
             hipStream_t st = mEngine.stream();
             VO_HIP(hipMemcpyAsync(mRef[0], kf.image, (size_t)H * W, hipMemcpyHostToDevice, st));
@@ -235,6 +237,7 @@ namespace SLAM
 
         int BlurAwareDirectTracker::uploadCurrentFrame(const FrameView &f)
         { // :112-117: pyramid of the blurred frame, on device
+            mbavo::PhaseScope ps(mbavo::PhaseTimers::kUpload);
             const int H = mOptions.im_size_HW[0], W = mOptions.im_size_HW[1];
             hipStream_t st = mEngine.stream();
             VO_HIP(hipMemcpyAsync(mCur[0], f.image, (size_t)H * W, hipMemcpyHostToDevice, st));

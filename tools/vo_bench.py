@@ -22,7 +22,11 @@ seq = frontend.make_sequence(orc, H=480, W=640, M=M, trans_scale=0.15, rot_scale
 cfg = dict(frontend.DEFAULTS, levels=4, S=(8, 8, 8, 8), thr=3.0, cell=30, flow0=10.0, flow1=24.0)
 ctx = mbavo.capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 frontend.run_gpu_vo(mbavo, ctx, seq, cfg)  # warm-up (allocations, code objects)
+if os.environ.get('MBAVO_TIMING'):
+    print('-- warm-up run', file=sys.stderr); ctx.lib.mbavo_timing_report()
 t = time.perf_counter(); got = frontend.run_gpu_vo(mbavo, ctx, seq, cfg); t_gpu = time.perf_counter() - t
+if os.environ.get('MBAVO_TIMING'):
+    print('-- timed run', file=sys.stderr); ctx.lib.mbavo_timing_report()
 t = time.perf_counter(); want = frontend.run_oracle_vo(orc, seq, cfg); t_cpu = time.perf_counter() - t
 gt = frontend.gt_relative(orc, seq)
 err = [frontend.reprojection_error(seq, o["T"], g)[0] for o, g in zip(got[1:], gt[1:])]
