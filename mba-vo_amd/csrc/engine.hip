@@ -434,8 +434,13 @@ namespace mbavo
         }
     }
 
+#if defined(MBAVO_MIN_WAVES_EU) // experiments with several smaller workgroups per CU: keep the 3-waves-per-SIMD register budget
+#define MBAVO_FUSED_OCC __attribute__((amdgpu_waves_per_eu(MBAVO_MIN_WAVES_EU)))
+#else
+#define MBAVO_FUSED_OCC
+#endif
     template <int KD, bool WITH_J, bool HALF_GRAD>
-    __global__ __launch_bounds__((waves_of<KD, WITH_J>() * 64)) void k_fused(const ProblemDesc *__restrict__ descs,
+    __global__ __launch_bounds__((waves_of<KD, WITH_J>() * 64)) MBAVO_FUSED_OCC void k_fused(const ProblemDesc *__restrict__ descs,
                                                         const TileDesc *__restrict__ tiles,
                                                         const PoseEntry<KD> *__restrict__ table,
                                                         double *__restrict__ rho_out,
