@@ -16,6 +16,10 @@ pytestmark = pytest.mark.gpu
     ("k2_semidense", dict(H=120, W=160, levels=3, S=8, k=2, seed=2)),
     ("k4_dense_2frames", dict(H=96, W=128, levels=2, S=4, k=4, F=2, seed=3, mode="dense")),
     ("k4_ldlt", dict(H=120, W=160, levels=3, S=8, k=4, seed=4)),
+    # BASELINE size: 640x480, 4-level pyramid, 8 blur samples (configs[1]), ~1 080 semi-dense keypoints x 8-pixel pattern
+    ("k4_fullsize", dict(H=480, W=640, levels=4, S=8, k=4, seed=5)),
+    ("k2_fullsize", dict(H=480, W=640, levels=4, S=8, k=2, seed=6)),
+    ("k4_fullsize_2frames", dict(H=480, W=640, levels=4, S=8, k=4, F=2, seed=7)),
 ])
 def test_tracker_matches_oracle(orc, mbavo, gpu_ctx, name, kw):
     sc = tracking.make_tracking_scene(orc, **kw)
