@@ -443,14 +443,18 @@ namespace mbavo
             if (lds > 48 * 1024)
             { // more than 8 control knots: the three n x n areas need the large-LDS attribute
                 if (k == 4) LM_HIP(hipFuncSetAttribute((const void *)k_lm_solve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#if !defined(MBAVO_LM_K4_ONLY) // reproducer variant (tools/micro/lm_solve_calls.sh): one kernel only reaches the solvers
                 else LM_HIP(hipFuncSetAttribute((const void *)k_lm_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#endif
             }
             for (int slot = 0; slot <= o.max_it + 1; ++slot)
             {
                 if (k == 4)
                     hipLaunchKernelGGL((k_lm_solve<4>), dim3(B), dim3(64), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
+#if !defined(MBAVO_LM_K4_ONLY)
                 else
                     hipLaunchKernelGGL((k_lm_solve<2>), dim3(B), dim3(64), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
+#endif
                 if (slot % sync_every == sync_every - 1 || slot == o.max_it + 1)
                 {
                     LM_HIP(hipMemcpyAsync(&h_done, num_done, sizeof(int), hipMemcpyDeviceToHost, st));

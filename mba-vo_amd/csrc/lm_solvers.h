@@ -7,12 +7,47 @@
 
 #include <cfloat>
 #include <hip/hip_runtime.h>
-// Several lanes per column pair (svd_sweeps<2>, <4>).  All solver functions are force-inlined: as real (called)
-// device functions the multi-lane variant faulted inside k_lm_solve on this toolchain -- rocgdb showed the `lane`
-// argument of svd_solve corrupted after the sweeps (HSA aperture violation on the next LDS access through a
-// generic pointer) -- while the same code passed the standalone check; inlined it is correct in both.
+// Several lanes per column pair (svd_sweeps<2>, <4>).
+// All solver functions are force-inlined.  As real (called) device functions they fault inside k_lm_solve
+// (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION) while passing the standalone check -- root cause (round 2, rocgdb +
+// ISA, profiles/r02_lm_solve_fault.txt; reproducer tools/micro/lm_solve_calls.sh): a MISCOMPILE of the CALLER by this
+// toolchain (ROCm 7.2.0, AMD clang 22.0.0git roc-7.2.0, -O2 / -O3; -O1 is correct).  To keep `lane` alive across the call
+// the register allocator copies it into a callee-saved VGPR (v_mov_b32 v40, v0) and places that copy in the exit block of
+// the preceding divergent loop (the H -> G copy) BEFORE the s_or_b64 that restores the exec mask: the loop leaves with
+// exec == 0, so the copy writes no lane and the callee receives whatever v40 held.  The solvers themselves are not at
+// fault (no lane of theirs touches another's data out of turn; the standalone kernel's block layout happens to be
+// compiled correctly); inlined there is no call and no copy.
 #ifndef MBAVO_SVD_MULTILANE
 #define MBAVO_SVD_MULTILANE 1
+#endif
+
+// -DMBAVO_SOLVERS_NOINLINE builds the three solver entry points as real (called) device functions: the configuration
+// that faulted in round 1; kept as a build variant for the reproducer (tools/micro/lm_solve_calls.sh).
+#if defined(MBAVO_SOLVERS_LDS_PTR) // experiment: the matrices as LDS-typed pointers instead of generic ones
+#define MBAVO_LDS __attribute__((address_space(3)))
+#else
+#define MBAVO_LDS
+#endif
+#if defined(MBAVO_SOLVERS_NOINLINE)
+#define MBAVO_SOLVER_FN __device__ __noinline__
+#else
+#define MBAVO_SOLVER_FN __device__ __forceinline__
+#endif
+// finer switches of the reproducer: one function at a time as a real call
+#if defined(MBAVO_NOINLINE_SWEEPS)
+#define MBAVO_SWEEPS_FN __device__ __noinline__
+#else
+#define MBAVO_SWEEPS_FN MBAVO_SOLVER_FN
+#endif
+#if defined(MBAVO_NOINLINE_SVD)
+#define MBAVO_SVD_FN __device__ __noinline__
+#else
+#define MBAVO_SVD_FN MBAVO_SOLVER_FN
+#endif
+#if defined(MBAVO_NOINLINE_LDLT)
+#define MBAVO_LDLT_FN __device__ __noinline__
+#else
+#define MBAVO_LDLT_FN MBAVO_SOLVER_FN
 #endif
 
 namespace mbavo
@@ -42,7 +77,7 @@ namespace mbavo
         // One sweep structure for SUB lanes per column pair: the N six-row groups of a column are dealt out to the SUB
         // lanes of a pair, partial dot products meet by xor-shuffles inside the (adjacent) lane group.
         template <int SUB>
-        __device__ __forceinline__ bool svd_sweeps(double *G, double *V, int n, int ld, int lane)
+        MBAVO_SWEEPS_FN bool svd_sweeps(double *G, double *V, int n, int ld, int lane)
         {
             const double eps = DBL_EPSILON;
             const int half = n / 2, m1 = n - 1, N6 = n / 6; // n = 6N is even
@@ -106,7 +141,7 @@ namespace mbavo
             return false;
         }
 
-        __device__ __forceinline__ void svd_solve(double *G, double *V, const double *b, double *x, double *tmp, int n, int ld, int lane)
+        MBAVO_SVD_FN void svd_solve(double *G, double *V, const double *b, double *x, double *tmp, int n, int ld, int lane)
         {
             for (int i = lane; i < n * n; i += 64) V[(i / n) * ld + i % n] = (i / n == i % n) ? 1.0 : 0.0;
             __syncthreads();
@@ -150,7 +185,7 @@ namespace mbavo
         }
 
         // x = A^-1 b by LDL^T with diagonal pivoting (host_math.cpp:solve_ldlt); M holds A on entry
-        __device__ __forceinline__ void ldlt_solve(double *M, const double *b, double *x, double *y, int *order, int n, int lane)
+        MBAVO_LDLT_FN void ldlt_solve(double *M, const double *b, double *x, double *y, int *order, int n, int lane)
         {
             for (int i = lane; i < n; i += 64) order[i] = i;
             __syncthreads();
@@ -171,6 +206,7 @@ namespace mbavo
                     const int op = __shfl_xor(piv, o, 64);
                     if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
                 }
+                if (piv == 0x7fffffff) piv = k; // every remaining diagonal entry is NaN: the host scan keeps k (no swap)
                 // the host scan keeps k unless a later entry is strictly larger: identical to first-maximum
                 if (piv != k)
                 {
