@@ -473,6 +473,24 @@ namespace mbavo
                                const unsigned char *__restrict__ I, const float *__restrict__ G, SampleInFlight &f)
     {
         const double *R = pe.R;
+#if defined(MBAVO_UV_NO_CONTRACT)
+        // Experiment (profiles/r02_ablations.txt): the whole warp up to the tap coordinates without FMA contraction, as the
+        // oracle rounds it.  It does NOT make the coordinates bit-identical -- the pose entries (R, t) come out of a
+        // log / exp / sin / cos chain evaluated by different math libraries on the two sides -- and costs instructions.
+        double u, v;
+        {
+#pragma clang fp contract(off)
+            f.rx = R[0] * ray[0] + R[1] * ray[1] + R[2] * ray[2];
+            f.ry = R[3] * ray[0] + R[4] * ray[1] + R[5] * ray[2];
+            const double rz = R[6] * ray[0] + R[7] * ray[1] + R[8] * ray[2];
+            f.C1 = reciprocal(rz);
+            f.sc = (D - pe.t[2]) * f.C1;
+            const double Px = f.sc * f.rx + pe.t[0];
+            const double Py = f.sc * f.ry + pe.t[1];
+            u = cam.fx * (Px * iz) + cam.cx;
+            v = cam.fy * (Py * iz) + cam.cy;
+        }
+#else
         f.rx = R[0] * ray[0] + R[1] * ray[1] + R[2] * ray[2];
         f.ry = R[3] * ray[0] + R[4] * ray[1] + R[5] * ray[2];
         const double rz = R[6] * ray[0] + R[7] * ray[1] + R[8] * ray[2];
@@ -487,6 +505,7 @@ namespace mbavo
         }
         const double u = cam.fx * (Px * iz) + cam.cx;
         const double v = cam.fy * (Py * iz) + cam.cy;
+#endif
         tap_fetch<WITH_J, HALF_GRAD>(I, G, cam.H, cam.W, u, v, f.taps);
     }
 

@@ -16,6 +16,8 @@ import test_gpu_fuzz as T
 orc.build()
 M.load()
 ctx = M.capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+if os.environ.get("MBAVO_FUZZ_FLAT_TOL"):  # experiment: a flat 1e-9 instead of the small-problem allowance of _tol()
+    T._tol = lambda sc: 1e-9
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 bad = 0

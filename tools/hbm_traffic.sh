@@ -14,7 +14,7 @@ for _ in range(5):
 torch.cuda.synchronize()
 PY
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d "$OUT/bench_$C" -o p -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline $HBM_BENCH_ARGS > /dev/null 2> "$OUT/err_$C.txt"
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/bench_$C" -o p -- python bench.py --steps 20 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-configs $HBM_BENCH_ARGS > /dev/null 2> "$OUT/err_$C.txt"
   rocprofv3 --pmc $C --output-format csv -d "$OUT/calib_$C" -o p -- python /tmp/calib.py > /dev/null 2>> "$OUT/err_$C.txt"
 done
 python - "$OUT" <<'PY'
@@ -33,4 +33,7 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
                 res["%s|%s|%s" % (kind, C, k)] = dict(mean=sum(v) / len(v), n=len(v))
 print(json.dumps(res, indent=1))
 json.dump(res, open(out + "/hbm_counters.json", "w"), indent=1)
+import os
+if os.environ.get("HBM_OUT"):
+    json.dump(res, open(os.environ["HBM_OUT"], "w"), indent=1)
 PY

@@ -6,20 +6,8 @@ TAG=${1:-r01}; shift || true
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT" profiles
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o trace -- python bench.py --no-cpu-baseline "$@" > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o trace -- python bench.py --no-cpu-baseline --no-configs "$@" > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
 STATS=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
 cp "$STATS" profiles/${TAG}_kernel_stats.csv
 tail -1 "$OUT/bench.json" > profiles/${TAG}_bench_under_rocprof.json
-# per-kernel register / LDS footprint from the trace
-TRACE=$(find "$OUT" -name "*kernel_trace.csv" | head -1)
-python - "$TRACE" > profiles/${TAG}_kernel_resources.txt <<'PY'
-import csv, sys
-seen = {}
-for r in csv.DictReader(open(sys.argv[1])):
-    n = r["Kernel_Name"]
-    if n not in seen:
-        seen[n] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
-for n, v in seen.items():
-    print(n[:100], v)
-PY
 cat profiles/${TAG}_kernel_stats.csv | cut -c1-200
