@@ -134,6 +134,21 @@ def executed_fp64_flops(workload, kernel):
     return None, None
 
 
+def issue_busy_fraction(workload, kernel, k_ms):
+    """Share of the kernel's duration in which a SIMD's VALU / matrix issue port is busy, from the committed SQ counters
+    (tools/pmc_all.sh): ((SQ_INSTS_VALU - SQ_INSTS_MFMA) x 4 cycles + SQ_VALU_MFMA_BUSY_CYCLES) / 1024 SIMDs / kernel
+    cycles at the nominal 2.4 GHz.  Counts every vector instruction (fp32 bilinear, integer, moves), not only flops."""
+    h, src = committed_counters("pmc_sq", workload)
+    if h is None or k_ms <= 0:
+        return None
+    base = kernel.split("<")[0]
+    for k, v in h.items():
+        if base + "<" in k and "SQ_INSTS_VALU" in v and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+            cyc = (v["SQ_INSTS_VALU"] - v.get("SQ_INSTS_MFMA", 0.0)) * 4.0 + v["SQ_VALU_MFMA_BUSY_CYCLES"]
+            return round(cyc / 1024.0 / (k_ms * 1e-3 * 2.4e9), 4)
+    return None
+
+
 def cpu_baseline(probs, budget_s):
     """The reference's per-sample code (oracle/_ref; kind "reference") or the oracle's fused port (kind "port") timed on
     the host cores on the SAME workload: one sample on 1 thread and one on all host threads, each bounded by `budget_s`
@@ -370,13 +385,15 @@ def main():
                          "frac": round(ach_tf / FP64_PEAK_TFLOPS, 5),
                          "frac_executed": round(exe / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5) if exe and k_ms > 0 else None,
                          "executed_fp64_flops_per_launch": exe, "executed_source": exe_src,
+                         "issue_busy_frac": issue_busy_fraction(args.workload, kernel, k_ms),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel, "kernel_ms": round(k_ms, 6), "launches_timed": int(nlaunch[0]),
                          "algorithmic_flops_per_launch": flops,
                          "note": "binding roofline = the FP64 pipe (FP64 VALU and f64 MFMA share it; 78.6 TFLOP/s; this is "
                                  "the contract's 'mfma' bound): intensity ~150 flop/B >> 9.8 flop/B balance.  frac counts flops "
                                  "as the reference source writes them (SURVEY.md 8d) and can exceed 1 because the kernel "
-                                 "applies CSE; frac_executed counts the FP64 flops the kernel issues (SQ counters) and cannot"},
+                                 "applies CSE; frac_executed counts the FP64 flops the kernel issues (SQ counters) and cannot; "
+                                 "issue_busy_frac = share of SIMD issue cycles taken by ANY vector / matrix instruction"},
             "roofline_hbm": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": nbytes,
                              "traffic": traffic,
