@@ -128,11 +128,9 @@ namespace mbavo
         int sp_logs_ = 0; // > 0: the cached layout is tiled for the sample-parallel kernel with S = 2^sp_logs_
         bool flat_finalize_ = false; // many (problem, frame) slots of <= 4 tiles each: k_finalize_flat
 
-        void *d_descs_ = nullptr; size_t cap_descs_ = 0;
-        void *d_tiles_ = nullptr; size_t cap_tiles_ = 0;
-        void *d_bf_tile_begin_ = nullptr; size_t cap_bf_ = 0;
-        void *d_bf_prob_ = nullptr; size_t cap_bfp_ = 0;
-        void *d_entry_prob_ = nullptr; size_t cap_ep_ = 0;
+        void *d_layout_ = nullptr; size_t cap_layout_ = 0; // one arena: descs | tiles | bf_tile_begin | bf_prob | entry_prob
+        std::vector<char> h_layout_;
+        void *d_descs_ = nullptr, *d_tiles_ = nullptr, *d_bf_tile_begin_ = nullptr, *d_bf_prob_ = nullptr, *d_entry_prob_ = nullptr;
         void *d_poses_ = nullptr; size_t cap_poses_ = 0;
         void *d_rho_ = nullptr; size_t cap_rho_ = 0;
         void *d_partials_ = nullptr; size_t cap_partials_ = 0;

@@ -20,6 +20,7 @@
 #include <hip/hip_ext.h>
 #include "pixel_math.h"
 #include "se3_math.h"
+#include "timing.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -1173,7 +1174,7 @@ namespace mbavo
     Engine::~Engine()
     {
         (void)comm_destroy();
-        void *bufs[] = {d_descs_, d_tiles_, d_bf_tile_begin_, d_bf_prob_, d_entry_prob_, d_poses_, d_rho_, d_partials_,
+        void *bufs[] = {d_layout_, d_poses_, d_rho_, d_partials_,
                         d_status_, d_tickets_};
         if (h_flag_) (void)hipHostFree(h_flag_);
         for (void *p : bufs)
@@ -1353,11 +1354,24 @@ namespace mbavo
         const size_t pose_bytes = (size_t)entries * (kdeg == 2 ? sizeof(PoseEntry<2>) : sizeof(PoseEntry<4>));
         const size_t pstride = kdeg == 2 ? Pack<2>::PSTRIDE : Pack<4>::PSTRIDE;
         int rc;
-        if ((rc = ensure(&d_descs_, &cap_descs_, h_descs_.size() * sizeof(ProblemDesc)))) return rc;
-        if ((rc = ensure(&d_tiles_, &cap_tiles_, (h_tiles_.size() + 1) * sizeof(TileDesc)))) return rc;
-        if ((rc = ensure(&d_bf_tile_begin_, &cap_bf_, h_bf_tile_begin_.size() * sizeof(int)))) return rc;
-        if ((rc = ensure(&d_bf_prob_, &cap_bfp_, (h_bf_prob_.size() + 1) * sizeof(int)))) return rc;
-        if ((rc = ensure(&d_entry_prob_, &cap_ep_, h_entry_prob_.size() * sizeof(int)))) return rc;
+        // descriptors, tiles and index tables live in ONE device arena filled by ONE copy: a pageable H2D copy is staged
+        // synchronously by the runtime (~2.5 us each), and the layout changes with every pyramid level and every outlier
+        // update of the LM loop -- five copies were half of that loop's enqueue time (host phase timers)
+        auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t o_descs = 0, o_tiles = align(h_descs_.size() * sizeof(ProblemDesc));
+        const size_t o_bf = o_tiles + align((h_tiles_.size() + 1) * sizeof(TileDesc));
+        const size_t o_bfp = o_bf + align(h_bf_tile_begin_.size() * sizeof(int));
+        const size_t o_ep = o_bfp + align((h_bf_prob_.size() + 1) * sizeof(int));
+        const size_t layout_bytes = o_ep + align(h_entry_prob_.size() * sizeof(int));
+        if ((rc = ensure(&d_layout_, &cap_layout_, layout_bytes))) return rc;
+        d_descs_ = (char *)d_layout_ + o_descs; d_tiles_ = (char *)d_layout_ + o_tiles; d_bf_tile_begin_ = (char *)d_layout_ + o_bf;
+        d_bf_prob_ = (char *)d_layout_ + o_bfp; d_entry_prob_ = (char *)d_layout_ + o_ep;
+        h_layout_.resize(layout_bytes);
+        memcpy(h_layout_.data() + o_descs, h_descs_.data(), h_descs_.size() * sizeof(ProblemDesc));
+        if (!h_tiles_.empty()) memcpy(h_layout_.data() + o_tiles, h_tiles_.data(), h_tiles_.size() * sizeof(TileDesc));
+        memcpy(h_layout_.data() + o_bf, h_bf_tile_begin_.data(), h_bf_tile_begin_.size() * sizeof(int));
+        if (!h_bf_prob_.empty()) memcpy(h_layout_.data() + o_bfp, h_bf_prob_.data(), h_bf_prob_.size() * sizeof(int));
+        memcpy(h_layout_.data() + o_ep, h_entry_prob_.data(), h_entry_prob_.size() * sizeof(int));
         if ((rc = ensure(&d_poses_, &cap_poses_, pose_bytes + 64))) return rc; // + one cache line: the scalar-cache warm-up reads whole lines
         if ((rc = ensure(&d_rho_, &cap_rho_, (size_t)(pixels + 1) * sizeof(double)))) return rc;
         if ((rc = ensure(&d_partials_, &cap_partials_, (h_tiles_.size() + 1) * pstride * sizeof(double)))) return rc;
@@ -1372,13 +1386,8 @@ namespace mbavo
             HIP_TRY(hipMalloc(&d_status_, sizeof(int)));
             HIP_TRY(hipMemset(d_status_, 0, sizeof(int)));
         }
-        // pageable copies are staged synchronously by the runtime, so the vectors may change afterwards
-        HIP_TRY(hipMemcpyAsync(d_descs_, h_descs_.data(), h_descs_.size() * sizeof(ProblemDesc), hipMemcpyHostToDevice, stream_));
-        if (!h_tiles_.empty())
-            HIP_TRY(hipMemcpyAsync(d_tiles_, h_tiles_.data(), h_tiles_.size() * sizeof(TileDesc), hipMemcpyHostToDevice, stream_));
-        HIP_TRY(hipMemcpyAsync(d_bf_tile_begin_, h_bf_tile_begin_.data(), h_bf_tile_begin_.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-        HIP_TRY(hipMemcpyAsync(d_bf_prob_, h_bf_prob_.data(), h_bf_prob_.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-        HIP_TRY(hipMemcpyAsync(d_entry_prob_, h_entry_prob_.data(), h_entry_prob_.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+        // a pageable copy is staged synchronously by the runtime, so the host buffer may change afterwards
+        HIP_TRY(hipMemcpyAsync(d_layout_, h_layout_.data(), layout_bytes, hipMemcpyHostToDevice, stream_));
         layout_uploaded_ = true;
         return 0;
     }
@@ -1488,8 +1497,15 @@ namespace mbavo
     {
         if (B < 1 || !probs || !d_frame_blocks || (kdeg != 2 && kdeg != 4)) return MBAVO_E_ARG;
         if (d_patch_blocks_strided && B != 1) return MBAVO_E_ARG;
-        HIP_TRY(hipSetDevice(device_));
-        int rc = rebuild_layout(B, probs, kdeg, d_active, d_inv);
+        int rc;
+        {
+            PhaseScope ps_layout(PhaseTimers::kOther);
+            // hipSetDevice costs ~5 us per call on this runtime (measured with the host phase timers: it was two thirds of
+            // the enqueue time of an evaluation); hipGetDevice is a thread-local read
+            int cur = -1;
+            if (hipGetDevice(&cur) != hipSuccess || cur != device_) HIP_TRY(hipSetDevice(device_));
+            rc = rebuild_layout(B, probs, kdeg, d_active, d_inv);
+        }
         if (rc) return rc;
         const ProblemDesc *descs = (const ProblemDesc *)d_descs_;
         const TileDesc *tiles = (const TileDesc *)d_tiles_;

@@ -236,7 +236,9 @@ namespace mbavo
             bf += p.F;
             sys += len;
         }
-        hipError_t e = hipSetDevice(device_);
+        hipError_t e = hipSuccess;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != device_) e = hipSetDevice(device_); // ~5 us per call on this runtime
         if (e != hipSuccess) return (int)e;
         // descriptors and start indices are re-uploaded only when they change (pageable source: the runtime stages the
         // copy before returning, so the vectors may go away)

@@ -11,6 +11,7 @@
 // radius and outlier flags are reset per level, the spline is warm-started (:590-606).
 #include "tracker.h"
 #include "host_math.h"
+#include "se3_math.h"
 #include "timing.h"
 
 #include <cmath>
@@ -74,7 +75,7 @@ namespace mbavo
         for (int f = 0; f < F; ++f) start_idx[f] = (int)((h_cap[f] - t0) / dt); // :549-560
         if (start_idx_out) memcpy(start_idx_out, start_idx.data(), sizeof(int) * F);
 
-        std::vector<double> H((size_t)n * n), g(n), step(n), cand_t(3 * N), cand_R(4 * N), fb((size_t)F * E);
+        std::vector<double> H((size_t)n * n), g(n), step(n), cand_t(3 * N), cand_R(4 * N);
         SLAM::VO::LevenbergMarquardtStrategy lm;
         SLAM::VO::TrustRegionStepEvaluator evaluator(o.max_consecutive_nonmonotonic_steps);
         double eval_cost = 0.0;
@@ -83,7 +84,7 @@ namespace mbavo
         for (int l = 0; l < o.num_levels; ++l) maxK = levels[l].K > maxK ? levels[l].K : maxK;
         double *d_cap = nullptr, *d_exp = nullptr, *d_kt = nullptr, *d_kR = nullptr, *d_pc = nullptr;
         unsigned char *d_flags = nullptr;
-        double *h_pin = nullptr;
+        double *h_pin = nullptr, *h_inv = nullptr; // pinned: frame blocks; 1 / ((K - bad) F P), read by the kernels
         unsigned char *flags = nullptr; // pinned host staging of the outlier flags
 
         TRK_HIP(hipSetDevice(eng.device()));
@@ -102,7 +103,8 @@ namespace mbavo
         d_flags = (unsigned char *)eng.named_scratch(6, maxK > 0 ? maxK : 1);
         h_pin = eng.host_frame_blocks((size_t)F * E); // device-visible pinned host memory
         if (h_pin) memset(h_pin, 0, sizeof(double) * (size_t)F * E);
-        if (!d_cap || !d_exp || !d_kt || !d_kR || !d_pc || !d_flags || !flags || !h_pin) { rc_ = (int)hipErrorOutOfMemory; goto done; }
+        h_inv = (double *)eng.pinned_scratch(3, sizeof(double));
+        if (!h_inv || !d_cap || !d_exp || !d_kt || !d_kR || !d_pc || !d_flags || !flags || !h_pin) { rc_ = (int)hipErrorOutOfMemory; goto done; }
         TRK_HIP(hipMemcpyAsync(d_cap, h_cap, sizeof(double) * F, hipMemcpyHostToDevice, st)); // :701-719
         TRK_HIP(hipMemcpyAsync(d_exp, h_exp, sizeof(double) * F, hipMemcpyHostToDevice, st));
 
@@ -119,11 +121,31 @@ namespace mbavo
             p.d_ref_img = L.d_ref_img; p.d_ref_dIxy = L.d_ref_dIxy; p.d_cur_imgs = L.d_cur_imgs;
             p.d_kp_xy = L.d_kp_xy; p.kp_stride = 2; p.d_kp_z = L.d_kp_z; p.d_pattern = L.d_pattern;
             p.d_outlier = d_flags; p.num_bad = 0;
+            // The outlier count changes with every accepted step; it reaches the kernels through a pinned word (inv_ptr)
+            // instead of the problem descriptor, so the engine's cached layout stays valid for the whole level
+            int num_bad = 0;
+            auto set_inv = [&]() {
+                const long long nres = (long long)(L.K - num_bad) * F * L.P; // spline_update_step.cpp:116-117
+                *h_inv = nres > 0 ? 1.0 / (double)nres : 0.0;
+            };
+            set_inv();
             for (int a = 0; a < 4; ++a) p.intrinsics[a] = o.intrinsics[a] / scale; // :766-770
             p.d_cap_time = d_cap; p.d_exp_time = d_exp; p.t0 = t0; p.dt = dt;
             p.d_knots_t = d_kt; p.d_knots_R = d_kR; p.h_start_idx = start_idx.data(); p.huber_a = o.huber_k;
 
-            bool check_range = true;
+            // every blur sample must fall on knots that exist (the reference reads past its arrays otherwise,
+            // SplineFunctor.h:13-19).  The sample times depend on (cap, exp, S) only: checked here on the host with the
+            // kernels' own formula instead of reading the device's status counter back (a synchronous copy per level:
+            // 30 us, 12 % of a tracked frame)
+            for (int f = 0; f < F; ++f)
+                for (int smp = 0; smp < L.S; ++smp)
+                {
+                    const double ts = h_cap[f] - h_exp[f] * 0.5 + smp * h_exp[f] / (L.S - 1 + 1e-8); // compute_virtual_camera_poses.cu:33
+                    int idx;
+                    double u;
+                    spline_segment(ts, t0, dt, idx, u);
+                    if (idx < 0 || idx + k > N) { rc_ = MBAVO_E_RANGE; goto done; }
+                }
             // one evaluation at the given knots: knots into the pinned buffer, ONE launch for these problem sizes (pose
             // prologue + fused + last-workgroup finalize) whose frame blocks land in pinned host memory (h_pin), then a
             // spin on the kernel's completion word: no copies, no stream synchronisation
@@ -133,7 +155,7 @@ namespace mbavo
                     PhaseScope ps(PhaseTimers::kEnqueue);
                     memcpy(d_kt, kt, sizeof(double) * 3 * N);
                     memcpy(d_kR, kR, sizeof(double) * 4 * N);
-                    r = eng.evaluate(1, &p, k, with_h, h_pin, d_pc, nullptr, nullptr, nullptr, nullptr, true);
+                    r = eng.evaluate(1, &p, k, with_h, h_pin, d_pc, nullptr, nullptr, nullptr, h_inv, true);
                 }
                 if (r) return r;
                 {
@@ -142,14 +164,8 @@ namespace mbavo
                 }
                 if (r) return r;
                 PhaseScope ps(PhaseTimers::kMerge);
-                memcpy(fb.data(), h_pin, sizeof(double) * (size_t)F * E);
-                if (check_range) // depends on the times only, not on the knot values: once per level
-                {
-                    check_range = false;
-                    if ((r = (int)hipStreamSynchronize(st)) != 0) return r;
-                    if (eng.fetch_status() != 0) return MBAVO_E_RANGE;
-                }
-                merge_blocks_host(F, k, fb.data(), start_idx.data(), N, cost, with_h ? H.data() : nullptr,
+
+                merge_blocks_host(F, k, h_pin, start_idx.data(), N, cost, with_h ? H.data() : nullptr,
                                   with_h ? g.data() : nullptr);
                 return 0;
             };
@@ -157,7 +173,7 @@ namespace mbavo
                 if (trace && ntrace < trace_cap)
                 {
                     mbavo_trace_rec &r = trace[ntrace];
-                    r.level = lv; r.iter = iter; r.kind = kind; r.num_outliers = p.num_bad;
+                    r.level = lv; r.iter = iter; r.kind = kind; r.num_outliers = num_bad;
                     r.radius = lm.get_radius(); r.eval_cost = eval_cost; r.candidate_cost = cc;
                     r.model_change = model; r.quality = q;
                 }
@@ -207,7 +223,8 @@ namespace mbavo
                 { // isStepSuccessful (:890-894) -> detectOutliers + handleSuccessfulStep (:896-903)
                     {
                         PhaseScope ps(PhaseTimers::kOutliers);
-                        p.num_bad = detect_outliers(d_pc, L.K, o.max_chi_square_error, flags); // frame 0's costs, just written
+                        num_bad = detect_outliers(d_pc, L.K, o.max_chi_square_error, flags); // frame 0's costs, just written
+                        set_inv();
                         TRK_HIP(hipMemcpyAsync(d_flags, flags, L.K, hipMemcpyHostToDevice, st));
                     }
                     spline.InvalidParameter(cand_t.data(), cand_R.data());
