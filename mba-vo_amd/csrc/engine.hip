@@ -62,16 +62,19 @@ namespace mbavo
     };
 
     // ------------------------------------------------------------------ pose table
-    // grid = (ceil(entries * NCOL / 64), WITH_J ? KD : 1).  Latency-bound (one serial fp64 log / exp / product chain
-    // per sample, a few thousand dependent instructions), so the independent pieces of a sample are spread out
-    // instead of run back to back on one lane: one WAVE per knot (blockIdx.y; compile-time knot index, so each
-    // knot only differentiates the segments it touches) and one LANE per column of that knot's 4x3 Jacobian block
-    // (NCOL = 3 lanes per sample).  The pose itself is written by knot 0 / column 0.
+    // Latency-bound: one sample's pose and pose-to-knot Jacobians are a chain of fp64 log / atan / exp / sin / cos and
+    // quaternion products, ~2 600 dependent instructions if one lane does it all.  Two stages per workgroup
+    // (se3_math.h "two STAGES"): A -- one lane per (sample, segment) evaluates A_g = exp(c_g log(R_g^-1 R_g+1)) with both
+    // Jacobians, segment g on wave g; B -- one WAVE per knot (compile-time knot index, so each knot only touches the
+    // segments it differentiates), one LANE per (sample, column of that knot's 4x3 block), reading the segments from LDS.
+    // The pose itself is written by knot 0 / column 0.  kPoseSPB samples per workgroup: 21 x 3 columns fill a wave.
+    constexpr int kPoseSPB = 21;
+
     template <int KD, int KNOT>
-    __device__ __forceinline__ Quat pose_table_entry(const double *kR, double u, int col, PoseEntry<KD> &pe)
+    __device__ __forceinline__ Quat pose_table_entry(const double *kR, double u, int col, const SplineSeg *sg, PoseEntry<KD> &pe)
     {
         JacC<1> blk;
-        const Quat q = spline_rotation_knot<KD, 1, KNOT>(kR, u, col, blk);
+        const Quat q = spline_rotation_knot_from_segs<KD, 1, KNOT>(kR, u, col, sg, blk);
         // tangent form of this column: A[a][3*knot + col] = 2 * L3(q)^T[a] . blk      (pixel_math.h)
         const double L3[4][3] = {{q.w, -q.z, q.y}, {q.z, q.w, -q.x}, {-q.y, q.x, q.w}, {-q.x, -q.y, -q.z}};
         const Quat &v = blk.c[0];
@@ -86,56 +89,48 @@ namespace mbavo
         return q;
     }
 
-    template <int KD, bool WITH_J>
-    __global__ __launch_bounds__(64) void k_pose_table(const ProblemDesc *__restrict__ descs, const int *__restrict__ entry_prob,
-                                                       int total_entries, PoseEntry<KD> *__restrict__ table,
-                                                       int *__restrict__ status)
+    // sample time, segment index (clamped into the knot range, reported through *oob) and normalised time of sample
+    // `smp` of frame f (compute_virtual_camera_poses.cu:33: S == 1 samples the START of the exposure)
+    template <int KD>
+    __device__ __forceinline__ void pose_sample_segment(const ProblemDesc &d, int f, int smp, int &idx, double &u, bool &oob)
     {
-        constexpr int NCOL = WITH_J ? 3 : 1;
-        const int lane_id = blockIdx.x * blockDim.x + threadIdx.x;
-        const int gid = lane_id / NCOL, col = lane_id - gid * NCOL;
-        const int knot = blockIdx.y;
-        if (gid >= total_entries) return;
-        const ProblemDesc &d = descs[entry_prob[gid]]; // one load instead of a search over the problems' pose_base
-        const int local = gid - d.pose_base;
-        const int f = local / d.S, s = local - f * d.S;
         const double t_cap = d.cap[f], t_mu = d.exp_t[f];
-        // sample time (compute_virtual_camera_poses.cu:33): S == 1 samples the START of the exposure
-        const double t = t_cap - t_mu * 0.5 + s * t_mu / (d.S - 1 + 1e-8);
-        int idx;
-        double u;
+        const double t = t_cap - t_mu * 0.5 + smp * t_mu / (d.S - 1 + 1e-8);
         spline_segment(t, d.t0, d.dt, idx, u);
-        if (idx < 0 || idx + KD > d.N)
-        { // the reference reads out of bounds here; clamp for memory safety and report
-            if (knot == 0 && col == 0) atomicAdd(status, 1);
-            idx = idx < 0 ? 0 : d.N - KD;
-        }
-        PoseEntry<KD> &pe = table[gid];
-        // this sample's KD knots (device memory, or pinned host memory the host-driven LM loop writes before each call)
-        double kR[4 * KD], kt[3 * KD];
+        oob = idx < 0 || idx + KD > d.N;
+        if (oob) idx = idx < 0 ? 0 : d.N - KD; // the reference reads out of bounds here; clamp for memory safety and report
+    }
+
+    // stage B for one (sample, knot = wave, column) lane + the pose record by knot 0 / column 0
+    template <int KD, bool WITH_J>
+    __device__ __forceinline__ void pose_stage_b(const ProblemDesc &d, int idx, double u, int wave, int col, const SplineSeg *sg,
+                                                 PoseEntry<KD> &pe)
+    {
+        double kR[4 * KD];
         for (int i = 0; i < 4 * KD; ++i) kR[i] = d.knots_R[4 * idx + i];
-        for (int i = 0; i < 3 * KD; ++i) kt[i] = d.knots_t[3 * idx + i];
         Quat q;
-        if (WITH_J)
+        if constexpr (WITH_J)
         {
-            if (KD == 2)
-                q = knot == 0 ? pose_table_entry<KD, 0>(kR, u, col, pe) : pose_table_entry<KD, 1>(kR, u, col, pe);
+            if constexpr (KD == 2)
+                q = wave == 0 ? pose_table_entry<KD, 0>(kR, u, col, sg, pe) : pose_table_entry<KD, 1>(kR, u, col, sg, pe);
             else
-                switch (knot)
+                switch (wave)
                 {
-                case 0: q = pose_table_entry<KD, 0>(kR, u, col, pe); break;
-                case 1: q = pose_table_entry<KD, 1>(kR, u, col, pe); break;
-                case 2: q = pose_table_entry<KD, KD == 4 ? 2 : 0>(kR, u, col, pe); break;
-                default: q = pose_table_entry<KD, KD == 4 ? 3 : 1>(kR, u, col, pe); break;
+                case 0: q = pose_table_entry<KD, 0>(kR, u, col, sg, pe); break;
+                case 1: q = pose_table_entry<KD, 1>(kR, u, col, sg, pe); break;
+                case 2: q = pose_table_entry<KD, KD == 4 ? 2 : 0>(kR, u, col, sg, pe); break;
+                default: q = pose_table_entry<KD, KD == 4 ? 3 : 1>(kR, u, col, sg, pe); break;
                 }
         }
         else
         {
-            q = spline_rotation<KD, false>(kR, u, nullptr);
+            q = spline_rotation_from_segs<KD>(kR, sg);
             for (int i = 0; i < 9 * KD; ++i) pe.A[i] = 0.0;
         }
-        if (knot == 0 && col == 0)
+        if (wave == 0 && col == 0)
         {
+            double kt[3 * KD];
+            for (int i = 0; i < 3 * KD; ++i) kt[i] = d.knots_t[3 * idx + i];
             double c[KD], p[3], qv[4] = {q.x, q.y, q.z, q.w}, R[9];
             trans_coeffs<KD>(u, c);
             spline_translation<KD>(kt, c, p);
@@ -147,6 +142,88 @@ namespace mbavo
             for (int i = 0; i < 9; ++i) pe.R[i] = R[i];
             for (int i = 0; i < KD; ++i) pe.c[i] = c[i];
         }
+    }
+
+    // the whole chain on one lane (spline_rotation_knot: logs, exps and products back to back); used where there is a single
+    // segment (k = 2) inside the fused kernel's prologue
+    template <int KD, bool WITH_J>
+    __device__ __forceinline__ void pose_unstaged(const ProblemDesc &d, int idx, double u, int wave, int col, PoseEntry<KD> &pe)
+    {
+        double kR[4 * KD];
+        for (int i = 0; i < 4 * KD; ++i) kR[i] = d.knots_R[4 * idx + i];
+        Quat q;
+        if constexpr (WITH_J)
+        {
+            JacC<1> blk;
+            q = wave == 0 ? spline_rotation_knot<KD, 1, 0>(kR, u, col, blk) : spline_rotation_knot<KD, 1, KD - 1>(kR, u, col, blk);
+            static_assert(KD == 2, "one wave per knot beyond k = 2 goes through the staged form");
+            const double L3[4][3] = {{q.w, -q.z, q.y}, {q.z, q.w, -q.x}, {-q.y, q.x, q.w}, {-q.x, -q.y, -q.z}};
+            const Quat &v = blk.c[0];
+            for (int a = 0; a < 3; ++a)
+            {
+                double r = L3[0][a] * v.x;
+                r += L3[1][a] * v.y;
+                r += L3[2][a] * v.z;
+                r += L3[3][a] * v.w;
+                pe.A[a * 3 * KD + 3 * wave + col] = 2.0 * r;
+            }
+        }
+        else
+            q = spline_rotation<KD, false>(kR, u, nullptr);
+        if (wave == 0 && col == 0)
+        {
+            double kt[3 * KD];
+            for (int i = 0; i < 3 * KD; ++i) kt[i] = d.knots_t[3 * idx + i];
+            double c[KD], p[3], qv[4] = {q.x, q.y, q.z, q.w}, R[9];
+            trans_coeffs<KD>(u, c);
+            spline_translation<KD>(kt, c, p);
+            rotation_entries(qv, R);
+            double rt[3];
+            rotated_translation(p, qv, rt);
+            for (int i = 0; i < 3; ++i) { pe.t[i] = p[i]; pe.rt[i] = rt[i]; }
+            for (int i = 0; i < 4; ++i) pe.q[i] = qv[i];
+            for (int i = 0; i < 9; ++i) pe.R[i] = R[i];
+            for (int i = 0; i < KD; ++i) pe.c[i] = c[i];
+        }
+    }
+
+    // grid = ceil(entries / kPoseSPB), block = KD waves
+    template <int KD, bool WITH_J>
+    __global__ __launch_bounds__(64 * KD) void k_pose_table(const ProblemDesc *__restrict__ descs, const int *__restrict__ entry_prob,
+                                                            int total_entries, PoseEntry<KD> *__restrict__ table,
+                                                            int *__restrict__ status)
+    {
+        constexpr int NCOL = WITH_J ? 3 : 1, NSEG = KD - 1;
+        __shared__ SplineSeg segs[kPoseSPB][NSEG];
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const int e0 = blockIdx.x * kPoseSPB;
+        // stage A: wave g evaluates segment g of sample `lane`
+        if (wave < NSEG && lane < kPoseSPB && e0 + lane < total_entries)
+        {
+            const int gid = e0 + lane;
+            const ProblemDesc &d = descs[entry_prob[gid]]; // one load instead of a search over the problems' pose_base
+            const int local = gid - d.pose_base;
+            const int f = local / d.S;
+            int idx;
+            double u;
+            bool oob;
+            pose_sample_segment<KD>(d, f, local - f * d.S, idx, u, oob);
+            spline_segment_eval<WITH_J>(d.knots_R + 4 * (idx + wave), d.knots_R + 4 * (idx + wave + 1), seg_weight<KD>(u, wave),
+                                        segs[lane][wave]);
+        }
+        __syncthreads();
+        // stage B: wave = knot, lane = (sample, column); cost-only: wave 0, one lane per sample
+        const int sl = lane / NCOL, col = lane - sl * NCOL, gid = e0 + sl;
+        if (sl >= kPoseSPB || gid >= total_entries || (!WITH_J && wave != 0)) return;
+        const ProblemDesc &d = descs[entry_prob[gid]];
+        const int local = gid - d.pose_base;
+        const int f = local / d.S;
+        int idx;
+        double u;
+        bool oob;
+        pose_sample_segment<KD>(d, f, local - f * d.S, idx, u, oob);
+        if (oob && wave == 0 && col == 0) atomicAdd(status, 1);
+        pose_stage_b<KD, WITH_J>(d, idx, u, wave, col, segs[sl], table[gid]);
     }
 
     // ------------------------------------------------------------------ fused kernel
@@ -679,63 +756,58 @@ namespace mbavo
         int nbf;
     };
 
-    // S pose entries of (problem d, frame) -> dst[0 .. S-1] (LDS).  Waves 0 .. KD-1 take one knot each (WITH_J), lanes
-    // (sample, column); the pose itself is written by knot 0 / column 0.  Caller synchronises the workgroup afterwards.
+    // S pose entries of (problem d, frame) -> dst[0 .. S-1] (LDS), in the two stages of k_pose_table: segment g of sample
+    // `lane` on wave g into `segs` (LDS scratch: S x (KD - 1) SplineSeg), a workgroup barrier, then knot = wave and
+    // lane = (sample, column).  EVERY wave of the workgroup calls this (it contains barriers); the caller synchronises
+    // the workgroup once more afterwards.
     template <int KD, bool WITH_J>
-    __device__ __forceinline__ void frame_pose_entries(const ProblemDesc &d, int frame, PoseEntry<KD> *dst, int wave, int lane,
-                                                       int *status, bool report)
+    __device__ __forceinline__ void frame_pose_entries(const ProblemDesc &d, int frame, PoseEntry<KD> *dst, SplineSeg *segs, int wave,
+                                                       int lane, int *status, bool report)
     {
-        constexpr int NCOL = WITH_J ? 3 : 1, NKW = WITH_J ? KD : 1, PER = 64 / NCOL;
-        if (wave >= NKW) return;
+        constexpr int NCOL = WITH_J ? 3 : 1, NKW = WITH_J ? KD : 1, NSEG = KD - 1;
         const int S = d.S;
-        const double t_cap = d.cap[frame], t_mu = d.exp_t[frame];
-        for (int s0 = 0; s0 < S; s0 += PER)
+        if constexpr (KD == 2)
+        { // one segment only: nothing to spread out, every (sample, column) lane evaluates it itself -- no barrier, no LDS
+          // round trip (the staged form measured +1.1 us per evaluation here)
+            (void)segs;
+            for (int s0 = 0; s0 < S; s0 += kPoseSPB)
+            {
+                const int sl = lane / NCOL, col = lane - sl * NCOL, smp = s0 + sl;
+                if (wave < NKW && sl < kPoseSPB && smp < S)
+                {
+                    int idx;
+                    double u;
+                    bool oob;
+                    pose_sample_segment<KD>(d, frame, smp, idx, u, oob);
+                    if (oob && report && wave == 0 && col == 0) atomicAdd(status, 1);
+                    pose_unstaged<KD, WITH_J>(d, idx, u, wave, col, dst[smp]);
+                }
+            }
+            return;
+        }
+        for (int s0 = 0; s0 < S; s0 += kPoseSPB)
         {
+            if (wave < NSEG && lane < kPoseSPB && s0 + lane < S)
+            {
+                int idx;
+                double u;
+                bool oob;
+                pose_sample_segment<KD>(d, frame, s0 + lane, idx, u, oob);
+                spline_segment_eval<WITH_J>(d.knots_R + 4 * (idx + wave), d.knots_R + 4 * (idx + wave + 1), seg_weight<KD>(u, wave),
+                                            segs[lane * NSEG + wave]);
+            }
+            __syncthreads();
             const int sl = lane / NCOL, col = lane - sl * NCOL, smp = s0 + sl;
-            if (sl >= PER || smp >= S) continue;
-            const double t = t_cap - t_mu * 0.5 + smp * t_mu / (S - 1 + 1e-8); // compute_virtual_camera_poses.cu:33
-            int idx;
-            double u;
-            spline_segment(t, d.t0, d.dt, idx, u);
-            if (idx < 0 || idx + KD > d.N)
+            if (wave < NKW && sl < kPoseSPB && smp < S)
             {
-                if (report && wave == 0 && col == 0) atomicAdd(status, 1);
-                idx = idx < 0 ? 0 : d.N - KD;
+                int idx;
+                double u;
+                bool oob;
+                pose_sample_segment<KD>(d, frame, smp, idx, u, oob);
+                if (oob && report && wave == 0 && col == 0) atomicAdd(status, 1);
+                pose_stage_b<KD, WITH_J>(d, idx, u, wave, col, segs + sl * NSEG, dst[smp]);
             }
-            double kR[4 * KD];
-            for (int i = 0; i < 4 * KD; ++i) kR[i] = d.knots_R[4 * idx + i];
-            PoseEntry<KD> &pe = dst[smp];
-            Quat q;
-            if constexpr (WITH_J)
-            {
-                if constexpr (KD == 2)
-                    q = wave == 0 ? pose_table_entry<KD, 0>(kR, u, col, pe) : pose_table_entry<KD, 1>(kR, u, col, pe);
-                else
-                    switch (wave)
-                    {
-                    case 0: q = pose_table_entry<KD, 0>(kR, u, col, pe); break;
-                    case 1: q = pose_table_entry<KD, 1>(kR, u, col, pe); break;
-                    case 2: q = pose_table_entry<KD, KD == 4 ? 2 : 0>(kR, u, col, pe); break;
-                    default: q = pose_table_entry<KD, KD == 4 ? 3 : 1>(kR, u, col, pe); break;
-                    }
-            }
-            else
-                q = spline_rotation<KD, false>(kR, u, nullptr);
-            if (wave == 0 && col == 0)
-            {
-                double kt[3 * KD];
-                for (int i = 0; i < 3 * KD; ++i) kt[i] = d.knots_t[3 * idx + i];
-                double c[KD], p[3], qv[4] = {q.x, q.y, q.z, q.w}, R[9];
-                trans_coeffs<KD>(u, c);
-                spline_translation<KD>(kt, c, p);
-                rotation_entries(qv, R);
-                double rt[3];
-                rotated_translation(p, qv, rt);
-                for (int i = 0; i < 3; ++i) { pe.t[i] = p[i]; pe.rt[i] = rt[i]; }
-                for (int i = 0; i < 4; ++i) pe.q[i] = qv[i];
-                for (int i = 0; i < 9; ++i) pe.R[i] = R[i];
-                for (int i = 0; i < KD; ++i) pe.c[i] = c[i];
-            }
+            if (s0 + kPoseSPB < S) __syncthreads(); // the next pass overwrites the segments
         }
     }
 
@@ -835,7 +907,9 @@ namespace mbavo
         static constexpr bool kFits = kBase + kEntries <= 160 * 1024;
         static constexpr bool kStage = (WITH_J || ONE) && kFits;
         // the ticket epilogue needs LANES * EPAD doubles of scratch: the slabs when there are any, else its own area
-        static constexpr size_t kEpilogue = ONE && !WITH_J ? (size_t)kSpWaves * 64 * sizeof(double) : 0;
+        // ... and the pose prologue S x (KD - 1) SplineSeg (<= 21 samples per pass): both live in the slabs when there are any
+        static constexpr size_t kSegs = (size_t)(((1 << LOGS) < kPoseSPB ? (1 << LOGS) : kPoseSPB) * (KD - 1)) * sizeof(SplineSeg);
+        static constexpr size_t kEpilogue = ONE && !WITH_J ? (kSegs > (size_t)kSpWaves * 64 * sizeof(double) ? kSegs : (size_t)kSpWaves * 64 * sizeof(double)) : 0;
         static constexpr size_t kBytes = kBase + (kStage ? kEntries : 0) + kEpilogue;
     };
     // can the single-launch form of the sample-parallel kernel run this (k, S)?  (k = 4, S = 32: the entries do not fit)
@@ -882,7 +956,8 @@ namespace mbavo
         if constexpr (ONE)
         {
 #if !defined(MBAVO_EXP_ONE_NOPOSE) // timing experiment: entries left uninitialised
-            frame_pose_entries<KD, WITH_J>(d, frame, (PoseEntry<KD> *)stage, wave, lane, oa.status, tile.kp_begin == 0);
+            SplineSeg *segs = (SplineSeg *)(WITH_J ? rows : stage + SS * (int)(sizeof(PoseEntry<KD>) / sizeof(double)));
+            frame_pose_entries<KD, WITH_J>(d, frame, (PoseEntry<KD> *)stage, segs, wave, lane, oa.status, tile.kp_begin == 0);
 #endif
             __syncthreads();
         }
@@ -1437,8 +1512,8 @@ namespace mbavo
             HIP_TRY(hipGetLastError());
             return 0;
         }
-        const dim3 pose_grid((entries * (WITH_J ? 3 : 1) + 63) / 64, WITH_J ? KD : 1);
-        hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), pose_grid, dim3(64), 0, st, descs, entry_prob, entries, table, status);
+        hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries + kPoseSPB - 1) / kPoseSPB), dim3(64 * KD), 0, st, descs, entry_prob,
+                           entries, table, status);
         if (ntiles > 0)
         {
             constexpr int kWavesPerGroup = waves_of<KD, WITH_J>(), kThreads = kWavesPerGroup * 64;
@@ -1517,13 +1592,10 @@ namespace mbavo
         for (const ProblemDesc &pd : h_descs_)
             if ((pd.grad_fp16 != 0) != half_grad) return MBAVO_E_ARG;
         // small problems: ONE launch (pose entries in the fused kernel's prologue, finalize by the last workgroup of a slot)
-        // -- where it wins: k = 2 (two knots, one log / exp segment) and the cost-only passes (no pose Jacobians): the
-        // prologue costs ~2-4 us there.  The k = 4 chain with Jacobians (three segments, four knots: ~2 600 dependent
-        // instructions per wave, and vector spills at 12 waves per workgroup) costs 6-12 us, more than the two launches it
-        // saves (profiles/r02_single_launch_ab.txt).
-        // MBAVO_ONE=0 / 2 forces it off / on for every k.
-        const int one_env = env_int("MBAVO_ONE", 1);
-        const bool one = sp_logs_ > 0 && sp_one_fits(kdeg, sp_logs_) && (one_env == 2 || (one_env == 1 && (kdeg == 2 || !with_hessian)));
+        // (profiles/r02_single_launch_ab.txt: with the two-stage pose prologue it wins for every spline degree and mode;
+        // before it, the k = 4 H/g prologue was a 2 600-instruction chain with vector spills and lost to three launches).
+        // MBAVO_ONE=0 forces three launches.
+        const bool one = sp_logs_ > 0 && sp_one_fits(kdeg, sp_logs_) && env_int("MBAVO_ONE", 1) != 0;
         OneArgs oa;
         memset(&oa, 0, sizeof(oa));
         flag_pending_ = false;

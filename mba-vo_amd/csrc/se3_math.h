@@ -437,6 +437,104 @@ namespace mbavo
         }
     }
 
+    // ---- the same spline sample in two STAGES (the pose kernels: engine.hip).  The cumulative factors of a sample,
+    // A_g = exp(c_g * log(R_g^-1 R_{g+1})), are independent of each other and every Jacobian column needs them all, so
+    // one lane per (sample, segment) evaluates a segment ONCE (stage A: the log, the exp and their Jacobians -- the
+    // transcendental part, ~2/3 of the chain) and the (sample, knot, column) lanes pick the results up from shared memory
+    // (stage B: the products).  Arithmetic per quantity is that of spline_rotation_knot, so the results are bit-identical;
+    // the dependent chain per lane is one segment + the products instead of three segments + the products.
+    struct SplineSeg
+    {
+        Quat A;    // exp(c * log(Ra^-1 Rb))
+        LogJac dl; // d log / d quaternion   at Ra^-1 Rb
+        ExpJac de; // d exp / d tangent      at c * log(Ra^-1 Rb)
+    };
+    // cumulative-spline weight of segment g at normalised time u (SplineFunctor.h:232-234; k = 2: the lerp weight u)
+    template <int KDEG>
+    MBAVO_HD double seg_weight(double u, int g)
+    {
+        if constexpr (KDEG == 2)
+            return u;
+        else
+        {
+            const double uu = u * u, uuu = uu * u, s = 1. / 6.;
+            return g == 0 ? 5 * s + 0.5 * u - 0.5 * uu + s * uuu : (g == 1 ? s + 0.5 * u + 0.5 * uu - 2 * s * uuu : s * uuu);
+        }
+    }
+    template <bool WITH_J>
+    MBAVO_HD void spline_segment_eval(const double *Ra4, const double *Rb4, double c, SplineSeg &out)
+    {
+        double om[3];
+        qlog<WITH_J>(qmul(qconj(load_quat(Ra4)), load_quat(Rb4)), om, &out.dl);
+        om[0] *= c; om[1] *= c; om[2] *= c;
+        out.A = qexp<WITH_J>(om, &out.de);
+    }
+    // rotation of the sample from its evaluated segments (no Jacobian)
+    template <int KDEG>
+    MBAVO_HD Quat spline_rotation_from_segs(const double *kR, const SplineSeg *sg)
+    {
+        if constexpr (KDEG == 2)
+            return qmul(load_quat(kR), sg[0].A);
+        else
+            return qmul(qmul(qmul(load_quat(kR), sg[0].A), sg[1].A), sg[2].A);
+    }
+    // stage B: columns col0 .. col0 + NC - 1 of knot J's 4x3 Jacobian block, from the evaluated segments
+    template <int KDEG, int NC, int J>
+    MBAVO_HD Quat spline_rotation_knot_from_segs(const double *kR, double u, int col0, const SplineSeg *sg, JacC<NC> &block)
+    {
+        if constexpr (KDEG == 2)
+        {
+            const Quat R0 = load_quat(kR), R1 = load_quat(kR + 4);
+            const Quat R0c = qconj(R0);
+            const Quat A0 = sg[0].A;
+            if constexpr (J == 0)
+            {
+                const JacC<NC> E0 = local_param_jac_cols<NC>(R0, col0);
+                block = jadd(rmul(E0, A0), lmul(R0, through_log_exp(sg[0].de, u, sg[0].dl, rmul(conj_cols(E0), R1))));
+            }
+            else
+                block = lmul(R0, through_log_exp(sg[0].de, u, sg[0].dl, lmul(R0c, local_param_jac_cols<NC>(R1, col0))));
+            return qmul(R0, A0);
+        }
+        else
+        {
+            const double c1 = seg_weight<4>(u, 0), c2 = seg_weight<4>(u, 1), c3 = seg_weight<4>(u, 2);
+            const Quat R0 = load_quat(kR), R1 = load_quat(kR + 4), R2 = load_quat(kR + 8), R3 = load_quat(kR + 12);
+            const Quat R0c = qconj(R0), R1c = qconj(R1), R2c = qconj(R2);
+            const Quat A0 = sg[0].A, A1 = sg[1].A, A2 = sg[2].A;
+            const Quat R0A0 = qmul(R0, A0);
+            const Quat R0A0A1 = qmul(R0A0, A1);
+            const Quat A12 = qmul(A1, A2);
+            if constexpr (J == 0)
+            {
+                const JacC<NC> E0 = local_param_jac_cols<NC>(R0, col0);
+                const Quat A012 = qmul(qmul(A0, A1), A2);
+                const JacC<NC> dA0 = through_log_exp(sg[0].de, c1, sg[0].dl, rmul(conj_cols(E0), R1));
+                block = jadd(rmul(E0, A012), lmul(R0, rmul(dA0, A12)));
+            }
+            else if constexpr (J == 1)
+            {
+                const JacC<NC> E1 = local_param_jac_cols<NC>(R1, col0);
+                const JacC<NC> dA0 = through_log_exp(sg[0].de, c1, sg[0].dl, lmul(R0c, E1));
+                const JacC<NC> dA1 = through_log_exp(sg[1].de, c2, sg[1].dl, rmul(conj_cols(E1), R2));
+                block = jadd(lmul(R0, rmul(dA0, A12)), lmul(R0A0, rmul(dA1, A2)));
+            }
+            else if constexpr (J == 2)
+            {
+                const JacC<NC> E2 = local_param_jac_cols<NC>(R2, col0);
+                const JacC<NC> dA1 = through_log_exp(sg[1].de, c2, sg[1].dl, lmul(R1c, E2));
+                const JacC<NC> dA2 = through_log_exp(sg[2].de, c3, sg[2].dl, rmul(conj_cols(E2), R3));
+                block = jadd(lmul(R0A0, rmul(dA1, A2)), lmul(R0A0A1, dA2));
+            }
+            else
+            {
+                const JacC<NC> dA2 = through_log_exp(sg[2].de, c3, sg[2].dl, lmul(R2c, local_param_jac_cols<NC>(R3, col0)));
+                block = lmul(R0A0A1, dA2);
+            }
+            return qmul(R0A0A1, A2);
+        }
+    }
+
     // SO(3) exponential as a unit quaternion (what Spline.h:302,326 gets from
     // Sophus::SO3d::exp): series below theta^2 < 1e-20, closed form above.
     MBAVO_HD Quat so3_exp(const double om[3])
