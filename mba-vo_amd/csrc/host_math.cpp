@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <vector>
 
 namespace mbavo
 {
@@ -48,39 +49,103 @@ namespace mbavo
     // Minimum-norm least squares by one-sided (Hestenes) Jacobi: rotate the columns of
     // G = A until they are orthogonal, G = U S, A V = G.  Singular values below
     // n * eps * s_max are treated as zero (Eigen's default JacobiSVD rank threshold).
+    // The LM loop of a tracked frame spends more host time here than anywhere else (a 12 x 12 solve per iteration), so
+    // the three dot products of a column pair run as FOUR interleaved partial sums each (element i goes to sum i mod 4,
+    // combined as (s0 + s1) + (s2 + s3)): a fixed association, written out, so that the result does not depend on the
+    // vector width the compiler picks, with four independent dependency chains instead of one.
+    namespace
+    {
+        struct Dots { double a, c, d; };
+        inline Dots pair_dots(const double *gp, const double *gq, int n)
+        {
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+            int i = 0;
+            for (; i + 4 <= n; i += 4)
+            {
+                a0 += gp[i] * gp[i]; a1 += gp[i + 1] * gp[i + 1]; a2 += gp[i + 2] * gp[i + 2]; a3 += gp[i + 3] * gp[i + 3];
+                c0 += gq[i] * gq[i]; c1 += gq[i + 1] * gq[i + 1]; c2 += gq[i + 2] * gq[i + 2]; c3 += gq[i + 3] * gq[i + 3];
+                d0 += gp[i] * gq[i]; d1 += gp[i + 1] * gq[i + 1]; d2 += gp[i + 2] * gq[i + 2]; d3 += gp[i + 3] * gq[i + 3];
+            }
+            if (i < n) { a0 += gp[i] * gp[i]; c0 += gq[i] * gq[i]; d0 += gp[i] * gq[i]; ++i; }
+            if (i < n) { a1 += gp[i] * gp[i]; c1 += gq[i] * gq[i]; d1 += gp[i] * gq[i]; ++i; }
+            if (i < n) { a2 += gp[i] * gp[i]; c2 += gq[i] * gq[i]; d2 += gp[i] * gq[i]; ++i; }
+            return Dots{(a0 + a1) + (a2 + a3), (c0 + c1) + (c2 + c3), (d0 + d1) + (d2 + d3)};
+        }
+        inline void rotate_pair(double *p, double *q, int n, double cs, double sn)
+        {
+            for (int i = 0; i < n; ++i)
+            {
+                const double u = p[i], w = q[i];
+                p[i] = cs * u - sn * w;
+                q[i] = sn * u + cs * w;
+            }
+        }
+    } // namespace
+
     static int solve_svd(const double *A, const double *b, int n, double *x)
     {
-        std::vector<double> G(A, A + (size_t)n * n), V((size_t)n * n, 0.0);
+        // work arrays kept per thread: no allocation in the LM loop
+        static thread_local std::vector<double> Gv, Vv, s2v;
+        Gv.assign(A, A + (size_t)n * n);
+        Vv.assign((size_t)n * n, 0.0);
+        s2v.resize(n);
+        double *G = Gv.data(), *V = Vv.data(), *s2 = s2v.data();
         for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
         const double eps = std::numeric_limits<double>::epsilon();
+        // Rotations of a sweep in round-robin (tournament) order, as the device solver takes them (lm_solvers.h): the
+        // n / 2 column pairs of a round are disjoint, so their dot products, their rotation parameters (two square roots
+        // and two divisions each: the latency chain that dominated the row-cyclic order) and their updates are independent
+        // pieces of work for the out-of-order core.  Odd n takes the row-cyclic order.
+        const int half = n / 2, m1 = n - 1;
+        static thread_local std::vector<int> pp_, qq_;
+        static thread_local std::vector<double> cs_, sn_;
+        pp_.resize(half + 1); qq_.resize(half + 1); cs_.resize(half + 1); sn_.resize(half + 1);
         for (int sweep = 0; sweep < 60; ++sweep)
         {
             bool rotated = false;
-            for (int p = 0; p < n - 1; ++p)
-                for (int q = p + 1; q < n; ++q)
+            if ((n & 1) == 0 && n >= 4)
+            {
+                for (int r = 0; r < m1; ++r)
                 {
-                    double *gp = &G[(size_t)p * n], *gq = &G[(size_t)q * n];
-                    double a = 0, c = 0, d = 0;
-                    for (int i = 0; i < n; ++i) { a += gp[i] * gp[i]; c += gq[i] * gq[i]; d += gp[i] * gq[i]; }
-                    if (d == 0.0 || std::fabs(d) <= eps * std::sqrt(a * c)) continue;
-                    rotated = true;
-                    const double zeta = (c - a) / (2.0 * d);
-                    const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-                    const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
-                    double *vp = &V[(size_t)p * n], *vq = &V[(size_t)q * n];
-                    for (int i = 0; i < n; ++i)
+                    for (int pr = 0; pr < half; ++pr)
                     {
-                        const double u = gp[i], w = gq[i];
-                        gp[i] = cs * u - sn * w;
-                        gq[i] = sn * u + cs * w;
-                        const double y = vp[i], z = vq[i];
-                        vp[i] = cs * y - sn * z;
-                        vq[i] = sn * y + cs * z;
+                        int p = pr == 0 ? m1 : (r + pr) % m1, q = pr == 0 ? r : (r - pr + m1) % m1;
+                        if (p > q) std::swap(p, q);
+                        pp_[pr] = p; qq_[pr] = q;
+                        const Dots t3 = pair_dots(G + (size_t)p * n, G + (size_t)q * n, n);
+                        const double a = t3.a, c = t3.c, d = t3.d;
+                        if (d == 0.0 || std::fabs(d) <= eps * std::sqrt(a * c)) { cs_[pr] = 1.0; sn_[pr] = 0.0; pp_[pr] = -1; continue; }
+                        const double zeta = (c - a) / (2.0 * d);
+                        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                        const double cs = 1.0 / std::sqrt(1.0 + t * t);
+                        cs_[pr] = cs; sn_[pr] = cs * t;
+                    }
+                    for (int pr = 0; pr < half; ++pr)
+                    {
+                        if (pp_[pr] < 0) continue;
+                        rotated = true;
+                        rotate_pair(G + (size_t)pp_[pr] * n, G + (size_t)qq_[pr] * n, n, cs_[pr], sn_[pr]);
+                        rotate_pair(V + (size_t)pp_[pr] * n, V + (size_t)qq_[pr] * n, n, cs_[pr], sn_[pr]);
                     }
                 }
+            }
+            else
+                for (int p = 0; p < n - 1; ++p)
+                    for (int q = p + 1; q < n; ++q)
+                    {
+                        double *gp = G + (size_t)p * n, *gq = G + (size_t)q * n;
+                        const Dots t3 = pair_dots(gp, gq, n);
+                        const double a = t3.a, c = t3.c, d = t3.d;
+                        if (d == 0.0 || std::fabs(d) <= eps * std::sqrt(a * c)) continue;
+                        rotated = true;
+                        const double zeta = (c - a) / (2.0 * d);
+                        const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                        const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+                        rotate_pair(gp, gq, n, cs, sn);
+                        rotate_pair(V + (size_t)p * n, V + (size_t)q * n, n, cs, sn);
+                    }
             if (!rotated) break;
         }
-        std::vector<double> s2(n);
         double smax2 = 0.0;
         for (int j = 0; j < n; ++j)
         {
