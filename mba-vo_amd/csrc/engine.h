@@ -73,6 +73,24 @@ namespace mbavo
                      bool signal_host = false /* arm the pinned completion word (see wait_evaluation) */);
         // blocks until the evaluation just enqueued has completed (completion word, or the stream)
         int wait_evaluation();
+
+        // Persistent evaluation of ONE small problem (host-driven LM loop, tracker.cpp): one launch per pyramid level, the
+        // resident workgroups take commands from a pinned block (see k_sp_persist).  begin: 0 = started, 1 = not applicable
+        // (the problem does not take the single-launch sample-parallel kernel: use evaluate()), < 0 / > 0 = error.  The
+        // problem's knots, outlier flags, patch-cost output, frame blocks (h_frame_blocks) and residual scale (h_inv) must
+        // all be pinned host memory the caller updates between evaluations.  eval: one synchronous evaluation.  end: tells
+        // the workgroups to exit (asynchronous).  No other work may be enqueued on the engine's stream in between.
+        int persistent_begin(const mbavo_problem &p, int kdeg, double *h_frame_blocks, double *h_patch_cost, const double *h_inv);
+        // Fine-grained DEVICE memory the CPU writes directly through the PCIe BAR (write-combining: stores + sfence; never
+        // read it from the CPU): the persistent kernel's command block (its first 64 bytes, owned by the engine) and the
+        // per-evaluation inputs the caller lays out behind it (knots, residual scale, outlier flags).  Pushing the inputs
+        // costs the GPU nothing; PULLING them from pinned host memory is bounded by the bus' small-read rate (~10 M/s:
+        // 35 us per evaluation for a dozen words per workgroup; tools/micro/host_push_probe.hip: 1.9 us round trip pushed).
+        // nullptr when the platform cannot do it.
+        void *push_block(size_t bytes);
+        static constexpr size_t kPushHeader = 64;
+        int persistent_eval(bool with_hessian);
+        int persistent_end();
         const ProblemDesc *device_descs() const { return (const ProblemDesc *)d_descs_; }
 
         // range status since the previous fetch (call after a stream sync): non-zero if a blur
@@ -139,6 +157,9 @@ namespace mbavo
         void *h_flag_ = nullptr;            // pinned completion word of the single-launch kernels
         unsigned long long flag_seq_ = 0;
         bool flag_pending_ = false;
+        void *d_push_ = nullptr; size_t cap_push_ = 0; // fine-grained device memory, CPU-writable; starts with the PersistCmd
+        bool persist_active_ = false;
+        int persist_gen_ = 0;
         int status_seen_ = 0;
         void *h_fb_ = nullptr; size_t cap_hfb_ = 0;
         static constexpr int kPinnedSlots = 4;

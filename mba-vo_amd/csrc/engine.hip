@@ -23,6 +23,7 @@
 #include "timing.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -103,11 +104,11 @@ namespace mbavo
 
     // stage B for one (sample, knot = wave, column) lane + the pose record by knot 0 / column 0
     template <int KD, bool WITH_J>
-    __device__ __forceinline__ void pose_stage_b(const ProblemDesc &d, int idx, double u, int wave, int col, const SplineSeg *sg,
-                                                 PoseEntry<KD> &pe)
+    __device__ __forceinline__ void pose_stage_b(const double *knots_t, const double *knots_R, int idx, double u, int wave, int col,
+                                                 const SplineSeg *sg, PoseEntry<KD> &pe)
     {
         double kR[4 * KD];
-        for (int i = 0; i < 4 * KD; ++i) kR[i] = d.knots_R[4 * idx + i];
+        for (int i = 0; i < 4 * KD; ++i) kR[i] = knots_R[4 * idx + i];
         Quat q;
         if constexpr (WITH_J)
         {
@@ -130,7 +131,7 @@ namespace mbavo
         if (wave == 0 && col == 0)
         {
             double kt[3 * KD];
-            for (int i = 0; i < 3 * KD; ++i) kt[i] = d.knots_t[3 * idx + i];
+            for (int i = 0; i < 3 * KD; ++i) kt[i] = knots_t[3 * idx + i];
             double c[KD], p[3], qv[4] = {q.x, q.y, q.z, q.w}, R[9];
             trans_coeffs<KD>(u, c);
             spline_translation<KD>(kt, c, p);
@@ -147,10 +148,11 @@ namespace mbavo
     // the whole chain on one lane (spline_rotation_knot: logs, exps and products back to back); used where there is a single
     // segment (k = 2) inside the fused kernel's prologue
     template <int KD, bool WITH_J>
-    __device__ __forceinline__ void pose_unstaged(const ProblemDesc &d, int idx, double u, int wave, int col, PoseEntry<KD> &pe)
+    __device__ __forceinline__ void pose_unstaged(const double *knots_t, const double *knots_R, int idx, double u, int wave, int col,
+                                                  PoseEntry<KD> &pe)
     {
         double kR[4 * KD];
-        for (int i = 0; i < 4 * KD; ++i) kR[i] = d.knots_R[4 * idx + i];
+        for (int i = 0; i < 4 * KD; ++i) kR[i] = knots_R[4 * idx + i];
         Quat q;
         if constexpr (WITH_J)
         {
@@ -173,7 +175,7 @@ namespace mbavo
         if (wave == 0 && col == 0)
         {
             double kt[3 * KD];
-            for (int i = 0; i < 3 * KD; ++i) kt[i] = d.knots_t[3 * idx + i];
+            for (int i = 0; i < 3 * KD; ++i) kt[i] = knots_t[3 * idx + i];
             double c[KD], p[3], qv[4] = {q.x, q.y, q.z, q.w}, R[9];
             trans_coeffs<KD>(u, c);
             spline_translation<KD>(kt, c, p);
@@ -223,7 +225,7 @@ namespace mbavo
         bool oob;
         pose_sample_segment<KD>(d, f, local - f * d.S, idx, u, oob);
         if (oob && wave == 0 && col == 0) atomicAdd(status, 1);
-        pose_stage_b<KD, WITH_J>(d, idx, u, wave, col, segs[sl], table[gid]);
+        pose_stage_b<KD, WITH_J>(d.knots_t, d.knots_R, idx, u, wave, col, segs[sl], table[gid]);
     }
 
     // ------------------------------------------------------------------ fused kernel
@@ -350,6 +352,31 @@ namespace mbavo
     };
 
 #endif
+
+    // 1 / ((K - bad) F P) of a problem.  Device-side LM and the host-driven loop keep it outside the descriptor (inv_ptr:
+    // device memory -- for the host-driven loop a word of the CPU-writable push block, see Engine::push_block): read FRESH
+    // by one lane per wave (a scalar load could hit a stale scalar-cache line inside the persistent kernel) and broadcast.
+    // (Not from pinned HOST memory: a system-scope load per wave from there measured +35 us per evaluation.)
+    template <bool FRESH>
+    __device__ __forceinline__ double residual_scale(const ProblemDesc &d, int lane)
+    {
+        if (d.inv_ptr == nullptr) return d.inv_num_residuals;
+        if constexpr (!FRESH) return *d.inv_ptr; // one evaluation per launch: the caches start empty
+        double v = 0.0;
+        if (lane == 0) v = __hip_atomic_load(d.inv_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __shfl(v, 0, 64);
+    }
+
+    // outlier flag of a keypoint.  FRESH (persistent kernel: the host rewrites the flags between commands while the caches
+    // stay warm): the aligned word that holds the byte, through a device-scope atomic load that bypasses the caches.
+    template <bool FRESH>
+    __device__ __forceinline__ unsigned outlier_flag(const unsigned char *flags, int kp)
+    {
+        if constexpr (!FRESH) return flags[kp];
+        const unsigned long long a = (unsigned long long)(flags + kp);
+        const unsigned w = __hip_atomic_load((const unsigned *)(a & ~3ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (w >> (8 * (unsigned)(a & 3ull))) & 0xffu;
+    }
 
     // pixel index -> patch index; P is wave-uniform, so the branches are scalar and the common patch sizes (1, and
     // the 8-pixel pattern of the reference's tests) skip the ~14-instruction integer division
@@ -593,7 +620,7 @@ namespace mbavo
         // SIMD: 7 chunks against 6 on the others) at the end.
         // One-pixel patches (dense mode): the patch cost is the pixel's own, taken where rho is computed; the
         // per-pixel rho scratch (8 B per pixel written and read back at the end of the tile) is not touched.
-        const double inv = d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals;
+        const double inv = residual_scale<false>(d, lane);
         double cost_local = 0.0;
         int main_end = npx;
         if (sp_ok)
@@ -744,6 +771,16 @@ namespace mbavo
     //  * epilogue: the workgroup that retires the LAST tile of a (problem, frame) slot -- a ticket counter, device-scope
     //    fences -- sums the slot's tile partials in a fixed order and writes the frame block.  No float atomics, still
     //    bit-reproducible run to run.
+#if defined(MBAVO_PERSIST_STAMPS)
+    __device__ __forceinline__ unsigned long long *stamp_area()
+    {
+        __shared__ unsigned long long st[4];
+        return st;
+    }
+#define MBAVO_STAMP(i) do { if (threadIdx.x == 0) stamp_area()[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MBAVO_STAMP(i) do { } while (0)
+#endif
     struct OneArgs
     {
         const int *bf_tile_begin;                // [nBF + 1]
@@ -754,6 +791,7 @@ namespace mbavo
         unsigned long long *host_flag;           // pinned host word, or null: set to `seq` when every slot is done
         unsigned long long seq;
         int nbf;
+        unsigned long long t_seen;               // (timing experiment MBAVO_PERSIST_STAMPS)
     };
 
     // S pose entries of (problem d, frame) -> dst[0 .. S-1] (LDS), in the two stages of k_pose_table: segment g of sample
@@ -761,8 +799,8 @@ namespace mbavo
     // lane = (sample, column).  EVERY wave of the workgroup calls this (it contains barriers); the caller synchronises
     // the workgroup once more afterwards.
     template <int KD, bool WITH_J>
-    __device__ __forceinline__ void frame_pose_entries(const ProblemDesc &d, int frame, PoseEntry<KD> *dst, SplineSeg *segs, int wave,
-                                                       int lane, int *status, bool report)
+    __device__ __forceinline__ void frame_pose_entries(const ProblemDesc &d, const double *knots_t, const double *knots_R, int frame,
+                                                       PoseEntry<KD> *dst, SplineSeg *segs, int wave, int lane, int *status, bool report)
     {
         constexpr int NCOL = WITH_J ? 3 : 1, NKW = WITH_J ? KD : 1, NSEG = KD - 1;
         const int S = d.S;
@@ -780,7 +818,7 @@ namespace mbavo
                     bool oob;
                     pose_sample_segment<KD>(d, frame, smp, idx, u, oob);
                     if (oob && report && wave == 0 && col == 0) atomicAdd(status, 1);
-                    pose_unstaged<KD, WITH_J>(d, idx, u, wave, col, dst[smp]);
+                    pose_unstaged<KD, WITH_J>(knots_t, knots_R, idx, u, wave, col, dst[smp]);
                 }
             }
             return;
@@ -793,7 +831,7 @@ namespace mbavo
                 double u;
                 bool oob;
                 pose_sample_segment<KD>(d, frame, s0 + lane, idx, u, oob);
-                spline_segment_eval<WITH_J>(d.knots_R + 4 * (idx + wave), d.knots_R + 4 * (idx + wave + 1), seg_weight<KD>(u, wave),
+                spline_segment_eval<WITH_J>(knots_R + 4 * (idx + wave), knots_R + 4 * (idx + wave + 1), seg_weight<KD>(u, wave),
                                             segs[lane * NSEG + wave]);
             }
             __syncthreads();
@@ -805,7 +843,7 @@ namespace mbavo
                 bool oob;
                 pose_sample_segment<KD>(d, frame, smp, idx, u, oob);
                 if (oob && report && wave == 0 && col == 0) atomicAdd(status, 1);
-                pose_stage_b<KD, WITH_J>(d, idx, u, wave, col, segs + sl * NSEG, dst[smp]);
+                pose_stage_b<KD, WITH_J>(knots_t, knots_R, idx, u, wave, col, segs + sl * NSEG, dst[smp]);
             }
             if (s0 + kPoseSPB < S) __syncthreads(); // the next pass overwrites the segments
         }
@@ -818,7 +856,7 @@ namespace mbavo
     // doubles of LDS nobody else is using any more.
     template <int KD, bool WITH_J, int NTHREADS>
     __device__ __forceinline__ void ticket_finalize(const ProblemDesc &d, int bf, const double *__restrict__ partials,
-                                                    const OneArgs &oa, double *scratch)
+                                                    const OneArgs &oa, double *scratch, double inv)
     {
         constexpr int E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
         constexpr int EPAD = KD == 4 ? 384 : 128, LANES = NTHREADS / EPAD;
@@ -831,6 +869,9 @@ namespace mbavo
         __syncthreads();
         if (threadIdx.x == 0)
         {
+            // (device scope also when the per-patch costs go to pinned host memory: the fence waits until this workgroup's
+            // stores are acknowledged, i.e. on their way to the host ahead of the completion word the LAST workgroup
+            // publishes after its own system-scope fence; a system-scope fence here costs 40 us per evaluation)
             __threadfence();
             const int n = oa.bf_tile_begin[bf + 1] - oa.bf_tile_begin[bf];
             s_last = atomicAdd(&oa.tickets[bf], 1) == n - 1 ? 1 : 0;
@@ -838,6 +879,7 @@ namespace mbavo
         }
         __syncthreads();
         if (!s_last) return;
+        MBAVO_STAMP(2);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int t0 = oa.bf_tile_begin[bf], t1 = oa.bf_tile_begin[bf + 1];
         const int e = threadIdx.x % EPAD, l = threadIdx.x / EPAD;
@@ -867,17 +909,26 @@ namespace mbavo
         {
             if (e == 0) { if (oa.valid_out) oa.valid_out[bf] = acc; }
             else if (e == E) oa.frame_blocks[(size_t)bf * E] = acc; // cost: patch costs are already scaled
-            else oa.frame_blocks[(size_t)bf * E + e] = acc * (d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals);
+            else oa.frame_blocks[(size_t)bf * E + e] = acc * inv; // (the caller's copy: the scale may live in host memory)
         }
-        if (to_host) __threadfence_system(); // the frame block (pinned host memory) lands before the flag does
+        // the frame block (pinned host memory) must land before the completion word does: every wave's stores are performed
+        // at workgroup scope before the barrier, ONE thread then fences at system scope (a system-scope fence by all 768
+        // threads was 3 of the 4.8 us this epilogue took inside the persistent kernel)
+        if (to_host) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         if (threadIdx.x == 0)
         {
             oa.tickets[bf] = 0; // ready for the next launch (stream order)
+            if (to_host) __threadfence_system(); // THIS slot's frame block is on its way to the host before the slot counts as done
             if (to_host && atomicAdd(oa.slots_done, 1) == oa.nbf - 1)
             {
                 *oa.slots_done = 0;
+#if defined(MBAVO_PERSIST_STAMPS) // timing experiment: when this workgroup saw the command / finished (100 MHz ticks)
+                oa.host_flag[1] = __builtin_amdgcn_s_memrealtime();
+                oa.host_flag[2] = oa.t_seen;
+                for (int i = 0; i < 4; ++i) oa.host_flag[3 + i] = stamp_area()[i];
                 __threadfence_system();
+#endif
                 __hip_atomic_store(oa.host_flag, oa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
@@ -919,21 +970,22 @@ namespace mbavo
         return logs >= 2 && logs <= 4;
     }
 
-    template <int KD, bool WITH_J, bool HALF_GRAD, int LOGS, bool ONE>
-    __global__ __launch_bounds__((kSpWaves * 64)) void k_fused_sp(const ProblemDesc *__restrict__ descs,
-                                                        const TileDesc *__restrict__ tiles,
-                                                        const PoseEntry<KD> *__restrict__ table,
-                                                        double *__restrict__ rho_out,
-                                                        double *__restrict__ patch_cost,
-                                                        double *__restrict__ patch_blocks_strided,
-                                                        double *__restrict__ partials, const OneArgs oa)
+    // the body of k_fused_sp (one tile of one evaluation); also run, evaluation after evaluation, by the persistent kernel
+    template <int KD, bool WITH_J, bool HALF_GRAD, int LOGS, bool ONE, bool PERSIST = false>
+    __device__ __forceinline__ void sp_tile_body(double *lds, const ProblemDesc *__restrict__ descs,
+                                                 const TileDesc *__restrict__ tiles,
+                                                 const PoseEntry<KD> *__restrict__ table,
+                                                 double *__restrict__ rho_out,
+                                                 double *__restrict__ patch_cost,
+                                                 double *__restrict__ patch_blocks_strided,
+                                                 double *__restrict__ partials, const OneArgs &oa,
+                                                 const double *knots_t_fresh = nullptr, const double *knots_R_fresh = nullptr)
     {
         constexpr int ND = Pack<KD>::ND, E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
         constexpr int kWavesPerGroup = kSpWaves, kThreads = kWavesPerGroup * 64;
         constexpr int SS = 1 << LOGS, PXW = 64 >> LOGS, PXG = kWavesPerGroup * PXW; // lanes per pixel, pixels per wave / per round
         constexpr int SLAB = OuterAcc<ND>::SLAB;     // doubles per wave: rows, and the parked accumulators at the end
         constexpr int RS = OuterAcc<ND>::STRIDE;     // row stride (>= ND, zero padded)
-        extern __shared__ __attribute__((aligned(16))) double lds[];
         double *rows = lds;                                               // [12 waves][64 pixels][ND] (WITH_J only)
         double *red = lds + (WITH_J ? kWavesPerGroup * SLAB : 0);         // [2][12]
 
@@ -957,9 +1009,11 @@ namespace mbavo
         {
 #if !defined(MBAVO_EXP_ONE_NOPOSE) // timing experiment: entries left uninitialised
             SplineSeg *segs = (SplineSeg *)(WITH_J ? rows : stage + SS * (int)(sizeof(PoseEntry<KD>) / sizeof(double)));
-            frame_pose_entries<KD, WITH_J>(d, frame, (PoseEntry<KD> *)stage, segs, wave, lane, oa.status, tile.kp_begin == 0);
+            frame_pose_entries<KD, WITH_J>(d, PERSIST ? knots_t_fresh : d.knots_t, PERSIST ? knots_R_fresh : d.knots_R, frame,
+                                           (PoseEntry<KD> *)stage, segs, wave, lane, oa.status, tile.kp_begin == 0);
 #endif
             __syncthreads();
+            MBAVO_STAMP(0);
         }
         else if constexpr (STAGE)
         {
@@ -988,7 +1042,7 @@ namespace mbavo
         double *slab = rows + wave * SLAB;
         int nvalid = 0;
         double cost_local = 0.0;
-        const double inv = d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals;
+        const double inv = residual_scale<PERSIST>(d, lane);
         // Power-of-two patches that fit the pixels of one wave round (the 8-pixel pattern at S <= 8): the patch cost is
         // reduced across the wave in the order of the reference's reduce() -- no rho scratch, no second pass.
         const bool wave_patches = (P & (P - 1)) == 0 && P <= PXW;
@@ -1008,7 +1062,7 @@ namespace mbavo
             {
                 const int kpl = patch_of(g, P), pp = g - kpl * P;
                 kp = tile.kp_begin + kpl;
-                flagged = d.outlier != nullptr && d.outlier[kp] == 1;
+                flagged = d.outlier != nullptr && outlier_flag<PERSIST>(d.outlier, kp) == 1;
                 const double kx = d.kp_xy[(size_t)kp * d.kp_stride], ky = d.kp_xy[(size_t)kp * d.kp_stride + 1];
                 const double kz = d.kp_z[kp];
                 double pcx, pcy;
@@ -1156,9 +1210,100 @@ namespace mbavo
             // scratch for the tile-lane sums: the slabs (every thread is past its gather after the barrier inside),
             // or the kernel's epilogue area when there are none
             double *scratch = WITH_J ? rows : stage + SS * (int)(sizeof(PoseEntry<KD>) / sizeof(double));
+            MBAVO_STAMP(1);
 #if !defined(MBAVO_EXP_ONE_NOTICKET) // timing experiment: no finalize at all
-            ticket_finalize<KD, WITH_J, kThreads>(d, d.bf_base + frame, partials, oa, scratch);
+            ticket_finalize<KD, WITH_J, kThreads>(d, d.bf_base + frame, partials, oa, scratch, inv);
 #endif
+        }
+    }
+
+    template <int KD, bool WITH_J, bool HALF_GRAD, int LOGS, bool ONE>
+    __global__ __launch_bounds__((kSpWaves * 64)) void k_fused_sp(const ProblemDesc *__restrict__ descs,
+                                                        const TileDesc *__restrict__ tiles,
+                                                        const PoseEntry<KD> *__restrict__ table,
+                                                        double *__restrict__ rho_out,
+                                                        double *__restrict__ patch_cost,
+                                                        double *__restrict__ patch_blocks_strided,
+                                                        double *__restrict__ partials, const OneArgs oa)
+    {
+        extern __shared__ __attribute__((aligned(16))) double lds[];
+        sp_tile_body<KD, WITH_J, HALF_GRAD, LOGS, ONE>(lds, descs, tiles, table, rho_out, patch_cost, patch_blocks_strided, partials, oa);
+    }
+
+    // ------------------------------------------------------------------ persistent evaluation (host-driven LM loop)
+    // One launch per pyramid level instead of one per evaluation: the workgroups of the level's tiles stay resident and
+    // take COMMANDS from a pinned host block -- the host writes the next knots (pinned), the outlier flags (pinned), the
+    // residual scale (pinned) and then {mode, seq}; thread 0 of every workgroup polls seq with system-scope loads, the
+    // workgroup runs the single-launch body (pose prologue, tile, ticket finalize into pinned host memory) and the last
+    // slot's workgroup publishes seq in the completion word the host spins on.  What a launch costs per evaluation (~4 us
+    // of host enqueue + ~6 us until the kernel starts) is paid once per level.  A workgroup gives up after ~2 s without a
+    // command (s_memrealtime, 100 MHz), so a dead host cannot hang the device.
+#ifndef MBAVO_PERSIST_SLEEP
+#define MBAVO_PERSIST_SLEEP 8
+#endif
+    struct PersistCmd
+    {
+        unsigned long long seq; // incremented by the host AFTER mode and the inputs are in place
+        int mode;               // 0 = exit, 1 = cost-only evaluation, 2 = H/g evaluation
+        int gen;                // which launch the command is for: workgroups of an earlier launch that have not seen their
+                                // exit command yet leave when they meet a command of a later generation
+    };
+    template <int KD, int LOGS>
+    __global__ __launch_bounds__((kSpWaves * 64)) void k_sp_persist(const ProblemDesc *__restrict__ descs, const TileDesc *__restrict__ tiles,
+                                                                  double *__restrict__ rho_out, double *__restrict__ patch_cost,
+                                                                  double *__restrict__ partials, OneArgs oa,
+                                                                  const PersistCmd *__restrict__ cmd, unsigned long long last_seq, int gen)
+    {
+        extern __shared__ __attribute__((aligned(16))) double lds[];
+        __shared__ unsigned long long s_seq;
+        __shared__ int s_mode;
+        __shared__ double knots_lds[7 * 16]; // this command's control knots [t (3N) | R (4N)], N <= 16
+        for (;;)
+        {
+            if (threadIdx.x == 0)
+            {
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned long long q;
+                int m = 0;
+                for (;;)
+                { // relaxed: an acquire here would invalidate the caches on every poll
+                    q = __hip_atomic_load(&cmd->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (q != last_seq)
+                    {
+                        m = __hip_atomic_load(&cmd->mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (__hip_atomic_load(&cmd->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != gen) m = 0;
+                        break;
+                    }
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { m = 0; break; } // ~2 s: give up
+                    __builtin_amdgcn_s_sleep(MBAVO_PERSIST_SLEEP);
+                }
+                s_seq = q;
+                s_mode = m;
+            }
+            __syncthreads();
+            const int mode = s_mode;
+            last_seq = s_seq;
+            if (mode == 0) return;
+            // nothing read from memory may be carried over from the previous command, and nothing should be: values
+            // hoisted out of this loop stay live across both bodies and spill
+            asm volatile("" ::: "memory");
+            // The inputs the host rewrote (it wrote them BEFORE the sequence number, sfence in between): the knots go into
+            // LDS through cache-bypassing loads, the residual scale and the outlier flags are read the same way where they
+            // are used.  No acquire fence: the images, keypoints and descriptors stay in the caches across commands.
+            const ProblemDesc &d0 = descs[0];
+            double *kn = knots_lds;
+            for (int i = threadIdx.x; i < 7 * d0.N; i += kSpWaves * 64)
+                kn[i] = __hip_atomic_load(i < 3 * d0.N ? d0.knots_t + i : d0.knots_R + (i - 3 * d0.N), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            oa.seq = last_seq;
+#if defined(MBAVO_PERSIST_STAMPS)
+            oa.t_seen = __builtin_amdgcn_s_memrealtime();
+#endif
+            if (mode == 2)
+                sp_tile_body<KD, true, false, LOGS, true, true>(lds, descs, tiles, nullptr, rho_out, patch_cost, nullptr, partials, oa, kn, kn + 3 * d0.N);
+            else
+                sp_tile_body<KD, false, false, LOGS, true, true>(lds, descs, tiles, nullptr, rho_out, patch_cost, nullptr, partials, oa, kn, kn + 3 * d0.N);
+            __syncthreads(); // LDS (and s_seq / s_mode) are reused by the next command
         }
     }
 
@@ -1248,10 +1393,12 @@ namespace mbavo
 
     Engine::~Engine()
     {
+        (void)persistent_end();
         (void)comm_destroy();
         void *bufs[] = {d_layout_, d_poses_, d_rho_, d_partials_,
                         d_status_, d_tickets_};
         if (h_flag_) (void)hipHostFree(h_flag_);
+        if (d_push_) (void)hipFree(d_push_);
         for (void *p : bufs)
             if (p) (void)hipFree(p);
         if (h_fb_) (void)hipHostFree(h_fb_);
@@ -1572,6 +1719,7 @@ namespace mbavo
     {
         if (B < 1 || !probs || !d_frame_blocks || (kdeg != 2 && kdeg != 4)) return MBAVO_E_ARG;
         if (d_patch_blocks_strided && B != 1) return MBAVO_E_ARG;
+        if (persist_active_) return MBAVO_E_ARG; // the stream is held by the persistent kernel: persistent_end() first
         int rc;
         {
             PhaseScope ps_layout(PhaseTimers::kOther);
@@ -1627,6 +1775,129 @@ namespace mbavo
         last_kernel_id_[0] = kdeg; last_kernel_id_[1] = with_hessian; last_kernel_id_[2] = half_grad; last_kernel_id_[3] = sp_logs_;
         last_kernel_id_[4] = one;
         return rc;
+    }
+
+    void *Engine::push_block(size_t bytes)
+    {
+        if (persist_active_) return nullptr;
+        if (d_push_ && bytes <= cap_push_) return d_push_;
+        if (d_push_) { (void)hipFree(d_push_); d_push_ = nullptr; cap_push_ = 0; }
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != device_) (void)hipSetDevice(device_);
+        const size_t want = (bytes + 4095) & ~(size_t)4095;
+        if (hipExtMallocWithFlags(&d_push_, want, hipDeviceMallocFinegrained) != hipSuccess) { d_push_ = nullptr; (void)hipGetLastError(); return nullptr; }
+        if (hipMemset(d_push_, 0, want) != hipSuccess) { (void)hipFree(d_push_); d_push_ = nullptr; return nullptr; }
+        (void)hipDeviceSynchronize();
+        cap_push_ = want;
+        return d_push_;
+    }
+
+    int Engine::persistent_begin(const mbavo_problem &p, int kdeg, double *h_frame_blocks, double *h_patch_cost, const double *h_inv)
+    {
+        if (persist_active_ || !h_frame_blocks || !h_inv || (kdeg != 2 && kdeg != 4)) return MBAVO_E_ARG;
+        if (env_int("MBAVO_PERSIST", 1) == 0 || env_int("MBAVO_ONE", 1) == 0) return 1;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != device_) HIP_TRY(hipSetDevice(device_));
+        int rc = rebuild_layout(1, &p, kdeg, nullptr, h_inv);
+        if (rc) return rc;
+        const int ntiles = (int)h_tiles_.size();
+        if (sp_logs_ <= 0 || !sp_one_fits(kdeg, sp_logs_) || ntiles < 1 || ntiles > num_cus_ || h_descs_[0].grad_fp16 || p.N > 16) return 1;
+        if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 64, hipHostMallocDefault) != hipSuccess) { h_flag_ = nullptr; return (int)hipErrorOutOfMemory; }
+        if (!d_push_) return 1; // no CPU-writable device memory: the caller takes the per-evaluation launches
+        volatile PersistCmd *cmd = (volatile PersistCmd *)d_push_;
+        cmd->mode = 0;
+        cmd->gen = ++persist_gen_;
+        __builtin_ia32_sfence();
+        cmd->seq = flag_seq_;
+        __builtin_ia32_sfence();
+        OneArgs oa;
+        memset(&oa, 0, sizeof(oa));
+        oa.bf_tile_begin = (const int *)d_bf_tile_begin_;
+        oa.tickets = (int *)d_tickets_;
+        oa.slots_done = (int *)d_tickets_ + total_bf_;
+        oa.frame_blocks = h_frame_blocks; oa.valid_out = nullptr; oa.status = (int *)d_status_;
+        oa.nbf = total_bf_;
+        oa.host_flag = (unsigned long long *)h_flag_;
+        hipStream_t st = stream_;
+#define MBAVO_PERSIST_LAUNCH(KD, LG)                                                                                              \
+    do                                                                                                                            \
+    {                                                                                                                             \
+        if constexpr (SpLds<KD, true, LG, true>::kFits)                                                                           \
+        {                                                                                                                         \
+            const size_t lds_sp = SpLds<KD, true, LG, true>::kBytes > SpLds<KD, false, LG, true>::kBytes                          \
+                                      ? SpLds<KD, true, LG, true>::kBytes : SpLds<KD, false, LG, true>::kBytes;                    \
+            HIP_TRY(ensure_lds((const void *)k_sp_persist<KD, LG>, lds_sp));                                                      \
+            hipLaunchKernelGGL((k_sp_persist<KD, LG>), dim3(ntiles), dim3(kSpWaves * 64), lds_sp, st, (const ProblemDesc *)d_descs_, \
+                               (const TileDesc *)d_tiles_, (double *)d_rho_, h_patch_cost, (double *)d_partials_, oa,             \
+                               (const PersistCmd *)d_push_, flag_seq_, persist_gen_);                                              \
+        }                                                                                                                         \
+    } while (0)
+#define MBAVO_PERSIST_K(KD)                                     \
+    switch (sp_logs_)                                           \
+    {                                                           \
+    case 2: MBAVO_PERSIST_LAUNCH(KD, 2); break;                  \
+    case 3: MBAVO_PERSIST_LAUNCH(KD, 3); break;                  \
+    case 4: MBAVO_PERSIST_LAUNCH(KD, 4); break;                  \
+    default: MBAVO_PERSIST_LAUNCH(KD, 5); break;                 \
+    }
+        if (kdeg == 4) { MBAVO_PERSIST_K(4) } else { MBAVO_PERSIST_K(2) }
+#undef MBAVO_PERSIST_K
+#undef MBAVO_PERSIST_LAUNCH
+        HIP_TRY(hipGetLastError());
+        persist_active_ = true;
+        last_kernel_id_[0] = kdeg; last_kernel_id_[1] = 1; last_kernel_id_[2] = 0; last_kernel_id_[3] = sp_logs_; last_kernel_id_[4] = 1;
+        return 0;
+    }
+
+    int Engine::persistent_eval(bool with_hessian)
+    {
+        if (!persist_active_) return MBAVO_E_ARG;
+        volatile PersistCmd *cmd = (volatile PersistCmd *)d_push_;
+        const unsigned long long seq = ++flag_seq_;
+        const auto t0 = std::chrono::steady_clock::now();
+        cmd->mode = with_hessian ? 2 : 1;
+        __builtin_ia32_sfence(); // the inputs (knots, flags, scale: the push block, write-combining) and the mode are out ...
+        cmd->seq = seq;
+        __builtin_ia32_sfence(); // ... before the sequence number, which leaves the write-combining buffer now
+        volatile unsigned long long *f = (volatile unsigned long long *)h_flag_;
+        for (long spins = 1;; ++spins)
+        {
+            if (*f == seq)
+            {
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+#if defined(MBAVO_PERSIST_STAMPS)
+                {
+                    static double sum = 0, host = 0; static long cnt = 0;
+                    static double ph[3] = {0, 0, 0};
+                    sum += (double)(f[1] - f[2]) * 0.01; host += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6;
+                    ph[0] += (double)(f[3] - f[2]) * 0.01; ph[1] += (double)(f[4] - f[3]) * 0.01; ph[2] += (double)(f[5] - f[4]) * 0.01;
+                    if (++cnt % 50 == 0)
+                        fprintf(stderr, "persist: kernel-side %.2f us (pose prologue %.2f, tile %.2f, partial + ticket wait %.2f, final %.2f), host round trip %.2f us (mean of %ld)\n",
+                                sum / cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, (sum - ph[0] - ph[1] - ph[2]) / cnt, host / cnt, cnt);
+                }
+#endif
+                return 0;
+            }
+            __builtin_ia32_pause();
+            if ((spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) break;
+        }
+        fprintf(stderr, "mbavo: persistent evaluation timed out\n");
+        persist_active_ = false; // the workgroups give up by themselves (~2 s)
+        (void)hipStreamSynchronize(stream_);
+        (void)hipMemsetAsync(d_tickets_, 0, cap_tickets_, stream_);
+        return (int)hipErrorLaunchTimeOut;
+    }
+
+    int Engine::persistent_end()
+    {
+        if (!persist_active_) return 0;
+        volatile PersistCmd *cmd = (volatile PersistCmd *)d_push_;
+        cmd->mode = 0;
+        __builtin_ia32_sfence();
+        cmd->seq = ++flag_seq_;
+        __builtin_ia32_sfence();
+        persist_active_ = false;
+        return 0;
     }
 
     // Wait for the evaluation just enqueued: spin on the completion word the last workgroup writes to pinned host memory

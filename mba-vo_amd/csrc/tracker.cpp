@@ -124,9 +124,10 @@ namespace mbavo
             // The outlier count changes with every accepted step; it reaches the kernels through a pinned word (inv_ptr)
             // instead of the problem descriptor, so the engine's cached layout stays valid for the whole level
             int num_bad = 0;
+            double *inv_word = h_inv; // where the kernels read the scale: re-pointed at the push block in persistent mode
             auto set_inv = [&]() {
                 const long long nres = (long long)(L.K - num_bad) * F * L.P; // spline_update_step.cpp:116-117
-                *h_inv = nres > 0 ? 1.0 / (double)nres : 0.0;
+                *inv_word = nres > 0 ? 1.0 / (double)nres : 0.0;
             };
             set_inv();
             for (int a = 0; a < 4; ++a) p.intrinsics[a] = o.intrinsics[a] / scale; // :766-770
@@ -146,6 +147,35 @@ namespace mbavo
                     spline_segment(ts, t0, dt, idx, u);
                     if (idx < 0 || idx + k > N) { rc_ = MBAVO_E_RANGE; goto done; }
                 }
+            // Small levels (everything the reference's semi-dense detector produces): ONE persistent launch for the whole
+            // level -- the evaluations below are commands to its resident workgroups (Engine::persistent_*), the outlier
+            // flags are read from the pinned staging buffer directly.  Otherwise one launch (or three) per evaluation.
+            // The per-evaluation inputs of the persistent workgroups live in the engine's push block: fine-grained DEVICE
+            // memory the CPU writes through the PCIe BAR (write-only for the host): [command 64 B | scale | knots t | knots R
+            // | outlier flags].  Without such a block (or for levels too large for the sample-parallel kernel) the inputs
+            // stay in pinned host memory / device copies and every evaluation is its own launch.
+            char *push = (char *)eng.push_block(Engine::kPushHeader + 64 + sizeof(double) * 7 * N + (size_t)(maxK > 0 ? maxK : 1) + 64);
+            double *w_inv = h_inv, *w_kt = d_kt, *w_kR = d_kR;
+            unsigned char *w_flags = flags;
+            int pr = 1;
+            if (push)
+            {
+                double *b = (double *)(push + Engine::kPushHeader);
+                w_inv = b; w_kt = b + 8; w_kR = w_kt + 3 * N;
+                w_flags = (unsigned char *)(w_kR + 4 * N);
+                p.d_knots_t = w_kt; p.d_knots_R = w_kR; p.d_outlier = w_flags;
+                memset(w_flags, 0, L.K > 0 ? L.K : 1);
+                *w_inv = *h_inv;
+                pr = eng.persistent_begin(p, k, h_pin, d_pc, w_inv);
+                if (pr < 0 || pr > 1) { rc_ = pr; goto done; }
+            }
+            const bool persistent = pr == 0;
+            if (persistent) inv_word = w_inv;
+            if (!persistent)
+            {
+                w_inv = h_inv; w_kt = d_kt; w_kR = d_kR; w_flags = flags;
+                p.d_knots_t = d_kt; p.d_knots_R = d_kR; p.d_outlier = d_flags; // per-evaluation launches read the device copy
+            }
             // one evaluation at the given knots: knots into the pinned buffer, ONE launch for these problem sizes (pose
             // prologue + fused + last-workgroup finalize) whose frame blocks land in pinned host memory (h_pin), then a
             // spin on the kernel's completion word: no copies, no stream synchronisation
@@ -153,14 +183,15 @@ namespace mbavo
                 int r;
                 {
                     PhaseScope ps(PhaseTimers::kEnqueue);
-                    memcpy(d_kt, kt, sizeof(double) * 3 * N);
-                    memcpy(d_kR, kR, sizeof(double) * 4 * N);
-                    r = eng.evaluate(1, &p, k, with_h, h_pin, d_pc, nullptr, nullptr, nullptr, h_inv, true);
+                    memcpy(w_kt, kt, sizeof(double) * 3 * N);
+                    memcpy(w_kR, kR, sizeof(double) * 4 * N);
+                    if (!persistent) r = eng.evaluate(1, &p, k, with_h, h_pin, d_pc, nullptr, nullptr, nullptr, h_inv, true);
+                    else r = 0;
                 }
                 if (r) return r;
                 {
                     PhaseScope ps(PhaseTimers::kWait);
-                    r = eng.wait_evaluation();
+                    r = persistent ? eng.persistent_eval(with_h) : eng.wait_evaluation();
                 }
                 if (r) return r;
                 PhaseScope ps(PhaseTimers::kMerge);
@@ -223,9 +254,9 @@ namespace mbavo
                 { // isStepSuccessful (:890-894) -> detectOutliers + handleSuccessfulStep (:896-903)
                     {
                         PhaseScope ps(PhaseTimers::kOutliers);
-                        num_bad = detect_outliers(d_pc, L.K, o.max_chi_square_error, flags); // frame 0's costs, just written
+                        num_bad = detect_outliers(d_pc, L.K, o.max_chi_square_error, w_flags); // frame 0's costs, just written
                         set_inv();
-                        TRK_HIP(hipMemcpyAsync(d_flags, flags, L.K, hipMemcpyHostToDevice, st));
+                        if (!persistent) TRK_HIP(hipMemcpyAsync(d_flags, w_flags, L.K, hipMemcpyHostToDevice, st));
                     }
                     spline.InvalidParameter(cand_t.data(), cand_R.data());
                     if ((rc_ = evaluate(spline.get_knot_data_t(), spline.get_knot_data_R(), true, &eval_cost))) goto done;
@@ -237,11 +268,13 @@ namespace mbavo
                 lm.step_rejected(); // handleUnsuccessfulStep
                 record(iter, 2, cand_cost, model, quality);
             }
+            (void)eng.persistent_end(); // the level's resident workgroups exit; the next level's launch queues behind them
         }
         memcpy(knots_t, spline.get_knot_data_t(), sizeof(double) * 3 * N);
         memcpy(knots_R, spline.get_knot_data_R(), sizeof(double) * 4 * N);
         if (final_cost) *final_cost = eval_cost;
     done:
+        (void)eng.persistent_end();
         return rc_ ? (rc_ > 0 ? -1000 - rc_ : rc_) : ntrace;
     }
 } // namespace mbavo
