@@ -539,6 +539,25 @@ namespace mbavo
         }
     }
 
+#if defined(MBAVO_FUSED_STAMPS) // timing experiment (tools/fused_stamps.py): where a workgroup of k_fused spends its time
+    __device__ unsigned long long g_fused_stamps[2048 * 8];
+    __device__ unsigned long long g_wave_stamps[1024 * 16 * 4]; // [block][wave][loop start, loop end, HW_ID, rounds]
+#define MBAVO_WSTAMP(i, v) do { if (lane == 0 && blockIdx.x < 1024) g_wave_stamps[(blockIdx.x * 16 + wave) * 4 + (i)] = (v); } while (0)
+#define MBAVO_FSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_fused_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MBAVO_FSTAMP(i) do { } while (0)
+#define MBAVO_WSTAMP(i, v) do { } while (0)
+#endif
+    __device__ __forceinline__ void set_prio(int p) // s_setprio takes an immediate; p is wave-uniform
+    {
+        switch (p)
+        {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    }
 #if defined(MBAVO_MIN_WAVES_EU) // experiments with several smaller workgroups per CU: keep the 3-waves-per-SIMD register budget
 #define MBAVO_FUSED_OCC __attribute__((amdgpu_waves_per_eu(MBAVO_MIN_WAVES_EU)))
 #else
@@ -563,6 +582,16 @@ namespace mbavo
 
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        MBAVO_FSTAMP(0);
+#if defined(MBAVO_FUSED_STAMPS)
+        if (threadIdx.x == 0 && blockIdx.x < 2048)
+        {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_fused_stamps[blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+        }
+#endif
         const int tile_id = xcd_tile_of_block((int)blockIdx.x, (int)gridDim.x);
         const TileDesc tile = tiles[tile_id];
         const ProblemDesc &d = descs[tile.prob];
@@ -623,6 +652,14 @@ namespace mbavo
         const double inv = residual_scale<false>(d, lane);
         double cost_local = 0.0;
         int main_end = npx;
+        MBAVO_FSTAMP(1);
+        // The SIMD arbiter serves the OLDEST ready wave first: of the three waves a SIMD holds, the oldest ran ahead
+        // through all its rounds and the youngest finished last, alone, at a third of the SIMD's rate (s_memrealtime
+        // stamps per wave, tools/fused_stamps.py: 24.4 / 29.9 / 33.7 us on configs[1]).  The user priority outranks
+        // age: every wave starts at 3 and steps down over its last three rounds (3, 2, 1; the parking + MFMA phase of a
+        // round one lower), so that a wave that is behind overtakes and the three finish together.  A/B, fused kernel:
+        // configs[1] 34.6 -> 33.4 us, 512 pairs 106.1 -> 101.5, 1080p S=16 212.4 -> 196.0 (profiles/r02_kfused_experiments.txt).
+        __builtin_amdgcn_s_setprio(3);
         if (sp_ok)
         {
             const int rem = npx % kThreads;
@@ -651,6 +688,15 @@ namespace mbavo
 #if defined(MBAVO_EXP_NO_ROUNDS) // timing experiment: launch + prologue + end-of-tile work only
         main_end = 0;
 #endif
+        MBAVO_FSTAMP(2);
+        MBAVO_WSTAMP(0, __builtin_amdgcn_s_memrealtime());
+#if defined(MBAVO_FUSED_STAMPS)
+        {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            MBAVO_WSTAMP(2, hw);
+        }
+#endif
         for (int base = 0; base < main_end; base += kThreads)
         {
             const int g = base + (int)threadIdx.x;
@@ -670,8 +716,14 @@ namespace mbavo
 #else
                 patch_centre_rt(mid.rt, mid.q, kx, ky, kz, cam, pcx, pcy);
 #endif
+                // Wave priority by remaining work (see below the round loop's head): the sample loop of a wave that is
+                // behind goes first, the row parking + MFMA phase one step lower.
+                const int rem_rounds = (main_end - base + kThreads - 1) / kThreads; // 1 in the last round
+                const int prio = rem_rounds > 3 ? 3 : rem_rounds;
+                set_prio(prio);
                 const bool valid = pixel_row<KD, WITH_J, HALF_GRAD>(ftab, S, cam, d.ref_img, d.ref_dIxy, I_cur, pcx, pcy, kz,
                                                          d.pattern[2 * pp], d.pattern[2 * pp + 1], res, Jrow, inv_S);
+                set_prio(prio - 1);
                 huber_weight(res, d.huber_a, w, rho);
                 if (P == 1)
                 {
@@ -720,6 +772,8 @@ namespace mbavo
 #if defined(MBAVO_EXP_NO_TAIL) // timing experiment: no end-of-tile work
         if (npx >= 0) return;
 #endif
+        MBAVO_WSTAMP(1, __builtin_amdgcn_s_memrealtime());
+        MBAVO_FSTAMP(3); // (wave 0's own rounds are done; the barrier below waits for the slowest wave)
         // per-patch cost = slot 0 of the reference's patch block (:232-238), and the
         // tile's share of the frame cost (outlier patches skipped, :265-272)
         if (P != 1)
@@ -744,6 +798,7 @@ namespace mbavo
         // over waves (and pixel groups) in a fixed order.  One barrier for the scratch and the slabs.
         if (WITH_J) acc.store(slab, lane);
         __syncthreads();
+        MBAVO_FSTAMP(4);
         double *out = partials + (size_t)tile_id * PS;
         if (threadIdx.x == 0)
         {
@@ -761,6 +816,10 @@ namespace mbavo
                 out[e] = OuterAcc<ND>::gather(rows, i, j, kWavesPerGroup);
             }
         }
+#if defined(MBAVO_FUSED_STAMPS)
+        __syncthreads();
+        MBAVO_FSTAMP(5);
+#endif
     }
 
     // ------------------------------------------------------------------ single-launch pieces
@@ -1992,3 +2051,16 @@ namespace mbavo
         return delta;
     }
 } // namespace mbavo
+
+#if defined(MBAVO_FUSED_STAMPS) // experiment builds only (tools/fused_stamps.py)
+extern "C" int mbavo_debug_fused_stamps(unsigned long long *out, int n)
+{
+    if (n > 2048 * 8) n = 2048 * 8;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mbavo::g_fused_stamps), sizeof(unsigned long long) * n);
+}
+extern "C" int mbavo_debug_wave_stamps(unsigned long long *out, int n)
+{
+    if (n > 1024 * 16 * 4) n = 1024 * 16 * 4;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mbavo::g_wave_stamps), sizeof(unsigned long long) * n);
+}
+#endif
