@@ -443,6 +443,25 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:  # a failing side config must not cost the headline line
                 cfgs[key] = {"error": repr(e)}
+        # the caller of the path: BlurAwareDirectTracker::trackFrame on a GPU-rendered blurred sequence, reference-shaped
+        # configuration (blur_aware_direct_tracker.cpp:88-203,544-637); wall time of the mbavo_vo_track_frame calls
+        try:
+            from mba_vo_amd import sequence
+            seq = sequence.make_sequence(ctx, H=480, W=640, M=8, device=dev)
+            sequence.track_sequence(ctx, seq)  # warm-up: allocations, code objects
+            runs = [sequence.track_sequence(ctx, seq) for _ in range(5)]
+            per_frame = sorted(sum(f["seconds"] for f in r) / len(r) for r in runs)
+            r0 = runs[0]
+            cfgs["trackframe_640x480"] = {
+                "workload": "BlurAwareDirectTracker::trackFrame, 640x480, 4 levels, 30-px grid keypoints x 8-pixel pattern, k = 2, "
+                            "S = 8, %d frames (GPU-rendered blurred sequence on a textured plane), host-driven LM loop on "
+                            "persistent evaluation kernels" % len(r0),
+                "ms_per_frame": round(1e3 * per_frame[len(per_frame) // 2], 4), "ms_per_frame_min": round(1e3 * per_frame[0], 4),
+                "passes": len(runs), "frames": len(r0), "keyframes": int(sum(f["is_keyframe"] for f in r0)),
+                "keypoints_level0": int(r0[0]["K0"]), "lm_trace_records": int(sum(f["num_trace"] for f in r0)),
+                "poses_reproducible": bool(all(np.array_equal(a["T"], b["T"]) for r in runs[1:] for a, b in zip(r0, r)))}
+        except Exception as e:
+            cfgs["trackframe_640x480"] = {"error": repr(e)}
         out["configs"] = cfgs
 
     if rank == 0 and not args.no_cpu_baseline and world == 1 and fb_gpu is not None:  # rank 0 at N = 1 only

@@ -149,6 +149,24 @@ namespace mbavo
         void *d_layout_ = nullptr; size_t cap_layout_ = 0; // one arena: descs | tiles | bf_tile_begin | bf_prob | entry_prob
         std::vector<char> h_layout_;
         void *d_descs_ = nullptr, *d_tiles_ = nullptr, *d_bf_tile_begin_ = nullptr, *d_bf_prob_ = nullptr, *d_entry_prob_ = nullptr;
+        // The trackers cycle through a few layouts (one per pyramid level, the same ones frame after frame until the
+        // keyframe changes): the layouts that are not active wait here with their device arenas, and a problem list that
+        // matches one is a pointer swap instead of a tiling pass and an upload (4 uploads per tracked frame otherwise).
+        struct ParkedLayout
+        {
+            std::vector<ProblemDesc> descs;
+            std::vector<TileDesc> tiles;
+            std::vector<int> bf_tile_begin, bf_prob, entry_prob;
+            int kdeg = 0, total_bf = 0, total_entries = 0, sp_logs = 0;
+            long long total_pixels = 0, total_patches = 0;
+            bool uploaded = false, flat_finalize = false;
+            void *d_layout = nullptr; size_t cap_layout = 0;
+            void *d_descs = nullptr, *d_tiles = nullptr, *d_bf_tile_begin = nullptr, *d_bf_prob = nullptr, *d_entry_prob = nullptr;
+        };
+        static constexpr int kParkedLayouts = 4;
+        ParkedLayout parked_[kParkedLayouts];
+        int parked_victim_ = 0;
+        void swap_layout(ParkedLayout &s);
         void *d_poses_ = nullptr; size_t cap_poses_ = 0;
         void *d_rho_ = nullptr; size_t cap_rho_ = 0;
         void *d_partials_ = nullptr; size_t cap_partials_ = 0;
@@ -162,7 +180,7 @@ namespace mbavo
         int persist_gen_ = 0;
         int status_seen_ = 0;
         void *h_fb_ = nullptr; size_t cap_hfb_ = 0;
-        static constexpr int kPinnedSlots = 4;
+        static constexpr int kPinnedSlots = 6;
         void *pinned_[kPinnedSlots] = {};
         size_t pinned_cap_[kPinnedSlots] = {};
 

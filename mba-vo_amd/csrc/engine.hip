@@ -1460,6 +1460,8 @@ namespace mbavo
         if (d_push_) (void)hipFree(d_push_);
         for (void *p : bufs)
             if (p) (void)hipFree(p);
+        for (ParkedLayout &s : parked_)
+            if (s.d_layout) (void)hipFree(s.d_layout);
         if (h_fb_) (void)hipHostFree(h_fb_);
         for (void *q : pinned_)
             if (q) (void)hipHostFree(q);
@@ -1517,6 +1519,18 @@ namespace mbavo
         return v && *v ? atoi(v) : dflt;
     }
 
+    void Engine::swap_layout(ParkedLayout &s)
+    {
+        h_descs_.swap(s.descs); h_tiles_.swap(s.tiles); h_bf_tile_begin_.swap(s.bf_tile_begin); h_bf_prob_.swap(s.bf_prob);
+        h_entry_prob_.swap(s.entry_prob);
+        std::swap(cached_kdeg_, s.kdeg); std::swap(total_bf_, s.total_bf); std::swap(total_entries_, s.total_entries);
+        std::swap(sp_logs_, s.sp_logs); std::swap(total_pixels_, s.total_pixels); std::swap(total_patches_, s.total_patches);
+        std::swap(layout_uploaded_, s.uploaded); std::swap(flat_finalize_, s.flat_finalize);
+        std::swap(d_layout_, s.d_layout); std::swap(cap_layout_, s.cap_layout);
+        std::swap(d_descs_, s.d_descs); std::swap(d_tiles_, s.d_tiles); std::swap(d_bf_tile_begin_, s.d_bf_tile_begin);
+        std::swap(d_bf_prob_, s.d_bf_prob); std::swap(d_entry_prob_, s.d_entry_prob);
+    }
+
     int Engine::rebuild_layout(int B, const mbavo_problem *probs, int kdeg, const int *d_active, const double *d_inv)
     {
         std::vector<ProblemDesc> &descs = scratch_descs_; // member: no allocation per call in the LM loop
@@ -1555,6 +1569,23 @@ namespace mbavo
         const bool same = kdeg == cached_kdeg_ && descs.size() == h_descs_.size() &&
                           memcmp(descs.data(), h_descs_.data(), descs.size() * sizeof(ProblemDesc)) == 0;
         if (same && layout_uploaded_) return 0;
+        if (B <= 8)
+        { // a parked layout of the same problem list?  Otherwise the active one is parked (oldest slot) and the new one
+          // is built over that slot's buffers (stream order protects an arena a queued kernel still reads)
+            for (ParkedLayout &s : parked_)
+                if (s.uploaded && s.kdeg == kdeg && s.descs.size() == descs.size() &&
+                    memcmp(descs.data(), s.descs.data(), descs.size() * sizeof(ProblemDesc)) == 0)
+                {
+                    swap_layout(s);
+                    return 0;
+                }
+            if (layout_uploaded_ && h_descs_.size() <= 8)
+            {
+                swap_layout(parked_[parked_victim_]);
+                parked_victim_ = (parked_victim_ + 1) % kParkedLayouts;
+                layout_uploaded_ = false;
+            }
+        }
 
         // tiles: contiguous keypoint ranges of one (problem, frame).  One workgroup is resident per CU (LDS), so
         // the tile count must not exceed CUs x rounds or a nearly empty extra round doubles the time: take the
@@ -1781,7 +1812,7 @@ namespace mbavo
         if (persist_active_) return MBAVO_E_ARG; // the stream is held by the persistent kernel: persistent_end() first
         int rc;
         {
-            PhaseScope ps_layout(PhaseTimers::kOther);
+            PhaseScope ps_layout(PhaseTimers::kLevel);
             // hipSetDevice costs ~5 us per call on this runtime (measured with the host phase timers: it was two thirds of
             // the enqueue time of an evaluation); hipGetDevice is a thread-local read
             int cur = -1;

@@ -40,12 +40,6 @@ namespace mbavo
         mag[(size_t)y * W + x] = gradient_magnitude(src, H, W, x, y);
     }
 
-    struct CellPick
-    {
-        int x, y, keep;
-        float z;
-    };
-
     // level-0 depth of a level-`lv` pixel (blur_aware_direct_tracker.cpp:398-400): int(x * 2^lv + 0.5)
     __device__ __forceinline__ bool depth_of(const float *__restrict__ depth, int W0, double scale, int x, int y, float &z)
     {
@@ -86,7 +80,7 @@ namespace mbavo
             if (!(best < 1e-6)) // FeatureDetectorBase.cpp:82-85
             {
                 p.y = best_idx / W; p.x = best_idx - p.y * W;
-                p.keep = depth_of(depth, W0, scale, p.x, p.y, p.z) ? 1 : 0;
+                p.keep = depth == nullptr ? 1 : (depth_of(depth, W0, scale, p.x, p.y, p.z) ? 1 : 0); // (null: the caller tests the depth)
             }
             picks[ci] = p;
         }
@@ -236,6 +230,24 @@ namespace mbavo
         if ((e = hipGetLastError()) != hipSuccess) return (int)e;
         if ((e = hipMemcpyAsync(h_count, d_count, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return (int)e;
         return (int)hipStreamSynchronize(st);
+    }
+
+    int detect_cells_enqueue(Engine &eng, const unsigned char *d_img, int H, int W, int level, int im_H0, int im_W0, int cell_H,
+                             int cell_W, float thr, CellPick *d_picks, int *num_cells)
+    {
+        if (!d_img || !d_picks || !num_cells || H < 1 || W < 1 || level < 0 || level > 30 || cell_H < 1 || cell_W < 1) return MBAVO_E_ARG;
+        // FeatureDetectorBase.cpp:56-64 (as in detect_semidense)
+        const int sf = (int)std::pow(2, level);
+        const int Hl = im_H0 / sf, Wl = im_W0 / sf;
+        const int ch = (int)(cell_H / std::pow(1.414, level)), cw = (int)(cell_W / std::pow(1.414, level));
+        if (ch < 1 || cw < 1) return MBAVO_E_ARG;
+        const int cells_h = Hl / ch + 1, cells_w = Wl / cw + 1;
+        if ((H - 1) / ch >= cells_h || (W - 1) / cw >= cells_w) return MBAVO_E_RANGE;
+        const int nc = cells_h * cells_w;
+        hipLaunchKernelGGL(k_detect_cells, dim3(nc), dim3(64), 0, eng.stream(), d_img, H, W, ch, cw, cells_w, thr, (const float *)nullptr,
+                           im_W0, std::pow(2, level), d_picks);
+        *num_cells = nc;
+        return (int)hipGetLastError();
     }
 } // namespace mbavo
 

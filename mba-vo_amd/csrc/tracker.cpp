@@ -89,8 +89,8 @@ namespace mbavo
 
         TRK_HIP(hipSetDevice(eng.device()));
         // engine-owned scratch, reused by every call (no hipMalloc / hipFree in the tracking loop)
-        d_cap = (double *)eng.named_scratch(0, sizeof(double) * F);
-        d_exp = (double *)eng.named_scratch(1, sizeof(double) * F);
+        d_cap = (double *)eng.named_scratch(0, sizeof(double) * 2 * F);
+        d_exp = d_cap ? d_cap + F : nullptr;
         // the knots live in pinned, device-visible host memory [t (3N) | R (4N)]: the host writes them before an
         // evaluation and the kernels' pose prologue reads them over the bus -- no copy, no launch
         d_kt = (double *)eng.pinned_scratch(2, sizeof(double) * 7 * N);
@@ -105,16 +105,20 @@ namespace mbavo
         if (h_pin) memset(h_pin, 0, sizeof(double) * (size_t)F * E);
         h_inv = (double *)eng.pinned_scratch(3, sizeof(double));
         if (!h_inv || !d_cap || !d_exp || !d_kt || !d_kR || !d_pc || !d_flags || !flags || !h_pin) { rc_ = (int)hipErrorOutOfMemory; goto done; }
-        TRK_HIP(hipMemcpyAsync(d_cap, h_cap, sizeof(double) * F, hipMemcpyHostToDevice, st)); // :701-719
-        TRK_HIP(hipMemcpyAsync(d_exp, h_exp, sizeof(double) * F, hipMemcpyHostToDevice, st));
+        { // capture / exposure times: one asynchronous copy from pinned staging [cap F | exp F] (:701-719)
+            double *stage = (double *)eng.pinned_scratch(4, sizeof(double) * 2 * F);
+            if (!stage) { rc_ = (int)hipErrorOutOfMemory; goto done; }
+            memcpy(stage, h_cap, sizeof(double) * F);
+            memcpy(stage + F, h_exp, sizeof(double) * F);
+            TRK_HIP(hipMemcpyAsync(d_cap, stage, sizeof(double) * 2 * F, hipMemcpyHostToDevice, st));
+        }
 
         for (int li = 0; li < o.num_levels; ++li)
         {
             const int lv = o.num_levels - li - 1; // coarse to fine (:571-575)
             const mbavo_level &L = levels[lv];
             const int scale = 1 << lv;
-            memset(flags, 0, L.K > 0 ? L.K : 1);
-            TRK_HIP(hipMemsetAsync(d_flags, 0, L.K > 0 ? L.K : 1, st)); // :601
+            memset(flags, 0, L.K > 0 ? L.K : 1); // :601 (the device copy below, where it is used)
             mbavo_problem p;
             memset(&p, 0, sizeof(p));
             p.S = L.S; p.F = F; p.K = L.K; p.P = L.P; p.N = N; p.H = L.H; p.W = L.W;
@@ -158,6 +162,7 @@ namespace mbavo
             double *w_inv = h_inv, *w_kt = d_kt, *w_kR = d_kR;
             unsigned char *w_flags = flags;
             int pr = 1;
+            PhaseScope ps_level(PhaseTimers::kLevel);
             if (push)
             {
                 double *b = (double *)(push + Engine::kPushHeader);
@@ -169,12 +174,15 @@ namespace mbavo
                 pr = eng.persistent_begin(p, k, h_pin, d_pc, w_inv);
                 if (pr < 0 || pr > 1) { rc_ = pr; goto done; }
             }
+            ps_level.~PhaseScope();
+            ps_level.on = false;
             const bool persistent = pr == 0;
             if (persistent) inv_word = w_inv;
             if (!persistent)
             {
                 w_inv = h_inv; w_kt = d_kt; w_kR = d_kR; w_flags = flags;
                 p.d_knots_t = d_kt; p.d_knots_R = d_kR; p.d_outlier = d_flags; // per-evaluation launches read the device copy
+                TRK_HIP(hipMemsetAsync(d_flags, 0, L.K > 0 ? L.K : 1, st));
             }
             // one evaluation at the given knots: knots into the pinned buffer, ONE launch for these problem sizes (pose
             // prologue + fused + last-workgroup finalize) whose frame blocks land in pinned host memory (h_pin), then a

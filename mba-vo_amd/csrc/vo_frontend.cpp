@@ -161,7 +161,7 @@ namespace SLAM
 
         BlurAwareDirectTracker::BlurAwareDirectTracker(mbavo::Engine &engine, const BlurAwareDirectTrackerOptions &options)
             : mEngine(engine), mOptions(options), mPrevTimestamp(0), mEvaluationPointCost(0), mIsFirstFrame(true),
-              mCurCap(0), mCurExp(0), mStatus(0), mDepth(nullptr)
+              mCurCap(0), mCurExp(0), mStatus(0), mDepth(nullptr), mPicksDev(nullptr), mPicksHost(nullptr), mKpStage(nullptr)
         { // blur_aware_direct_tracker.cpp:14-34; the shared storages are the engine's
             for (int i = 0; i < 6; ++i) mNeighFrameVelocity[i] = mSplineVelocity[i] = 0;
             for (int l = 0; l < 8; ++l)
@@ -173,11 +173,12 @@ namespace SLAM
             const int H = mOptions.im_size_HW[0], W = mOptions.im_size_HW[1], L = mOptions.num_pyramid_levels;
             if (L < 1 || L > 8 || H < 2 || W < 2) { mStatus = MBAVO_E_ARG; return; }
             auto alloc = [&](void **p, size_t bytes) { if (mStatus == 0) { hipError_t e = hipMalloc(p, bytes ? bytes : 1); if (e != hipSuccess) mStatus = (int)e; } };
-            alloc((void **)&mDepth, sizeof(float) * (size_t)H * W);
+            const bool grid = mOptions.grid_selection_cell_H > 0 && mOptions.grid_selection_cell_W > 0;
+            if (!grid) alloc((void **)&mDepth, sizeof(float) * (size_t)H * W); // (grid selection tests the depth on the host)
+            mPickOff[0] = mStageOff[0] = 0;
             for (int l = 0; l < L && mStatus == 0; ++l)
             {
                 const size_t n = (size_t)(H >> l) * (W >> l);
-                const bool grid = mOptions.grid_selection_cell_H > 0 && mOptions.grid_selection_cell_W > 0;
                 mKpCap[l] = grid ? grid_cells(H, W, l, mOptions.grid_selection_cell_H, mOptions.grid_selection_cell_W) : (int)n;
                 if (mKpCap[l] < 1) { mStatus = MBAVO_E_ARG; return; }
                 alloc((void **)&mRef[l], n); alloc((void **)&mCur[l], n); alloc((void **)&mGrad[l], n * 2 * sizeof(float));
@@ -186,6 +187,8 @@ namespace SLAM
                 const int P = mOptions.patch_size[l];
                 if (P < 1 || !mOptions.local_patch_pattern_xy[l]) { mStatus = MBAVO_E_ARG; return; }
                 alloc((void **)&mPattern[l], sizeof(int) * 2 * P);
+                mPickOff[l + 1] = mPickOff[l] + (size_t)mKpCap[l];
+                mStageOff[l + 1] = mStageOff[l] + 3 * (size_t)mKpCap[l];
                 if (mStatus == 0)
                 {
                     hipError_t e = hipMemcpy(mPattern[l], mOptions.local_patch_pattern_xy[l], sizeof(int) * 2 * P, hipMemcpyHostToDevice);
@@ -195,9 +198,20 @@ namespace SLAM
             }
         }
 
+        int BlurAwareDirectTracker::ensureGridBuffers()
+        { // first keyframe with grid selection: picks of every cell of every level, device + pinned; pinned keypoint staging
+            if (mPicksDev) return 0;
+            const int L = mOptions.num_pyramid_levels;
+            VO_HIP(hipMalloc((void **)&mPicksDev, sizeof(mbavo::CellPick) * mPickOff[L]));
+            VO_HIP(hipHostMalloc((void **)&mPicksHost, sizeof(mbavo::CellPick) * mPickOff[L], hipHostMallocDefault));
+            VO_HIP(hipHostMalloc((void **)&mKpStage, sizeof(double) * mStageOff[L], hipHostMallocDefault));
+            return 0;
+        }
+
         BlurAwareDirectTracker::~BlurAwareDirectTracker()
         {
             (void)hipFree(mDepth);
+            (void)hipFree(mPicksDev); (void)hipHostFree(mPicksHost); (void)hipHostFree(mKpStage);
             for (int l = 0; l < 8; ++l)
             {
                 (void)hipFree(mRef[l]); (void)hipFree(mCur[l]); (void)hipFree(mGrad[l]); (void)hipFree(mCurPtr[l]);
@@ -211,6 +225,51 @@ namespace SLAM
             const int H = mOptions.im_size_HW[0], W = mOptions.im_size_HW[1], L = mOptions.num_pyramid_levels;
             hipStream_t st = mEngine.stream();
             VO_HIP(hipMemcpyAsync(mRef[0], kf.image, (size_t)H * W, hipMemcpyHostToDevice, st));
+            if (mOptions.grid_selection_cell_H > 0 && mOptions.grid_selection_cell_W > 0)
+            { // grid selection: every level's kernels back to back, ONE read-back (the cells' picks) and ONE synchronisation;
+              // depth test (:398-404) and ordered compaction of the few hundred picks on the host, keypoints uploaded from
+              // pinned staging -- the 4 H x W bytes of depth never cross the bus
+                int rc = ensureGridBuffers();
+                if (rc != 0) return rc;
+                for (int l = 0; l < L; ++l)
+                {
+                    const int Hl = H >> l, Wl = W >> l;
+                    int nc = 0;
+                    if (l > 0 && (rc = mbavo_pyramid_down_u8(mRef[l - 1], H >> (l - 1), W >> (l - 1), mRef[l], st)) != 0) return rc;
+                    if ((rc = mbavo_image_gradients_u8(mRef[l], Hl, Wl, mGrad[l], st)) != 0) return rc;
+                    rc = mbavo::detect_cells_enqueue(mEngine, mRef[l], Hl, Wl, l, H, W, mOptions.grid_selection_cell_H,
+                                                     mOptions.grid_selection_cell_W, mOptions.score_threshold, mPicksDev + mPickOff[l], &nc);
+                    if (rc != 0) return rc;
+                    if (nc != mKpCap[l]) return MBAVO_E_ARG;
+                }
+                VO_HIP(hipMemcpyAsync(mPicksHost, mPicksDev, sizeof(mbavo::CellPick) * mPickOff[L], hipMemcpyDeviceToHost, st));
+                VO_HIP(hipStreamSynchronize(st));
+                for (int l = 0; l < L; ++l)
+                {
+                    const double scale = std::pow(2, l);
+                    double *xy = mKpStage + mStageOff[l], *z = xy + 2 * (size_t)mKpCap[l];
+                    int n = 0;
+                    for (int c = 0; c < mKpCap[l]; ++c)
+                    {
+                        const mbavo::CellPick &p = mPicksHost[mPickOff[l] + c];
+                        if (!p.keep) continue;
+                        const int x0 = (int)((float)p.x * scale + 0.5), y0 = (int)((float)p.y * scale + 0.5); // :398-400
+                        const float zz = depth_z[(size_t)y0 * W + x0];
+                        if ((double)zz < 1e-2) continue;
+                        xy[2 * n] = (double)p.x; xy[2 * n + 1] = (double)p.y; z[n] = (double)zz;
+                        ++n;
+                    }
+                    mNumKeypoints[l] = n;
+                    if (n > 0)
+                    {
+                        VO_HIP(hipMemcpyAsync(mKpXY[l], xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
+                        VO_HIP(hipMemcpyAsync(mKpZ[l], z, sizeof(double) * n, hipMemcpyHostToDevice, st));
+                    }
+                }
+                mHostKpXY0.assign(mKpStage, mKpStage + 2 * (size_t)mNumKeypoints[0]);
+                mHostKpZ0.assign(mKpStage + 2 * (size_t)mKpCap[0], mKpStage + 2 * (size_t)mKpCap[0] + mNumKeypoints[0]);
+                return 0;
+            }
             VO_HIP(hipMemcpyAsync(mDepth, depth_z, sizeof(float) * (size_t)H * W, hipMemcpyHostToDevice, st));
             for (int l = 0; l < L; ++l)
             {
@@ -316,6 +375,7 @@ namespace SLAM
         int BlurAwareDirectTracker::trackFrame(const FrameView &sharp, const FrameView &blur, const float *depth_z,
                                                Core::Transformation *T_out, TrackInfo *info)
         { // :88-203
+            mbavo::PhaseScope ps_all(mbavo::PhaseTimers::kTrack);
             if (mStatus != 0) return mStatus;
             if (!T_out || !sharp.image || !depth_z) return MBAVO_E_ARG;
             if (info) memset(info, 0, sizeof(*info));

@@ -21,6 +21,19 @@ namespace mbavo
     // keyframe_ops.hip: semi-dense keypoints of one pyramid level, device in / device out; count to the host
     int detect_semidense(Engine &eng, const unsigned char *d_img, int H, int W, int level, int im_H0, int im_W0, int cell_H,
                          int cell_W, float thr, const float *d_depth_z, double *d_kp_xy, double *d_kp_z, int cap, int *h_count);
+
+    // one grid cell's strongest pixel (k_detect_cells); keep = a pixel above the threshold exists (and, when the kernel is
+    // given the depth map, its depth is valid)
+    struct CellPick
+    {
+        int x, y, keep;
+        float z;
+    };
+    // grid selection only, nothing read back: the picks of the level's cells (row-major cells) -> d_picks, *num_cells of
+    // them.  The front end's keyframe path: depth test + ordered compaction of the few hundred picks happen on the host, so
+    // the depth map is never uploaded and a keyframe costs ONE stream synchronisation.
+    int detect_cells_enqueue(Engine &eng, const unsigned char *d_img, int H, int W, int level, int im_H0, int im_W0, int cell_H,
+                             int cell_W, float thr, CellPick *d_picks, int *num_cells);
 }
 
 namespace SLAM
@@ -105,6 +118,7 @@ namespace SLAM
 
         private:
             int tmpProcessKeyframe(const FrameView &keyframe, const float *depth_z);
+            int ensureGridBuffers();
             int uploadCurrentFrame(const FrameView &frame);
             int optimizeTrajectory(int *num_trace, int *start_idx);
 
@@ -126,6 +140,11 @@ namespace SLAM
             int *mPattern[8];
             int mKpCap[8], mNumKeypoints[8];
             std::vector<double> mHostKpXY0, mHostKpZ0; // level-0 keypoints for the keyframe test
+            // grid selection: the cells' picks of all levels (device + pinned host copy) and the pinned staging of the
+            // compacted keypoints [level][xy | z]
+            mbavo::CellPick *mPicksDev, *mPicksHost;
+            double *mKpStage;
+            size_t mPickOff[9], mStageOff[9];
         };
     } // namespace VO
 } // namespace SLAM

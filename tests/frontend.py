@@ -124,7 +124,9 @@ def run_oracle_vo(orc, seq, cfg=DEFAULTS):
     return out
 
 
-def run_gpu_vo(mbavo, ctx, seq, cfg=DEFAULTS):
+def run_gpu_vo(mbavo, ctx, seq, cfg=DEFAULTS, frame_seconds=None):
+    """frame_seconds: optional list, receives the wall time of every mbavo_vo_track_frame call (tools/vo_bench.py)."""
+    import time
     capi = mbavo.capi
     o, keep = fill_gpu_opts(capi, seq, cfg)
     vo = capi.vp()
@@ -135,8 +137,11 @@ def run_gpu_vo(mbavo, ctx, seq, cfg=DEFAULTS):
             T = np.zeros(7)
             info = capi.VoInfo()
             sharp, depth, blur = seq["sharp"][i], seq["depth"][i], seq["blur"][i]
+            t_call = time.perf_counter()
             rc = ctx.lib.mbavo_vo_track_frame(vo, sharp.ctypes.data, depth.ctypes.data, float(t), blur.ctypes.data, float(t),
                                               float(seq["exp"]), capi.dp(T), C.byref(info))
+            if frame_seconds is not None:
+                frame_seconds.append(time.perf_counter() - t_call)
             assert rc == 0, rc
             K = [ctx.lib.mbavo_vo_num_keypoints(vo, l) for l in range(cfg["levels"])]
             out.append(dict(T=T, is_keyframe=info.is_keyframe, K=K, num_trace=info.num_trace, start_idx=info.start_idx,

@@ -177,3 +177,29 @@ def test_track_frame_full_size_sequence_k2(orc, mbavo, gpu_ctx):
     assert abs(_ate(got, gt) - _ate(want, gt)) <= 1e-5
     rmse = float(np.sqrt(np.mean([np.sum((a["T"][:3] - b["T"][:3]) ** 2) for a, b in zip(got, want)])))
     assert rmse <= 1e-5                                                              # trajectory RMSE gpu vs oracle
+
+
+def test_product_sequence_module_matches_oracle_rendering(orc, mbavo, gpu_ctx):
+    """mba_vo_amd/sequence.py (bench.py's trackframe config: GPU-rendered sequence + trackFrame driver, no oracle inside)
+    against the oracle-rendered twin of tests/frontend.py: identical blurred frames, depth maps and ground truth; sharp
+    frames within one grey level (two-sample mean at zero exposure vs a single warp); the tracked poses of both drivers
+    agree to 1e-6 where the inputs are identical, and the run is reproducible bit for bit."""
+    from mba_vo_amd import sequence
+    a = sequence.make_sequence(gpu_ctx, H=120, W=160, M=4, blur_samples=12)
+    b = frontend.make_sequence(orc, H=120, W=160, M=4, blur_samples=12)
+    assert np.array_equal(a["times"], b["times"]) and np.abs(a["gt"] - b["gt"]).max() < 1e-12
+    for i in range(5):
+        assert np.array_equal(a["blur"][i], b["blur"][i]) and np.array_equal(a["depth"][i], b["depth"][i])
+        assert np.abs(a["sharp"][i].astype(int) - b["sharp"][i].astype(int)).max() <= 1
+    cfg = dict(frontend.DEFAULTS)
+    # same inputs through both drivers
+    for k in ("sharp",):
+        a[k] = b[k]
+    r1 = sequence.track_sequence(gpu_ctx, a, cfg)
+    r2 = sequence.track_sequence(gpu_ctx, a, cfg)
+    ref = frontend.run_gpu_vo(mbavo, gpu_ctx, b, cfg)
+    assert all(np.array_equal(x["T"], y["T"]) for x, y in zip(r1, r2))
+    for x, y in zip(r1, ref):
+        assert x["is_keyframe"] == y["is_keyframe"] and x["num_trace"] == y["num_trace"] and x["K0"] == y["K"][0]
+        assert np.abs(x["T"] - y["T"]).max() < 1e-6
+        assert x["seconds"] > 0
