@@ -5,6 +5,9 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -80,6 +83,79 @@ namespace mbavo
                 q[i] = sn * u + cs * w;
             }
         }
+#if defined(__x86_64__)
+        // The same two pieces on 256-bit vectors (AVX2, no FMA): lane j of an accumulator IS partial sum j of pair_dots,
+        // every product is rounded before it is added, the lanes are combined as (s0 + s1) + (s2 + s3) -- bit-identical
+        // results, chosen once at run time.  n must be a multiple of 4 (the tracker's 6N with even N).
+        __attribute__((target("avx2"))) inline Dots pair_dots_avx2(const double *gp, const double *gq, int n)
+        {
+            __m256d a = _mm256_setzero_pd(), c = _mm256_setzero_pd(), d = _mm256_setzero_pd();
+            for (int i = 0; i < n; i += 4)
+            {
+                const __m256d u = _mm256_loadu_pd(gp + i), w = _mm256_loadu_pd(gq + i);
+                a = _mm256_add_pd(a, _mm256_mul_pd(u, u));
+                c = _mm256_add_pd(c, _mm256_mul_pd(w, w));
+                d = _mm256_add_pd(d, _mm256_mul_pd(u, w));
+            }
+            // (s0 + s1) + (s2 + s3): hadd gives [s0 + s1, ., s2 + s3, .] per source
+            const __m256d ac = _mm256_hadd_pd(a, c);                   // a0+a1, c0+c1, a2+a3, c2+c3
+            const __m128d acs = _mm_add_pd(_mm256_castpd256_pd128(ac), _mm256_extractf128_pd(ac, 1));
+            const __m256d dd = _mm256_hadd_pd(d, d);
+            const __m128d ds = _mm_add_pd(_mm256_castpd256_pd128(dd), _mm256_extractf128_pd(dd, 1));
+            Dots r;
+            r.a = _mm_cvtsd_f64(acs);
+            r.c = _mm_cvtsd_f64(_mm_unpackhi_pd(acs, acs));
+            r.d = _mm_cvtsd_f64(ds);
+            return r;
+        }
+        __attribute__((target("avx2"))) inline void rotate_pair_avx2(double *p, double *q, int n, double cs, double sn)
+        {
+            const __m256d vc = _mm256_set1_pd(cs), vs = _mm256_set1_pd(sn);
+            for (int i = 0; i < n; i += 4)
+            {
+                const __m256d u = _mm256_loadu_pd(p + i), w = _mm256_loadu_pd(q + i);
+                _mm256_storeu_pd(p + i, _mm256_sub_pd(_mm256_mul_pd(vc, u), _mm256_mul_pd(vs, w)));
+                _mm256_storeu_pd(q + i, _mm256_add_pd(_mm256_mul_pd(vs, u), _mm256_mul_pd(vc, w)));
+            }
+        }
+        // rotation parameters of four column pairs at a time (the same IEEE operations per pair as the scalar loop:
+        // packed sqrt / div are correctly rounded); returns the number of pairs done (a multiple of 4)
+        __attribute__((target("avx2"))) inline int rotation_params_avx2(const double *a_, const double *c_, const double *d_, int npairs,
+                                                                        double eps, double *cs_, double *sn_, double *skip_)
+        {
+            const __m256d one = _mm256_set1_pd(1.0), zero = _mm256_setzero_pd(), sign = _mm256_set1_pd(-0.0);
+            int pr = 0;
+            for (; pr + 4 <= npairs; pr += 4)
+            {
+                const __m256d a = _mm256_loadu_pd(a_ + pr), c = _mm256_loadu_pd(c_ + pr), d = _mm256_loadu_pd(d_ + pr);
+                const __m256d absd = _mm256_andnot_pd(sign, d);
+                const __m256d lim = _mm256_mul_pd(_mm256_set1_pd(eps), _mm256_sqrt_pd(_mm256_mul_pd(a, c)));
+                const __m256d skip = _mm256_or_pd(_mm256_cmp_pd(d, zero, _CMP_EQ_OQ), _mm256_cmp_pd(absd, lim, _CMP_LE_OQ));
+                const __m256d zeta = _mm256_div_pd(_mm256_sub_pd(c, a), _mm256_mul_pd(_mm256_set1_pd(2.0), d));
+                const __m256d sgn = _mm256_blendv_pd(_mm256_set1_pd(-1.0), one, _mm256_cmp_pd(zeta, zero, _CMP_GE_OQ));
+                const __m256d den = _mm256_add_pd(_mm256_andnot_pd(sign, zeta), _mm256_sqrt_pd(_mm256_add_pd(one, _mm256_mul_pd(zeta, zeta))));
+                const __m256d t = _mm256_div_pd(sgn, den);
+                const __m256d cs = _mm256_div_pd(one, _mm256_sqrt_pd(_mm256_add_pd(one, _mm256_mul_pd(t, t))));
+                _mm256_storeu_pd(cs_ + pr, cs);
+                _mm256_storeu_pd(sn_ + pr, _mm256_mul_pd(cs, t));
+                _mm256_storeu_pd(skip_ + pr, _mm256_and_pd(skip, one));
+            }
+            return pr;
+        }
+        const bool kHaveAvx2 = __builtin_cpu_supports("avx2");
+        inline int rotation_params_wide(const double *a, const double *c, const double *d, int npairs, double eps, double *cs, double *sn,
+                                        double *skip)
+        {
+            return rotation_params_avx2(a, c, d, npairs, eps, cs, sn, skip);
+        }
+        inline Dots pair_dots_wide(const double *gp, const double *gq, int n) { return pair_dots_avx2(gp, gq, n); }
+        inline void rotate_pair_wide(double *p, double *q, int n, double cs, double sn) { rotate_pair_avx2(p, q, n, cs, sn); }
+#else
+        const bool kHaveAvx2 = false;
+        inline int rotation_params_wide(const double *, const double *, const double *, int, double, double *, double *, double *) { return 0; }
+        inline Dots pair_dots_wide(const double *gp, const double *gq, int n) { return pair_dots(gp, gq, n); }
+        inline void rotate_pair_wide(double *p, double *q, int n, double cs, double sn) { rotate_pair(p, q, n, cs, sn); }
+#endif
     } // namespace
 
     static int solve_svd(const double *A, const double *b, int n, double *x)
@@ -97,33 +173,65 @@ namespace mbavo
         // and two divisions each: the latency chain that dominated the row-cyclic order) and their updates are independent
         // pieces of work for the out-of-order core.  Odd n takes the row-cyclic order.
         const int half = n / 2, m1 = n - 1;
+        const bool wide = kHaveAvx2 && (n & 3) == 0;
         static thread_local std::vector<int> pp_, qq_;
-        static thread_local std::vector<double> cs_, sn_;
+        static thread_local std::vector<double> cs_, sn_, da_, dc_, dd_, skip_;
         pp_.resize(half + 1); qq_.resize(half + 1); cs_.resize(half + 1); sn_.resize(half + 1);
+        da_.resize(half + 4); dc_.resize(half + 4); dd_.resize(half + 4); skip_.resize(half + 4);
+        static thread_local std::vector<int> sched_; // the tournament schedule of this n: m1 rounds x half pairs (p < q)
+        static thread_local int sched_n_ = 0;
+        if ((n & 1) == 0 && n >= 4 && sched_n_ != n)
+        {
+            sched_.resize((size_t)2 * m1 * half);
+            for (int r = 0; r < m1; ++r)
+                for (int pr = 0; pr < half; ++pr)
+                {
+                    int p = pr == 0 ? m1 : (r + pr) % m1, q = pr == 0 ? r : (r - pr + m1) % m1;
+                    if (p > q) std::swap(p, q);
+                    sched_[2 * (r * half + pr)] = p; sched_[2 * (r * half + pr) + 1] = q;
+                }
+            sched_n_ = n;
+        }
         for (int sweep = 0; sweep < 60; ++sweep)
         {
             bool rotated = false;
             if ((n & 1) == 0 && n >= 4)
             {
                 for (int r = 0; r < m1; ++r)
-                {
+                { // three passes over the round's disjoint pairs, each a loop of independent iterations: dot products;
+                  // rotation parameters (branch-free: the two square roots and three divisions of a pair overlap with the
+                  // other pairs' instead of forming one chain per pair); rotations
                     for (int pr = 0; pr < half; ++pr)
                     {
-                        int p = pr == 0 ? m1 : (r + pr) % m1, q = pr == 0 ? r : (r - pr + m1) % m1;
-                        if (p > q) std::swap(p, q);
+                        const int p = sched_[2 * (r * half + pr)], q = sched_[2 * (r * half + pr) + 1];
                         pp_[pr] = p; qq_[pr] = q;
-                        const Dots t3 = pair_dots(G + (size_t)p * n, G + (size_t)q * n, n);
-                        const double a = t3.a, c = t3.c, d = t3.d;
-                        if (d == 0.0 || std::fabs(d) <= eps * std::sqrt(a * c)) { cs_[pr] = 1.0; sn_[pr] = 0.0; pp_[pr] = -1; continue; }
+                        const Dots t3 = wide ? pair_dots_wide(G + (size_t)p * n, G + (size_t)q * n, n) : pair_dots(G + (size_t)p * n, G + (size_t)q * n, n);
+                        da_[pr] = t3.a; dc_[pr] = t3.c; dd_[pr] = t3.d;
+                    }
+                    int pr0 = 0;
+                    if (wide) pr0 = rotation_params_wide(da_.data(), dc_.data(), dd_.data(), half, eps, cs_.data(), sn_.data(), skip_.data());
+                    for (int pr = pr0; pr < half; ++pr)
+                    {
+                        const double a = da_[pr], c = dc_[pr], d = dd_[pr];
+                        const bool skip = d == 0.0 || std::fabs(d) <= eps * std::sqrt(a * c);
                         const double zeta = (c - a) / (2.0 * d);
                         const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
                         const double cs = 1.0 / std::sqrt(1.0 + t * t);
                         cs_[pr] = cs; sn_[pr] = cs * t;
+                        skip_[pr] = skip ? 1.0 : 0.0;
                     }
+                    for (int pr = 0; pr < half; ++pr)
+                        if (skip_[pr] != 0.0) pp_[pr] = -1;
                     for (int pr = 0; pr < half; ++pr)
                     {
                         if (pp_[pr] < 0) continue;
                         rotated = true;
+                        if (wide)
+                        {
+                            rotate_pair_wide(G + (size_t)pp_[pr] * n, G + (size_t)qq_[pr] * n, n, cs_[pr], sn_[pr]);
+                            rotate_pair_wide(V + (size_t)pp_[pr] * n, V + (size_t)qq_[pr] * n, n, cs_[pr], sn_[pr]);
+                            continue;
+                        }
                         rotate_pair(G + (size_t)pp_[pr] * n, G + (size_t)qq_[pr] * n, n, cs_[pr], sn_[pr]);
                         rotate_pair(V + (size_t)pp_[pr] * n, V + (size_t)qq_[pr] * n, n, cs_[pr], sn_[pr]);
                     }
