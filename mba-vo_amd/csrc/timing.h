@@ -10,7 +10,7 @@ namespace mbavo
 {
     struct PhaseTimers
     {
-        enum { kUpload, kKeyframe, kEnqueue, kWait, kMerge, kSolve, kOutliers, kLevel, kTrack, kCount };
+        enum { kUpload, kKeyframe, kEnqueue, kWait, kMerge, kSolve, kOutliers, kLevel, kTrack, kFlagsChanged, kFlagsSame, kCount };
         double sec[kCount] = {};
         long calls[kCount] = {};
         bool on;
@@ -20,7 +20,7 @@ namespace mbavo
         {
             if (!on) return;
             static const char *names[kCount] = {"upload+pyramid", "keyframe processing", "evaluate enqueue", "evaluate wait", "host merge",
-                                                "host solve+step", "outlier detection", "level setup", "trackFrame (all)"};
+                                                "host solve+step", "outlier detection", "level setup", "trackFrame (all)", "accepted: flags changed", "accepted: flags same"};
             for (int i = 0; i < kCount; ++i)
                 if (calls[i]) fprintf(stderr, "mbavo timing: %-20s %8ld calls  %9.3f ms total  %7.2f us each\n", names[i], calls[i], sec[i] * 1e3, sec[i] * 1e6 / calls[i]);
             for (int i = 0; i < kCount; ++i) { sec[i] = 0; calls[i] = 0; }

@@ -262,7 +262,9 @@ namespace mbavo
                 { // isStepSuccessful (:890-894) -> detectOutliers + handleSuccessfulStep (:896-903)
                     {
                         PhaseScope ps(PhaseTimers::kOutliers);
+                        const int bad_before = num_bad;
                         num_bad = detect_outliers(d_pc, L.K, o.max_chi_square_error, w_flags); // frame 0's costs, just written
+                        if (PhaseTimers::get().on) ++PhaseTimers::get().calls[num_bad != bad_before ? PhaseTimers::kFlagsChanged : PhaseTimers::kFlagsSame];
                         set_inv();
                         if (!persistent) TRK_HIP(hipMemcpyAsync(d_flags, w_flags, L.K, hipMemcpyHostToDevice, st));
                     }
