@@ -46,3 +46,30 @@ def test_tracker_matches_oracle(orc, mbavo, gpu_ctx, name, kw):
     assert abs(ate_o - ate_g) <= 1e-5
     assert rg["cost"] < rg["trace"][0][5]                                # and it actually tracked
     assert tracking.flow_error(orc, sc, rg["kt"], rg["kR"]) < tracking.flow_error(orc, sc, sc["kt0"], sc["kR0"])
+
+
+@pytest.mark.parametrize("kw", [dict(H=120, W=160, levels=3, S=8, k=2, seed=2), dict(H=480, W=640, levels=4, S=8, k=4, F=2, seed=7)])
+def test_tracker_evaluation_paths_agree(orc, mbavo, gpu_ctx, kw, monkeypatch):
+    """The three ways an evaluation of the host-driven LM loop reaches the GPU -- commands to a persistent kernel (default),
+    one single-launch kernel per evaluation (MBAVO_PERSIST=0), three launches per evaluation (MBAVO_ONE=0) -- run the same
+    arithmetic per pixel and differ only in the order the tile partials are added (1e-16 per evaluation, amplified by the
+    conditioning of the normal equations along the iterates): identical accept / reject / outlier traces; costs 1e-6 and knots 1e-4, the
+    tolerances of the oracle comparison above (observed here: 1e-7 on the k = 4 scene, whose outer knots are weakly
+    observed), on a small k = 2 scene and on the BASELINE-size two-frame k = 4 scene."""
+    import tracking
+    sc = tracking.make_tracking_scene(orc, **kw)
+    runs = {}
+    for name, env in (("persistent", {}), ("one_launch", {"MBAVO_PERSIST": "0"}), ("three_launches", {"MBAVO_PERSIST": "0", "MBAVO_ONE": "0"})):
+        for k in ("MBAVO_PERSIST", "MBAVO_ONE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        runs[name] = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, dict(tracking.OPTS))
+    ref = runs["persistent"]
+    for name in ("one_launch", "three_launches"):
+        r = runs[name]
+        assert np.array_equal(ref["start"], r["start"]) and len(ref["trace"]) == len(r["trace"]), name
+        for a, b in zip(ref["trace"], r["trace"]):
+            assert a[:4] == b[:4], (name, a, b)
+            assert a[5] == pytest.approx(b[5], rel=1e-6, abs=1e-12) and a[6] == pytest.approx(b[6], rel=1e-6, abs=1e-12)
+        assert np.abs(ref["kt"] - r["kt"]).max() < 1e-4 and np.abs(ref["kR"] - r["kR"]).max() < 1e-4, name
