@@ -931,10 +931,13 @@ namespace mbavo
             // (device scope also when the per-patch costs go to pinned host memory: the fence waits until this workgroup's
             // stores are acknowledged, i.e. on their way to the host ahead of the completion word the LAST workgroup
             // publishes after its own system-scope fence; a system-scope fence here costs 40 us per evaluation)
-            __threadfence();
+            // release only (L2 write-back); the acquire -- an invalidation of this XCD's L2 -- is the LAST workgroup's
+            // business: done by every workgroup it threw the pyramid out of the L2s once per evaluation
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             const int n = oa.bf_tile_begin[bf + 1] - oa.bf_tile_begin[bf];
-            s_last = atomicAdd(&oa.tickets[bf], 1) == n - 1 ? 1 : 0;
-            __threadfence(); // acquire side: the other workgroups' partials (other XCDs' L2s) are read from memory
+            const int last = atomicAdd(&oa.tickets[bf], 1) == n - 1 ? 1 : 0;
+            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the other workgroups' partials (other XCDs' L2s) are read from memory
+            s_last = last;
         }
         __syncthreads();
         if (!s_last) return;
