@@ -75,22 +75,32 @@ namespace mbavo
         int wait_evaluation();
 
         // Persistent evaluation of ONE small problem (host-driven LM loop, tracker.cpp): one launch per pyramid level, the
-        // resident workgroups take commands from a pinned block (see k_sp_persist).  begin: 0 = started, 1 = not applicable
-        // (the problem does not take the single-launch sample-parallel kernel: use evaluate()), < 0 / > 0 = error.  The
-        // problem's knots, outlier flags, patch-cost output, frame blocks (h_frame_blocks) and residual scale (h_inv) must
-        // all be pinned host memory the caller updates between evaluations.  eval: one synchronous evaluation.  end: tells
-        // the workgroups to exit (asynchronous).  No other work may be enqueued on the engine's stream in between.
-        int persistent_begin(const mbavo_problem &p, int kdeg, double *h_frame_blocks, double *h_patch_cost, const double *h_inv);
+        // resident workgroups take commands from a CPU-writable device block (see k_sp_persist).  There are kPushSlots
+        // independent command blocks ("slots"): the kernel of the NEXT level can be enqueued behind the running one while
+        // the current level is still being evaluated (it starts the moment its predecessor exits, with its launch cost
+        // hidden behind an evaluation in flight); commands may only be posted to the oldest kernel that has not been ended.
+        // begin: 0 = started, 1 = not applicable (the problem does not take the single-launch sample-parallel kernel, or
+        // cached_only and its layout would have to be built and uploaded: use evaluate() / try again when its turn comes),
+        // < 0 / > 0 = error.  The problem's knots, outlier flags and residual scale live in the slot's push block, the
+        // patch-cost output and the frame blocks in pinned host memory.  post + wait (= eval): one evaluation.  end: tells
+        // the slot's workgroups to exit (asynchronous).  No other work may be enqueued on the engine's stream in between.
+        static constexpr int kPushSlots = 8;
+        int persistent_begin(int slot, const mbavo_problem &p, int kdeg, double *h_frame_blocks, double *h_patch_cost, const double *h_inv,
+                             bool cached_only = false);
         // Fine-grained DEVICE memory the CPU writes directly through the PCIe BAR (write-combining: stores + sfence; never
-        // read it from the CPU): the persistent kernel's command block (its first 64 bytes, owned by the engine) and the
-        // per-evaluation inputs the caller lays out behind it (knots, residual scale, outlier flags).  Pushing the inputs
-        // costs the GPU nothing; PULLING them from pinned host memory is bounded by the bus' small-read rate (~10 M/s:
-        // 35 us per evaluation for a dozen words per workgroup; tools/micro/host_push_probe.hip: 1.9 us round trip pushed).
-        // nullptr when the platform cannot do it.
-        void *push_block(size_t bytes);
+        // read it from the CPU): a slot's command block (its first 64 bytes, owned by the engine) and the per-evaluation
+        // inputs the caller lays out behind it (knots, residual scale, outlier flags).  Pushing the inputs costs the GPU
+        // nothing; PULLING them from pinned host memory is bounded by the bus' small-read rate (~10 M/s: 35 us per
+        // evaluation for a dozen words per workgroup; tools/micro/host_push_probe.hip: 1.9 us round trip pushed).
+        // nullptr when the platform cannot do it (or the blocks would have to grow while a persistent kernel runs).
+        void *push_block(int slot, size_t bytes);
         static constexpr size_t kPushHeader = 64;
-        int persistent_eval(bool with_hessian);
-        int persistent_end();
+        int persistent_post(int slot, bool with_hessian);
+        int persistent_wait();
+        int persistent_eval(int slot, bool with_hessian) { const int r = persistent_post(slot, with_hessian); return r ? r : persistent_wait(); }
+        int persistent_end(int slot);
+        int persistent_end_all();
+        bool persistent_active(int slot) const { return slot >= 0 && slot < kPushSlots && (persist_mask_ >> slot & 1u) != 0; }
         const ProblemDesc *device_descs() const { return (const ProblemDesc *)d_descs_; }
 
         // range status since the previous fetch (call after a stream sync): non-zero if a blur
@@ -127,7 +137,7 @@ namespace mbavo
 
     private:
         int ensure(void **ptr, size_t *cap, size_t bytes);
-        int rebuild_layout(int B, const mbavo_problem *probs, int kdeg, const int *d_active, const double *d_inv);
+        int rebuild_layout(int B, const mbavo_problem *probs, int kdeg, const int *d_active, const double *d_inv, bool cached_only = false);
 
         int device_;
         hipStream_t stream_ = nullptr;
@@ -175,8 +185,10 @@ namespace mbavo
         void *h_flag_ = nullptr;            // pinned completion word of the single-launch kernels
         unsigned long long flag_seq_ = 0;
         bool flag_pending_ = false;
-        void *d_push_ = nullptr; size_t cap_push_ = 0; // fine-grained device memory, CPU-writable; starts with the PersistCmd
-        bool persist_active_ = false;
+        void *d_push_ = nullptr; size_t cap_push_ = 0; // fine-grained device memory, CPU-writable: kPushSlots blocks of push_stride_
+        size_t push_stride_ = 0;                       // bytes, each starting with its PersistCmd
+        unsigned persist_mask_ = 0;                    // slots with a persistent kernel enqueued and not ended
+        unsigned long long pending_seq_ = 0;           // sequence number of the evaluation posted last
         int persist_gen_ = 0;
         int status_seen_ = 0;
         void *h_fb_ = nullptr; size_t cap_hfb_ = 0;

@@ -1456,7 +1456,7 @@ namespace mbavo
 
     Engine::~Engine()
     {
-        (void)persistent_end();
+        (void)persistent_end_all();
         (void)comm_destroy();
         void *bufs[] = {d_layout_, d_poses_, d_rho_, d_partials_,
                         d_status_, d_tickets_};
@@ -1535,7 +1535,7 @@ namespace mbavo
         std::swap(d_bf_prob_, s.d_bf_prob); std::swap(d_entry_prob_, s.d_entry_prob);
     }
 
-    int Engine::rebuild_layout(int B, const mbavo_problem *probs, int kdeg, const int *d_active, const double *d_inv)
+    int Engine::rebuild_layout(int B, const mbavo_problem *probs, int kdeg, const int *d_active, const double *d_inv, bool cached_only)
     {
         std::vector<ProblemDesc> &descs = scratch_descs_; // member: no allocation per call in the LM loop
         descs.resize((size_t)B);
@@ -1573,6 +1573,7 @@ namespace mbavo
         const bool same = kdeg == cached_kdeg_ && descs.size() == h_descs_.size() &&
                           memcmp(descs.data(), h_descs_.data(), descs.size() * sizeof(ProblemDesc)) == 0;
         if (same && layout_uploaded_) return 0;
+        if (cached_only && B > 8) return 2;
         if (B <= 8)
         { // a parked layout of the same problem list?  Otherwise the active one is parked (oldest slot) and the new one
           // is built over that slot's buffers (stream order protects an arena a queued kernel still reads)
@@ -1583,6 +1584,7 @@ namespace mbavo
                     swap_layout(s);
                     return 0;
                 }
+            if (cached_only) return 2; // (the caller must not build / upload now: a persistent kernel holds the stream)
             if (layout_uploaded_ && h_descs_.size() <= 8)
             {
                 swap_layout(parked_[parked_victim_]);
@@ -1813,7 +1815,7 @@ namespace mbavo
     {
         if (B < 1 || !probs || !d_frame_blocks || (kdeg != 2 && kdeg != 4)) return MBAVO_E_ARG;
         if (d_patch_blocks_strided && B != 1) return MBAVO_E_ARG;
-        if (persist_active_) return MBAVO_E_ARG; // the stream is held by the persistent kernel: persistent_end() first
+        if (persist_mask_) return MBAVO_E_ARG; // the stream is held by persistent kernels: persistent_end_all() first
         int rc;
         {
             PhaseScope ps_layout(PhaseTimers::kLevel);
@@ -1871,34 +1873,39 @@ namespace mbavo
         return rc;
     }
 
-    void *Engine::push_block(size_t bytes)
+    void *Engine::push_block(int slot, size_t bytes)
     {
-        if (persist_active_) return nullptr;
-        if (d_push_ && bytes <= cap_push_) return d_push_;
-        if (d_push_) { (void)hipFree(d_push_); d_push_ = nullptr; cap_push_ = 0; }
+        if (slot < 0 || slot >= kPushSlots) return nullptr;
+        const size_t stride = (bytes + 4095) & ~(size_t)4095;
+        if (d_push_ && stride <= push_stride_) return (char *)d_push_ + (size_t)slot * push_stride_;
+        if (persist_mask_) return nullptr; // cannot grow under a running kernel
+        if (d_push_) { (void)hipFree(d_push_); d_push_ = nullptr; cap_push_ = 0; push_stride_ = 0; }
         int cur = -1;
         if (hipGetDevice(&cur) != hipSuccess || cur != device_) (void)hipSetDevice(device_);
-        const size_t want = (bytes + 4095) & ~(size_t)4095;
+        const size_t want = stride * kPushSlots;
         if (hipExtMallocWithFlags(&d_push_, want, hipDeviceMallocFinegrained) != hipSuccess) { d_push_ = nullptr; (void)hipGetLastError(); return nullptr; }
         if (hipMemset(d_push_, 0, want) != hipSuccess) { (void)hipFree(d_push_); d_push_ = nullptr; return nullptr; }
         (void)hipDeviceSynchronize();
         cap_push_ = want;
-        return d_push_;
+        push_stride_ = stride;
+        return (char *)d_push_ + (size_t)slot * push_stride_;
     }
-
-    int Engine::persistent_begin(const mbavo_problem &p, int kdeg, double *h_frame_blocks, double *h_patch_cost, const double *h_inv)
+    int Engine::persistent_begin(int slot, const mbavo_problem &p, int kdeg, double *h_frame_blocks, double *h_patch_cost,
+                                 const double *h_inv, bool cached_only)
     {
-        if (persist_active_ || !h_frame_blocks || !h_inv || (kdeg != 2 && kdeg != 4)) return MBAVO_E_ARG;
+        if (slot < 0 || slot >= kPushSlots || persistent_active(slot) || !h_frame_blocks || !h_inv || (kdeg != 2 && kdeg != 4)) return MBAVO_E_ARG;
         if (env_int("MBAVO_PERSIST", 1) == 0 || env_int("MBAVO_ONE", 1) == 0) return 1;
+        if (!d_push_ || push_stride_ == 0) return 1; // no CPU-writable device memory: the caller takes the per-evaluation launches
+        if (cached_only && env_int("MBAVO_PRELAUNCH", 1) == 0) return 1;
         int cur = -1;
         if (hipGetDevice(&cur) != hipSuccess || cur != device_) HIP_TRY(hipSetDevice(device_));
-        int rc = rebuild_layout(1, &p, kdeg, nullptr, h_inv);
+        int rc = rebuild_layout(1, &p, kdeg, nullptr, h_inv, cached_only);
+        if (rc == 2) return 1;
         if (rc) return rc;
         const int ntiles = (int)h_tiles_.size();
         if (sp_logs_ <= 0 || !sp_one_fits(kdeg, sp_logs_) || ntiles < 1 || ntiles > num_cus_ || h_descs_[0].grad_fp16 || p.N > 16) return 1;
         if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 64, hipHostMallocDefault) != hipSuccess) { h_flag_ = nullptr; return (int)hipErrorOutOfMemory; }
-        if (!d_push_) return 1; // no CPU-writable device memory: the caller takes the per-evaluation launches
-        volatile PersistCmd *cmd = (volatile PersistCmd *)d_push_;
+        volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
         cmd->mode = 0;
         cmd->gen = ++persist_gen_;
         __builtin_ia32_sfence();
@@ -1923,7 +1930,7 @@ namespace mbavo
             HIP_TRY(ensure_lds((const void *)k_sp_persist<KD, LG>, lds_sp));                                                      \
             hipLaunchKernelGGL((k_sp_persist<KD, LG>), dim3(ntiles), dim3(kSpWaves * 64), lds_sp, st, (const ProblemDesc *)d_descs_, \
                                (const TileDesc *)d_tiles_, (double *)d_rho_, h_patch_cost, (double *)d_partials_, oa,             \
-                               (const PersistCmd *)d_push_, flag_seq_, persist_gen_);                                              \
+                               (const PersistCmd *)cmd, flag_seq_, persist_gen_);                                                  \
         }                                                                                                                         \
     } while (0)
 #define MBAVO_PERSIST_K(KD)                                     \
@@ -1938,21 +1945,28 @@ namespace mbavo
 #undef MBAVO_PERSIST_K
 #undef MBAVO_PERSIST_LAUNCH
         HIP_TRY(hipGetLastError());
-        persist_active_ = true;
+        persist_mask_ |= 1u << slot;
         last_kernel_id_[0] = kdeg; last_kernel_id_[1] = 1; last_kernel_id_[2] = 0; last_kernel_id_[3] = sp_logs_; last_kernel_id_[4] = 1;
         return 0;
     }
 
-    int Engine::persistent_eval(bool with_hessian)
+    int Engine::persistent_post(int slot, bool with_hessian)
     {
-        if (!persist_active_) return MBAVO_E_ARG;
-        volatile PersistCmd *cmd = (volatile PersistCmd *)d_push_;
+        if (!persistent_active(slot)) return MBAVO_E_ARG;
+        volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
         const unsigned long long seq = ++flag_seq_;
-        const auto t0 = std::chrono::steady_clock::now();
         cmd->mode = with_hessian ? 2 : 1;
         __builtin_ia32_sfence(); // the inputs (knots, flags, scale: the push block, write-combining) and the mode are out ...
         cmd->seq = seq;
         __builtin_ia32_sfence(); // ... before the sequence number, which leaves the write-combining buffer now
+        pending_seq_ = seq;
+        return 0;
+    }
+    int Engine::persistent_wait()
+    {
+        if (!persist_mask_) return MBAVO_E_ARG;
+        const unsigned long long seq = pending_seq_;
+        const auto t0 = std::chrono::steady_clock::now();
         volatile unsigned long long *f = (volatile unsigned long long *)h_flag_;
         for (long spins = 1;; ++spins)
         {
@@ -1976,27 +1990,28 @@ namespace mbavo
             if ((spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) break;
         }
         fprintf(stderr, "mbavo: persistent evaluation timed out\n");
-        persist_active_ = false; // the workgroups give up by themselves (~2 s)
+        persist_mask_ = 0; // the workgroups give up by themselves (~2 s each kernel)
         (void)hipStreamSynchronize(stream_);
         (void)hipMemsetAsync(d_tickets_, 0, cap_tickets_, stream_);
         return (int)hipErrorLaunchTimeOut;
     }
 
-    int Engine::persistent_end()
+    int Engine::persistent_end(int slot)
     {
-        if (!persist_active_) return 0;
-        volatile PersistCmd *cmd = (volatile PersistCmd *)d_push_;
+        if (!persistent_active(slot)) return 0;
+        volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
         cmd->mode = 0;
         __builtin_ia32_sfence();
         cmd->seq = ++flag_seq_;
         __builtin_ia32_sfence();
-        persist_active_ = false;
+        persist_mask_ &= ~(1u << slot);
         return 0;
     }
-
-    // Wait for the evaluation just enqueued: spin on the completion word the last workgroup writes to pinned host memory
-    // (~1 us after the kernel's last store, against the ~10 us a stream synchronisation takes to notice), falling back
-    // to the stream when no word was armed or it does not arrive.
+    int Engine::persistent_end_all()
+    {
+        for (int sl = 0; sl < kPushSlots; ++sl) (void)persistent_end(sl);
+        return 0;
+    }
     int Engine::wait_evaluation()
     {
         if (flag_pending_ && h_flag_)

@@ -113,31 +113,41 @@ namespace mbavo
             TRK_HIP(hipMemcpyAsync(d_cap, stage, sizeof(double) * 2 * F, hipMemcpyHostToDevice, st));
         }
 
-        for (int li = 0; li < o.num_levels; ++li)
         {
-            const int lv = o.num_levels - li - 1; // coarse to fine (:571-575)
+        // One run per pyramid level, coarse to fine (:571-575).  Small levels (everything the reference's semi-dense detector
+        // produces) are ONE persistent launch each -- the evaluations are commands to its resident workgroups
+        // (Engine::persistent_*).  The per-evaluation inputs of a level's workgroups live in the level's slot of the engine's
+        // push block: fine-grained DEVICE memory the CPU writes through the PCIe BAR (write-only for the host): [command 64 B |
+        // scale | knots t | knots R | outlier flags].  The kernel of level li + 1 is enqueued while the first evaluation of
+        // level li is in flight (its launch cost hides behind that evaluation, and it starts the moment level li's kernel
+        // exits).  Without a push block (or for levels too large for the sample-parallel kernel) the inputs stay in pinned
+        // host memory / device copies and every evaluation is its own launch.
+        struct LevelRun
+        {
+            mbavo_problem p;
+            double *w_inv, *w_kt, *w_kR;
+            unsigned char *w_flags;
+            bool prepared, launched;
+        };
+        LevelRun runs[8];
+        memset(runs, 0, sizeof(runs));
+        const size_t push_bytes = Engine::kPushHeader + 64 + sizeof(double) * 7 * N + (size_t)(maxK > 0 ? maxK : 1) + 64;
+        // problem descriptor of level li, its slot's inputs initialised (no outliers, :601); < 0: error code
+        auto prepare = [&](int li) -> int {
+            LevelRun &R = runs[li];
+            if (R.prepared) return 0;
+            const int lv = o.num_levels - li - 1;
             const mbavo_level &L = levels[lv];
             const int scale = 1 << lv;
-            memset(flags, 0, L.K > 0 ? L.K : 1); // :601 (the device copy below, where it is used)
-            mbavo_problem p;
+            mbavo_problem &p = R.p;
             memset(&p, 0, sizeof(p));
             p.S = L.S; p.F = F; p.K = L.K; p.P = L.P; p.N = N; p.H = L.H; p.W = L.W;
             p.d_ref_img = L.d_ref_img; p.d_ref_dIxy = L.d_ref_dIxy; p.d_cur_imgs = L.d_cur_imgs;
             p.d_kp_xy = L.d_kp_xy; p.kp_stride = 2; p.d_kp_z = L.d_kp_z; p.d_pattern = L.d_pattern;
             p.d_outlier = d_flags; p.num_bad = 0;
-            // The outlier count changes with every accepted step; it reaches the kernels through a pinned word (inv_ptr)
-            // instead of the problem descriptor, so the engine's cached layout stays valid for the whole level
-            int num_bad = 0;
-            double *inv_word = h_inv; // where the kernels read the scale: re-pointed at the push block in persistent mode
-            auto set_inv = [&]() {
-                const long long nres = (long long)(L.K - num_bad) * F * L.P; // spline_update_step.cpp:116-117
-                *inv_word = nres > 0 ? 1.0 / (double)nres : 0.0;
-            };
-            set_inv();
             for (int a = 0; a < 4; ++a) p.intrinsics[a] = o.intrinsics[a] / scale; // :766-770
             p.d_cap_time = d_cap; p.d_exp_time = d_exp; p.t0 = t0; p.dt = dt;
             p.d_knots_t = d_kt; p.d_knots_R = d_kR; p.h_start_idx = start_idx.data(); p.huber_a = o.huber_k;
-
             // every blur sample must fall on knots that exist (the reference reads past its arrays otherwise,
             // SplineFunctor.h:13-19).  The sample times depend on (cap, exp, S) only: checked here on the host with the
             // kernels' own formula instead of reading the device's status counter back (a synchronous copy per level:
@@ -149,41 +159,63 @@ namespace mbavo
                     int idx;
                     double u;
                     spline_segment(ts, t0, dt, idx, u);
-                    if (idx < 0 || idx + k > N) { rc_ = MBAVO_E_RANGE; goto done; }
+                    if (idx < 0 || idx + k > N) return MBAVO_E_RANGE;
                 }
-            // Small levels (everything the reference's semi-dense detector produces): ONE persistent launch for the whole
-            // level -- the evaluations below are commands to its resident workgroups (Engine::persistent_*), the outlier
-            // flags are read from the pinned staging buffer directly.  Otherwise one launch (or three) per evaluation.
-            // The per-evaluation inputs of the persistent workgroups live in the engine's push block: fine-grained DEVICE
-            // memory the CPU writes through the PCIe BAR (write-only for the host): [command 64 B | scale | knots t | knots R
-            // | outlier flags].  Without such a block (or for levels too large for the sample-parallel kernel) the inputs
-            // stay in pinned host memory / device copies and every evaluation is its own launch.
-            char *push = (char *)eng.push_block(Engine::kPushHeader + 64 + sizeof(double) * 7 * N + (size_t)(maxK > 0 ? maxK : 1) + 64);
-            double *w_inv = h_inv, *w_kt = d_kt, *w_kR = d_kR;
-            unsigned char *w_flags = flags;
-            int pr = 1;
-            PhaseScope ps_level(PhaseTimers::kLevel);
+            char *push = (char *)eng.push_block(li, push_bytes);
             if (push)
             {
                 double *b = (double *)(push + Engine::kPushHeader);
-                w_inv = b; w_kt = b + 8; w_kR = w_kt + 3 * N;
-                w_flags = (unsigned char *)(w_kR + 4 * N);
-                p.d_knots_t = w_kt; p.d_knots_R = w_kR; p.d_outlier = w_flags;
-                memset(w_flags, 0, L.K > 0 ? L.K : 1);
-                *w_inv = *h_inv;
-                pr = eng.persistent_begin(p, k, h_pin, d_pc, w_inv);
+                R.w_inv = b; R.w_kt = b + 8; R.w_kR = R.w_kt + 3 * N;
+                R.w_flags = (unsigned char *)(R.w_kR + 4 * N);
+                p.d_knots_t = R.w_kt; p.d_knots_R = R.w_kR; p.d_outlier = R.w_flags;
+                memset(R.w_flags, 0, L.K > 0 ? L.K : 1);
+                const long long nres = (long long)L.K * F * L.P; // spline_update_step.cpp:116-117, no outliers yet
+                *R.w_inv = nres > 0 ? 1.0 / (double)nres : 0.0;
+            }
+            R.prepared = true;
+            return 0;
+        };
+        // enqueue level li's persistent kernel: 0 = enqueued, 1 = not applicable (now), otherwise an error
+        auto launch = [&](int li, bool cached_only) -> int {
+            LevelRun &R = runs[li];
+            if (R.launched) return 0;
+            if (!R.w_inv) return 1;
+            PhaseScope ps_level(PhaseTimers::kLevel);
+            const int pr = eng.persistent_begin(li, R.p, k, h_pin, d_pc, R.w_inv, cached_only);
+            if (pr == 0) R.launched = true;
+            return pr;
+        };
+
+        for (int li = 0; li < o.num_levels; ++li)
+        {
+            const int lv = o.num_levels - li - 1; // coarse to fine (:571-575)
+            const mbavo_level &L = levels[lv];
+            memset(flags, 0, L.K > 0 ? L.K : 1); // :601 (the device copy below, where it is used)
+            if ((rc_ = prepare(li)) != 0) goto done;
+            {
+                const int pr = launch(li, false);
                 if (pr < 0 || pr > 1) { rc_ = pr; goto done; }
             }
-            ps_level.~PhaseScope();
-            ps_level.on = false;
-            const bool persistent = pr == 0;
-            if (persistent) inv_word = w_inv;
+            LevelRun &R = runs[li];
+            const bool persistent = R.launched;
+            mbavo_problem p = R.p;
+            // The outlier count changes with every accepted step; it reaches the kernels through a word (inv_ptr) instead of the
+            // problem descriptor, so the engine's cached layout stays valid for the whole level
+            int num_bad = 0;
+            double *w_inv = persistent ? R.w_inv : h_inv, *w_kt = persistent ? R.w_kt : d_kt, *w_kR = persistent ? R.w_kR : d_kR;
+            unsigned char *w_flags = persistent ? R.w_flags : flags;
+            double *inv_word = w_inv; // where the kernels read the scale: the level's push slot in persistent mode
+            auto set_inv = [&]() {
+                const long long nres = (long long)(L.K - num_bad) * F * L.P; // spline_update_step.cpp:116-117
+                *inv_word = nres > 0 ? 1.0 / (double)nres : 0.0;
+            };
+            set_inv();
             if (!persistent)
             {
-                w_inv = h_inv; w_kt = d_kt; w_kR = d_kR; w_flags = flags;
                 p.d_knots_t = d_kt; p.d_knots_R = d_kR; p.d_outlier = d_flags; // per-evaluation launches read the device copy
                 TRK_HIP(hipMemsetAsync(d_flags, 0, L.K > 0 ? L.K : 1, st));
             }
+            bool want_prelaunch = persistent && li + 1 < o.num_levels;
             // one evaluation at the given knots: knots into the pinned buffer, ONE launch for these problem sizes (pose
             // prologue + fused + last-workgroup finalize) whose frame blocks land in pinned host memory (h_pin), then a
             // spin on the kernel's completion word: no copies, no stream synchronisation
@@ -194,12 +226,23 @@ namespace mbavo
                     memcpy(w_kt, kt, sizeof(double) * 3 * N);
                     memcpy(w_kR, kR, sizeof(double) * 4 * N);
                     if (!persistent) r = eng.evaluate(1, &p, k, with_h, h_pin, d_pc, nullptr, nullptr, nullptr, h_inv, true);
-                    else r = 0;
+                    else r = eng.persistent_post(li, with_h);
                 }
                 if (r) return r;
+                if (want_prelaunch)
+                { // with this level's first evaluation in flight: the next level's kernel goes into the queue (only if its layout
+                  // is one of the engine's parked ones -- nothing may be built or uploaded behind a running persistent kernel;
+                  // otherwise it is launched when its turn comes)
+                    want_prelaunch = false;
+                    if (prepare(li + 1) == 0)
+                    {
+                        const int pr = launch(li + 1, true);
+                        if (pr < 0 || pr > 1) return pr;
+                    }
+                }
                 {
                     PhaseScope ps(PhaseTimers::kWait);
-                    r = persistent ? eng.persistent_eval(with_h) : eng.wait_evaluation();
+                    r = persistent ? eng.persistent_wait() : eng.wait_evaluation();
                 }
                 if (r) return r;
                 PhaseScope ps(PhaseTimers::kMerge);
@@ -278,13 +321,14 @@ namespace mbavo
                 lm.step_rejected(); // handleUnsuccessfulStep
                 record(iter, 2, cand_cost, model, quality);
             }
-            (void)eng.persistent_end(); // the level's resident workgroups exit; the next level's launch queues behind them
+            (void)eng.persistent_end(li); // the level's resident workgroups exit; the next level's kernel is already queued behind them
+        }
         }
         memcpy(knots_t, spline.get_knot_data_t(), sizeof(double) * 3 * N);
         memcpy(knots_R, spline.get_knot_data_R(), sizeof(double) * 4 * N);
         if (final_cost) *final_cost = eval_cost;
     done:
-        (void)eng.persistent_end();
+        (void)eng.persistent_end_all();
         return rc_ ? (rc_ > 0 ? -1000 - rc_ : rc_) : ntrace;
     }
 } // namespace mbavo
