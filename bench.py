@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--time-every", type=int, default=8,
                     help="HIP-event pair around the dominant kernel on every n-th timed step (events cost launch gaps)")
     ap.add_argument("--min-seconds", type=float, default=0.3, help="repeat the K-step region until this much was timed")
+    ap.add_argument("--no-spin-sync", action="store_true", help="synchronize without polling the stream first (A/B of the bracket's own cost)")
     ap.add_argument("--max-repeats", type=int, default=200)
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="budget of EACH bounded CPU baseline sample (1 and T threads)")
     return ap.parse_args()
@@ -301,6 +302,11 @@ def main():
         rccl_ranks = shard.comm_init(ctx, rank, world, shard.torch_bcast(dev))
 
     def sync():
+        # torch.cuda.synchronize() is the contract's bracket; the stream is polled first because the runtime's blocking wait
+        # wakes up ~20 us after the last kernel retires -- 2.5 % of a 20-step region (measured: --steps 20 vs --steps 300)
+        if not args.no_spin_sync:
+            while not stream.query():
+                pass
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
