@@ -406,7 +406,7 @@ namespace mbavo
     // more chunk for one wave, i.e. 7 chunks on its SIMD against 6 on the others (+5 us measured against a tile of
     // exactly two rounds).
     // LOGS_CT >= 0: S is the compile-time 2^LOGS_CT (the exchange loops over the samples unroll); -1: run-time `logs_rt`.
-    template <int KD, bool WITH_J, bool HALF_GRAD, int NWAVES, int LOGS_CT = -1>
+    template <int KD, bool WITH_J, bool HALF_GRAD, int NWAVES, int LOGS_CT = -1, int MS = 1>
     __device__ __forceinline__ void sp_round_rt(const ProblemDesc &d, const TileDesc &tile, const Camera &cam,
                                                 const PoseEntry<KD> *__restrict__ ftab, const PoseEntry<KD> &mid,
                                                 const unsigned char *__restrict__ I_cur, int logs_rt, int base, int npx,
@@ -420,10 +420,14 @@ namespace mbavo
         const int SS = 1 << logs, PXW = 64 >> logs, P = d.P;
         const int pw = lane >> logs, sidx = lane & (SS - 1), lane0 = lane & ~(SS - 1);
         const unsigned long long gmask = (SS == 64 ? ~0ull : ((1ull << SS) - 1ull)) << lane0;
-        const double fS = (double)(float)SS; // A8
+        // MS = 2: a pixel takes S / 2 lanes and every lane two consecutive blur samples, issued and retired as a pair like the
+        // lane-per-pixel loop's.  The per-pixel part of the lane (patch centre, ray, Huber, exchange: 600 of a lane's 751
+        // instructions at one sample) is then paid by half as many lanes -- the remainder round's waves halve.
+        const double fS = (double)(float)(SS * MS); // A8
         const int g = base + wave * PXW + pw;
         const bool in = g < npx;
-        double res = 0.0, w = 0.0, rho = 0.0, cur = 0.0, val = 0.0;
+        double res = 0.0, w = 0.0, rho = 0.0, cur = 0.0;
+        double vals[MS] = {};
         bool ok_l = false, flagged = false;
         double Jc[WITH_J ? 6 * KD : 1] = {};
         // A lane's pose entry is its SAMPLE's: 59 doubles per lane that no longer arrive as scalar operands.  Read from
@@ -431,11 +435,11 @@ namespace mbavo
         // round trip: 1.7 us of the round's 5.3 us.  So the wave first copies the frame's S entries into its own slab
         // (free until the samples are done and the rows are exchanged) and every lane reads its entry from LDS.
         constexpr int EW = (int)(sizeof(PoseEntry<KD>) / sizeof(double));
-        const bool staged = WITH_J && SS * EW <= OuterAcc<ND>::SLAB; // the cost-only kernels have no slabs (and need 15 of the 59 doubles)
+        const bool staged = WITH_J && SS * MS * EW <= OuterAcc<ND>::SLAB; // the cost-only kernels have no slabs (and need 15 of the 59 doubles)
         if (staged)
         {
             const MBAVO_GLOBAL double *src = (const MBAVO_GLOBAL double *)ftab;
-            for (int z = lane; z < SS * EW; z += 64) slab[z] = src[z];
+            for (int z = lane; z < SS * MS * EW; z += 64) slab[z] = src[z];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -457,16 +461,29 @@ namespace mbavo
                 double ray[3];
                 unit_ray(cam, (double)px, (double)py, ray);
                 const double iz = reciprocal(kz + 1e-8);
-                auto one_sample = [&](const PoseEntry<KD> &pe) {
-                    SampleInFlight f;
-                    sample_issue<KD, WITH_J, HALF_GRAD>(pe, ray, kz, iz, cam, d.ref_img, d.ref_dIxy, f);
-                    ok_l = f.taps.ok;
-                    sample_retire<KD, WITH_J>(pe, f, ray, iz, cam, val, Jc);
+                auto lane_samples = [&](const PoseEntry<KD> *pe) {
+                    if constexpr (MS == 1)
+                    {
+                        SampleInFlight f;
+                        sample_issue<KD, WITH_J, HALF_GRAD>(pe[0], ray, kz, iz, cam, d.ref_img, d.ref_dIxy, f);
+                        ok_l = f.taps.ok;
+                        sample_retire<KD, WITH_J>(pe[0], f, ray, iz, cam, vals[0], Jc);
+                    }
+                    else
+                    {
+                        static_assert(MS == 1 || MS == 2, "one or two samples per lane");
+                        SampleInFlight fa, fb;
+                        sample_issue<KD, WITH_J, HALF_GRAD>(pe[0], ray, kz, iz, cam, d.ref_img, d.ref_dIxy, fa);
+                        sample_issue<KD, WITH_J, HALF_GRAD>(pe[1], ray, kz, iz, cam, d.ref_img, d.ref_dIxy, fb);
+                        ok_l = fa.taps.ok && fb.taps.ok;
+                        sample_retire<KD, WITH_J>(pe[0], fa, ray, iz, cam, vals[0], Jc);
+                        sample_retire<KD, WITH_J>(pe[1], fb, ray, iz, cam, vals[MS - 1], Jc);
+                    }
                 };
                 if (staged)
-                    one_sample(((const PoseEntry<KD> *)slab)[sidx]); // LDS
+                    lane_samples(((const PoseEntry<KD> *)slab) + MS * sidx); // LDS
                 else
-                    one_sample(ftab[sidx]);
+                    lane_samples(ftab + MS * sidx);
             }
         }
         if (staged)
@@ -476,7 +493,9 @@ namespace mbavo
         }
         const bool valid = in && (__ballot(ok_l) & gmask) == gmask;
         double isum = 0.0;
-        for (int j = 0; j < SS; ++j) isum += __shfl(val, lane0 + j, 64); // sample order, as the sequential loop
+        for (int j = 0; j < SS; ++j)
+#pragma unroll
+            for (int m = 0; m < MS; ++m) isum += __shfl(vals[m], lane0 + j, 64); // sample order, as the sequential loop
         if (valid) res = quotient(isum, fS) - cur;
         huber_weight(res, d.huber_a, w, rho);
         if (in && sidx == 0)
@@ -662,25 +681,45 @@ namespace mbavo
         __builtin_amdgcn_s_setprio(3);
         if (sp_ok)
         {
+            // S >= 8: two samples per lane (S / 2 lanes per pixel), see sp_round_rt
+#if defined(MBAVO_SP_MS1)
+            const int ms = 1;
+#else
+            const int ms = sp_logs >= 3 ? 2 : 1;
+#endif
+            const int lane_logs = sp_logs - (ms == 2 ? 1 : 0);
             const int rem = npx % kThreads;
-            if (rem > 0 && (long long)rem * S <= kThreads)
+            // worth it while the remainder's lanes, spread over the four SIMDs, cost a SIMD fewer instructions than the one
+            // more 64-pixel chunk it would otherwise get (per lane ~600 per-pixel + 151 per sample, profiles/r02_pmc_sq.json)
+            const long long sp_lanes = (long long)rem << lane_logs;
+            if (rem > 0 && sp_lanes <= kThreads && sp_lanes * (600 + 151 * ms) < 256ll * (600 + 151 * S))
             {
                 main_end = npx - rem;
-                if (main_end + wave * (64 >> sp_logs) < npx)
+                if (main_end + wave * (64 >> lane_logs) < npx)
                 {
-#define MBAVO_SP_ROUND(L)                                                                                              \
-    sp_round_rt<KD, WITH_J, HALF_GRAD, kWavesPerGroup, L>(d, tile, cam, ftab, mid, I_cur, sp_logs, main_end, npx, pix0, lane, \
-                                                          wave, slab, acc, rho_out, nvalid, inv, patch_cost,                 \
-                                                          patch_blocks_strided, frame, cost_local)
+#define MBAVO_SP_ROUND(L, M)                                                                                           \
+    sp_round_rt<KD, WITH_J, HALF_GRAD, kWavesPerGroup, L, M>(d, tile, cam, ftab, mid, I_cur, lane_logs, main_end, npx, pix0, \
+                                                             lane, wave, slab, acc, rho_out, nvalid, inv, patch_cost,        \
+                                                             patch_blocks_strided, frame, cost_local)
                     // S = 4, 8, 16 as compile-time cases (the exchange loops over the samples unroll: -1 us of the
                     // remainder round's 4.4 us on configs[1]); other powers of two take the run-time form
-                    switch (sp_logs)
-                    {
-                    case 2: MBAVO_SP_ROUND(2); break;
-                    case 3: MBAVO_SP_ROUND(3); break;
-                    case 4: MBAVO_SP_ROUND(4); break;
-                    default: MBAVO_SP_ROUND(-1); break;
-                    }
+                    if (ms == 2)
+                        switch (sp_logs)
+                        {
+                        case 3: MBAVO_SP_ROUND(2, 2); break;
+                        case 4: MBAVO_SP_ROUND(3, 2); break;
+                        default: MBAVO_SP_ROUND(-1, 2); break;
+                        }
+                    else
+                        switch (sp_logs)
+                        {
+                        case 2: MBAVO_SP_ROUND(2, 1); break;
+#if defined(MBAVO_SP_MS1)
+                        case 3: MBAVO_SP_ROUND(3, 1); break;
+                        case 4: MBAVO_SP_ROUND(4, 1); break;
+#endif
+                        default: MBAVO_SP_ROUND(-1, 1); break;
+                        }
 #undef MBAVO_SP_ROUND
                 }
             }
