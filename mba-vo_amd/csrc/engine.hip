@@ -577,6 +577,9 @@ namespace mbavo
         default: __builtin_amdgcn_s_setprio(3); break;
         }
     }
+#ifndef MBAVO_SP_REM_MOD
+#define MBAVO_SP_REM_MOD 256 // (kThreads: the remainder beyond the last FULL round only, the scheme before)
+#endif
 #if defined(MBAVO_MIN_WAVES_EU) // experiments with several smaller workgroups per CU: keep the 3-waves-per-SIMD register budget
 #define MBAVO_FUSED_OCC __attribute__((amdgpu_waves_per_eu(MBAVO_MIN_WAVES_EU)))
 #else
@@ -688,18 +691,23 @@ namespace mbavo
             const int ms = sp_logs >= 3 ? 2 : 1;
 #endif
             const int lane_logs = sp_logs - (ms == 2 ? 1 : 0);
-            const int rem = npx % kThreads;
-            // worth it while the remainder's lanes, spread over the four SIMDs, cost a SIMD fewer instructions than the one
+            // The lane-per-pixel rounds take a multiple of 256 pixels (the same number of 64-pixel chunks on each of the four
+            // SIMDs; the last of these rounds may be a partial one), the pixels beyond go sample-parallel.
+            // Worth it while the remainder's lanes, spread over the four SIMDs, cost a SIMD fewer instructions than the one
             // more 64-pixel chunk it would otherwise get (per lane ~600 per-pixel + 151 per sample, profiles/r02_pmc_sq.json)
+            const int rem = npx % MBAVO_SP_REM_MOD;
             const long long sp_lanes = (long long)rem << lane_logs;
             if (rem > 0 && sp_lanes <= kThreads && sp_lanes * (600 + 151 * ms) < 256ll * (600 + 151 * S))
             {
                 main_end = npx - rem;
-                if (main_end + wave * (64 >> lane_logs) < npx)
+                // dealt out from the LAST wave down: when the last lane-per-pixel round is a partial one, the waves without
+                // a chunk in it take the remainder (64 pairs: the other way round cost 1.4 us, waves 0-4 then had both)
+                const int sp_wave = kWavesPerGroup - 1 - wave;
+                if (main_end + sp_wave * (64 >> lane_logs) < npx)
                 {
 #define MBAVO_SP_ROUND(L, M)                                                                                           \
     sp_round_rt<KD, WITH_J, HALF_GRAD, kWavesPerGroup, L, M>(d, tile, cam, ftab, mid, I_cur, lane_logs, main_end, npx, pix0, \
-                                                             lane, wave, slab, acc, rho_out, nvalid, inv, patch_cost,        \
+                                                             lane, sp_wave, slab, acc, rho_out, nvalid, inv, patch_cost,     \
                                                              patch_blocks_strided, frame, cost_local)
                     // S = 4, 8, 16 as compile-time cases (the exchange loops over the samples unroll: -1 us of the
                     // remainder round's 4.4 us on configs[1]); other powers of two take the run-time form
@@ -742,7 +750,7 @@ namespace mbavo
             double res = 0.0, w = 0.0, rho = 0.0, inv_S = 0.0;
             bool keep = false;
             double Jrow[WITH_J ? 6 * KD : 1]; // the SUM over the samples, defined only where keep (see pixel_row)
-            if (g < npx)
+            if (g < main_end)
             {
                 const int kpl = patch_of(g, P), pp = g - kpl * P;
                 const int kp = tile.kp_begin + kpl;
