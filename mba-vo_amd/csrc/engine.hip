@@ -244,10 +244,61 @@ namespace mbavo
     // of 24.  The MFMA shares the FP64 pipe with the VALU, so instructions saved here are kernel time saved.
     // (Layout probed in tools/micro/mfma4_probe.hip and mfma4_outer_probe.hip; the cbsz / abid broadcast controls
     // are ignored by this instruction, which rules out a 7-instruction scheme with A broadcast from block 0.)
+    // G = 7 (k = 4: 25 entries): SEVEN instructions instead of eight.  The 28 unordered pairs of 7 groups (self-pairs
+    // included) are the edges of K7 with a loop at every vertex -- every degree is 8, even -- and that graph splits into
+    // four CLOSED TRAILS of length 7 (found by exhaustive search, tools/mfma_trails.py).  Block d walks trail d: the lane
+    // loads W[m] = group kTrail7[d][m] (seven LDS reads, as before; only the lane's read offsets differ) and instruction
+    // m multiplies W[m] by W[m + 1 mod 7] -- the same two registers for every lane, a different pair of groups in every
+    // block, every pair exactly once in the 28 block slots.  One MFMA in eight and two accumulator VGPRs saved.
+    constexpr int kTrail7[4][7] = {{0, 0, 1, 1, 2, 2, 3}, {0, 2, 4, 0, 5, 1, 6}, {1, 3, 3, 5, 2, 6, 4}, {3, 4, 4, 5, 5, 6, 6}};
+    constexpr unsigned trail7_word(int d) // the seven groups of trail d, three bits each
+    {
+        unsigned w = 0;
+        for (int m = 0; m < 7; ++m) w |= (unsigned)kTrail7[d][m] << (3 * m);
+        return w;
+    }
+    // where the product of groups I <= J sits: bits 0-2 instruction, 3-4 block, 5 = the block holds J x I (transposed)
+    constexpr unsigned trail7_pair(int I, int J)
+    {
+        for (int d = 0; d < 4; ++d)
+            for (int m = 0; m < 7; ++m)
+            {
+                const int a = kTrail7[d][m], b = kTrail7[d][(m + 1) % 7];
+                if (a == I && b == J) return (unsigned)m | (unsigned)d << 3;
+                if (a == J && b == I) return (unsigned)m | (unsigned)d << 3 | 32u;
+            }
+        return 0xffu; // (never: the trails cover every pair, checked below)
+    }
+    constexpr unsigned long long trail7_row(int I) // codes of (I, J), J = 0 .. 6, six bits each
+    {
+        unsigned long long w = 0;
+        for (int J = I; J < 7; ++J) w |= (unsigned long long)(trail7_pair(I, J) & 63u) << (6 * J);
+        return w;
+    }
+    constexpr bool trail7_covers()
+    {
+        unsigned seen = 0;
+        for (int I = 0; I < 7; ++I)
+            for (int J = I; J < 7; ++J)
+            {
+                const unsigned c = trail7_pair(I, J);
+                if (c == 0xffu) return false;
+                seen |= 1u << ((c & 7u) + 7u * ((c >> 3) & 3u));
+            }
+        return seen == (1u << 28) - 1u; // 28 pairs in 28 different slots
+    }
+    static_assert(trail7_covers(), "the four trails must cover every pair of groups exactly once");
+
     template <int ND>
     struct OuterAcc
     {
-        static constexpr int G = (ND + 3) / 4, ND_DELTA = G / 2 + 1, NH = (G + 3) / 4, NI = ND_DELTA * NH;
+        static constexpr int G = (ND + 3) / 4, ND_DELTA = G / 2 + 1, NH = (G + 3) / 4;
+#if defined(MBAVO_NO_TRAIL7) // A/B switch: the rotation scheme for every G (eight instructions for G = 7)
+        static constexpr bool TRAIL7 = false;
+#else
+        static constexpr bool TRAIL7 = G == 7;
+#endif
+        static constexpr int NI = TRAIL7 ? 7 : ND_DELTA * NH;
         static constexpr int STRIDE = ND;
         static constexpr int ROWS = 64;
         static constexpr int SLAB = ROWS * ND > 768 ? ROWS * ND : 768;
@@ -265,19 +316,37 @@ namespace mbavo
             asm volatile("" : "+v"(lane));
             const int kq = lane >> 4, d = (lane >> 2) & 3, e = lane & 3;
             const double *base[G];
+            if constexpr (TRAIL7)
+            {
+                constexpr unsigned t0 = trail7_word(0), t1 = trail7_word(1), t2 = trail7_word(2), t3 = trail7_word(3);
+                const unsigned tw = d == 0 ? t0 : d == 1 ? t1 : d == 2 ? t2 : t3;
 #pragma unroll
-            for (int m = 0; m < G; ++m) base[m] = slab + kq * ND + 4 * ((m + d) % G) + e;
+                for (int m = 0; m < G; ++m) base[m] = slab + kq * ND + 4 * (int)((tw >> (3 * m)) & 7u) + e;
+            }
+            else
+            {
+#pragma unroll
+                for (int m = 0; m < G; ++m) base[m] = slab + kq * ND + 4 * ((m + d) % G) + e;
+            }
 #pragma unroll 4
             for (int step = 0; step < nsteps; ++step)
             {
                 double W[G];
 #pragma unroll
                 for (int m = 0; m < G; ++m) W[m] = base[m][4 * step * ND];
+                if constexpr (TRAIL7)
+                {
 #pragma unroll
-                for (int dl = 0; dl < ND_DELTA; ++dl)
+                    for (int m = 0; m < 7; ++m) acc[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(W[m], W[(m + 1) % 7], acc[m], 0, 0, 0);
+                }
+                else
+                {
 #pragma unroll
-                    for (int h = 0; h < NH; ++h)
-                        acc[dl * NH + h] = __builtin_amdgcn_mfma_f64_4x4x4f64(W[(4 * h) % G], W[(4 * h + dl) % G], acc[dl * NH + h], 0, 0, 0);
+                    for (int dl = 0; dl < ND_DELTA; ++dl)
+#pragma unroll
+                        for (int h = 0; h < NH; ++h)
+                            acc[dl * NH + h] = __builtin_amdgcn_mfma_f64_4x4x4f64(W[(4 * h) % G], W[(4 * h + dl) % G], acc[dl * NH + h], 0, 0, 0);
+                }
             }
         }
         __device__ __forceinline__ void store(double *dst, int lane) const
@@ -289,11 +358,25 @@ namespace mbavo
         static __device__ __forceinline__ double gather(const double *rows, int i, int j, int nwaves)
         {
             const int I = i >> 2, J = j >> 2, dd = J - I; // 0 .. G - 1
-            int dl, g, ri, cj;
-            if (dd <= G / 2) { dl = dd; g = I; ri = i & 3; cj = j & 3; }
-            else { dl = G - dd; g = J; ri = j & 3; cj = i & 3; } // the block holds group J x group I: transposed
-            const int h = g >> 2, d = g & 3;
-            const int off = (dl * NH + h) * 64 + 16 * ri + 4 * d + cj;
+            int off;
+            if constexpr (TRAIL7)
+            {
+                constexpr unsigned long long r0 = trail7_row(0), r1 = trail7_row(1), r2 = trail7_row(2), r3 = trail7_row(3),
+                                             r4 = trail7_row(4), r5 = trail7_row(5), r6 = trail7_row(6);
+                const unsigned long long rw = I == 0 ? r0 : I == 1 ? r1 : I == 2 ? r2 : I == 3 ? r3 : I == 4 ? r4 : I == 5 ? r5 : r6;
+                const unsigned c = (unsigned)(rw >> (6 * J)) & 63u;
+                const bool flip = (c & 32u) != 0; // the block holds group J x group I: transposed
+                const int ri = flip ? j & 3 : i & 3, cj = flip ? i & 3 : j & 3;
+                off = (int)(c & 7u) * 64 + 16 * ri + 4 * (int)((c >> 3) & 3u) + cj;
+            }
+            else
+            {
+                int dl, g, ri, cj;
+                if (dd <= G / 2) { dl = dd; g = I; ri = i & 3; cj = j & 3; }
+                else { dl = G - dd; g = J; ri = j & 3; cj = i & 3; } // the block holds group J x group I: transposed
+                const int h = g >> 2, d = g & 3;
+                off = (dl * NH + h) * 64 + 16 * ri + 4 * d + cj;
+            }
             double s = 0.0;
             for (int wv = 0; wv < nwaves; ++wv) s += rows[wv * SLAB + off];
             return s;
@@ -388,6 +471,16 @@ namespace mbavo
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
         return v;
     }
+
+    // A wave-uniform 64-bit value moved into SGPRs.  The compiler keeps the result of a uniform VECTOR operation (a pointer
+    // fetched through a descriptor, an fp64 quotient -- there is no scalar fp64 unit) in a VGPR pair for the whole kernel;
+    // the k = 4 kernel has none to spare (168 of 170), a spilled SGPR costs one v_readlane per use instead.
+    __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v)
+    {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    }
+    __device__ __forceinline__ double uniform_f64(double v) { return __builtin_bit_cast(double, uniform_u64(__builtin_bit_cast(unsigned long long, v))); }
 
     // Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and every XCD has its own L2:
     // give each XCD a CONTIGUOUS range of tiles (= a band of the keyframe and of the current image), so that the
@@ -653,9 +746,10 @@ namespace mbavo
         }
 #endif
         const PoseEntry<KD> &mid = ftab[S / 2]; // patch centres use sample S/2 (compute_local_patches_xy.cu:26)
-        const unsigned char *__restrict__ I_cur = d.cur_imgs[frame];
+        const unsigned char *__restrict__ I_cur = (const unsigned char *)uniform_u64((unsigned long long)d.cur_imgs[frame]);
         const long long pix0 = d.pixel_base + ((long long)frame * K + tile.kp_begin) * P;
         const int npx = tile.kp_count * P;
+        const double inv_S_u = uniform_f64(1.0 / (double)(float)S); // pixel_row's inv_S (A8), wave-uniform
 
         OuterAcc<ND> acc;
         acc.init(lane);
@@ -795,7 +889,7 @@ namespace mbavo
                 double *mine = slab + lane * RS;
                 if (keep)
                 {
-                    const double wj = w * inv_S; // Huber weight times the 1/S of the mean over the samples
+                    const double wj = w * inv_S_u; // Huber weight times the 1/S of the mean over the samples
                     mine[0] = w * res;
 #pragma unroll
                     for (int i = 0; i < 6 * KD; ++i) mine[1 + i] = wj * Jrow[i];
