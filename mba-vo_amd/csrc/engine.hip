@@ -328,6 +328,39 @@ namespace mbavo
 #pragma unroll
                 for (int m = 0; m < G; ++m) base[m] = slab + kq * ND + 4 * ((m + d) % G) + e;
             }
+#if !defined(MBAVO_MFMA_NOT_PIPELINED) // (A/B switch; 1080p S=16 193.2 -> 191.6 us, 512 pairs 95.4 -> 94.6, configs[1] unchanged)
+            if constexpr (TRAIL7)
+            {
+                if (nsteps == ROWS / 4)
+                { // full slab: the reads of the next two steps are in flight while the current two are multiplied
+                    double Wa[2 * G], Wb[2 * G];
+#pragma unroll
+                    for (int m = 0; m < G; ++m) { Wa[m] = base[m][0]; Wa[G + m] = base[m][4 * ND]; }
+#pragma unroll
+                    for (int step = 0; step < ROWS / 4; step += 4)
+                    {
+#pragma unroll
+                        for (int m = 0; m < G; ++m) { Wb[m] = base[m][4 * (step + 2) * ND]; Wb[G + m] = base[m][4 * (step + 3) * ND]; }
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int m = 0; m < 7; ++m)
+                                acc[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(Wa[h * G + m], Wa[h * G + (m + 1) % 7], acc[m], 0, 0, 0);
+                        if (step + 4 < ROWS / 4)
+                        {
+#pragma unroll
+                            for (int m = 0; m < G; ++m) { Wa[m] = base[m][4 * (step + 4) * ND]; Wa[G + m] = base[m][4 * (step + 5) * ND]; }
+                        }
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int m = 0; m < 7; ++m)
+                                acc[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(Wb[h * G + m], Wb[h * G + (m + 1) % 7], acc[m], 0, 0, 0);
+                    }
+                    return;
+                }
+            }
+#endif
 #pragma unroll 4
             for (int step = 0; step < nsteps; ++step)
             {
