@@ -71,6 +71,28 @@ namespace mbavo
     // The pose itself is written by knot 0 / column 0.  kPoseSPB samples per workgroup: 21 x 3 columns fill a wave.
     constexpr int kPoseSPB = 21;
 
+    // The table holds R * A (pixel_math.h PoseEntry): this lane's column of A = d(body rotation) / d(knot rotation), turned
+    // into the keyframe's axes by the sample's own rotation matrix -- once per (sample, column) here instead of a transposed
+    // product per pixel-sample in the fused kernels.
+    template <int KD>
+    __device__ __forceinline__ void store_rotated_column(const Quat &q, const double av[3], int c, PoseEntry<KD> &pe)
+    {
+#if defined(MBAVO_A_BODY) // A/B switch: the body-frame table of before (sample_retire must be built with the same switch)
+        for (int a = 0; a < 3; ++a) pe.A[a * 3 * KD + c] = av[a];
+#else
+        const double qv[4] = {q.x, q.y, q.z, q.w};
+        double R[9];
+        rotation_entries(qv, R);
+        for (int b = 0; b < 3; ++b)
+        {
+            double r = R[3 * b] * av[0];
+            r += R[3 * b + 1] * av[1];
+            r += R[3 * b + 2] * av[2];
+            pe.A[b * 3 * KD + c] = r;
+        }
+#endif
+    }
+
     template <int KD, int KNOT>
     __device__ __forceinline__ Quat pose_table_entry(const double *kR, double u, int col, const SplineSeg *sg, PoseEntry<KD> &pe)
     {
@@ -79,14 +101,16 @@ namespace mbavo
         // tangent form of this column: A[a][3*knot + col] = 2 * L3(q)^T[a] . blk      (pixel_math.h)
         const double L3[4][3] = {{q.w, -q.z, q.y}, {q.z, q.w, -q.x}, {-q.y, q.x, q.w}, {-q.x, -q.y, -q.z}};
         const Quat &v = blk.c[0];
+        double av[3];
         for (int a = 0; a < 3; ++a)
         {
             double r = L3[0][a] * v.x;
             r += L3[1][a] * v.y;
             r += L3[2][a] * v.z;
             r += L3[3][a] * v.w;
-            pe.A[a * 3 * KD + 3 * KNOT + col] = 2.0 * r;
+            av[a] = 2.0 * r;
         }
+        store_rotated_column<KD>(q, av, 3 * KNOT + col, pe);
         return q;
     }
 
@@ -161,14 +185,16 @@ namespace mbavo
             static_assert(KD == 2, "one wave per knot beyond k = 2 goes through the staged form");
             const double L3[4][3] = {{q.w, -q.z, q.y}, {q.z, q.w, -q.x}, {-q.y, q.x, q.w}, {-q.x, -q.y, -q.z}};
             const Quat &v = blk.c[0];
+            double av[3];
             for (int a = 0; a < 3; ++a)
             {
                 double r = L3[0][a] * v.x;
                 r += L3[1][a] * v.y;
                 r += L3[2][a] * v.z;
                 r += L3[3][a] * v.w;
-                pe.A[a * 3 * KD + 3 * wave + col] = 2.0 * r;
+                av[a] = 2.0 * r;
             }
+            store_rotated_column<KD>(q, av, 3 * wave + col, pe);
         }
         else
             q = spline_rotation<KD, false>(kR, u, nullptr);
@@ -593,7 +619,7 @@ namespace mbavo
                         SampleInFlight f;
                         sample_issue<KD, WITH_J, HALF_GRAD>(pe[0], ray, kz, iz, cam, d.ref_img, d.ref_dIxy, f);
                         ok_l = f.taps.ok;
-                        sample_retire<KD, WITH_J>(pe[0], f, ray, iz, cam, vals[0], Jc);
+                        sample_retire<KD, WITH_J>(pe[0], f, ray, kz, iz, cam, vals[0], Jc);
                     }
                     else
                     {
@@ -602,8 +628,8 @@ namespace mbavo
                         sample_issue<KD, WITH_J, HALF_GRAD>(pe[0], ray, kz, iz, cam, d.ref_img, d.ref_dIxy, fa);
                         sample_issue<KD, WITH_J, HALF_GRAD>(pe[1], ray, kz, iz, cam, d.ref_img, d.ref_dIxy, fb);
                         ok_l = fa.taps.ok && fb.taps.ok;
-                        sample_retire<KD, WITH_J>(pe[0], fa, ray, iz, cam, vals[0], Jc);
-                        sample_retire<KD, WITH_J>(pe[1], fb, ray, iz, cam, vals[MS - 1], Jc);
+                        sample_retire<KD, WITH_J>(pe[0], fa, ray, kz, iz, cam, vals[0], Jc);
+                        sample_retire<KD, WITH_J>(pe[1], fb, ray, kz, iz, cam, vals[MS - 1], Jc);
                     }
                 };
                 if (staged)
@@ -1315,7 +1341,7 @@ namespace mbavo
                         SampleInFlight f;
                         sample_issue<KD, WITH_J, HALF_GRAD>(pe, ray, kz, iz, cam, d.ref_img, d.ref_dIxy, f);
                         ok_l = f.taps.ok;
-                        sample_retire<KD, WITH_J>(pe, f, ray, iz, cam, val, Jc);
+                        sample_retire<KD, WITH_J>(pe, f, ray, kz, iz, cam, val, Jc);
                     };
                     if constexpr (STAGE)
                         one_sample(((const PoseEntry<KD> *)stage)[sidx]); // LDS

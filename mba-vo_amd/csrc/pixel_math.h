@@ -68,7 +68,8 @@ namespace mbavo
         double q[4];          // R_c2r xyzw
         double R[9];          // rotation matrix of q, row-major, reference term order
         double c[KDEG];       // translation spline weights (J_t = kron(c, I3))
-        double A[9 * KDEG];   // 3 x 3k row-major d(body-frame rotation of the pose)/d(knot local rotations)
+        double A[9 * KDEG];   // 3 x 3k row-major: R * d(body-frame rotation of the pose)/d(knot local rotations), i.e. the
+                              // derivative of the pose's rotation about the KEYFRAME's axes (see sample_retire)
     };
 
     // The reference chains dI/dq (1x4) through J_R = dq/dw (4x3k).  I does not depend on |q| (the warped point
@@ -76,6 +77,8 @@ namespace mbavo
     // at q and equals 2 * L3(q) * phi, where phi = dI/d(body-frame rotation) and L3(q) = first three columns of
     // the left-product matrix (Quaternion.h:239-260).  Hence dI/dq * J_R == phi * A with A = 2 * L3(q)^T * J_R:
     // a 3x3k table instead of 4x3k, and phi (below) is cheaper to form than dI/dq.
+    // (The kernels go one step further and tabulate R * A: sample_retire then needs phi about the keyframe's axes, which
+    // costs 9 instructions per pixel-sample instead of 18.  This function returns the body-frame A.)
     template <int KDEG>
     MBAVO_HD void tangent_jacobian(const double q[4], const double *JR /*4 x 3k*/, double *A /*3 x 3k*/)
     {
@@ -512,7 +515,7 @@ namespace mbavo
     // FIRST: the pixel's first sample SETS isum and Jrow instead of adding to them (no zero-initialisation of the 6k
     // accumulators per pixel).
     template <int KDEG, bool WITH_J, bool FIRST = false>
-    MBAVO_HD void sample_retire(const PoseEntry<KDEG> &pe, const SampleInFlight &f, const double ray[3], double iz,
+    MBAVO_HD void sample_retire(const PoseEntry<KDEG> &pe, const SampleInFlight &f, const double ray[3], double D, double iz,
                                 const Camera &cam, double &isum, double *Jrow)
     {
         double val, gx = 0, gy = 0;
@@ -526,6 +529,7 @@ namespace mbavo
             const double dIx = gx * (iz * cam.fx); // iz * f is per pixel: hoisted out of the sample loop by the compiler
             const double dIy = gy * (iz * cam.fy);
             const double jt[3] = {dIx, dIy, -f.C1 * (dIx * rx + dIy * ry)};
+#if defined(MBAVO_A_BODY) // A/B switch: the table holds A in body axes (the pose kernels must be built with the same switch)
             // phi = dI/d(body rotation) = sc * ray x (R^T * dI/dt): the same derivative the reference forms as
             // twelve dP/dq terms (:179-206), restricted to the tangent space
             const double w0 = R[0] * jt[0] + R[3] * jt[1] + R[6] * jt[2];
@@ -533,6 +537,17 @@ namespace mbavo
             const double w2 = R[2] * jt[0] + R[5] * jt[1] + R[8] * jt[2];
             const double phi[3] = {f.sc * (ray[1] * w2 - ray[2] * w1), f.sc * (ray[2] * w0 - ray[0] * w2),
                                    f.sc * (ray[0] * w1 - ray[1] * w0)};
+#else
+            // phi = dI/d(rotation about the KEYFRAME's axes) = sc * (R ray) x dI/dt.  The derivative w.r.t. the body
+            // rotation is sc * ray x (R^T dI/dt) = R^T phi (a rotation carries a cross product along); its product with
+            // A = d(body rotation)/d(knots) is phi^T (R A), and R A is what the table holds: the nine-term transposed
+            // product per pixel-sample became one per table column.  sc * (R ray)_z = D - t_z, so no third ray entry is
+            // kept: 9 instructions instead of 18.  (The reference forms the same derivative as twelve dP/dq terms,
+            // :179-206.)
+            (void)R;
+            const double dz = D - pe.t[2], sj = f.sc * jt[2];
+            const double phi[3] = {ry * sj - dz * jt[1], dz * jt[0] - rx * sj, f.sc * (rx * jt[1] - ry * jt[0])};
+#endif
 #pragma unroll
             for (int j = 0; j < KDEG; ++j)
             {
@@ -593,28 +608,28 @@ namespace mbavo
             sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(0), ray, depth, iz, cam, I_ref, G_ref, fa);
             sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(1), ray, depth, iz, cam, I_ref, G_ref, fb);
             ok = fa.taps.ok && fb.taps.ok;
-            sample_retire<KDEG, WITH_J, true>(MBAVO_TAB(0), fa, ray, iz, cam, isum, Jrow);
-            sample_retire<KDEG, WITH_J>(MBAVO_TAB(1), fb, ray, iz, cam, isum, Jrow);
+            sample_retire<KDEG, WITH_J, true>(MBAVO_TAB(0), fa, ray, depth, iz, cam, isum, Jrow);
+            sample_retire<KDEG, WITH_J>(MBAVO_TAB(1), fb, ray, depth, iz, cam, isum, Jrow);
             for (s = 2; s + 1 < S; s += 2)
             {
                 sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s), ray, depth, iz, cam, I_ref, G_ref, fa);
                 sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s + 1), ray, depth, iz, cam, I_ref, G_ref, fb);
                 ok = ok && fa.taps.ok && fb.taps.ok;
-                sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, iz, cam, isum, Jrow);
-                sample_retire<KDEG, WITH_J>(MBAVO_TAB(s + 1), fb, ray, iz, cam, isum, Jrow);
+                sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, depth, iz, cam, isum, Jrow);
+                sample_retire<KDEG, WITH_J>(MBAVO_TAB(s + 1), fb, ray, depth, iz, cam, isum, Jrow);
             }
             if (s < S)
             { // odd S
                 sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s), ray, depth, iz, cam, I_ref, G_ref, fa);
                 ok = ok && fa.taps.ok;
-                sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, iz, cam, isum, Jrow);
+                sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, depth, iz, cam, isum, Jrow);
             }
         }
         else
         { // the sharp case S = 1
             sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(0), ray, depth, iz, cam, I_ref, G_ref, fa);
             ok = fa.taps.ok;
-            sample_retire<KDEG, WITH_J, true>(MBAVO_TAB(0), fa, ray, iz, cam, isum, Jrow);
+            sample_retire<KDEG, WITH_J, true>(MBAVO_TAB(0), fa, ray, depth, iz, cam, isum, Jrow);
         }
         if (!ok) return false;
         const double fS = (double)(float)S; // A8
