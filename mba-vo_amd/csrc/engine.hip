@@ -808,7 +808,10 @@ namespace mbavo
         const unsigned char *__restrict__ I_cur = (const unsigned char *)uniform_u64((unsigned long long)d.cur_imgs[frame]);
         const long long pix0 = d.pixel_base + ((long long)frame * K + tile.kp_begin) * P;
         const int npx = tile.kp_count * P;
-        const double inv_S_u = uniform_f64(1.0 / (double)(float)S); // pixel_row's inv_S (A8), wave-uniform
+        // (double)(float)S (A8), the reciprocal quotient() forms of it and 1 / it: the same bits pixel_row computes per call
+        const double fS_u = uniform_f64((double)(float)S), rS_u = uniform_f64(quotient_recip((double)(float)S)),
+                     inv_S_u = uniform_f64(1.0 / (double)(float)S);
+        const double inv_fx = uniform_f64(1.0 / d.fx), inv_fy = uniform_f64(1.0 / d.fy); // patch_centre_fast
 
         OuterAcc<ND> acc;
         acc.init(lane);
@@ -824,7 +827,7 @@ namespace mbavo
         // SIMD: 7 chunks against 6 on the others) at the end.
         // One-pixel patches (dense mode): the patch cost is the pixel's own, taken where rho is computed; the
         // per-pixel rho scratch (8 B per pixel written and read back at the end of the tile) is not touched.
-        const double inv = residual_scale<false>(d, lane);
+        const double inv = uniform_f64(residual_scale<false>(d, lane));
         double cost_local = 0.0;
         int main_end = npx;
         MBAVO_FSTAMP(1);
@@ -900,7 +903,7 @@ namespace mbavo
         for (int base = 0; base < main_end; base += kThreads)
         {
             const int g = base + (int)threadIdx.x;
-            double res = 0.0, w = 0.0, rho = 0.0, inv_S = 0.0;
+            double res = 0.0, w = 0.0, rho = 0.0;
             bool keep = false;
             double Jrow[WITH_J ? 6 * KD : 1]; // the SUM over the samples, defined only where keep (see pixel_row)
             if (g < main_end)
@@ -913,8 +916,15 @@ namespace mbavo
                 double pcx, pcy;
 #if defined(MBAVO_EXP_NO_CENTRE) // timing experiment switch
                 pcx = kx + mid.t[0]; pcy = ky + mid.t[1];
-#else
+#elif defined(MBAVO_CENTRE_EXACT) // A/B switch: the reference's operation order for every pixel
                 patch_centre_rt(mid.rt, mid.q, kx, ky, kz, cam, pcx, pcy);
+#else
+                // The pixel is (int)(centre + pattern offset): the cheap centre is good wherever that sum is not within
+                // 1e-5 of an integer; if ANY lane of the wave is (zero motion: all of them), the wave takes the reference's
+                // operation order -- a uniform branch, never taken on moving cameras (2e-5 of the pixels per axis).
+                patch_centre_fast(mid.rt, mid.R, kx, ky, kz, cam, inv_fx, inv_fy, pcx, pcy);
+                const bool unsure = !(patch_centre_sure(pcx + d.pattern[2 * pp]) && patch_centre_sure(pcy + d.pattern[2 * pp + 1]));
+                if (__builtin_amdgcn_ballot_w64(unsure) != 0) patch_centre_rt(mid.rt, mid.q, kx, ky, kz, cam, pcx, pcy);
 #endif
                 // Wave priority by remaining work (see below the round loop's head): the sample loop of a wave that is
                 // behind goes first, the row parking + MFMA phase one step lower.
@@ -922,7 +932,7 @@ namespace mbavo
                 const int prio = rem_rounds > 3 ? 3 : rem_rounds;
                 set_prio(prio);
                 const bool valid = pixel_row<KD, WITH_J, HALF_GRAD>(ftab, S, cam, d.ref_img, d.ref_dIxy, I_cur, pcx, pcy, kz,
-                                                         d.pattern[2 * pp], d.pattern[2 * pp + 1], res, Jrow, inv_S);
+                                                         d.pattern[2 * pp], d.pattern[2 * pp + 1], res, Jrow, fS_u, rS_u);
                 set_prio(prio - 1);
                 huber_weight(res, d.huber_a, w, rho);
                 if (P == 1)

@@ -154,6 +154,31 @@ namespace mbavo
 #endif
     }
 
+    // quotient() in two halves, for a denominator shared by many quotients (the number of samples: wave-uniform, the caller
+    // keeps both values in scalar registers): r = quotient_recip(d) once, then quotient_with(n, d, r) == quotient(n, d).
+    MBAVO_HD double quotient_recip(double d)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        double r = __builtin_amdgcn_rcp(d);
+        double e = __builtin_fma(-d, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-d, r, 1.0);
+        return __builtin_fma(r, e, r);
+#else
+        return 1. / d;
+#endif
+    }
+    MBAVO_HD double quotient_with(double n, double d, double r)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double q = n * r;
+        return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+#else
+        (void)r;
+        return n / d;
+#endif
+    }
+
     // unit ray through an integer pixel; z uses the reference's fp32 sqrt (A4)
     MBAVO_HD void unit_ray(const Camera &cam, double px, double py, double ray[3])
     {
@@ -375,6 +400,38 @@ namespace mbavo
         oy = Y / Z * cam.fy + cam.cy;
     }
 
+    // The same centre through the rotation MATRIX, fused multiply-adds and reciprocals (~30 instructions against ~110
+    // for the quaternion sandwich rounded operation by operation as the reference does it).  The two agree to ~1e-11 pixels;
+    // what the callers need is the TRUNCATED coordinate (A3), which can only differ when the value lies that close to an
+    // integer: a lane whose coordinate (centre + pattern offset) is farther than 1e-5 from every integer may keep this
+    // value, otherwise the caller evaluates patch_centre_rt (see patch_centre_sure).  R = rotation_entries(q_c2r),
+    // inv_fx = 1 / fx, inv_fy = 1 / fy.
+    MBAVO_HD void patch_centre_fast(const double rt[3], const double R[9], double kx, double ky, double kz, const Camera &cam,
+                                    double inv_fx, double inv_fy, double &ox, double &oy)
+    {
+        const double Px = kz * (kx - cam.cx) * inv_fx, Py = kz * (ky - cam.cy) * inv_fy;
+        // R_r2c = R^T
+        const double X = R[0] * Px + R[3] * Py + R[6] * kz - rt[0];
+        const double Y = R[1] * Px + R[4] * Py + R[7] * kz - rt[1];
+        const double Z = R[2] * Px + R[5] * Py + R[8] * kz - rt[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+        double r = __builtin_amdgcn_rcp(Z);
+        r = __builtin_fma(r, __builtin_fma(-Z, r, 1.0), r);
+        r = __builtin_fma(r, __builtin_fma(-Z, r, 1.0), r);
+#else
+        const double r = 1.0 / Z;
+#endif
+        ox = X * r * cam.fx + cam.cx;
+        oy = Y * r * cam.fy + cam.cy;
+    }
+    // true when truncating v (a coordinate computed to ~1e-11) is safe: v is farther than 1e-5 from every integer.
+    // NaN, infinities and |v| >= 2^52 (no fraction left) give false.
+    MBAVO_HD bool patch_centre_sure(double v)
+    {
+        const double dist = v - __builtin_rint(v);
+        return (dist < 0 ? -dist : dist) > 1e-5;
+    }
+
     MBAVO_HD void patch_centre(const double t_c2r[3], const double q_c2r[4], double kx, double ky, double kz,
                                const Camera &cam, double &ox, double &oy)
     {
@@ -576,13 +633,14 @@ namespace mbavo
     // pixel: false, residual = 0, and Jrow UNDEFINED (possibly non-finite: it must not be used, not even times zero).
     // `table` points at the S entries of this pixel's frame.  The sample loop is software pipelined: the tap loads
     // of sample s+1 are issued before sample s is consumed.
+    // (pixel_row_sum: the sum of the S interpolated intensities and the current image's pixel; pixel_row below forms the
+    // residual from them)
     template <int KDEG, bool WITH_J, bool HALF_GRAD = false>
-    MBAVO_HD bool pixel_row(const PoseEntry<KDEG> *__restrict__ table, int S, const Camera &cam,
-                            const unsigned char *__restrict__ I_ref, const float *__restrict__ G_ref,
-                            const unsigned char *__restrict__ I_cur, double centre_x, double centre_y,
-                            double depth, int dx, int dy, double &residual, double *Jrow, double &inv_S)
+    MBAVO_HD bool pixel_row_sum(const PoseEntry<KDEG> *__restrict__ table, int S, const Camera &cam,
+                                const unsigned char *__restrict__ I_ref, const float *__restrict__ G_ref,
+                                const unsigned char *__restrict__ I_cur, double centre_x, double centre_y,
+                                double depth, int dx, int dy, double &isum_out, double *Jrow, double &cur_out)
     {
-        residual = 0.0;
         const int px = (int)(centre_x + dx); // truncation, A3
         const int py = (int)(centre_y + dy);
         if (px < 0 || px > cam.W - 1 || py < 0 || py > cam.H - 1) return false;
@@ -632,9 +690,41 @@ namespace mbavo
             sample_retire<KDEG, WITH_J, true>(MBAVO_TAB(0), fa, ray, depth, iz, cam, isum, Jrow);
         }
         if (!ok) return false;
+        isum_out = isum;
+        cur_out = cur;
+        return true;
+    }
+
+    template <int KDEG, bool WITH_J, bool HALF_GRAD = false>
+    MBAVO_HD bool pixel_row(const PoseEntry<KDEG> *__restrict__ table, int S, const Camera &cam,
+                            const unsigned char *__restrict__ I_ref, const float *__restrict__ G_ref,
+                            const unsigned char *__restrict__ I_cur, double centre_x, double centre_y,
+                            double depth, int dx, int dy, double &residual, double *Jrow, double &inv_S)
+    {
+        double isum, cur;
+        residual = 0.0;
+        if (!pixel_row_sum<KDEG, WITH_J, HALF_GRAD>(table, S, cam, I_ref, G_ref, I_cur, centre_x, centre_y, depth, dx, dy, isum, Jrow, cur))
+            return false;
         const double fS = (double)(float)S; // A8
         residual = quotient(isum, fS) - cur;
         inv_S = 1.0 / fS;
+        return true;
+    }
+
+    // The same with the sample count's constants handed in: fS = (double)(float)S, rS = quotient_recip(fS), both kept in
+    // scalar registers by the caller (formed per call they are hoisted into VGPR pairs that stay live through the whole
+    // kernel).  The mean's factor 1 / fS is the caller's business.
+    template <int KDEG, bool WITH_J, bool HALF_GRAD = false>
+    MBAVO_HD bool pixel_row(const PoseEntry<KDEG> *__restrict__ table, int S, const Camera &cam,
+                            const unsigned char *__restrict__ I_ref, const float *__restrict__ G_ref,
+                            const unsigned char *__restrict__ I_cur, double centre_x, double centre_y,
+                            double depth, int dx, int dy, double &residual, double *Jrow, double fS, double rS)
+    {
+        double isum, cur;
+        residual = 0.0;
+        if (!pixel_row_sum<KDEG, WITH_J, HALF_GRAD>(table, S, cam, I_ref, G_ref, I_cur, centre_x, centre_y, depth, dx, dy, isum, Jrow, cur))
+            return false;
+        residual = quotient_with(isum, fS, rS) - cur;
         return true;
     }
 } // namespace mbavo
