@@ -136,6 +136,20 @@ namespace mbavo
 #endif
     }
 
+    // 1 / x to within one unit in the last place: v_rcp_f64 (2^-23) and two Newton steps, without reciprocal()'s final
+    // correctly-rounding correction (two instructions).  For the per-SAMPLE depth scale only: what it feeds (the tap
+    // coordinates) already differs from the reference's rounding by the fused multiply-adds of the rotation before it.
+    MBAVO_HD double reciprocal_1ulp(double x)
+    {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_SAMPLE_RCP_EXACT)
+        double r = __builtin_amdgcn_rcp(x);
+        r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+        return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+#else
+        return reciprocal(x);
+#endif
+    }
+
     // n / d the same way (the runtime's sequence minus v_div_scale x2 and v_div_fixup: 8 instructions instead of 11; the
     // same bits whenever d, n / d and the intermediate products are normal numbers or n is zero).  For the per-pixel
     // quotients with well-conditioned denominators only: focal lengths, the number of samples.
@@ -554,7 +568,7 @@ namespace mbavo
         f.rx = R[0] * ray[0] + R[1] * ray[1] + R[2] * ray[2];
         f.ry = R[3] * ray[0] + R[4] * ray[1] + R[5] * ray[2];
         const double rz = R[6] * ray[0] + R[7] * ray[1] + R[8] * ray[2];
-        f.C1 = reciprocal(rz);
+        f.C1 = reciprocal_1ulp(rz);
         f.sc = (D - pe.t[2]) * f.C1;
         double Px, Py;
         { // product and sum as written (as the oracle rounds them): the translation is a scalar operand of the add,
@@ -563,8 +577,14 @@ namespace mbavo
             Px = f.sc * f.rx + pe.t[0];
             Py = f.sc * f.ry + pe.t[1];
         }
+#if defined(MBAVO_UV_TWO_STEP) // A/B switch: u = fx * (Px * iz) + cx, two instructions per coordinate
         const double u = cam.fx * (Px * iz) + cam.cx;
         const double v = cam.fy * (Py * iz) + cam.cy;
+#else
+        // iz * f is per pixel (the retire half needs it anyway): one fused instruction per coordinate
+        const double u = (iz * cam.fx) * Px + cam.cx;
+        const double v = (iz * cam.fy) * Py + cam.cy;
+#endif
 #endif
         tap_fetch<WITH_J, HALF_GRAD>(I, G, cam.H, cam.W, u, v, f.taps);
     }
