@@ -5,7 +5,8 @@
 // entries in the prologue, finalize by the last workgroup of a slot), large ones with
 // three launches on one stream:
 //   k_pose_table  : F*S blur-sample poses + pose-to-knot Jacobians per problem
-//                   (the work of compute_virtual_camera_poses.cu:9-110)
+//                   (the work of compute_virtual_camera_poses.cu:9-110); when every tile has a CU to itself and
+//                   S <= 8 this is the fused kernel's prologue instead (k_fused<.., POSE = true>: two launches)
 //   k_fused       : patch centres, per-pixel residual / 1x6k Jacobian over the S
 //                   samples, Huber, packed outer products, per-tile partial sums
 //                   (compute_local_patches_xy.cu, compute_hessian_gradients_cost.cu:23-239)
@@ -201,7 +202,7 @@ namespace mbavo
         size_t slot_cap_[kSlots] = {};
 
         char last_kernel_[64] = "";
-        int last_kernel_id_[5] = {0, 0, 0, 0, 0};
+        int last_kernel_id_[6] = {0, 0, 0, 0, 0, 0};
         std::vector<ProblemDesc> scratch_descs_;
         void *comm_ = nullptr;          // ncclComm_t owned by this context (comm_init)
         std::vector<char> merge_descs_; // what merge_device last uploaded (re-uploaded only when it changes)

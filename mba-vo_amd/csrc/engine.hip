@@ -737,15 +737,21 @@ namespace mbavo
 #else
 #define MBAVO_FUSED_OCC
 #endif
-    template <int KD, bool WITH_J, bool HALF_GRAD>
+    // POSE: no pose kernel ahead of this one -- every workgroup computes ITS frame's S table entries itself (the two stages of
+    // k_pose_table, segments in the not-yet-used row slabs) into its own S entries of `table_w`, which the host passes as
+    // `table` too: the sample loop needs the entries behind wave-uniform SCALAR loads from read-only memory (through LDS it
+    // was 1.5x slower), so they go out through the L2 and come back through the scalar cache.
+    template <int KD, bool WITH_J, bool HALF_GRAD, bool POSE = false>
     __global__ __launch_bounds__((waves_of<KD, WITH_J>() * 64)) MBAVO_FUSED_OCC void k_fused(const ProblemDesc *__restrict__ descs,
                                                         const TileDesc *__restrict__ tiles,
                                                         const PoseEntry<KD> *__restrict__ table,
                                                         double *__restrict__ rho_out,
                                                         double *__restrict__ patch_cost,
                                                         double *__restrict__ patch_blocks_strided,
-                                                        double *__restrict__ partials)
+                                                        double *__restrict__ partials,
+                                                        PoseEntry<KD> *table_w, int *status, int table_stride)
     {
+
         constexpr int ND = Pack<KD>::ND, E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
         constexpr int kWavesPerGroup = waves_of<KD, WITH_J>(), kThreads = kWavesPerGroup * 64;
         constexpr int SLAB = OuterAcc<ND>::SLAB;     // doubles per wave: rows, and the parked accumulators at the end
@@ -792,7 +798,25 @@ namespace mbavo
         __syncthreads();
         const PoseEntry<KD> *__restrict__ ftab = ltab;
 #else
-        const PoseEntry<KD> *__restrict__ ftab = table + d.pose_base + frame * S;
+        long long tab_off = d.pose_base + frame * S;
+        if constexpr (POSE)
+        {
+            tab_off = (long long)blockIdx.x * table_stride; // (the batch's largest S: problems of a batch may differ)
+            // (cost-only kernels have no row slabs: the segments get their own LDS behind the wave sums, see the launch)
+            SplineSeg *segs = (SplineSeg *)(WITH_J ? rows : red + 2 * kWavesPerGroup);
+            frame_pose_entries<KD, WITH_J>(d, d.knots_t, d.knots_R, frame, table_w + tab_off, segs, wave, lane, status,
+                                           tile.kp_begin == 0);
+            // the entries are in this XCD's L2 (vector stores write through) once every wave's stores are performed; the
+            // scalar cache has never seen these lines in this launch.  The offset is made opaque AFTER the barrier: the
+            // reads below are loads from `table` (read-only, no alias as far as the compiler knows) and would otherwise be
+            // free to move above it.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_s_dcache_inv();
+            asm volatile("" : "+s"(tab_off) : : "memory");
+        }
+        const PoseEntry<KD> *__restrict__ ftab = table + tab_off;
         {
             // Warm the scalar cache: the frame's S entries were written by the pose kernel (cold here, often in another
             // XCD's L2), and the sample loop reads them in ~11 dependent scalar-load groups per sample pair -- each a
@@ -1879,7 +1903,11 @@ namespace mbavo
         cached_kdeg_ = kdeg;
         total_bf_ = bf; total_entries_ = entries; total_pixels_ = pixels; total_patches_ = patches;
 
-        const size_t pose_bytes = (size_t)entries * (kdeg == 2 ? sizeof(PoseEntry<2>) : sizeof(PoseEntry<4>));
+        int layout_max_S = 1;
+        for (const ProblemDesc &pd : h_descs_) layout_max_S = pd.S > layout_max_S ? pd.S : layout_max_S;
+        // (one table of max S entries per tile when the fused kernel computes its own: see fused_pose in evaluate)
+        const size_t pose_entries = std::max((size_t)entries, h_tiles_.size() <= (size_t)num_cus_ ? h_tiles_.size() * (size_t)layout_max_S : (size_t)0);
+        const size_t pose_bytes = pose_entries * (kdeg == 2 ? sizeof(PoseEntry<2>) : sizeof(PoseEntry<4>));
         const size_t pstride = kdeg == 2 ? Pack<2>::PSTRIDE : Pack<4>::PSTRIDE;
         int rc;
         // descriptors, tiles and index tables live in ONE device arena filled by ONE copy: a pageable H2D copy is staged
@@ -1937,9 +1965,11 @@ namespace mbavo
     static int launch_all(Engine *eng, hipStream_t st, int max_S, bool half_grad, int sp_logs, bool one, bool flat_finalize, const ProblemDesc *descs, const int *entry_prob, int entries, const TileDesc *tiles, int ntiles,
                           const int *bf_prob, const int *bf_tile_begin, int nbf, void *poses, double *rho,
                           double *patch_cost, double *patch_blocks_strided, double *partials, int *status,
-                          double *frame_blocks, double *valid, const OneArgs &oa)
+                          double *frame_blocks, double *valid, const OneArgs &oa, bool fused_pose_ok)
     {
         PoseEntry<KD> *table = (PoseEntry<KD> *)poses;
+        // one workgroup per CU at most, lane-per-pixel kernel with Jacobians: the pose entries are the fused kernel's prologue
+        const bool fused_pose = fused_pose_ok && sp_logs == 0 && !one && ntiles > 0;
         if (one)
         { // single launch: pose entries in the prologue, finalize by the last workgroup of every slot
             if (ntiles == 0) return 0;
@@ -1965,17 +1995,19 @@ namespace mbavo
             HIP_TRY(hipGetLastError());
             return 0;
         }
-        hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries + kPoseSPB - 1) / kPoseSPB), dim3(64 * KD), 0, st, descs, entry_prob,
-                           entries, table, status);
+        if (!fused_pose)
+            hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries + kPoseSPB - 1) / kPoseSPB), dim3(64 * KD), 0, st, descs, entry_prob,
+                               entries, table, status);
         if (ntiles > 0)
         {
             constexpr int kWavesPerGroup = waves_of<KD, WITH_J>(), kThreads = kWavesPerGroup * 64;
-            const size_t lds = (WITH_J ? (size_t)kWavesPerGroup * OuterAcc<Pack<KD>::ND>::SLAB : 0) * sizeof(double) +
+            const size_t lds_plain = (WITH_J ? (size_t)kWavesPerGroup * OuterAcc<Pack<KD>::ND>::SLAB : 0) * sizeof(double) +
                                2 * kWavesPerGroup * sizeof(double)
 #if defined(MBAVO_EXP_LDS_TABLE)
                                + (size_t)max_S * sizeof(PoseEntry<KD>)
 #endif
                 ;
+            const size_t lds = lds_plain;
             (void)max_S;
             // the large-LDS attribute is per device and per kernel: remembered per engine (= per device)
             if (half_grad)
@@ -2001,12 +2033,31 @@ namespace mbavo
                 }
 #undef MBAVO_SP_LAUNCH
             }
+            else if (fused_pose)
+            {
+                {
+                    // cost-only: the pose prologue's segments need LDS of their own (there are no slabs to borrow)
+                    const size_t lds = lds_plain + (WITH_J ? 0 : (size_t)kPoseSPB * (KD - 1) * sizeof(SplineSeg));
+                    if (half_grad)
+                    {
+                        HIP_TRY(eng->ensure_lds((const void *)k_fused<KD, WITH_J, true, true>, lds));
+                        MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, true, true>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho,
+                                           patch_cost, patch_blocks_strided, partials, table, status, max_S);
+                    }
+                    else
+                    {
+                        HIP_TRY(eng->ensure_lds((const void *)k_fused<KD, WITH_J, false, true>, lds));
+                        MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, false, true>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho,
+                                           patch_cost, patch_blocks_strided, partials, table, status, max_S);
+                    }
+                }
+            }
             else if (half_grad)
                 MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, true>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho, patch_cost,
-                                   patch_blocks_strided, partials);
+                                   patch_blocks_strided, partials, table, status, max_S);
             else
                 MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, false>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho, patch_cost,
-                                   patch_blocks_strided, partials);
+                                   patch_blocks_strided, partials, table, status, max_S);
         }
         static_assert(Pack<KD>::E + 1 <= 384, "one thread per partial slot");
         if (flat_finalize)
@@ -2071,15 +2122,21 @@ namespace mbavo
                 }
             }
         }
+        // Pose entries in the fused kernel's prologue (no pose launch) when every workgroup has a CU to itself -- with several
+        // tiles per CU the prologue would be paid once per tile -- and the per-workgroup tables fit the pose buffer
+        // (rebuild_layout sizes it for that).  MBAVO_FUSED_POSE=0 keeps the pose kernel.
+        // Measured (profiles/r02_kfused_experiments.txt 16.): S = 8: the prologue costs a workgroup 4.8 us against the pose
+        // kernel's 5.7; S = 16: 7.4 us, slower than the kernel.
+        const bool fused_pose_ok = ntiles <= num_cus_ && max_S <= 8 && env_int("MBAVO_FUSED_POSE", 1) != 0;
 #define MBAVO_LAUNCH(KD, WJ)                                                                                      \
     launch_all<KD, WJ>(this, stream_, max_S, half_grad, sp_logs_, one, flat_finalize_, descs, (const int *)d_entry_prob_, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
                        (const int *)d_bf_tile_begin_, total_bf_, d_poses_, (double *)d_rho_, d_patch_cost,        \
-                       d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid, oa)
+                       d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid, oa, fused_pose_ok)
         if (kdeg == 4) rc = with_hessian ? MBAVO_LAUNCH(4, true) : MBAVO_LAUNCH(4, false);
         else rc = with_hessian ? MBAVO_LAUNCH(2, true) : MBAVO_LAUNCH(2, false);
 #undef MBAVO_LAUNCH
         last_kernel_id_[0] = kdeg; last_kernel_id_[1] = with_hessian; last_kernel_id_[2] = half_grad; last_kernel_id_[3] = sp_logs_;
-        last_kernel_id_[4] = one;
+        last_kernel_id_[4] = one; last_kernel_id_[5] = fused_pose_ok && sp_logs_ == 0 && !one && ntiles > 0;
         return rc;
     }
 
@@ -2244,7 +2301,7 @@ namespace mbavo
         else if (k[3] > 0)
             snprintf(last_kernel_, sizeof(last_kernel_), "k_fused_sp<%d,%s,false,%d,%s>", k[0], k[1] ? "true" : "false", k[3], k[4] ? "true" : "false");
         else
-            snprintf(last_kernel_, sizeof(last_kernel_), "k_fused<%d,%s,%s>", k[0], k[1] ? "true" : "false", k[2] ? "true" : "false");
+            snprintf(last_kernel_, sizeof(last_kernel_), "k_fused<%d,%s,%s,%s>", k[0], k[1] ? "true" : "false", k[2] ? "true" : "false", k[5] ? "true" : "false");
         return last_kernel_;
     }
 
