@@ -263,6 +263,15 @@ class Runner:
         return flops, nbytes, ach_tf, ach_gbs
 
 
+def launches_per_step(kernel):
+    """What one evaluation enqueues, from the dominant kernel's label (Engine::last_kernel)."""
+    if kernel.startswith("k_fused_sp<") and kernel.endswith(",true>"):
+        return "1: k_fused_sp<.., ONE> (pose entries in its prologue, finalize by the last workgroup of a slot)"
+    if kernel.startswith("k_fused<") and kernel.endswith(",true>"):
+        return "2: k_fused<.., POSE> (pose entries in its prologue: inside kernel_ms, so frac is lower than the sample loop's) + k_finalize"
+    return "3: k_pose_table + fused kernel + k_finalize"
+
+
 def kernel_name(ctx):
     return ctx.lib.mbavo_last_kernel(ctx.handle).decode()
 
@@ -395,6 +404,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": kernel, "kernel_ms": round(k_ms, 6), "launches_timed": int(nlaunch[0]),
                          "algorithmic_flops_per_launch": flops,
+                         "step_frac": round(flops / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS, 5) if elapsed > 0 else None,
+                         "launches_per_step": launches_per_step(kernel),
                          "note": "binding roofline = the FP64 pipe (FP64 VALU and f64 MFMA share it; 78.6 TFLOP/s; this is "
                                  "the contract's 'mfma' bound): intensity ~150 flop/B >> 9.8 flop/B balance.  frac counts flops "
                                  "as the reference source writes them (SURVEY.md 8d) and can exceed 1 because the kernel "

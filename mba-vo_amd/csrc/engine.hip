@@ -1969,7 +1969,9 @@ namespace mbavo
     {
         PoseEntry<KD> *table = (PoseEntry<KD> *)poses;
         // one workgroup per CU at most, lane-per-pixel kernel with Jacobians: the pose entries are the fused kernel's prologue
-        const bool fused_pose = fused_pose_ok && sp_logs == 0 && !one && ntiles > 0;
+        // (k = 4 only: the k = 2 kernels run 16 waves on a 128-VGPR budget the one-lane k = 2 pose chain does not fit -- 36 vector
+        // spills; the instantiations exist but are not dispatched)
+        const bool fused_pose = fused_pose_ok && KD == 4 && sp_logs == 0 && !one && ntiles > 0;
         if (one)
         { // single launch: pose entries in the prologue, finalize by the last workgroup of every slot
             if (ntiles == 0) return 0;
@@ -2136,7 +2138,7 @@ namespace mbavo
         else rc = with_hessian ? MBAVO_LAUNCH(2, true) : MBAVO_LAUNCH(2, false);
 #undef MBAVO_LAUNCH
         last_kernel_id_[0] = kdeg; last_kernel_id_[1] = with_hessian; last_kernel_id_[2] = half_grad; last_kernel_id_[3] = sp_logs_;
-        last_kernel_id_[4] = one; last_kernel_id_[5] = fused_pose_ok && sp_logs_ == 0 && !one && ntiles > 0;
+        last_kernel_id_[4] = one; last_kernel_id_[5] = fused_pose_ok && kdeg == 4 && sp_logs_ == 0 && !one && ntiles > 0;
         return rc;
     }
 
