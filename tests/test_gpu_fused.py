@@ -267,3 +267,55 @@ def test_non_finite_depth_is_dropped_in_both_kernels(orc, mbavo, sp, monkeypatch
             assert (pc.reshape(sc.F, sc.K)[:, [3, 40, 77]] == 0.0).all()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("name", ["k4_dense_S8", "k4_dense_S1", "k4_P8_lane_per_pixel", "k4_batch_mixed_S"])
+def test_pose_prologue_equals_pose_kernel(orc, mbavo, monkeypatch, name):
+    """k = 4, tiles <= CUs, S <= 8: the pose entries are the fused kernel's prologue (k_fused<.., POSE>, two launches);
+    MBAVO_FUSED_POSE=0 keeps k_pose_table (three launches).  Same arithmetic per entry -> the frame blocks, per-patch
+    costs and valid counts must be IDENTICAL, H/g and cost-only, and both must match the oracle (1e-9)."""
+    import torch
+    monkeypatch.setenv("MBAVO_SP", "0")  # the lane-per-pixel kernel whatever the size
+    kws = {"k4_dense_S8": [dict(H=96, W=128, S=8, F=2, k=4, P=1, kp="dense", margin=0)],
+           "k4_dense_S1": [dict(H=60, W=80, S=1, F=1, k=4, P=1, kp="dense", margin=0)],
+           "k4_P8_lane_per_pixel": [dict(S=8, F=3, k=4, P=8, K=211, N=6)],
+           "k4_batch_mixed_S": [dict(S=8, F=1, k=4, P=8, K=97, seed=3), dict(S=4, F=2, k=4, P=5, K=60, seed=4),
+                                dict(S=2, F=1, k=4, P=8, K=31, seed=5)]}[name]
+    scs = [scenes.Scene(**kw) for kw in kws]
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MBAVO_FUSED_POSE", mode)
+        ctx = mbavo.capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        try:
+            ds = [scenes.DeviceScene(sc) for sc in scs]
+            fb, pc, valid = scenes.gpu_eval_batch(ctx, ds, 4)
+            kern = ctx.lib.mbavo_last_kernel(ctx.handle).decode()
+            fbc, pcc, _ = scenes.gpu_eval_batch(ctx, ds, 4, with_hessian=False)
+            got[mode] = (fb.copy(), pc.copy(), valid.copy(), fbc.copy(), pcc.copy(), kern)
+        finally:
+            ctx.close()
+    assert got["0"][5].endswith(",false>") and got["1"][5].endswith(",true>"), (got["0"][5], got["1"][5])
+    for a, b in zip(got["0"][:5], got["1"][:5]):
+        assert np.array_equal(a, b)
+    row = 0
+    for sc in scs:
+        p, keep = sc.oracle_problem(orc)
+        ro = orc.evaluate(p)
+        assert _rel(got["1"][0][row:row + sc.F], ro["frame_blocks"]) < RTOL
+        row += sc.F
+
+
+def test_patch_centre_near_integer_takes_reference_order(orc, mbavo, gpu_ctx):
+    """The round loop keeps the cheap patch centre (rotation matrix, fused arithmetic) only where centre + offset is
+    farther than 1e-5 from an integer; otherwise the wave evaluates the reference's operation order.  Zero motion puts
+    EVERY pixel of a dense grid exactly on an integer (all waves take the reference order); a translation that moves the
+    projections by ~1e-7 px puts them inside the guard band with fractions the two orders could truncate differently.
+    Valid counts exact, blocks 1e-9 against the oracle in both."""
+    for scale in (0.0, 1e-10):
+        sc = scenes.Scene(H=60, W=80, S=4, F=1, k=4, P=1, kp="dense", margin=0, trans_scale=scale, rot_scale=scale, seed=9)
+        p, keep = sc.oracle_problem(orc)
+        ro = orc.evaluate(p)
+        fb, pc, valid = scenes.gpu_eval_batch(gpu_ctx, [scenes.DeviceScene(sc)], 4)
+        assert np.array_equal(valid, _oracle_valid_counts(orc, sc))
+        assert _rel(fb, ro["frame_blocks"]) < RTOL
+        assert _rel(pc, ro["patch_blocks"][:, :, 0].ravel()) < RTOL
