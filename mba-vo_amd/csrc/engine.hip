@@ -714,8 +714,15 @@ namespace mbavo
     __device__ unsigned long long g_fused_stamps[2048 * 8];
     __device__ unsigned long long g_wave_stamps[1024 * 16 * 4]; // [block][wave][loop start, loop end, HW_ID, rounds]
 #define MBAVO_WSTAMP(i, v) do { if (lane == 0 && blockIdx.x < 1024) g_wave_stamps[(blockIdx.x * 16 + wave) * 4 + (i)] = (v); } while (0)
-#define MBAVO_FSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_fused_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#if defined(MBAVO_POSE_STAMPS) // (tools/pose_stamps.py) the pose prologue's steps instead of the kernel's phases: 1 descriptors read, 2 stage A done, 3 stage B done, 4 visible + scalar cache invalidated, 5 ready
+#define MBAVO_PSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_fused_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MBAVO_FSTAMP(i) do { if ((i) == 0 && threadIdx.x == 0 && blockIdx.x < 2048) g_fused_stamps[blockIdx.x * 8] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
+#define MBAVO_PSTAMP(i) do { } while (0)
+#define MBAVO_FSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_fused_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
+#else
+#define MBAVO_PSTAMP(i) do { } while (0)
 #define MBAVO_FSTAMP(i) do { } while (0)
 #define MBAVO_WSTAMP(i, v) do { } while (0)
 #endif
@@ -804,8 +811,10 @@ namespace mbavo
             tab_off = (long long)blockIdx.x * table_stride; // (the batch's largest S: problems of a batch may differ)
             // (cost-only kernels have no row slabs: the segments get their own LDS behind the wave sums, see the launch)
             SplineSeg *segs = (SplineSeg *)(WITH_J ? rows : red + 2 * kWavesPerGroup);
+            MBAVO_PSTAMP(1);
             frame_pose_entries<KD, WITH_J>(d, d.knots_t, d.knots_R, frame, table_w + tab_off, segs, wave, lane, status,
                                            tile.kp_begin == 0);
+            MBAVO_PSTAMP(3);
             // the entries are in this XCD's L2 (vector stores write through) once every wave's stores are performed; the
             // scalar cache has never seen these lines in this launch.  The offset is made opaque AFTER the barrier: the
             // reads below are loads from `table` (read-only, no alias as far as the compiler knows) and would otherwise be
@@ -815,6 +824,7 @@ namespace mbavo
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             __builtin_amdgcn_s_dcache_inv();
             asm volatile("" : "+s"(tab_off) : : "memory");
+            MBAVO_PSTAMP(4);
         }
         const PoseEntry<KD> *__restrict__ ftab = table + tab_off;
         {
@@ -855,6 +865,7 @@ namespace mbavo
         double cost_local = 0.0;
         int main_end = npx;
         MBAVO_FSTAMP(1);
+        MBAVO_PSTAMP(5);
         // The SIMD arbiter serves the OLDEST ready wave first: of the three waves a SIMD holds, the oldest ran ahead
         // through all its rounds and the youngest finished last, alone, at a third of the SIMD's rate (s_memrealtime
         // stamps per wave, tools/fused_stamps.py: 24.4 / 29.9 / 33.7 us on configs[1]).  The user priority outranks
@@ -1128,6 +1139,7 @@ namespace mbavo
                                             segs[lane * NSEG + wave]);
             }
             __syncthreads();
+            MBAVO_PSTAMP(2);
             const int sl = lane / NCOL, col = lane - sl * NCOL, smp = s0 + sl;
             if (wave < NKW && sl < kPoseSPB && smp < S)
             {
