@@ -4,12 +4,15 @@
 //   * one lane = one pixel (keypoint x pattern entry); the S blur samples run
 //     sequentially in registers, so the reference's S-wide shared-memory
 //     reductions and its per-sample Jacobian scratch do not exist here;
-//   * the per-sample pose table is read with wave-uniform addresses (scalar loads);
+//   * the per-sample pose table is read with wave-uniform addresses (scalar loads); where every
+//     tile has a CU to itself the workgroup computes its frame's entries itself (k_fused<.., POSE>:
+//     no pose launch);
 //   * each wave parks the weighted rows [r | J] of its own 64 pixels in a private LDS
 //     slab ([pixel][entry]) and feeds them back to the matrix core as BOTH operands of
 //     v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction): the row is
 //     cut into groups of four entries and every unordered pair of groups is one block slot
-//     (OuterAcc below; 8 instructions per four pixels for k = 4, 16 accumulator VGPRs).
+//     (OuterAcc below; k = 4: 7 instructions per four pixels -- the 28 pairs of 7 groups as four
+//     closed trails, one per block of the instruction -- and 14 accumulator VGPRs).
 //     On gfx950 the f64 MFMA issues at the FP64 VALU rate and SHARES that pipe
 //     (tools/micro/mfma_valu_overlap.hip), so it is not a free second engine: what it buys
 //     over per-lane VALU accumulators is registers and instruction count (no cross-wave
@@ -48,8 +51,8 @@ namespace mbavo
 #endif
     // Waves per workgroup of the fused kernel, per instantiation: one workgroup is resident per CU, so this is the
     // occupancy.  k = 4 with Jacobians: 168 VGPRs (the budget of 3 waves per SIMD = 12 per CU is 170; 16 waves spill
-    // vectors) and 53 scalar spills into VGPR lanes, none of them inside the sample-pair loop; k = 2 (126 VGPRs) and
-    // the cost-only kernels (64) take the 16 waves a workgroup can have.  Figures: profiles/r02_kernel_resources.txt
+    // vectors) and 44 scalar spills into VGPR lanes, none of them inside the sample-pair loop; k = 2 (124 VGPRs) and
+    // the cost-only kernels (63; 117 with the pose prologue) take the 16 waves a workgroup can have.  Figures: profiles/r02_kernel_resources.txt
     // (tools/kernel_resources.py, from the code-object metadata).
     template <int KD, bool WITH_J>
     constexpr int waves_of() { return WITH_J && KD == 4 ? MBAVO_WAVES_PER_GROUP : 16; }
