@@ -60,17 +60,42 @@ namespace mbavo
     }
 
     // One entry per (problem, frame, blur sample), written by the pose kernel.
+    // Field order follows the sample loop's SCALAR loads (the table is read with wave-uniform addresses, 16 dwords per load
+    // at most, and the kernel has ~100 SGPRs: it cannot fetch a whole entry ahead): what a sample's warp needs (R, t) is one
+    // contiguous 96 bytes at the head of the entry -- two loads and two waits where t, R and c apart took three dependent
+    // load-and-wait steps --, the Jacobian chain's c and A follow, and the two fields only the patch centre reads (from ONE
+    // entry per frame) come last.  (Removing the table loads altogether, an ablation, takes 4 % off the dense kernel at S = 8
+    // and 12 % at S = 16: most of that is the 40 doubles of c and A per sample, which no layout removes.)
+#if defined(MBAVO_POSE_ENTRY_OLD_LAYOUT) // A/B switch
     template <int KDEG>
     struct PoseEntry
     {
-        double t[3];          // t_c2r
-        double rt[3];         // conj(q) applied to t: the pixel-independent half of patch_centre (read from sample S/2)
-        double q[4];          // R_c2r xyzw
+        double t[3];
+        double rt[3];
+        double q[4];
+        double R[9];
+        double c[KDEG];
+        double A[9 * KDEG];
+    };
+#else
+#if defined(MBAVO_POSE_ENTRY_ALIGN64) // A/B switch: 512-byte entries (the sample-parallel kernels' per-lane reads of their
+                                      // sample's entry in LDS then hit one bank: +14 % on the semi-dense evaluation)
+#define MBAVO_POSE_ENTRY_ALIGN alignas(64)
+#else
+#define MBAVO_POSE_ENTRY_ALIGN
+#endif
+    template <int KDEG>
+    struct MBAVO_POSE_ENTRY_ALIGN PoseEntry
+    {
         double R[9];          // rotation matrix of q, row-major, reference term order
+        double t[3];          // t_c2r
         double c[KDEG];       // translation spline weights (J_t = kron(c, I3))
         double A[9 * KDEG];   // 3 x 3k row-major: R * d(body-frame rotation of the pose)/d(knot local rotations), i.e. the
                               // derivative of the pose's rotation about the KEYFRAME's axes (see sample_retire)
+        double rt[3];         // conj(q) applied to t: the pixel-independent half of patch_centre (read from sample S/2)
+        double q[4];          // R_c2r xyzw
     };
+#endif
 
     // The reference chains dI/dq (1x4) through J_R = dq/dw (4x3k).  I does not depend on |q| (the warped point
     // is (D - t_z) * rho / rho_z with rho = R_h(q) ray, homogeneous in q), so dI/dq is tangent to the unit sphere
