@@ -138,3 +138,34 @@ if __name__ == "__main__":  # under torchrun
     if r == 0:
         check(out, w)
         print("test_gpu_dist under torchrun: OK", json.dumps(out))
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_frame_shards_of_every_rank_add_up_on_one_gpu(mbavo, world):
+    """bench.py --gpus N on configs[1]: N blurred frames of one joint problem, frame r on rank r (mbavo_shard_frames),
+    every rank's blocks scattered into the 6N x 6N system on the device (mbavo_merge_device), the systems summed.  Here
+    the N ranks' shards are evaluated one after the other on THIS GPU by the HIP engine (a shard has one frame: the
+    fused kernel takes the pose prologue) and summed on the host in rank order, against the whole problem evaluated at
+    once: 1e-12 (only the summation order differs).  No communicator involved: what this pins is the sharding of
+    ranks > 0, which a one-GPU box cannot reach through RCCL."""
+    import torch
+    from mba_vo_amd import shard, workloads as wl
+    dev = "cuda:0"
+    ctx = mbavo.capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        probs = wl.pyramid_pair(240, 320, 3, S=8, k=4, N=4, mode="dense", seed=11, frames=world)
+        dw = wl.DeviceWorkload(probs, device=dev)
+        total, ref = None, None
+        for r in range(world):
+            se = shard.ShardedEvaluation(ctx, dw.array, 4, r, world, "frames", dev)
+            assert sum(se.shards[b].F for b in range(se.B)) == len(probs)  # one frame of every pyramid level
+            se.step(True, reduce=False)
+            torch.cuda.synchronize()
+            part = se.reduced.clone()
+            total = part if total is None else total + part
+            if r == world - 1:
+                ref = se.reference()
+        assert float(ref.abs().max()) > 0
+        assert float((total - ref).abs().max() / ref.abs().max()) <= 1e-12
+    finally:
+        ctx.close()
