@@ -822,10 +822,15 @@ namespace mbavo
             // scalar cache has never seen these lines in this launch.  The offset is made opaque AFTER the barrier: the
             // reads below are loads from `table` (read-only, no alias as far as the compiler knows) and would otherwise be
             // free to move above it.
+            // (vmcnt(0) explicitly: a workgroup-scope release only orders accesses through the CU's vector L1, which the
+            // stores write through; the READERS go through the scalar cache to the L2, so every storing wave waits for its
+            // stores to be acknowledged by the L2 before it arrives at the barrier)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             __builtin_amdgcn_s_dcache_inv();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the invalidation is complete before any table load issues
             asm volatile("" : "+s"(tab_off) : : "memory");
             MBAVO_PSTAMP(4);
         }
