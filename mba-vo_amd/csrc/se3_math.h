@@ -90,6 +90,19 @@ namespace mbavo
             }
             else
             {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_POSE_IEEE_DIV)
+                // device: ONE reciprocal of n and products where the reference divides by n four times (an IEEE fp64
+                // division is ~13 dependent instructions, and a pose lane walks this chain alone on its SIMD); the results
+                // differ from the quotients in the last place at most
+                const double rn = 1.0 / n;
+                lam = 2.0 * atan(n / w) * rn;
+                if (WITH_J)
+                {
+                    const double dn = (2 * w - lam) * rn * rn;
+                    dx = dn * x; dy = dn * y; dz = dn * z;
+                    dw = -2.;
+                }
+#else
                 lam = 2.0 * atan(n / w) / n;
                 if (WITH_J)
                 {
@@ -97,6 +110,7 @@ namespace mbavo
                     dx = dn * x / n; dy = dn * y / n; dz = dn * z / n;
                     dw = -2.;
                 }
+#endif
             }
         }
         if (WITH_J)
@@ -130,6 +144,16 @@ namespace mbavo
         {
             const double th = sqrt(th2);
             const double hs = sin(0.5 * th);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_POSE_IEEE_DIV)
+            const double rth = 1.0 / th; // (device: one reciprocal instead of six divisions by theta, see qlog)
+            im = hs * rth;
+            re = cos(0.5 * th);
+            if (WITH_J)
+            {
+                const double x = tg[0], y = tg[1], z = tg[2];
+                const double ux = x * rth, uy = y * rth, uz = z * rth;
+                const double dim = (0.5 * re - im) * rth;
+#else
             im = hs / th;
             re = cos(0.5 * th);
             if (WITH_J)
@@ -137,6 +161,7 @@ namespace mbavo
                 const double x = tg[0], y = tg[1], z = tg[2];
                 const double ux = x / th, uy = y / th, uz = z / th;
                 const double dim = 0.5 * re / th - im / th;
+#endif
                 const double dre = -0.5 * hs;
                 const double ax = dim * ux, ay = dim * uy, az = dim * uz;
                 double *m = J->m;
