@@ -94,7 +94,7 @@ namespace mbavo
                 // device: ONE reciprocal of n and products where the reference divides by n four times (an IEEE fp64
                 // division is ~13 dependent instructions, and a pose lane walks this chain alone on its SIMD); the results
                 // differ from the quotients in the last place at most
-                const double rn = 1.0 / n;
+                const double rn = 1.0 / n; // (v_rsq_f64 + Newton instead of sqrt + division: no measurable difference)
                 lam = 2.0 * atan(n / w) * rn;
                 if (WITH_J)
                 {
@@ -143,17 +143,19 @@ namespace mbavo
         else
         {
             const double th = sqrt(th2);
-            const double hs = sin(0.5 * th);
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_POSE_IEEE_DIV)
+            // (sincos() for the pair measured 2 us SLOWER per evaluation: its results come back through private memory)
+            const double hs = sin(0.5 * th), hc = cos(0.5 * th);
             const double rth = 1.0 / th; // (device: one reciprocal instead of six divisions by theta, see qlog)
             im = hs * rth;
-            re = cos(0.5 * th);
+            re = hc;
             if (WITH_J)
             {
                 const double x = tg[0], y = tg[1], z = tg[2];
                 const double ux = x * rth, uy = y * rth, uz = z * rth;
                 const double dim = (0.5 * re - im) * rth;
 #else
+            const double hs = sin(0.5 * th);
             im = hs / th;
             re = cos(0.5 * th);
             if (WITH_J)
