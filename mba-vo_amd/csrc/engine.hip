@@ -2149,7 +2149,8 @@ namespace mbavo
         // (rebuild_layout sizes it for that).  MBAVO_FUSED_POSE=0 keeps the pose kernel.
         // Measured (profiles/r02_kfused_experiments.txt 16.): S = 8: the prologue costs a workgroup 4.8 us against the pose
         // kernel's 5.7; S = 16: 7.4 us, slower than the kernel.
-        const bool fused_pose_ok = ntiles <= num_cus_ && max_S <= 8 && env_int("MBAVO_FUSED_POSE", 1) != 0;
+        const bool fused_pose_ok = ntiles <= num_cus_ && max_S <= env_int("MBAVO_FUSED_POSE_MAX_S", 8) && max_S <= kPoseSPB &&
+                                   env_int("MBAVO_FUSED_POSE", 1) != 0;
 #define MBAVO_LAUNCH(KD, WJ)                                                                                      \
     launch_all<KD, WJ>(this, stream_, max_S, half_grad, sp_logs_, one, flat_finalize_, descs, (const int *)d_entry_prob_, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
                        (const int *)d_bf_tile_begin_, total_bf_, d_poses_, (double *)d_rho_, d_patch_cost,        \
