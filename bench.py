@@ -9,17 +9,19 @@ resident in HBM, outputs (packed normal-equation blocks) left in HBM.  Default w
 640x480 keyframe pair, 4-level pyramid, 8 blur samples, 4 control poses (cubic, k = 4), dense mode (every pixel of every
 level a P=1 patch).
 
-N > 1 (one process per GPU, launched by torch.distributed.run): ONE joint problem is sharded over the ranks --
-  * c2_dense (default) and the other single-pair workloads: N blurred frames against the same keyframe on one spline
-    segment, frame r on rank r (weak scaling: the per-GPU work is the N = 1 workload); every rank scatters its frame's
-    packed blocks into the 6N x 6N normal equations on the device (mbavo_merge_device) and the partial systems are
-    summed with ONE all-reduce per step over xGMI;
-  * c4_batch512: every pair's keypoints are sharded over the ranks (strong scaling) and the 512 x E packed blocks are
-    summed with ONE all-reduce per step
--- through the PRODUCT's collective (mbavo_allreduce_blocks on the context's own RCCL communicator); torch.distributed
-(backend nccl == RCCL) is the rendezvous, the barrier and the max-over-ranks of the clock.  After the timed region the
-reduced normal equations are compared with a single-GPU evaluation of the whole joint problem (rank 0; 1e-12).
-value = pixel-samples of all ranks / max-over-ranks time.
+N > 1 (one process per GPU, launched by torch.distributed.run): the workload is sharded over the ranks --
+  * c2_dense (default) and the other single-pair workloads: ONE joint problem of N blurred frames against the same
+    keyframe on one spline segment, frame r on rank r (weak scaling: the per-GPU work is the N = 1 workload); every rank
+    scatters its frame's packed blocks into the 6N x 6N normal equations on the device (mbavo_merge_device) and the
+    partial systems are summed with ONE all-reduce per step over xGMI;
+  * c4_batch512 / c3_batch64 (independent keyframe pairs): pair b on rank b % N, whole (--shard pairs, the default;
+    strong scaling): every rank evaluates its pairs into its slice of a zero B x E send buffer and ONE out-of-place
+    all-reduce leaves every pair's packed blocks on every rank; --shard keypoints splits every pair's keypoints instead
+-- through the PRODUCT's collective (mbavo_allreduce_blocks[_to] on the context's own RCCL communicator);
+torch.distributed (backend nccl == RCCL) is the rendezvous, the barrier and the max-over-ranks of the clock.  After the
+timed region the reduced normal equations are compared with a single-GPU evaluation of the whole workload (rank 0;
+1e-12; pairs: bit-exact).  value = pixel-samples of all ranks / max-over-ranks time.  At N > 1 the line also carries, per
+rank, the dominant kernel's duration and the all-reduce's, and under "configs" the 512-pair batch in both shardings.
 
 The timed region (exactly K steps between barrier + synchronize) is repeated until >= 0.3 s have been timed and the
 MEDIAN region is reported, so that K = 20 does not rest on 1 ms of GPU work.  At N = 1 every other BASELINE config is
@@ -44,7 +46,9 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector == FP64 matrix (v_mfma_f64) peak:
                           # one shared pipe (tools/micro/mfma_valu_overlap.hip; 75.2 TFLOP/s sustained by v_mfma_f64_16x16x4)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
-WORKLOADS = ["c2_dense", "c2_semidense", "c1_dense", "c3_batch64", "c4_batch512", "c5_1080p"]
+WORKLOADS = ["c2_dense", "c2_semidense", "c1_dense", "c3_batch64", "c4_batch512", "c5_1080p",
+             "c3_batch64_shared", "c4_batch512_shared"]
+SIDE_CONFIGS = ["c2_semidense", "c1_dense", "c3_batch64", "c4_batch512", "c5_1080p"]  # + c5 fp16, the named extras below
 
 
 def parse():
@@ -53,6 +57,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2_dense", choices=WORKLOADS)
+    ap.add_argument("--shard", default=None, choices=["pairs", "keypoints", "frames"],
+                    help="N > 1 sharding (default: the workload's own -- frames for a single pair, pairs for a batch of pairs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the bounded runs of the other BASELINE configs")
     ap.add_argument("--grad-fp16", action="store_true",
@@ -66,8 +72,8 @@ def parse():
     return ap.parse_args()
 
 
-def build_workload(name, frames=1, seed=1):
-    """(list of Prob, description, sharding mode at N > 1)"""
+def build_workload(name, frames=1, seed=1, ctx=None, dev="cuda:0"):
+    """(list of Prob or a device-resident RenderedPairBatch, description, sharding mode at N > 1)"""
     from mba_vo_amd import workloads as wl
     if name == "c2_dense":
         return wl.pyramid_pair(480, 640, 4, S=8, k=4, N=4, mode="dense", seed=seed, frames=frames), \
@@ -80,14 +86,18 @@ def build_workload(name, frames=1, seed=1):
     if name == "c1_dense":
         return wl.pyramid_pair(480, 640, 1, S=1, k=4, N=4, mode="dense", seed=seed, frames=frames), \
             "640x480 pair, 1 level, S=1 (sharp degenerate case), dense (configs[0])", "frames"
-    if name == "c3_batch64":
-        return wl.pair_batch(64, S=8, k=4, N=4, mode="semidense", seed=seed), \
-            "batch of 64 independent 640x480 pairs, S=8, N=4, semi-dense; one shared keyframe, every pair its own knots and " \
-            "its own shifted-noise current image (configs[2] shape; not a rendered blurred sequence)", "keypoints"
-    if name == "c4_batch512":
-        return wl.pair_batch(512, S=8, k=4, N=4, mode="semidense", seed=seed), \
-            "batch of 512 independent 640x480 pairs, S=8, N=4, semi-dense; one shared keyframe, every pair its own knots " \
-            "and shifted-noise current image (configs[3] shape)", "keypoints"
+    if name in ("c3_batch64", "c4_batch512"):
+        B = 64 if name == "c3_batch64" else 512
+        return wl.RenderedPairBatch(ctx, B, S=8, k=4, device=dev, seed=seed), \
+            "batch of %d independent 640x480 pairs = %d consecutive frames of ONE GPU-rendered synthetic blurred sequence " \
+            "(textured plane, camera on a ground-truth spline; generate_synthetic_data.cpp:127-214): every pair has its OWN " \
+            "keyframe (sharp rendering), gradient image, grid-selected keypoints x 8-pixel pattern with depths from its own " \
+            "z-map, motion-blurred current image and control knots; S=8, N=4 (configs[%d])" % (B, B, 2 if B == 64 else 3), "pairs"
+    if name in ("c3_batch64_shared", "c4_batch512_shared"):
+        B = 64 if name.startswith("c3") else 512
+        return wl.pair_batch(B, S=8, k=4, N=4, mode="semidense", seed=seed), \
+            "NAMED EXTRA, not configs[%d]: %d pairs that share ONE keyframe / gradient image / keypoint set (L2-resident), " \
+            "every pair its own knots and shifted-noise current image" % (2 if B == 64 else 3, B), "pairs"
     if name == "c5_1080p":
         return wl.pyramid_pair(1080, 1920, 1, S=16, k=4, N=6, mode="dense", seed=seed, frames=frames), \
             "1920x1080 pair, 1 level, S=16, N=6 control poses, dense (configs[4])", "frames"
@@ -96,7 +106,8 @@ def build_workload(name, frames=1, seed=1):
 
 def committed_counters(kind, workload):
     """Counter extracts committed under profiles/ (the PMC passes need rocprofv3 and are collected outside this process,
-    tools/hbm_traffic.sh / tools/pmc_fp64.sh): newest round first.  kind 'hbm_counters' | 'pmc_fp64'."""
+    tools/hbm_traffic.sh / tools/pmc_fp64.sh / tools/pmc_all.sh): newest round first.  Every extract carries the hash of the
+    kernel sources it was collected at (`_source_sha`, mba_vo_amd.capi.kernel_source_sha)."""
     suffix = "" if workload == "c2_dense" else "_" + workload
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_%s%s.json" % (kind, suffix))), reverse=True):
         try:
@@ -104,6 +115,19 @@ def committed_counters(kind, workload):
         except Exception:
             continue
     return None, None
+
+
+def stale_flags(sources):
+    """{file: True/False}: was the committed extract collected at another revision of the kernel sources than the one
+    this process runs?  (True also for extracts of earlier rounds that carry no hash.)"""
+    from mba_vo_amd import capi
+    now = capi.kernel_source_sha()
+    out = {}
+    for kind, workload in sources:
+        h, src = committed_counters(kind, workload)
+        if h is not None:
+            out[src] = bool(h.get("_source_sha") != now)
+    return now, out
 
 
 def measured_hbm_traffic(workload, kernel):
@@ -130,7 +154,7 @@ def executed_fp64_flops(workload, kernel):
         return None, None
     base = kernel.split("<")[0]
     for k, v in h.items():
-        if base + "<" in k and "flops_fp64_per_launch" in v:
+        if isinstance(v, dict) and base + "<" in k and "flops_fp64_per_launch" in v:
             return float(v["flops_fp64_per_launch"]), src
     return None, None
 
@@ -144,7 +168,7 @@ def issue_busy_fraction(workload, kernel, k_ms):
         return None
     base = kernel.split("<")[0]
     for k, v in h.items():
-        if base + "<" in k and "SQ_INSTS_VALU" in v and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+        if isinstance(v, dict) and base + "<" in k and "SQ_INSTS_VALU" in v and "SQ_VALU_MFMA_BUSY_CYCLES" in v:
             cyc = (v["SQ_INSTS_VALU"] - v.get("SQ_INSTS_MFMA", 0.0)) * 4.0 + v["SQ_VALU_MFMA_BUSY_CYCLES"]
             return round(cyc / 1024.0 / (k_ms * 1e-3 * 2.4e9), 4)
     return None
@@ -197,8 +221,17 @@ def cpu_baseline(probs, budget_s):
                       % (r1, ps, t1, how), host_logical_cpus=os.cpu_count())
     if T > 1:
         vT, rT, tT, blocks = sample(T)
+        try:
+            usable = len(os.sched_getaffinity(0))
+        except Exception:
+            usable = None
         out["all_threads"] = dict(value=round(vT, 3), unit="Mpixel-samples/s", cores=T,
-                                  sample="%d evaluation(s) on %d threads, %.1f s" % (rT, T, tT))
+                                  sample="%d evaluation(s) on %d threads, %.1f s" % (rT, T, tT),
+                                  speedup_over_1_thread=round(vT / v1, 2), cpus_in_affinity_mask=usable,
+                                  note="a stated baseline, not a tuned one: the chunks run on a Python thread pool (the C "
+                                       "code releases the GIL) and the sandboxed host gives this process a fraction of its "
+                                       "logical CPUs' real time, so the speed-up over 1 thread is what the sandbox allows, "
+                                       "not what the code could reach on the bare host")
         if vT > v1:  # the better of the two is the quoted baseline, its thread count stated
             out.update(value=round(vT, 3), cores=T)
             out["single_thread"] = dict(value=round(v1, 3), cores=1)
@@ -210,21 +243,46 @@ def cpu_baseline(probs, budget_s):
 class Runner:
     """One workload resident on this rank's GPU: step(), unit counts, roofline figures."""
 
-    def __init__(self, M, ctx, name, dev, rank, world, sharded, grad_fp16=False):
+    def __init__(self, M, ctx, name, dev, rank, world, sharded, grad_fp16=False, shard_mode=None, sequential=False):
         from mba_vo_amd import shard, workloads as wl
         self.M, self.ctx, self.name, self.world, self.rank = M, ctx, name, world, rank
-        self.probs, self.desc, self.mode = build_workload(name, frames=world if sharded else 1)
-        if grad_fp16:
-            for p in self.probs:
-                p.grad_fp16 = True
-            self.desc += ", fp16 gradient pyramid"
-        self.dw = wl.DeviceWorkload(self.probs, device=dev)
+        built, self.desc, self.mode = build_workload(name, frames=world if sharded else 1, ctx=ctx, dev=dev)
+        if shard_mode is not None:
+            self.mode = shard_mode
+        if isinstance(built, wl.RenderedPairBatch):
+            self.dw, self.probs = built, built.probs
+        else:
+            self.probs = built
+            if grad_fp16:
+                for p in self.probs:
+                    p.grad_fp16 = True
+                self.desc += ", fp16 gradient pyramid"
+            self.dw = wl.DeviceWorkload(self.probs, device=dev)
         self.se = shard.ShardedEvaluation(ctx, self.dw.array, self.dw.k, rank, world, self.mode, dev) if sharded else None
         self.wl = wl
+        # the four pyramid levels one after the other, as blur_aware_direct_tracker.cpp:571-575 runs them (an LM loop cannot
+        # evaluate a finer level before the coarser one has converged): one mbavo_eval_batch call per problem
+        self.sequential = sequential
+        if sequential:
+            import ctypes as C
+            self.desc += "; the levels evaluated ONE AFTER THE OTHER, coarse to fine (one launch sequence per level)"
+            self._seq = []
+            rows = np.cumsum([0] + [p.F for p in self.probs])
+            for b in reversed(range(self.dw.B)):
+                one = (M.capi.Problem * 1)()
+                C.memmove(C.byref(one[0]), C.byref(self.dw.array[b]), C.sizeof(M.capi.Problem))
+                self._seq.append((one, int(rows[b])))
 
     def step(self):
         if self.se is not None:
             self.se.step(True)
+        elif self.sequential:
+            lib, dw = self.ctx.lib, self.dw
+            for one, row in self._seq:
+                rc = lib.mbavo_eval_batch(self.ctx.handle, 1, one, dw.k, 1, dw.frame_blocks.data_ptr() + 8 * row * dw.E, None,
+                                          dw.valid.data_ptr() + 8 * row)
+                if rc != 0:
+                    raise RuntimeError("mbavo_eval_batch failed: %d" % rc)
         else:
             self.dw.step(self.ctx, True)
 
@@ -241,7 +299,7 @@ class Runner:
                 out.append((float(valid[row:row + F].sum()), self.probs[b].S, self.probs[b]))
                 row += F
             return out
-        self.dw.step(self.ctx, True)
+        self.step()
         torch.cuda.synchronize()
         valid = self.dw.valid.cpu().numpy()
         row, out = 0, []
@@ -274,6 +332,74 @@ def launches_per_step(kernel):
 
 def kernel_name(ctx):
     return ctx.lib.mbavo_last_kernel(ctx.handle).decode()
+
+
+def bounded_run(M, ctx, r, min_steps=40, seconds=0.25, max_steps=4000, sync=None, every=4):
+    """(steps, seconds, kernel_ms, kernel name) of a bounded timing run of Runner r (side configs)."""
+    import torch
+    sync = sync or torch.cuda.synchronize
+    for _ in range(5):
+        r.step()
+    sync()
+    ctx.lib.mbavo_profile(ctx.handle, every)
+    n, t0 = 0, time.perf_counter()
+    while n < min_steps or (time.perf_counter() - t0 < seconds and n < max_steps):
+        for _ in range(20):
+            r.step()
+        sync()
+        n += 20
+        if r.se is not None and n >= min_steps:  # every rank must leave the loop after the same number of steps
+            break
+    dt = time.perf_counter() - t0
+    ms, nl = np.zeros(1), np.zeros(1, np.int32)
+    M.capi.check(ctx.lib.mbavo_profile_read(ctx.handle, M.capi.dp(ms), M.capi.ip(nl)), "mbavo_profile_read")
+    ctx.lib.mbavo_profile(ctx.handle, 0)
+    return n, dt, float(ms[0]) / max(int(nl[0]), 1), kernel_name(ctx)
+
+
+def trackframe_config(M, ctx, dev):
+    """BlurAwareDirectTracker::trackFrame on a GPU-rendered blurred sequence, reference-shaped configuration
+    (blur_aware_direct_tracker.cpp:88-203,544-637): wall time of the mbavo_vo_track_frame calls, and the absolute trajectory
+    error against the ground truth (product code only; the oracle comparison is in the checker leg)."""
+    from mba_vo_amd import sequence
+    seq = sequence.make_sequence(ctx, H=480, W=640, M=8, device=dev)
+    sequence.track_sequence(ctx, seq)  # warm-up: allocations, code objects
+    runs = [sequence.track_sequence(ctx, seq) for _ in range(5)]
+    per_frame = sorted(sum(f["seconds"] for f in r) / len(r) for r in runs)
+    r0 = runs[0]
+    gt_rel = sequence.gt_relative(ctx, seq)
+    out = {
+        "workload": "BlurAwareDirectTracker::trackFrame, 640x480, 4 levels, 30-px grid keypoints x 8-pixel pattern, k = 2, "
+                    "S = 8, %d frames (GPU-rendered blurred sequence on a textured plane), LM loop on persistent evaluation "
+                    "kernels" % len(r0),
+        "ms_per_frame": round(1e3 * per_frame[len(per_frame) // 2], 4), "ms_per_frame_min": round(1e3 * per_frame[0], 4),
+        "passes": len(runs), "frames": len(r0), "keyframes": int(sum(f["is_keyframe"] for f in r0)),
+        "keypoints_level0": int(r0[0]["K0"]), "lm_trace_records": int(sum(f["num_trace"] for f in r0)),
+        "poses_reproducible": bool(all(np.array_equal(a["T"], b["T"]) for r in runs[1:] for a, b in zip(r0, r))),
+        "ate_gt": sequence.ate(r0, gt_rel),
+        "ate_note": "RMSE over the frames of |t_est - t_gt| (metres of the synthetic scene; poses relative to the first "
+                    "keyframe, no alignment): the tracker's accuracy on this sequence, product code only"}
+    return out, seq, r0, gt_rel
+
+
+def trackframe_checker(ctx, seq, got, gt_rel):
+    """Checker leg (beside cpu_baseline): the CPU oracle's trackFrame on the SAME rendered sequence -- knot start indices
+    and keyframe decisions must be identical, |ATE_gt(gpu) - ATE_gt(oracle)| <= 1e-5 (BASELINE.json north_star)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import frontend
+    from oracle import binding as B
+    from mba_vo_amd import sequence
+    t0 = time.perf_counter()
+    want = frontend.run_oracle_vo(B, seq, sequence.REFERENCE_CFG)
+    dt = time.perf_counter() - t0
+    ate_o = float(np.sqrt(np.mean([np.sum((w["T"][:3] - g[:3]) ** 2) for w, g in zip(want, gt_rel)])))
+    ate_g = sequence.ate(got, gt_rel)
+    return {"ate_gt_oracle": ate_o, "abs_delta_ate_vs_oracle": abs(ate_g - ate_o),
+            "start_idx_equal": bool(all(a["start_idx"] == b["start_idx"] for a, b in zip(got, want))),
+            "keyframe_decisions_equal": bool(all(a["is_keyframe"] == b["is_keyframe"] for a, b in zip(got, want))),
+            "trace_lengths_equal": bool(all(a["num_trace"] == b["num_trace"] for a, b in zip(got, want))),
+            "max_abs_pose_diff": float(max(np.abs(a["T"] - b["T"]).max() for a, b in zip(got, want))),
+            "oracle_ms_per_frame_1_thread": round(1e3 * dt / len(want), 3), "within_1e-5": bool(abs(ate_g - ate_o) <= 1e-5)}
 
 
 def main():
@@ -335,7 +461,50 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
-    run = Runner(M, ctx, args.workload, dev, rank, world, use_dist, args.grad_fp16)
+    def per_rank(x):
+        """the value of every rank, in rank order (a list on every rank)"""
+        if not use_dist:
+            return [float(x)]
+        mine = torch.tensor([x], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        return [float(t.item()) for t in every]
+
+    def reduction_check(run):
+        """the reduced normal equations against a single-GPU evaluation of the whole workload (outside the timing)"""
+        run.se.step(True)
+        torch.cuda.synchronize()
+        got = run.se.reduced.clone()
+        ref = run.se.reference()
+        scale = float(ref.abs().max())
+        diff = float((got - ref).abs().max()) / (scale if scale > 0 else 1.0)
+        obj = {"frames": "merged [cost | g | H] systems", "keypoints": "packed frame blocks (partial sums over the ranks' keypoint bands)",
+               "pairs": "packed frame blocks (disjoint slices, rank-major)"}[run.mode]
+        return {"object": obj, "doubles": int(run.se.count), "max_rel_diff_vs_single_gpu": diff,
+                "ok": bool(diff <= 1e-12), "bit_exact": bool(torch.equal(got, ref)), "sharding": run.mode}
+
+    def comm_profile(run, n=40):
+        """Per-rank duration of the all-reduce alone (events around the collective, every rank's own evaluation before it:
+        the figure includes the wait for the slowest rank's evaluation) and of the local evaluation + merge alone."""
+        se = run.se
+        for _ in range(3):
+            se.step(True)
+        sync()
+        ev = []
+        for _ in range(n):
+            a, b, c = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            a.record(stream)
+            se.evaluate_local(True)
+            b.record(stream)
+            se.reduce()
+            c.record(stream)
+            ev.append((a, b, c))
+        sync()
+        loc = statistics.median(a.elapsed_time(b) for a, b, c in ev)
+        red = statistics.median(b.elapsed_time(c) for a, b, c in ev)
+        return loc, red
+
+    run = Runner(M, ctx, args.workload, dev, rank, world, use_dist, args.grad_fp16, shard_mode=args.shard)
 
     for _ in range(args.warmup):
         run.step()
@@ -356,19 +525,33 @@ def main():
     ctx.lib.mbavo_profile(ctx.handle, 0)
     elapsed = statistics.median(regions)
     kernel = kernel_name(ctx)
+    k_ms = float(fused_ms[0]) / max(int(nlaunch[0]), 1)
 
-    # N > 1: the reduced normal equations against a single-GPU evaluation of the whole joint problem (outside the timing)
-    reduction = None
+    reduction = reduction_check(run) if run.se is not None else None
+    k_ms_ranks = per_rank(k_ms)
+    comm_ms = None
     if run.se is not None:
-        run.se.step(True)
+        loc, red = comm_profile(run)
+        comm_ms = (per_rank(loc), per_rank(red))
+
+    # the D2H-inclusive step: the packed blocks copied to pinned host memory after every evaluation, which is
+    # what a host-side LM consumer of the blocks waits for (N = 1 only; never `value`)
+    d2h_ms = None
+    if run.se is None:
+        host = torch.empty(run.dw.frame_blocks.shape, dtype=torch.float64).pin_memory()
+        for _ in range(3):
+            run.step()
+            host.copy_(run.dw.frame_blocks, non_blocking=True)
         torch.cuda.synchronize()
-        got = run.se.reduced.clone()
-        ref = run.se.reference()
-        scale = float(ref.abs().max())
-        diff = float((got - ref).abs().max()) / (scale if scale > 0 else 1.0)
-        reduction = {"object": "merged [cost | g | H] systems" if run.mode == "frames" else "packed frame blocks",
-                     "doubles": int(run.se.count), "max_rel_diff_vs_single_gpu": diff, "ok": bool(diff <= 1e-12),
-                     "sharding": run.mode}
+        n_d2h = max(20, min(args.steps, 200))
+        t0 = time.perf_counter()
+        for _ in range(n_d2h):
+            run.step()
+            host.copy_(run.dw.frame_blocks, non_blocking=True)
+            while not stream.query():
+                pass
+        torch.cuda.synchronize()
+        d2h_ms = (time.perf_counter() - t0) / n_d2h * 1e3
 
     counts = run.local_counts()
     ps_rank = sum(px * S for px, S, _ in counts)
@@ -377,24 +560,25 @@ def main():
 
     out = None
     if rank == 0:
-        k_ms = float(fused_ms[0]) / max(int(nlaunch[0]), 1)
         flops, nbytes, ach_tf, ach_gbs = run.figures(counts, k_ms)
         traffic, traffic_src = measured_hbm_traffic(args.workload, kernel)
         exe, exe_src = executed_fp64_flops(args.workload, kernel)
+        sha_now, stale = stale_flags([("hbm_counters", args.workload), ("pmc_fp64", args.workload), ("pmc_sq", args.workload)])
         per_step = [r / args.steps * 1e3 for r in regions]
         out = {
             "metric": "Mpixel-samples/s per GN iteration (640x480, 4-lvl pyr, 8 blur samples)" if args.workload.startswith("c2")
                       else "Mpixel-samples/s per GN iteration (%s)" % args.workload,
             "value": round(ps_all * args.steps / elapsed / 1e6, 3), "unit": "Mpixel-samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "strong" if (run.se is not None and run.mode == "keypoints") else "weak",
+            "higher_is_better": True, "scaling": "strong" if (run.se is not None and run.mode in ("keypoints", "pairs")) else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "repeats": len(regions), "ms_per_step_min_max": [round(min(per_step), 5), round(max(per_step), 5)],
-            "config": {"workload": run.desc, "name": args.workload, "problems_per_rank": len(run.probs),
+            "config": {"workload": run.desc, "name": args.workload, "problems_per_rank": len(run.probs) if run.se is None else run.se.n_live,
                        "pixel_samples_per_step_per_rank": ps_rank, "pixel_samples_launched_per_rank": ps_launched,
-                       "parallelism": ("joint problem sharded by %s over %d rank(s): evaluation -> %sONE mbavo_allreduce_blocks "
+                       "parallelism": ("workload sharded by %s over %d rank(s): evaluation -> %sONE mbavo_allreduce_blocks%s "
                                        "(RCCL, context's own communicator) of %d doubles per step"
-                                       % (run.mode, world, "device merge -> " if run.mode == "frames" else "", run.se.count))
+                                       % (run.mode, world, "device merge -> " if run.mode == "frames" else "",
+                                          "_to" if run.mode == "pairs" else "", run.se.count))
                        if run.se is not None else "1 GPU"},
             "roofline": {"bound": "fp64", "achieved": round(ach_tf, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach_tf / FP64_PEAK_TFLOPS, 5),
@@ -402,6 +586,7 @@ def main():
                          "executed_fp64_flops_per_launch": exe, "executed_source": exe_src,
                          "issue_busy_frac": issue_busy_fraction(args.workload, kernel, k_ms),
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel_source_sha": sha_now, "counter_extracts_stale": stale, "stale": bool(any(stale.values())) if stale else None,
                          "kernel": kernel, "kernel_ms": round(k_ms, 6), "launches_timed": int(nlaunch[0]),
                          "algorithmic_flops_per_launch": flops,
                          "step_frac": round(flops / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS, 5) if elapsed > 0 else None,
@@ -410,81 +595,116 @@ def main():
                                  "the contract's 'mfma' bound): intensity ~150 flop/B >> 9.8 flop/B balance.  frac counts flops "
                                  "as the reference source writes them (SURVEY.md 8d) and can exceed 1 because the kernel "
                                  "applies CSE; frac_executed counts the FP64 flops the kernel issues (SQ counters) and cannot; "
-                                 "issue_busy_frac = share of SIMD issue cycles taken by ANY vector / matrix instruction"},
+                                 "issue_busy_frac = share of SIMD issue cycles taken by ANY vector / matrix instruction; "
+                                 "traffic, frac_executed and issue_busy_frac are read from committed counter extracts: "
+                                 "`stale` says whether any of them was collected at another revision of the kernel sources"},
             "roofline_hbm": {"bound": "hbm", "achieved": round(ach_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(ach_gbs / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": nbytes,
                              "traffic": traffic,
                              "note": "compulsory bytes only; compute-bound kernel, low by construction; traffic = "
                                      "(2*FETCH_SIZE + WRITE_SIZE) KiB from the committed TCC counter passes"},
         }
+        if d2h_ms is not None:
+            out["ms_per_step_incl_d2h"] = round(d2h_ms, 5)
+            out["d2h_note"] = "step + copy of the %d packed doubles to pinned host memory + wait (what a host LM loop pays per " \
+                              "evaluation; never `value`)" % int(run.dw.frame_blocks.numel())
         if use_dist:
             out["rccl_ranks"] = rccl_ranks
             out["reduction_check"] = reduction
+            out["per_rank"] = {"kernel_ms": [round(v, 6) for v in k_ms_ranks],
+                               "local_evaluation_ms": [round(v, 6) for v in comm_ms[0]],
+                               "allreduce_ms": [round(v, 6) for v in comm_ms[1]],
+                               "note": "kernel_ms: the dominant kernel's dispatch timestamps inside the timed region; "
+                                       "local_evaluation_ms / allreduce_ms: event pairs around the rank's evaluation (+ merge) "
+                                       "and around the collective in a separate pass of 40 steps -- the collective's figure "
+                                       "includes waiting for the slowest rank"}
     fb_gpu = None
     if rank == 0 and world == 1 and run.se is None:
+        run.step()
+        torch.cuda.synchronize()
         fb_gpu = run.dw.frame_blocks.cpu().numpy().reshape(run.dw.nbf, run.dw.E)
 
-    # the other BASELINE configs, bounded (N = 1 only): value, step time, dominant kernel time, both fractions
-    if rank == 0 and world == 1 and not use_dist and not args.no_configs:
-        cfgs = {}
-        todo = [(n, False) for n in WORKLOADS if n != args.workload] + [("c5_1080p", True)]
-        for name, half in todo:
-            key = name + ("_fp16grad" if half else "")
+    cfgs = {}
+    # N > 1: BASELINE configs[3] (512 pairs over the ranks) in both shardings, bounded -- the driver's scaling run only
+    # launches the default workload, so the batch's scaling points ride in its line
+    if use_dist and not args.no_configs and args.workload == "c2_dense":
+        for mode in ("pairs", "keypoints"):
+            key = "c4_batch512_" + mode
             try:
-                r = Runner(M, ctx, name, dev, 0, 1, False, half)
-                for _ in range(5):
-                    r.step()
-                torch.cuda.synchronize()
-                ctx.lib.mbavo_profile(ctx.handle, 4)
-                n, t0 = 0, time.perf_counter()
-                while n < 40 or (time.perf_counter() - t0 < 0.25 and n < 4000):
-                    for _ in range(20):
-                        r.step()
-                    torch.cuda.synchronize()
-                    n += 20
-                dt = time.perf_counter() - t0
-                ms, nl = np.zeros(1), np.zeros(1, np.int32)
-                M.capi.check(ctx.lib.mbavo_profile_read(ctx.handle, M.capi.dp(ms), M.capi.ip(nl)), "mbavo_profile_read")
-                ctx.lib.mbavo_profile(ctx.handle, 0)
-                kname = kernel_name(ctx)
+                r = Runner(M, ctx, "c4_batch512", dev, rank, world, True, shard_mode=mode)
+                n, dt, kms, kname = bounded_run(M, ctx, r, min_steps=60, sync=sync)
+                dt = max_over_ranks(dt)
+                chk = reduction_check(r)
+                loc, red = comm_profile(r)
                 c = r.local_counts()
-                kms = float(ms[0]) / max(int(nl[0]), 1)
+                ps = sum_over_ranks(sum(px * S for px, S, _ in c))
+                kr, lr, rr = per_rank(kms), per_rank(loc), per_rank(red)
+                if rank == 0:
+                    cfgs[key] = {"workload": r.desc, "sharding": mode, "n_gpus": world, "value": round(ps * n / dt / 1e6, 3),
+                                 "unit": "Mpixel-samples/s", "scaling": "strong", "steps": n, "ms_per_step": round(dt / n * 1e3, 5),
+                                 "kernel": kname, "per_rank": {"kernel_ms": [round(v, 6) for v in kr],
+                                                               "local_evaluation_ms": [round(v, 6) for v in lr],
+                                                               "allreduce_ms": [round(v, 6) for v in rr]},
+                                 "reduction_check": chk, "allreduce_doubles": int(r.se.count)}
+                del r
+                torch.cuda.empty_cache()
+            except Exception as e:
+                if rank == 0:
+                    cfgs[key] = {"error": repr(e)}
+                break  # the ranks may have diverged: no further collective configs
+        if rank == 0:
+            out["configs"] = cfgs
+
+    # the other BASELINE configs, bounded (N = 1 only): value, step time, dominant kernel time, both fractions
+    track = None
+    if rank == 0 and world == 1 and not use_dist and not args.no_configs:
+        todo = [(n, False, False) for n in SIDE_CONFIGS if n != args.workload] + [("c5_1080p", True, False)]
+        if args.workload == "c2_dense":
+            todo.insert(0, ("c2_dense", False, True))
+        todo += [("c3_batch64_shared", False, False)]
+        for name, half, seq_levels in todo:
+            key = name + ("_fp16grad" if half else "") + ("_sequential" if seq_levels else "")
+            try:
+                r = Runner(M, ctx, name, dev, 0, 1, False, half, sequential=seq_levels)
+                n, dt, kms, kname = bounded_run(M, ctx, r)
+                c = r.local_counts()
                 fl, nb, tf, gbs = r.figures(c, kms)
                 ex, _ = executed_fp64_flops(name, kname)
                 cfgs[key] = {"workload": r.desc, "value": round(sum(px * S for px, S, _ in c) * n / dt / 1e6, 3),
                              "unit": "Mpixel-samples/s", "steps": n, "ms_per_step": round(dt / n * 1e3, 5), "kernel": kname,
                              "kernel_ms": round(kms, 6), "frac": round(tf / FP64_PEAK_TFLOPS, 5),
-                             "frac_executed": round(ex / (kms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5) if ex and kms > 0 else None,
+                             "frac_executed": round(ex / (kms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5) if ex and kms > 0 and not seq_levels else None,
+                             "step_frac": round(fl / (dt / n) / 1e12 / FP64_PEAK_TFLOPS, 5),
                              "hbm_frac_algorithmic": round(gbs / HBM_PEAK_GBS, 6)}
+                if seq_levels:
+                    cfgs[key]["note"] = "kernel_ms / frac: mean over the four levels' dominant kernels (every 4th launch timed); " \
+                                        "step_frac: the four levels' flops over the whole sequential step"
                 del r
                 torch.cuda.empty_cache()
             except Exception as e:  # a failing side config must not cost the headline line
                 cfgs[key] = {"error": repr(e)}
-        # the caller of the path: BlurAwareDirectTracker::trackFrame on a GPU-rendered blurred sequence, reference-shaped
-        # configuration (blur_aware_direct_tracker.cpp:88-203,544-637); wall time of the mbavo_vo_track_frame calls
         try:
-            from mba_vo_amd import sequence
-            seq = sequence.make_sequence(ctx, H=480, W=640, M=8, device=dev)
-            sequence.track_sequence(ctx, seq)  # warm-up: allocations, code objects
-            runs = [sequence.track_sequence(ctx, seq) for _ in range(5)]
-            per_frame = sorted(sum(f["seconds"] for f in r) / len(r) for r in runs)
-            r0 = runs[0]
-            cfgs["trackframe_640x480"] = {
-                "workload": "BlurAwareDirectTracker::trackFrame, 640x480, 4 levels, 30-px grid keypoints x 8-pixel pattern, k = 2, "
-                            "S = 8, %d frames (GPU-rendered blurred sequence on a textured plane), host-driven LM loop on "
-                            "persistent evaluation kernels" % len(r0),
-                "ms_per_frame": round(1e3 * per_frame[len(per_frame) // 2], 4), "ms_per_frame_min": round(1e3 * per_frame[0], 4),
-                "passes": len(runs), "frames": len(r0), "keyframes": int(sum(f["is_keyframe"] for f in r0)),
-                "keypoints_level0": int(r0[0]["K0"]), "lm_trace_records": int(sum(f["num_trace"] for f in r0)),
-                "poses_reproducible": bool(all(np.array_equal(a["T"], b["T"]) for r in runs[1:] for a, b in zip(r0, r)))}
+            cfgs["trackframe_640x480"], *track = trackframe_config(M, ctx, dev)
         except Exception as e:
             cfgs["trackframe_640x480"] = {"error": repr(e)}
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import lm_bench
+            cfgs["lm_batch64"] = lm_bench.bench_line(M, ctx, dev)
+        except Exception as e:
+            cfgs["lm_batch64"] = {"error": repr(e)}
         out["configs"] = cfgs
 
     if rank == 0 and not args.no_cpu_baseline and world == 1 and fb_gpu is not None:  # rank 0 at N = 1 only
-        cb, fb_cpu = cpu_baseline(run.probs, args.cpu_seconds)
+        host_probs = run.probs if not hasattr(run.dw, "host_problem") else [run.dw.host_problem(b) for b in range(run.dw.B)]
+        cb, fb_cpu = cpu_baseline(host_probs, args.cpu_seconds)
         scale = np.abs(fb_cpu).max(axis=1, keepdims=True)
         cb["gpu_vs_cpu_max_rel_diff"] = float((np.abs(fb_gpu - fb_cpu) / scale).max())
+        if track:  # the caller of the path against the oracle's trackFrame on the same sequence
+            try:
+                cb["trackframe_vs_oracle"] = trackframe_checker(ctx, *track)
+            except Exception as e:
+                cb["trackframe_vs_oracle"] = {"error": repr(e)}
         out["cpu_baseline"] = cb
     if rank == 0:
         sys.stdout.flush()

@@ -27,7 +27,11 @@ typedef struct mbavo_ctx mbavo_ctx;
 /* One alignment problem = the argument list of evaluate_cost_hessian_gradient
  * (ba_tracker/spline_update_step.h:70-87) plus the CudaSharedStorages fields it
  * reads (spline_update_step.h:18-58), as POD.  All pointers are DEVICE pointers
- * except h_start_idx. */
+ * except h_start_idx.
+ * ZERO-INITIALISE the struct (memset / `= {0}`) before filling it in: fields appended by later library versions
+ * (grad_fp16, num_residuals -- ABI 0.2) select optional behaviour and must read 0 when a caller does not know them.
+ * mbavo_abi_version() returns the struct revision the loaded library expects (MBAVO_ABI_VERSION of this header). */
+#define MBAVO_ABI_VERSION 2
 typedef struct mbavo_problem {
     int S;                                /* n_vir_poses_per_frame */
     int F;                                /* n_frames */
@@ -294,6 +298,14 @@ int mbavo_comm_destroy(mbavo_ctx *ctx);
  * stream, ordered after the kernels that wrote them (RCCL over xGMI).  `rccl_comm` = a caller-owned ncclComm_t, or NULL
  * for the context's own communicator (mbavo_comm_init); with neither: MBAVO_E_ARG. */
 int mbavo_allreduce_blocks(mbavo_ctx *ctx, void *rccl_comm, double *d_blocks, long long count);
+/* The same sum out of place (d_recv = sum over ranks of d_send).  Independent keyframe pairs sharded pair -> rank
+ * (SURVEY.md 8e(1)): every rank evaluates its pairs straight into ITS slice of a send buffer whose other slices stay zero
+ * -- nothing else ever writes them -- so the slices are disjoint, the sum is exact (x + 0 + ... + 0) and no buffer has to
+ * be cleared between iterations. */
+int mbavo_allreduce_blocks_to(mbavo_ctx *ctx, void *rccl_comm, const double *d_send, double *d_recv, long long count);
+/* In-place ncclAllGather of equal slices: rank r's `count_per_rank` doubles sit at d_blocks + r * count_per_rank on entry,
+ * every rank holds all slices on return (half the all-reduce's traffic for disjoint slices; needs equal slice lengths). */
+int mbavo_allgather_blocks(mbavo_ctx *ctx, void *rccl_comm, double *d_blocks, long long count_per_rank);
 
 /* ---- measurement: HIP-event timing of the dominant kernel (the fused residual/Jacobian/JtJ
  * kernel) on the context's stream, attached to the kernel's own dispatch (hipExtLaunchKernelGGL: begin / end
@@ -310,6 +322,8 @@ const char *mbavo_last_kernel(mbavo_ctx *ctx);
 void mbavo_timing_report(void);
 
 const char *mbavo_version(void);
+/* revision of the POD structs above (MBAVO_ABI_VERSION of the header the library was built with): compare before use */
+int mbavo_abi_version(void);
 
 #ifdef __cplusplus
 }

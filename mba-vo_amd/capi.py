@@ -99,14 +99,29 @@ SYMBOLS = [
     "mbavo_lm_new", "mbavo_lm_delete", "mbavo_lm_reset", "mbavo_lm_step_accepted", "mbavo_lm_step_rejected",
     "mbavo_lm_get_radius", "mbavo_tr_new", "mbavo_tr_delete", "mbavo_tr_reset", "mbavo_tr_step_quality",
     "mbavo_tr_step_accepted", "mbavo_spline_get_pose", "mbavo_spline_plus", "mbavo_segment_start_index",
-    "mbavo_optimize_trajectory", "mbavo_pyramid_down_u8", "mbavo_image_gradients_u8", "mbavo_image_gradients_u8_half", "mbavo_synthesize_blur", "mbavo_allreduce_blocks",
-    "mbavo_profile", "mbavo_profile_read", "mbavo_version",
+    "mbavo_optimize_trajectory", "mbavo_pyramid_down_u8", "mbavo_image_gradients_u8", "mbavo_image_gradients_u8_half", "mbavo_synthesize_blur", "mbavo_allreduce_blocks", "mbavo_allreduce_blocks_to", "mbavo_allgather_blocks",
+    "mbavo_profile", "mbavo_profile_read", "mbavo_version", "mbavo_abi_version",
     "mbavo_gradient_magnitude_u8", "mbavo_detect_semidense", "mbavo_se3_exp", "mbavo_se3_log", "mbavo_transform_mul",
     "mbavo_transform_inverse", "mbavo_spline_transform_to", "mbavo_vo_create", "mbavo_vo_destroy", "mbavo_vo_set_spline",
     "mbavo_vo_get_spline", "mbavo_vo_num_keypoints", "mbavo_vo_get_keypoints", "mbavo_vo_track_frame", "mbavo_lm_batch",
     "mbavo_shard_keypoints", "mbavo_shard_frames", "mbavo_system_len", "mbavo_merge_device", "mbavo_comm_unique_id",
     "mbavo_comm_init", "mbavo_comm_ranks", "mbavo_comm_destroy", "mbavo_last_kernel", "mbavo_timing_report",
 ]
+
+
+KERNEL_SOURCES = ("csrc/engine.hip", "csrc/pixel_math.h", "csrc/se3_math.h")
+
+
+def kernel_source_sha():
+    """sha256[:16] over the sources of the evaluation kernels: stamped into the committed counter extracts
+    (profiles/*_pmc_*.json, *_hbm_counters*.json) when they are collected and compared by bench.py, which flags figures
+    read from an extract of another kernel revision as stale."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(_HERE, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def build(quiet=True):
@@ -180,6 +195,8 @@ def load():
     L.mbavo_synthesize_blur.argtypes = [vp, C.c_int, C.c_int, C.c_double, c_dp, C.c_int, C.c_double, C.c_double, c_dp,
                                         c_dp, C.c_int, C.c_double, C.c_double, C.c_int, vp, vp]
     L.mbavo_allreduce_blocks.argtypes = [vp, vp, vp, C.c_longlong]
+    L.mbavo_allreduce_blocks_to.argtypes = [vp, vp, vp, vp, C.c_longlong]
+    L.mbavo_allgather_blocks.argtypes = [vp, vp, vp, C.c_longlong]
     L.mbavo_shard_keypoints.argtypes = [C.POINTER(Problem), C.c_int, C.c_int, C.POINTER(Problem), c_ip]
     L.mbavo_shard_frames.argtypes = [C.POINTER(Problem), C.c_int, C.c_int, C.POINTER(Problem), c_ip]
     L.mbavo_system_len.argtypes = [C.c_int]

@@ -45,7 +45,8 @@ static int packed_len(int k)
 
 extern "C"
 {
-    const char *mbavo_version(void) { return "mbavo-mi355x 0.1 (gfx950)"; }
+    const char *mbavo_version(void) { return "mbavo-mi355x 0.2 (gfx950)"; }
+    int mbavo_abi_version(void) { return MBAVO_ABI_VERSION; }
 
     int mbavo_packed_len(int k) { return packed_len(k); }
 
@@ -450,6 +451,18 @@ extern "C"
     int mbavo_allreduce_blocks(mbavo_ctx *ctx, void *comm, double *d_blocks, long long count)
     {
         if (!ctx || !d_blocks || count < 0) return MBAVO_E_ARG;
-        return ctx->engine->allreduce(comm, d_blocks, count);
+        return ctx->engine->allreduce(comm, d_blocks, d_blocks, count);
+    }
+
+    int mbavo_allreduce_blocks_to(mbavo_ctx *ctx, void *comm, const double *d_send, double *d_recv, long long count)
+    {
+        if (!ctx || !d_send || !d_recv || count < 0) return MBAVO_E_ARG;
+        return ctx->engine->allreduce(comm, d_send, d_recv, count);
+    }
+
+    int mbavo_allgather_blocks(mbavo_ctx *ctx, void *comm, double *d_blocks, long long count_per_rank)
+    {
+        if (!ctx || !d_blocks || count_per_rank < 0) return MBAVO_E_ARG;
+        return ctx->engine->allgather(comm, d_blocks, count_per_rank);
     }
 }

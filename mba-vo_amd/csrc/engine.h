@@ -133,7 +133,8 @@ namespace mbavo
         int comm_init(const unsigned char *unique_id, int rank, int world);
         int comm_ranks() const;
         int comm_destroy();
-        int allreduce(void *caller_comm_or_null, double *d, long long count);
+        int allreduce(void *caller_comm_or_null, const double *d_send, double *d_recv, long long count);
+        int allgather(void *caller_comm_or_null, double *d, long long count_per_rank);
         int merge_device(int B, const mbavo_problem *probs, int kdeg, const double *d_frame_blocks, double *d_systems);
 
     private:
@@ -156,6 +157,7 @@ namespace mbavo
         bool layout_uploaded_ = false;
         int sp_logs_ = 0; // > 0: the cached layout is tiled for the sample-parallel kernel with S = 2^sp_logs_
         bool flat_finalize_ = false; // many (problem, frame) slots of <= 4 tiles each: k_finalize_flat
+        bool empty_slots_ = false;   // some (problem, frame) slot has no tile (K == 0): no workgroup would finalize it in the single-launch form
 
         void *d_layout_ = nullptr; size_t cap_layout_ = 0; // one arena: descs | tiles | bf_tile_begin | bf_prob | entry_prob
         std::vector<char> h_layout_;
@@ -170,7 +172,7 @@ namespace mbavo
             std::vector<int> bf_tile_begin, bf_prob, entry_prob;
             int kdeg = 0, total_bf = 0, total_entries = 0, sp_logs = 0;
             long long total_pixels = 0, total_patches = 0;
-            bool uploaded = false, flat_finalize = false;
+            bool uploaded = false, flat_finalize = false, empty_slots = false;
             void *d_layout = nullptr; size_t cap_layout = 0;
             void *d_descs = nullptr, *d_tiles = nullptr, *d_bf_tile_begin = nullptr, *d_bf_prob = nullptr, *d_entry_prob = nullptr;
         };
@@ -188,6 +190,7 @@ namespace mbavo
         bool flag_pending_ = false;
         void *d_push_ = nullptr; size_t cap_push_ = 0; // fine-grained device memory, CPU-writable: kPushSlots blocks of push_stride_
         size_t push_stride_ = 0;                       // bytes, each starting with its PersistCmd
+        int push_probe_ = 0;                           // 0 = not probed, 1 = the CPU can store into device memory (large BAR), -1 = it cannot
         unsigned persist_mask_ = 0;                    // slots with a persistent kernel enqueued and not ended
         unsigned long long pending_seq_ = 0;           // sequence number of the evaluation posted last
         int persist_gen_ = 0;

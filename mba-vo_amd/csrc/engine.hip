@@ -1179,6 +1179,9 @@ namespace mbavo
         // L2), then ONE thread makes them visible device-wide (L2 write-back) and takes the ticket.  A device-scope fence
         // by all 768 threads costs 9 us here (measured, tools/ab_run.sh).
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // (a workgroup-scope release emits no vmcnt wait outside tgsplit mode, and thread 0's agent-scope release below waits
+        // for wave 0's stores only: every wave waits for the acknowledgement of its own partial / patch-cost stores here)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0)
         {
@@ -1230,7 +1233,11 @@ namespace mbavo
         // the frame block (pinned host memory) must land before the completion word does: every wave's stores are performed
         // at workgroup scope before the barrier, ONE thread then fences at system scope (a system-scope fence by all 768
         // threads was 3 of the 4.8 us this epilogue took inside the persistent kernel)
-        if (to_host) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (to_host)
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave's frame-block stores are acknowledged
+        }
         __syncthreads();
         if (threadIdx.x == 0)
         {
@@ -1783,7 +1790,7 @@ namespace mbavo
         h_entry_prob_.swap(s.entry_prob);
         std::swap(cached_kdeg_, s.kdeg); std::swap(total_bf_, s.total_bf); std::swap(total_entries_, s.total_entries);
         std::swap(sp_logs_, s.sp_logs); std::swap(total_pixels_, s.total_pixels); std::swap(total_patches_, s.total_patches);
-        std::swap(layout_uploaded_, s.uploaded); std::swap(flat_finalize_, s.flat_finalize);
+        std::swap(layout_uploaded_, s.uploaded); std::swap(flat_finalize_, s.flat_finalize); std::swap(empty_slots_, s.empty_slots);
         std::swap(d_layout_, s.d_layout); std::swap(cap_layout_, s.cap_layout);
         std::swap(d_descs_, s.d_descs); std::swap(d_tiles_, s.d_tiles); std::swap(d_bf_tile_begin_, s.d_bf_tile_begin);
         std::swap(d_bf_prob_, s.d_bf_prob); std::swap(d_entry_prob_, s.d_entry_prob);
@@ -1912,6 +1919,8 @@ namespace mbavo
         for (size_t i = 0; i + 1 < bf_tile_begin.size(); ++i)
             max_tiles_per_bf = std::max(max_tiles_per_bf, bf_tile_begin[i + 1] - bf_tile_begin[i]);
         flat_finalize_ = bf_prob.size() >= 64 && max_tiles_per_bf <= 4;
+        empty_slots_ = false;
+        for (size_t i = 0; i + 1 < bf_tile_begin.size(); ++i) empty_slots_ = empty_slots_ || bf_tile_begin[i + 1] == bf_tile_begin[i];
 
         h_descs_ = descs;
         h_tiles_.swap(tiles);
@@ -1994,7 +2003,6 @@ namespace mbavo
         const bool fused_pose = fused_pose_ok && KD == 4 && sp_logs == 0 && !one && ntiles > 0;
         if (one)
         { // single launch: pose entries in the prologue, finalize by the last workgroup of every slot
-            if (ntiles == 0) return 0;
 #define MBAVO_SP_ONE(LG)                                                                                                       \
     do                                                                                                                         \
     {                                                                                                                          \
@@ -2122,7 +2130,9 @@ namespace mbavo
         // (profiles/r02_single_launch_ab.txt: with the two-stage pose prologue it wins for every spline degree and mode;
         // before it, the k = 4 H/g prologue was a 2 600-instruction chain with vector spills and lost to three launches).
         // MBAVO_ONE=0 forces three launches.
-        const bool one = sp_logs_ > 0 && sp_one_fits(kdeg, sp_logs_) && env_int("MBAVO_ONE", 1) != 0;
+        // A slot without tiles (K == 0: a pyramid level with no surviving keypoint, a keypoint shard of K < world) has no
+        // workgroup to finalize it: such lists take the finalize KERNEL, which writes the all-zero block and valid count.
+        const bool one = sp_logs_ > 0 && sp_one_fits(kdeg, sp_logs_) && !empty_slots_ && env_int("MBAVO_ONE", 1) != 0;
         OneArgs oa;
         memset(&oa, 0, sizeof(oa));
         flag_pending_ = false;
@@ -2163,9 +2173,32 @@ namespace mbavo
         return rc;
     }
 
+    // Host side of the push block: write-combining stores through the PCIe BAR, ordered by a store fence.  Only x86-64 is
+    // known to behave as the persistent path needs (sfence drains the write-combining buffers in order); elsewhere the
+    // push block is not offered and the trackers take one launch per evaluation.
+#if defined(__x86_64__)
+    static inline void host_store_fence() { __builtin_ia32_sfence(); }
+    static inline void host_spin_pause() { __builtin_ia32_pause(); }
+    static constexpr bool kHostCanPush = true;
+#else
+    static inline void host_store_fence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+    static inline void host_spin_pause() {}
+    static constexpr bool kHostCanPush = false;
+#endif
+
     void *Engine::push_block(int slot, size_t bytes)
     {
-        if (slot < 0 || slot >= kPushSlots) return nullptr;
+        if (slot < 0 || slot >= kPushSlots || !kHostCanPush) return nullptr;
+        if (env_int("MBAVO_PERSIST", 1) == 0) return nullptr; // opt-out before anything touches device memory from the CPU
+        if (push_probe_ == 0)
+        { // CPU stores into device memory need the whole VRAM behind the PCIe BAR (large / resizable BAR); without it the
+          // allocation below still succeeds and the first store faults
+            int cur0 = -1, large = 0;
+            if (hipGetDevice(&cur0) != hipSuccess || cur0 != device_) (void)hipSetDevice(device_);
+            if (hipDeviceGetAttribute(&large, hipDeviceAttributeIsLargeBar, device_) != hipSuccess) { large = 0; (void)hipGetLastError(); }
+            push_probe_ = large ? 1 : -1;
+        }
+        if (push_probe_ < 0) return nullptr;
         const size_t stride = (bytes + 4095) & ~(size_t)4095;
         if (d_push_ && stride <= push_stride_) return (char *)d_push_ + (size_t)slot * push_stride_;
         if (persist_mask_) return nullptr; // cannot grow under a running kernel
@@ -2198,9 +2231,9 @@ namespace mbavo
         volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
         cmd->mode = 0;
         cmd->gen = ++persist_gen_;
-        __builtin_ia32_sfence();
+        host_store_fence();
         cmd->seq = flag_seq_;
-        __builtin_ia32_sfence();
+        host_store_fence();
         OneArgs oa;
         memset(&oa, 0, sizeof(oa));
         oa.bf_tile_begin = (const int *)d_bf_tile_begin_;
@@ -2246,9 +2279,9 @@ namespace mbavo
         volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
         const unsigned long long seq = ++flag_seq_;
         cmd->mode = with_hessian ? 2 : 1;
-        __builtin_ia32_sfence(); // the inputs (knots, flags, scale: the push block, write-combining) and the mode are out ...
+        host_store_fence(); // the inputs (knots, flags, scale: the push block, write-combining) and the mode are out ...
         cmd->seq = seq;
-        __builtin_ia32_sfence(); // ... before the sequence number, which leaves the write-combining buffer now
+        host_store_fence(); // ... before the sequence number, which leaves the write-combining buffer now
         pending_seq_ = seq;
         return 0;
     }
@@ -2276,7 +2309,7 @@ namespace mbavo
 #endif
                 return 0;
             }
-            __builtin_ia32_pause();
+            host_spin_pause();
             if ((spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) break;
         }
         fprintf(stderr, "mbavo: persistent evaluation timed out\n");
@@ -2291,9 +2324,9 @@ namespace mbavo
         if (!persistent_active(slot)) return 0;
         volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
         cmd->mode = 0;
-        __builtin_ia32_sfence();
+        host_store_fence();
         cmd->seq = ++flag_seq_;
-        __builtin_ia32_sfence();
+        host_store_fence();
         persist_mask_ &= ~(1u << slot);
         return 0;
     }
@@ -2310,7 +2343,7 @@ namespace mbavo
             for (long spins = 0; spins < 20000000L; ++spins)
             {
                 if (*f == flag_seq_) { flag_pending_ = false; return 0; }
-                __builtin_ia32_pause();
+                host_spin_pause();
             }
         }
         flag_pending_ = false;

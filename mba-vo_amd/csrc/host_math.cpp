@@ -142,7 +142,15 @@ namespace mbavo
             }
             return pr;
         }
-        const bool kHaveAvx2 = __builtin_cpu_supports("avx2");
+        inline bool have_avx2()
+        { // evaluated on first use (no static-initialisation-order dependence); the file is also parsed for the device
+#if defined(__HIP_DEVICE_COMPILE__)
+            return false;
+#else
+            static const bool v = (__builtin_cpu_init(), __builtin_cpu_supports("avx2") != 0);
+            return v;
+#endif
+        }
         inline int rotation_params_wide(const double *a, const double *c, const double *d, int npairs, double eps, double *cs, double *sn,
                                         double *skip)
         {
@@ -151,7 +159,7 @@ namespace mbavo
         inline Dots pair_dots_wide(const double *gp, const double *gq, int n) { return pair_dots_avx2(gp, gq, n); }
         inline void rotate_pair_wide(double *p, double *q, int n, double cs, double sn) { rotate_pair_avx2(p, q, n, cs, sn); }
 #else
-        const bool kHaveAvx2 = false;
+        inline bool have_avx2() { return false; }
         inline int rotation_params_wide(const double *, const double *, const double *, int, double, double *, double *, double *) { return 0; }
         inline Dots pair_dots_wide(const double *gp, const double *gq, int n) { return pair_dots(gp, gq, n); }
         inline void rotate_pair_wide(double *p, double *q, int n, double cs, double sn) { rotate_pair(p, q, n, cs, sn); }
@@ -173,7 +181,7 @@ namespace mbavo
         // and two divisions each: the latency chain that dominated the row-cyclic order) and their updates are independent
         // pieces of work for the out-of-order core.  Odd n takes the row-cyclic order.
         const int half = n / 2, m1 = n - 1;
-        const bool wide = kHaveAvx2 && (n & 3) == 0;
+        const bool wide = have_avx2() && (n & 3) == 0;
         static thread_local std::vector<int> pp_, qq_;
         static thread_local std::vector<double> cs_, sn_, da_, dc_, dd_, skip_;
         pp_.resize(half + 1); qq_.resize(half + 1); cs_.resize(half + 1); sn_.resize(half + 1);

@@ -26,6 +26,7 @@ namespace mbavo
             int (*CommCount)(const void *, int *) = nullptr;
             int (*CommDestroy)(void *) = nullptr;
             int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+            int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
             const char *(*GetErrorString)(int) = nullptr;
             bool ok = false;
         };
@@ -50,6 +51,7 @@ namespace mbavo
             r.CommCount = (decltype(r.CommCount))dlsym(h, "ncclCommCount");
             r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
             r.AllReduce = (decltype(r.AllReduce))dlsym(h, "ncclAllReduce");
+            r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
             r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
             r.ok = r.GetUniqueId && r.CommInitRank && r.CommCount && r.CommDestroy && r.AllReduce;
             if (!r.ok) fprintf(stderr, "mbavo: librccl.so lacks an expected symbol\n");
@@ -108,15 +110,38 @@ namespace mbavo
         return rccl_rc(rc, "ncclCommDestroy");
     }
 
-    int Engine::allreduce(void *comm, double *d, long long count)
+    int Engine::allreduce(void *comm, const double *send, double *recv, long long count)
     {
         const Rccl &r = rccl();
         if (!r.ok) return MBAVO_E_NODEVICE;
         void *c = comm ? comm : comm_;
-        if (!c) return MBAVO_E_ARG;
+        if (!c || !send || !recv || count < 0) return MBAVO_E_ARG;
         if (count == 0) return 0;
-        // ncclDouble = 8, ncclSum = 0 (rccl.h); in place, on the stream the evaluation and the merge were enqueued on
-        return rccl_rc(r.AllReduce(d, d, (size_t)count, 8, 0, c, stream_), "ncclAllReduce");
+        // ncclDouble = 8, ncclSum = 0 (rccl.h); on the stream the evaluation and the merge were enqueued on
+        return rccl_rc(r.AllReduce(send, recv, (size_t)count, 8, 0, c, stream_), "ncclAllReduce");
+    }
+
+    int Engine::allgather(void *comm, double *d, long long count_per_rank)
+    {
+        const Rccl &r = rccl();
+        if (!r.ok || !r.AllGather) return MBAVO_E_NODEVICE;
+        void *c = comm ? comm : comm_;
+        if (!c || !d || count_per_rank < 0) return MBAVO_E_ARG;
+        if (count_per_rank == 0) return 0;
+        int rank = 0;
+        { // in place: this rank's slice sits at its rank offset of the receive buffer
+            static int (*UserRank)(const void *, int *) = nullptr;
+            if (!UserRank)
+            {
+                void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+                UserRank = h ? (decltype(UserRank))dlsym(h, "ncclCommUserRank") : nullptr;
+            }
+            if (!UserRank) return MBAVO_E_NODEVICE;
+            const int rc = UserRank(c, &rank);
+            if (rc) return rccl_rc(rc, "ncclCommUserRank");
+        }
+        return rccl_rc(r.AllGather(d + (size_t)rank * (size_t)count_per_rank, d, (size_t)count_per_rank, 8, c, stream_), "ncclAllGather");
     }
 
     // ------------------------------------------------------------------ shards (host pointer arithmetic only)

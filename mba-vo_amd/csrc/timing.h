@@ -33,9 +33,11 @@ namespace mbavo
         std::chrono::steady_clock::time_point t0;
         bool on;
         explicit PhaseScope(int i) : id(i), on(PhaseTimers::get().on) { if (on) t0 = std::chrono::steady_clock::now(); }
-        ~PhaseScope()
+        ~PhaseScope() { stop(); }
+        void stop() // ends the phase early; the destructor then adds nothing
         {
             if (!on) return;
+            on = false;
             PhaseTimers &t = PhaseTimers::get();
             t.sec[id] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             ++t.calls[id];

@@ -289,8 +289,7 @@ namespace mbavo
                     xHx += step[r] * a;
                 }
                 const double model = -(gx + 0.5 * xHx);
-                ps_solve.~PhaseScope();
-                ps_solve.on = false;
+                ps_solve.stop();
                 if (model < 0) { lm.step_rejected(); record(iter, 3, 0.0, model, 0.0); continue; } // handleInvalidStep
 
                 // computeCandidatePointAndEvaluateCost (:833-883)

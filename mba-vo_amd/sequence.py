@@ -98,7 +98,26 @@ def track_sequence(ctx, seq, cfg=REFERENCE_CFG):
             dt = time.perf_counter() - t_call
             capi.check(rc, "mbavo_vo_track_frame")
             out.append(dict(T=T, is_keyframe=info.is_keyframe, K0=info.num_keypoints0, num_trace=info.num_trace, cost=info.final_cost,
-                            seconds=dt))
+                            start_idx=info.start_idx, seconds=dt))
     finally:
         ctx.lib.mbavo_vo_destroy(vo)
     return out
+
+
+def gt_relative(ctx, seq):
+    """Ground-truth pose of every frame relative to the first sharp frame (the tracker's world), through the product's
+    own Transformation helpers (core/states/Transformation.cpp)."""
+    L = ctx.lib
+    T0i = np.zeros(7)
+    capi.check(L.mbavo_transform_inverse(capi.dp(np.ascontiguousarray(seq["gt"][0])), capi.dp(T0i)), "mbavo_transform_inverse")
+    out = []
+    for g in seq["gt"]:
+        T = np.zeros(7)
+        capi.check(L.mbavo_transform_mul(capi.dp(T0i), capi.dp(np.ascontiguousarray(g)), capi.dp(T)), "mbavo_transform_mul")
+        out.append(T)
+    return np.array(out)
+
+
+def ate(run, gt_rel):
+    """Absolute trajectory error: RMSE over the frames of |t_est - t_gt| (same world frame, no alignment)."""
+    return float(np.sqrt(np.mean([np.sum((f["T"][:3] - g[:3]) ** 2) for f, g in zip(run, gt_rel)])))

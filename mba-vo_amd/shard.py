@@ -5,10 +5,14 @@ equations (the reference's reduction point is merge_hessian_gradie
   * ONE joint problem, keypoints sharded (`mbavo_shard_keypoints`): contiguous keypoint bands per rank; every rank's
     packed frame blocks are partial sums scaled by the WHOLE problem's residual count (`num_residuals`), so the blocks
     of all ranks add up to the whole problem's blocks: one all-reduce of the B*F*E packed doubles.
+  * B INDEPENDENT pairs, pairs sharded (`pairs_of_rank`): pair b on rank b % world, whole; every rank
+    evaluates its pairs into ITS contiguous slice of a B*F*E send buffer whose other slices are zero and stay zero
+    (`pair_layout`), and ONE out-of-place all-reduce (`mbavo_allreduce_blocks_to`) leaves every pair's blocks on every
+    rank -- disjoint slices, so the sum is exact and bit-identical to a single-GPU evaluation.
   * ONE joint problem, frames sharded (`mbavo_shard_frames`): rank r owns a contiguous frame range; every rank scatters
     its frames' blocks into the 6N x 6N system on the device (`mbavo_merge_device`) and the partial systems
     [cost | g | H] are summed: one all-reduce of 1 + 6N + 36N^2 doubles per problem.
-Both end in `mbavo_allreduce_blocks` on the context's own RCCL communicator (`mbavo_comm_init`), enqueued on the stream
+All end in ONE `mbavo_allreduce_blocks[_to]` on the context's own RCCL communicator (`mbavo_comm_init`), enqueued on the stream
 of the evaluation.  torch.distributed is used for the rendezvous only (broadcast of the 128-byte communicator id).
 The pure index helpers below are also what the CPU (gloo) tests exercise.
 """
@@ -22,6 +26,23 @@ from . import capi
 def pairs_of_rank(num_pairs, rank, world):
     """Indices of the independent pairs owned by `rank` (round-robin: pair b -> rank b % world)."""
     return list(range(rank, num_pairs, world))
+
+
+def pair_layout(frames_per_pair, world):
+    """Rank-major layout of the packed frame blocks of B independent pairs sharded pair -> rank b % world.
+    Returns (row_base, row_of_pair): rank r's pairs occupy rows [row_base[r], row_base[r + 1]) of the reduced buffer, in
+    ascending pair order; pair b's first frame block is row row_of_pair[b].  Every rank writes a CONTIGUOUS slice, so its
+    evaluation writes straight into the send buffer of the all-reduce (no scatter kernel)."""
+    B = len(frames_per_pair)
+    row_base = [0]
+    row_of_pair = [0] * B
+    for r in range(world):
+        row = row_base[-1]
+        for b in pairs_of_rank(B, r, world):
+            row_of_pair[b] = row
+            row += int(frames_per_pair[b])
+        row_base.append(row)
+    return row_base, row_of_pair
 
 
 def keypoint_range_of_rank(K, rank, world):
@@ -82,17 +103,21 @@ class ShardedEvaluation:
 
         step()      : evaluate the shard (+ device merge in 'frames' mode) + ONE all-reduce; asynchronous
         reduced     : device tensor holding the reduced object after step(): packed frame blocks of the whole workload
-                      ('keypoints') or the merged [cost | g | H] systems ('frames')
+                      ('keypoints'; 'pairs': the same rows in the rank-major order of pair_layout, see blocks_of_pair) or
+                      the merged [cost | g | H] systems ('frames')
         reference() : the same object computed by THIS rank alone from the whole workload (for the N = 1 equality check)
     """
 
     def __init__(self, ctx, whole, k, rank, world, mode, device):
         import torch
-        assert mode in ("keypoints", "frames")
+        assert mode in ("keypoints", "frames", "pairs")
         self.ctx, self.whole, self.k, self.rank, self.world, self.mode = ctx, whole, k, rank, world, mode
         self.B = len(whole)
         lib = ctx.lib
         self.E = lib.mbavo_packed_len(k)
+        if mode == "pairs":
+            self._init_pairs(device)
+            return
         self.shards, self.first = shard_array(lib, whole, rank, world, mode)
         live = [b for b in range(self.B) if self.shards[b].F > 0]
         self.live = (capi.Problem * max(len(live), 1))(*[self.shards[b] for b in live])
@@ -107,6 +132,41 @@ class ShardedEvaluation:
         self.count = self.sys_len if mode == "frames" else self.nbf * self.E
         self._ref_fb, self._ref_sys = z(self.nbf_whole * self.E), z(self.sys_len)
 
+    def _init_pairs(self, device):
+        import torch
+        lib, whole, rank, world = self.ctx.lib, self.whole, self.rank, self.world
+        mine = pairs_of_rank(self.B, rank, world)
+        self.row_base, self.row_of_pair = pair_layout([whole[b].F for b in range(self.B)], world)
+        self.shards = (capi.Problem * self.B)()   # this rank's pairs whole, the others empty (F == 0)
+        for b in range(self.B):
+            C.memmove(C.byref(self.shards[b]), C.byref(whole[b]), C.sizeof(capi.Problem))
+            if b % world != rank:
+                self.shards[b].F = 0
+        self.first = np.zeros(self.B, np.int32)
+        self.live = (capi.Problem * max(len(mine), 1))(*[whole[b] for b in mine])
+        self.n_live = len(mine)
+        self.nbf = sum(whole[b].F for b in mine)
+        self.nbf_whole = sum(whole[b].F for b in range(self.B))
+        assert self.row_base[rank + 1] - self.row_base[rank] == self.nbf and self.row_base[-1] == self.nbf_whole
+        self.sys_len = 0
+        z = lambda n: torch.zeros(max(n, 1), dtype=torch.float64, device=device)
+        self.send = z(self.nbf_whole * self.E)     # zero outside this rank's slice, for good: nothing else writes there
+        self.frame_blocks = self.send[self.row_base[rank] * self.E:(self.row_base[rank] + max(self.nbf, 0)) * self.E] \
+            if self.nbf else z(1)
+        self.valid = z(self.nbf)
+        self.systems = None
+        self.reduced = z(self.nbf_whole * self.E)  # rank-major rows (pair_layout)
+        self.count = self.nbf_whole * self.E
+        self._ref_fb, self._ref_sys = z(self.nbf_whole * self.E), None
+        # rows of the whole workload in problem order -> rank-major rows
+        rows, first_row = [], 0
+        perm = np.zeros(self.nbf_whole, np.int64)
+        for b in range(self.B):
+            for f in range(whole[b].F):
+                perm[self.row_of_pair[b] + f] = first_row + f
+            first_row += whole[b].F
+        self._perm = torch.from_numpy(perm).to(device)
+
     def evaluate_local(self, with_hessian=True):
         lib, ctx = self.ctx.lib, self.ctx
         if self.n_live:
@@ -116,9 +176,20 @@ class ShardedEvaluation:
             capi.check(lib.mbavo_merge_device(ctx.handle, self.B, self.shards, self.k, self.frame_blocks.data_ptr(),
                                               self.systems.data_ptr()), "mbavo_merge_device")
 
+    def reduce(self):
+        self._reduce()
+
     def step(self, with_hessian=True, reduce=True):
         self.evaluate_local(with_hessian)
         if reduce:
+            self._reduce()
+
+    def _reduce(self):
+        reduce = True
+        if reduce and self.mode == "pairs":
+            capi.check(self.ctx.lib.mbavo_allreduce_blocks_to(self.ctx.handle, None, self.send.data_ptr(),
+                                                              self.reduced.data_ptr(), self.count), "mbavo_allreduce_blocks_to")
+        elif reduce:
             capi.check(self.ctx.lib.mbavo_allreduce_blocks(self.ctx.handle, None, self.reduced.data_ptr(), self.count),
                        "mbavo_allreduce_blocks")
 
@@ -132,7 +203,14 @@ class ShardedEvaluation:
             capi.check(lib.mbavo_merge_device(ctx.handle, self.B, self.whole, self.k, self._ref_fb.data_ptr(),
                                               self._ref_sys.data_ptr()), "mbavo_merge_device")
         torch.cuda.synchronize()
+        if self.mode == "pairs":  # the same rows in the rank-major order of the reduced buffer
+            return self._ref_fb.view(self.nbf_whole, self.E)[self._perm].reshape(-1).clone()
         return (self._ref_sys if self.mode == "frames" else self._ref_fb).clone()
+
+    def blocks_of_pair(self, b):
+        """'pairs' mode: the reduced packed frame blocks [F_b, E] of pair b (a view of `reduced`)."""
+        r0 = self.row_of_pair[b]
+        return self.reduced.view(self.nbf_whole, self.E)[r0:r0 + self.whole[b].F]
 
 
 def allreduce_blocks(blocks, group=None):

@@ -95,6 +95,176 @@ def pair_batch(B, H=480, W=640, S=8, k=4, N=4, mode="semidense", seed=1, huber=1
     return probs
 
 
+def _qmul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def _qrot(q, v):
+    x, y, z, w = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return R @ v
+
+
+def loop_spline(n_knots, dt=0.5, amp=(0.5, 0.35, 0.04), period=(2.1, 1.7, 3.3), rot_amp=(0.012, 0.01, 0.006)):
+    """Control knots of a bounded ground-truth trajectory (a Lissajous loop in front of the textured plane, small periodic
+    roll / pitch / yaw): any number of frames stays on the texture, unlike the harness spline's straight line."""
+    kt = np.zeros((n_knots, 3))
+    kR = np.zeros((n_knots, 4))
+    for i in range(n_knots):
+        t = i * dt
+        kt[i] = [amp[a] * np.sin(2 * np.pi * t / period[a] + 0.7 * a) for a in range(3)]
+        kR[i] = synth.rpy_quat(*[rot_amp[a] * np.sin(2 * np.pi * t / (period[a] * 1.3) + 1.1 * a) for a in range(3)])
+    return np.ascontiguousarray(kt), np.ascontiguousarray(kR)
+
+
+class _PairInfo:
+    """What bench.py's accounting needs to know about one device-resident pair (no host copies of the images)."""
+
+    def __init__(self, S, k, N, F, K, P, H, W):
+        self.S, self.k, self.N, self.F, self.K, self.P, self.H, self.W = S, k, N, F, K, P, H, W
+        self.image_bytes = H * W * (1 + 8) + F * H * W  # keyframe u8 + gradient 2 x f32 + current u8, all this pair's own
+
+    @property
+    def pixel_samples(self):
+        return self.F * self.K * self.P * self.S
+
+
+class RenderedPairBatch:
+    """BASELINE configs[2]/[3] as the configs describe them: B independent keyframe pairs = B consecutive frames of ONE
+    synthetic blurred sequence (a textured plane, a camera on a ground-truth spline; generate_synthetic_data.cpp:127-214),
+    every pair with its OWN keyframe image (the sharp rendering at the keyframe's time), its own gradient image, its own
+    grid-selected keypoints with depths read from its own z-depth map, its own current image (the motion-blurred
+    rendering one frame later, mbavo_synthesize_blur) and its own control knots (the ground-truth spline expressed in the
+    keyframe's camera by left-multiplication -- the cumulative B-spline is left-invariant -- plus a small perturbation).
+    Everything is rendered and detected on the GPU and stays there; `host_problem(b)` downloads one pair for the parity
+    tests.  Same interface as DeviceWorkload (array, step, frame_blocks, valid, probs)."""
+
+    def __init__(self, ctx, B, H=480, W=640, S=8, k=4, device="cuda:0", seed=1, huber=10.0, D=7.5, frame_dt=0.1, exp=0.04,
+                 cell=30, thresh=4.0, perturb=2e-3, pairs=None):
+        import torch
+        L = ctx.lib
+        rng = np.random.default_rng(seed)
+        self.B, self.k, self.S, self.H, self.W, self.device = B, k, S, H, W, device
+        self.E = synth.packed_len(k)
+        dtk, t0w, t_first = 0.5, 0.0, 0.55  # frame times t_first + i * frame_dt never straddle a knot (multiples of 0.5 +- exp)
+        n_world = int((t_first + (B + 2) * frame_dt + exp) / dtk) + 5
+        self.kt_w, self.kR_w = loop_spline(n_world, dtk)
+        ktw, kRw = np.ascontiguousarray(self.kt_w.ravel()), np.ascontiguousarray(self.kR_w.ravel())
+        intr = np.array([W / 2.0, W / 2.0, W / 2.0, H / 2.0])
+        self.intr, self.D = intr, D
+        base = torch.from_numpy(synth.texture_image(H, W, seed=seed, octaves=(32, 16, 8, 4))).to(device)
+        xs = torch.arange(W, dtype=torch.float64, device=device)[None, :].expand(H, W)
+        ys = torch.arange(H, dtype=torch.float64, device=device)[:, None].expand(H, W)
+        pat = torch.from_numpy(synth.PATTERN8).to(device)
+        margin = 20
+        self.keep = [base, pat]
+        self.array = (capi.Problem * B)()
+        self.probs, self._host = [], []
+        own = range(B) if pairs is None else pairs  # (a rank may build only its own pairs; the others stay zero-filled)
+        own = set(own)
+        cap_kp = (H // cell + 1) * (W // cell + 1)
+        for b in range(B):
+            if b not in own:
+                self.probs.append(_PairInfo(S, k, 4, 1, 0, 8, H, W))
+                self._host.append(None)
+                continue
+            tk, tc = t_first + b * frame_dt, t_first + (b + 1) * frame_dt
+            pk, qk = np.zeros(3), np.zeros(4)
+            capi.check(L.mbavo_spline_get_pose(4, t0w, dtk, capi.dp(ktw), capi.dp(kRw), n_world, float(tk), capi.dp(pk), capi.dp(qk),
+                                               None, None), "mbavo_spline_get_pose")
+            ref = torch.empty(H * W, dtype=torch.uint8, device=device)
+            cur = torch.empty(H * W, dtype=torch.uint8, device=device)
+            for (t, e, ns, dst) in ((tk, 0.0, 2, ref), (tc, exp, 8, cur)):
+                capi.check(L.mbavo_synthesize_blur(base.data_ptr(), H, W, float(D), capi.dp(intr), 4, t0w, dtk, capi.dp(ktw),
+                                                   capi.dp(kRw), n_world, float(t), float(e), ns, dst.data_ptr(), None),
+                           "mbavo_synthesize_blur")
+            grad = torch.empty(H * W * 2, dtype=torch.float32, device=device)
+            capi.check(L.mbavo_image_gradients_u8(ref.data_ptr(), H, W, grad.data_ptr(), None), "mbavo_image_gradients_u8")
+            # z-depth of the plane z = D (plane frame) in the keyframe camera (camera -> plane pose (qk, pk))
+            x, y, z, w = qk
+            r2 = (2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y))
+            rz = (xs - intr[2]) / intr[0] * r2[0] + (ys - intr[3]) / intr[1] * r2[1] + r2[2]
+            depth = ((D - pk[2]) / rz).to(torch.float32).contiguous()
+            torch.cuda.synchronize()
+            xy = torch.empty(cap_kp * 2, dtype=torch.float64, device=device)
+            kz = torch.empty(cap_kp, dtype=torch.float64, device=device)
+            cnt = C.c_int(0)
+            capi.check(L.mbavo_detect_semidense(ctx.handle, ref.data_ptr(), H, W, 0, H, W, cell, cell, float(thresh),
+                                                depth.data_ptr(), xy.data_ptr(), kz.data_ptr(), cap_kp, C.byref(cnt)),
+                       "mbavo_detect_semidense")
+            K = cnt.value
+            # keep the keypoints whose patch stays `margin` pixels inside the image (as the semi-dense builder does)
+            xyv = xy[:2 * K].view(K, 2)
+            ok = (xyv[:, 0] >= margin) & (xyv[:, 0] < W - margin) & (xyv[:, 1] >= margin) & (xyv[:, 1] < H - margin)
+            xy = xyv[ok].contiguous().view(-1)
+            kz = kz[:K][ok].contiguous()
+            K = int(kz.shape[0])
+            # knots of the segment that holds the current frame's exposure, in the keyframe's camera
+            idx = int((tc - exp * 0.5 - t0w) / dtk)
+            assert int((tc + exp * 0.5 - t0w) / dtk) == idx and idx + 4 <= n_world
+            qk_inv = np.array([-qk[0], -qk[1], -qk[2], qk[3]])
+            kt = np.stack([_qrot(qk_inv, self.kt_w[idx + i] - pk) for i in range(4)])
+            kR = np.stack([_qmul(qk_inv, self.kR_w[idx + i]) for i in range(4)])
+            kR /= np.linalg.norm(kR, axis=1, keepdims=True)
+            kt_gt = kt.copy()
+            kt = kt + rng.normal(0, perturb, kt.shape)
+            t0 = t0w + idx * dtk
+            capt, expt = torch.tensor([tc], dtype=torch.float64, device=device), torch.tensor([exp], dtype=torch.float64, device=device)
+            dkt, dkR = torch.from_numpy(kt.ravel().copy()).to(device), torch.from_numpy(kR.ravel().copy()).to(device)
+            cur_ptrs = torch.tensor([cur.data_ptr()], dtype=torch.int64, device=device)
+            start = np.array([synth.segment_start_index(tc, t0, dtk)], np.int32)
+            assert start[0] == 0
+            self.keep += [ref, cur, grad, xy, kz, capt, expt, dkt, dkR, cur_ptrs, start]
+            q = self.array[b]
+            q.S, q.F, q.K, q.P, q.N, q.H, q.W = S, 1, K, 8, 4, H, W
+            q.d_ref_img, q.d_ref_dIxy, q.d_cur_imgs = ref.data_ptr(), grad.data_ptr(), cur_ptrs.data_ptr()
+            q.d_kp_xy, q.kp_stride, q.d_kp_z, q.d_pattern = xy.data_ptr(), 2, kz.data_ptr(), pat.data_ptr()
+            q.d_outlier, q.num_bad = None, 0
+            for i in range(4):
+                q.intrinsics[i] = float(intr[i])
+            q.d_cap_time, q.d_exp_time, q.t0, q.dt = capt.data_ptr(), expt.data_ptr(), t0, dtk
+            q.d_knots_t, q.d_knots_R = dkt.data_ptr(), dkR.data_ptr()
+            q.h_start_idx = start.ctypes.data_as(C.POINTER(C.c_int))
+            q.huber_a, q.grad_fp16 = huber, 0
+            self.probs.append(_PairInfo(S, k, 4, 1, K, 8, H, W))
+            self._host.append(dict(ref=ref, cur=cur, grad=grad, xy=xy, kz=kz, kt=kt, kR=kR, kt_gt=kt_gt, t0=t0, cap=tc, exp=exp,
+                                   huber=huber, pk=pk, qk=qk, dkt=dkt, dkR=dkR))
+        self.nbf = B
+        self.frame_blocks = torch.zeros(self.nbf * self.E, dtype=torch.float64, device=device)
+        self.valid = torch.zeros(self.nbf, dtype=torch.float64, device=device)
+        torch.cuda.synchronize()
+
+    def reset_knots(self):
+        """Initial control knots back into the device buffers (mbavo_lm_batch updates them in place)."""
+        import torch
+        for h in self._host:
+            if h is not None:
+                h["dkt"].copy_(torch.from_numpy(h["kt"].ravel().copy()))
+                h["dkR"].copy_(torch.from_numpy(h["kR"].ravel().copy()))
+        torch.cuda.synchronize()
+
+    def host_problem(self, b):
+        """Pair b as a numpy Prob (images downloaded): what the oracle is given in the parity tests."""
+        h = self._host[b]
+        H, W = self.H, self.W
+        return Prob(h["ref"].cpu().numpy().reshape(H, W), [h["cur"].cpu().numpy().reshape(H, W)],
+                    h["xy"].cpu().numpy().reshape(-1, 2), h["kz"].cpu().numpy(), synth.PATTERN8, self.intr, self.S, self.k, 4,
+                    [h["cap"]], [h["exp"]], h["t0"], 0.5, h["kt"], h["kR"], h["huber"],
+                    grad=h["grad"].cpu().numpy().reshape(H, W, 2))
+
+    def step(self, ctx, with_hessian=True, out=None):
+        fb = self.frame_blocks if out is None else out
+        rc = ctx.lib.mbavo_eval_batch(ctx.handle, self.B, self.array, self.k, 1 if with_hessian else 0,
+                                      fb.data_ptr(), None, self.valid.data_ptr())
+        if rc != 0:
+            raise RuntimeError("mbavo_eval_batch failed: %d" % rc)
+
+
 class DeviceWorkload:
     """Uploads a list of Prob once; builds the mbavo_problem array (inputs resident in HBM)."""
 
@@ -177,15 +347,19 @@ def algorithmic_bytes(probs, shard=None):
     """compulsory HBM bytes: images once (ref u8 + gradient 2 x f32 + current u8 per frame),
     keypoints (xy, z), pose tables, packed output blocks.  shard = (mode, rank, world): the bytes of that rank's share
     of the workload -- 'frames': keyframe images and keypoints in full, its own frames' current images; 'keypoints': a
-    1/world band of every image and of the keypoints."""
+    1/world band of every image and of the keypoints; 'pairs': the pairs b % world == rank, whole."""
     total = 0.0
     seen = set()
     mode, rank, world = shard if shard is not None else ("none", 0, 1)
-    for p in probs:
+    for b, p in enumerate(probs):
+        if mode == "pairs" and b % world != rank:
+            continue
         E = synth.packed_len(p.k)
         f0, f1 = ((p.F * rank) // world, (p.F * (rank + 1)) // world) if mode == "frames" else (0, p.F)
         band = 1.0 / world if mode == "keypoints" else 1.0
-        for a in [p.ref, p.grad] + list(p.cur[f0:f1]):
+        if hasattr(p, "image_bytes"):  # a device-resident pair with its own images (RenderedPairBatch)
+            total += p.image_bytes * band
+        for a in ([] if hasattr(p, "image_bytes") else [p.ref, p.grad] + list(p.cur[f0:f1])):
             key = a.__array_interface__["data"][0]
             if key not in seen:
                 seen.add(key)

@@ -92,14 +92,23 @@ def _worker(rank, world, port, out_dir):
                                 M.capi.dp(g)) == 0
     system = torch.from_numpy(np.concatenate([cost, g, H]))
     shard.allreduce_blocks(system)
-    # (3) independent pairs, round-robin, gathered by one all-reduce of a zero-padded buffer
-    pairs = shard.pairs_of_rank(6, rank, world)
-    acc = torch.zeros(6, sc.E, dtype=torch.float64)
-    for b in pairs:
-        s3 = scenes.Scene(S=2, F=1, k=4, P=8, K=40, seed=100 + b)
+    # (3) independent pairs, pair b -> rank b % world, in the product's rank-major layout (shard.pair_layout):
+    # every rank fills ITS contiguous slice of a zero send buffer, one all-reduce leaves every pair's blocks everywhere.
+    # Pairs have different frame counts here (1 or 2), so the slices have different lengths.
+    frames = [1 + (b % 3 == 1) for b in range(7)]
+    row_base, row_of_pair = shard.pair_layout(frames, world)
+    send = torch.zeros(row_base[-1], sc.E, dtype=torch.float64)
+    row = row_base[rank]
+    for b in shard.pairs_of_rank(7, rank, world):
+        s3 = scenes.Scene(S=2, F=frames[b], k=4, P=8, K=40, seed=100 + b)
         p3, keep3 = s3.oracle_problem(B)
-        acc[b] = torch.from_numpy(B.evaluate(p3)["frame_blocks"][0].copy())
+        assert row == row_of_pair[b]
+        send[row:row + frames[b]] = torch.from_numpy(B.evaluate(p3)["frame_blocks"].copy())
+        row += frames[b]
+    assert row == row_base[rank + 1]
+    acc = send.clone()  # (gloo's all-reduce is in place; the product's RCCL call is out of place, send stays untouched)
     shard.allreduce_blocks(acc)
+    assert torch.equal(acc[row_base[rank]:row_base[rank + 1]], send[row_base[rank]:row_base[rank + 1]])  # x + 0 is exact
     if rank == 0:
         np.save(os.path.join(out_dir, "joint.npy"), blocks.numpy())
         np.save(os.path.join(out_dir, "system.npy"), system.numpy())
@@ -125,10 +134,34 @@ def test_world_size_2_gloo(orc, mbavo, tmp_path):
     ref_sys = np.concatenate([[r2["cost"]], r2["g"], r2["H"].T.ravel()])
     assert system.shape == ref_sys.shape == (mbavo.load().mbavo_system_len(sc2.N),)
     assert np.abs(system - ref_sys).max() <= 1e-12 * np.abs(ref_sys).max()
-    for b in range(6):
-        s3 = scenes.Scene(S=2, F=1, k=4, P=8, K=40, seed=100 + b)
+    from mba_vo_amd import shard
+    frames = [1 + (b % 3 == 1) for b in range(7)]
+    row_base, row_of_pair = shard.pair_layout(frames, 2)
+    assert pairs.shape[0] == sum(frames) == row_base[-1]
+    for b in range(7):
+        s3 = scenes.Scene(S=2, F=frames[b], k=4, P=8, K=40, seed=100 + b)
         p3, keep3 = s3.oracle_problem(orc)
-        assert np.array_equal(pairs[b], orc.evaluate(p3)["frame_blocks"][0])
+        assert np.array_equal(pairs[row_of_pair[b]:row_of_pair[b] + frames[b]], orc.evaluate(p3)["frame_blocks"])  # bit-exact
+
+
+def test_pair_layout_is_a_rank_major_partition(mbavo):
+    from mba_vo_amd import shard
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 3, 4, 8):
+        for B in (1, 5, 64, 512):
+            frames = [int(f) for f in rng.integers(1, 4, B)]
+            row_base, row_of_pair = shard.pair_layout(frames, world)
+            assert row_base[0] == 0 and row_base[-1] == sum(frames) and len(row_base) == world + 1
+            rows = np.full(sum(frames), -1)
+            for b in range(B):
+                r = b % world
+                assert row_base[r] <= row_of_pair[b] and row_of_pair[b] + frames[b] <= row_base[r + 1]  # inside its rank's slice
+                assert (rows[row_of_pair[b]:row_of_pair[b] + frames[b]] == -1).all()                   # disjoint
+                rows[row_of_pair[b]:row_of_pair[b] + frames[b]] = b
+            assert (rows >= 0).all()
+            for r in range(world):  # ascending pair order inside a slice
+                mine = shard.pairs_of_rank(B, r, world)
+                assert [row_of_pair[b] for b in mine] == sorted(row_of_pair[b] for b in mine)
 
 
 def test_shard_partitions_cover_everything(mbavo):

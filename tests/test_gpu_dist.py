@@ -85,7 +85,22 @@ def rank_body(rank, world, local_rank, port, out_path):
     torch.cuda.synchronize()
     got2, ref2 = se2.reduced.clone(), se2.reference()
     res["keypoints_vs_single_gpu"] = rel(got2, ref2)
-    res["nonzero"] = bool(float(ref.abs().max()) > 0 and float(ref2.abs().max()) > 0)
+    # ---- pairs mode: 7 rendered pairs, pair b on rank b % world, slices of one zero send buffer, ONE
+    # out-of-place all-reduce; three steps in a row (the send buffer's foreign slices must still be zero afterwards)
+    rb = wl.RenderedPairBatch(ctx, 7, H=240, W=320, S=8, k=4, device=dev, seed=5)
+    se3 = shard.ShardedEvaluation(ctx, rb.array, 4, rank, world, "pairs", dev)
+    for _ in range(3):
+        se3.step(True)
+    torch.cuda.synchronize()
+    got3, ref3 = se3.reduced.clone(), se3.reference()
+    res["pairs_vs_single_gpu"] = rel(got3, ref3)
+    lo, hi = se3.row_base[rank] * se3.E, se3.row_base[rank + 1] * se3.E
+    res["pairs_own_slice_exact"] = bool(torch.equal(got3[lo:hi], se3.send[lo:hi]))
+    res["pairs_foreign_slices_zero"] = bool(float(se3.send[:lo].abs().sum() + se3.send[hi:].abs().sum()) == 0.0)
+    o3 = B.evaluate(B.make_problem(*_oracle_args(rb.host_problem(3)))[0])["frame_blocks"][0]
+    g3 = se3.blocks_of_pair(3)[0].cpu().numpy()
+    res["pairs_vs_oracle"] = float(np.abs(g3 - o3).max() / np.abs(o3).max())
+    res["nonzero"] = bool(float(ref.abs().max()) > 0 and float(ref2.abs().max()) > 0 and float(ref3.abs().max()) > 0)
     # every rank holds the same reduced object
     chk = got2.clone()
     dist.all_reduce(chk, op=dist.ReduceOp.MAX)
@@ -99,11 +114,17 @@ def rank_body(rank, world, local_rank, port, out_path):
     return res
 
 
+def _oracle_args(p):
+    return (p.S, p.F, p.K, p.P, p.k, p.N, p.H, p.W, p.ref, p.grad, p.cur, p.kp_xy, p.kp_z, p.pattern, p.intr, p.cap, p.exp,
+            p.t0, p.dt, p.knots_t, p.knots_R, p.start_idx, p.huber)
+
+
 def check(res, world):
     assert res["world"] == world and res["rccl_ranks"] == world
     assert res["nonzero"] and res["ranks_agree"] and res["device_merge_equals_host_merge"]
     assert res["frames_vs_single_gpu"] <= 1e-12 and res["keypoints_vs_single_gpu"] <= 1e-12
-    assert res["frames_vs_oracle"] <= 1e-9
+    assert res["frames_vs_oracle"] <= 1e-9 and res["pairs_vs_oracle"] <= 1e-9
+    assert res["pairs_vs_single_gpu"] <= 1e-12 and res["pairs_own_slice_exact"] and res["pairs_foreign_slices_zero"]
 
 
 def _spawned(rank, world, port, out_path):

@@ -171,3 +171,69 @@ def test_c4_batch512_full_size(orc, mbavo, gpu_ctx):
             total += part
         got = total.cpu().numpy().reshape(512, dw.E)
         assert np.abs(got - fb).max() <= 1e-12 * np.abs(fb).max()
+
+
+def test_c1_dense_full_size_properties(orc, mbavo, gpu_ctx):
+    """configs[0] at its full size (640x480, 1 level, S = 1: the sharp-image degenerate case, dense): run-to-run bit
+    reproducibility, additivity over a keypoint split, cost-only == slot 0 (1e-11), batch invariance, and three sampled
+    4 096-keypoint chunks against the plain oracle (un-normalised sums, 1e-9) -- S = 1 samples the START of the exposure
+    (compute_virtual_camera_poses.cu:33) and takes the lane-per-pixel kernel with no sample-parallel remainder."""
+    probs = wl.pyramid_pair(480, 640, 1, S=1, k=4, N=4, mode="dense", seed=1)
+    p = probs[0]
+    fb, valid = _run(gpu_ctx, probs)
+    fb2, _ = _run(gpu_ctx, probs)
+    assert np.array_equal(fb, fb2) and np.isfinite(fb).all() and fb[0, 0] > 0
+    assert valid[0] > 0.95 * p.K
+    cut = p.K // 3 + 11
+    a, va = _run(gpu_ctx, [_split(p, 0, cut)])
+    b, vb = _run(gpu_ctx, [_split(p, cut, p.K)])
+    whole, parts = fb[0] * p.K, a[0] * cut + b[0] * (p.K - cut)
+    assert np.abs(whole - parts).max() <= 1e-11 * np.abs(whole).max() and va[0] + vb[0] == valid[0]
+    fc, _ = _run(gpu_ctx, probs, with_h=False)
+    assert abs(fc[0, 0] - fb[0, 0]) <= 1e-11 * abs(fb[0, 0])
+    both, _ = _run(gpu_ctx, [p, _split(p, 0, cut)])
+    assert np.abs(both[0] - fb[0]).max() <= 1e-12 * np.abs(fb[0]).max()
+    for lo in (0, 150_000, p.K - 4096):
+        q = _split(p, lo, lo + 4096)
+        g, _ = _run(gpu_ctx, [q])
+        op, keep = orc.make_problem(q.S, q.F, q.K, q.P, q.k, q.N, q.H, q.W, q.ref, q.grad, q.cur, q.kp_xy, q.kp_z, q.pattern,
+                                    q.intr, q.cap, q.exp, q.t0, q.dt, q.knots_t, q.knots_R, q.start_idx, q.huber)
+        ro = orc.evaluate(op)
+        assert np.abs(ro["frame_blocks"][0] - g[0]).max() <= 1e-9 * np.abs(g[0]).max()
+
+
+def test_c4_batch512_rendered_pairs_full_size(orc, mbavo, gpu_ctx):
+    """configs[3] as the config describes it: 512 pairs of ONE rendered blurred sequence, every pair with its own keyframe,
+    gradient image, keypoints and knots (workloads.RenderedPairBatch) in ONE evaluation: reproducible bit for bit, six
+    sampled pairs against the oracle (1e-9), and the pair -> rank sharding of bench.py --gpus N (pairs b % N == r into the
+    rank's slice of the zero send buffer; ranks of a 2-, 4- and 8-rank run one after the other on this GPU): the summed
+    send buffers equal the whole batch evaluated at once to 1e-12 (another tile partition), every slice untouched by the
+    other ranks."""
+    import torch
+    from mba_vo_amd import shard
+    batch = wl.RenderedPairBatch(gpu_ctx, 512, S=8, k=4, seed=1)
+    batch.step(gpu_ctx, True)
+    torch.cuda.synchronize()
+    fb = batch.frame_blocks.cpu().numpy().reshape(512, batch.E).copy()
+    valid = batch.valid.cpu().numpy().copy()
+    batch.step(gpu_ctx, True)
+    torch.cuda.synchronize()
+    assert np.array_equal(batch.frame_blocks.cpu().numpy().reshape(512, batch.E), fb)
+    K = np.array([p.K for p in batch.probs])
+    assert np.isfinite(fb).all() and (fb[:, 0] > 0).all() and K.min() > 150 and (valid > 0.9 * K * 8).all()
+    for b in (0, 63, 128, 300, 457, 511):
+        p = batch.host_problem(b)
+        op, keep = orc.make_problem(p.S, p.F, p.K, p.P, p.k, p.N, p.H, p.W, p.ref, p.grad, p.cur, p.kp_xy, p.kp_z, p.pattern,
+                                    p.intr, p.cap, p.exp, p.t0, p.dt, p.knots_t, p.knots_R, p.start_idx, p.huber)
+        ro = orc.evaluate(op)
+        assert np.abs(ro["frame_blocks"][0] - fb[b]).max() <= 1e-9 * np.abs(fb[b]).max()
+    for world in (2, 4, 8):
+        total = None
+        for r in range(world):
+            se = shard.ShardedEvaluation(gpu_ctx, batch.array, 4, r, world, "pairs", "cuda:0")
+            se.step(True, reduce=False)
+            torch.cuda.synchronize()
+            total = se.send.clone() if total is None else total + se.send
+        got = total.cpu().numpy().reshape(512, batch.E)
+        order = np.array(se.row_of_pair)
+        assert np.abs(got[order] - fb).max() <= 1e-12 * np.abs(fb).max()

@@ -121,3 +121,23 @@ def test_patch_sizes_sum_in_reference_order(orc, mbavo, gpu_ctx, P, S):
     got_pc = pc.ravel()[:want_pc.size]
     assert (got_pc != want_pc).sum() <= max(1, int(0.01 * want_pc.size)), int((got_pc != want_pc).sum())
     assert np.abs(got_pc - want_pc).max() <= 1e-5 * np.abs(want_pc).max()
+
+
+def test_flat_tolerance_failure_rate_is_bounded(orc, mbavo, gpu_ctx, monkeypatch):
+    """The widened small-problem tolerance of _tol() must not hide a NEW class of difference: with a FLAT 1e-9 on the
+    packed blocks the known one-ulp fp32-weight flips fail about once in 2 000 random problems (profiles/r02_fuzz.txt:
+    6 of 12 000).  200 further seeds: at most ONE may exceed the flat bound, and a failure must stay inside _tol()."""
+    import sys
+    mod = sys.modules[__name__]
+    widened = _tol
+    worst = []
+    monkeypatch.setattr(mod, "_tol", lambda sc: 1e-9)
+    for seed in range(5000, 5200):
+        try:
+            test_random_problem_matches_oracle(orc, mbavo, gpu_ctx, seed)
+        except AssertionError:
+            worst.append(seed)
+    monkeypatch.setattr(mod, "_tol", widened)
+    for seed in worst:  # whatever exceeded the flat bound is one of the small-problem flips: inside the stated tolerance
+        test_random_problem_matches_oracle(orc, mbavo, gpu_ctx, seed)
+    assert len(worst) <= 1, worst

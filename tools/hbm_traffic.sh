@@ -31,6 +31,9 @@ for C in ("FETCH_SIZE", "WRITE_SIZE"):
         for k, v in acc.items():
             if "k_fused" in k or "k_pose" in k or "k_finalize" in k or "copy" in k.lower() or "elementwise" in k:
                 res["%s|%s|%s" % (kind, C, k)] = dict(mean=sum(v) / len(v), n=len(v))
+sys.path.insert(0, ".")
+import mba_vo_amd
+res["_source_sha"] = mba_vo_amd.capi.kernel_source_sha()
 print(json.dumps(res, indent=1))
 json.dump(res, open(out + "/hbm_counters.json", "w"), indent=1)
 import os

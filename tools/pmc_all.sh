@@ -20,7 +20,10 @@ for f in glob.glob(sys.argv[1] + "/set*/**/*counter_collection.csv", recursive=T
         if "mbavo::" in k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
-json.dump(out, open(sys.argv[2], "w"), indent=1)
+sys.path.insert(0, ".")
+import mba_vo_amd
+sha = mba_vo_amd.capi.kernel_source_sha()
+json.dump(dict(out, _source_sha=sha), open(sys.argv[2], "w"), indent=1)
 for k, d in out.items():
     if "k_fused" in k and d.get("SQ_WAVE_CYCLES"):
         wc = d["SQ_WAVE_CYCLES"]

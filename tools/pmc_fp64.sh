@@ -32,6 +32,9 @@ for k, d in acc.items():
                                      + 512.0 * m.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0)
     m["launches"] = max(len(v) for v in d.values())
     out[k] = m
+sys.path.insert(0, ".")
+import mba_vo_amd
+out["_source_sha"] = mba_vo_amd.capi.kernel_source_sha()
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 for k, m in out.items():
     if "k_fused" in k:
