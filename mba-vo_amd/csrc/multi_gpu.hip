@@ -117,6 +117,12 @@ namespace mbavo
         void *c = comm ? comm : comm_;
         if (!c || !send || !recv || count < 0) return MBAVO_E_ARG;
         if (count == 0) return 0;
+        int nranks = 0;
+        if (r.CommCount(c, &nranks) == 0 && nranks == 1)
+        { // a communicator of one rank has nothing to add: no collective kernel (~4.5 us in the stream), at most a copy
+            if (send == recv) return 0;
+            return (int)hipMemcpyAsync(recv, send, (size_t)count * sizeof(double), hipMemcpyDeviceToDevice, stream_);
+        }
         // ncclDouble = 8, ncclSum = 0 (rccl.h); on the stream the evaluation and the merge were enqueued on
         return rccl_rc(r.AllReduce(send, recv, (size_t)count, 8, 0, c, stream_), "ncclAllReduce");
     }

@@ -127,7 +127,10 @@ class _PairInfo:
 
     def __init__(self, S, k, N, F, K, P, H, W):
         self.S, self.k, self.N, self.F, self.K, self.P, self.H, self.W = S, k, N, F, K, P, H, W
-        self.image_bytes = H * W * (1 + 8) + F * H * W  # keyframe u8 + gradient 2 x f32 + current u8, all this pair's own
+        # SURVEY.md 8(d), semi-dense: the compulsory bytes are the taps of the distinct tap locations, bounded above by the
+        # gather figure 36 B per pixel-sample (2 x 2 u8 + 2 x 2 x 8 B gradient taps) + the current pixel -- and by the
+        # whole images (keyframe u8 + gradient 2 x f32 + current u8), all of them this pair's own
+        self.image_bytes = min(H * W * (1 + 8) + F * H * W, F * K * P * (S * 36 + 1))
 
     @property
     def pixel_samples(self):

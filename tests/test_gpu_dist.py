@@ -97,7 +97,8 @@ def rank_body(rank, world, local_rank, port, out_path):
     lo, hi = se3.row_base[rank] * se3.E, se3.row_base[rank + 1] * se3.E
     res["pairs_own_slice_exact"] = bool(torch.equal(got3[lo:hi], se3.send[lo:hi]))
     res["pairs_foreign_slices_zero"] = bool(float(se3.send[:lo].abs().sum() + se3.send[hi:].abs().sum()) == 0.0)
-    o3 = B.evaluate(B.make_problem(*_oracle_args(rb.host_problem(3)))[0])["frame_blocks"][0]
+    op3, keep3 = B.make_problem(*_oracle_args(rb.host_problem(3)))  # (keep3: the arrays the problem struct points into)
+    o3 = B.evaluate(op3)["frame_blocks"][0]
     g3 = se3.blocks_of_pair(3)[0].cpu().numpy()
     res["pairs_vs_oracle"] = float(np.abs(g3 - o3).max() / np.abs(o3).max())
     res["nonzero"] = bool(float(ref.abs().max()) > 0 and float(ref2.abs().max()) > 0 and float(ref3.abs().max()) > 0)
