@@ -24,6 +24,16 @@
 #include "pixel_math.h"
 #include "se3_math.h"
 #include "timing.h"
+#include "lm_state.h"
+// the one-wave solvers run on wave 0 of the resident LM kernel's leader workgroup: a wave-level fence between their steps
+#define MBAVO_SOLVER_SYNC()                                          \
+    do                                                               \
+    {                                                                \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
+        __builtin_amdgcn_wave_barrier();                             \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
+    } while (0)
+#include "lm_solvers.h"
 
 #include <algorithm>
 #include <chrono>
@@ -1103,6 +1113,9 @@ namespace mbavo
         unsigned long long *host_flag;           // pinned host word, or null: set to `seq` when every slot is done
         unsigned long long seq;
         int nbf;
+        int lm;                                  // resident LM kernel (k_lm_level): the slots finished in this evaluation are counted,
+                                                 // every slot's frame block is released device-wide, and ticket_finalize tells its
+                                                 // caller whether THIS workgroup finished the evaluation's last slot
         unsigned long long t_seen;               // (timing experiment MBAVO_PERSIST_STAMPS)
     };
 
@@ -1168,12 +1181,14 @@ namespace mbavo
     // (t0 + t2) + (t1 + t3), the order of k_finalize_flat) -- and writes the frame block.  `scratch`: LANES * EPAD
     // doubles of LDS nobody else is using any more.
     template <int KD, bool WITH_J, int NTHREADS>
-    __device__ __forceinline__ void ticket_finalize(const ProblemDesc &d, int bf, const double *__restrict__ partials,
+    __device__ __forceinline__ bool ticket_finalize(const ProblemDesc &d, int bf, const double *__restrict__ partials,
                                                     const OneArgs &oa, double *scratch, double inv)
     {
         constexpr int E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
-        constexpr int EPAD = KD == 4 ? 384 : 128, LANES = NTHREADS / EPAD;
-        static_assert(E + 1 <= EPAD && LANES >= 1, "one thread per partial slot and tile-lane");
+        // (workgroups of fewer threads than partial slots -- four waves, k = 4 -- take the slots in passes, one tile-lane)
+        constexpr int EFULL = KD == 4 ? 384 : 128, EPAD = EFULL <= NTHREADS ? EFULL : NTHREADS, LANES = NTHREADS / EPAD;
+        constexpr int NPASS = (EFULL + EPAD - 1) / EPAD;
+        static_assert(E + 1 <= EFULL && LANES >= 1 && (NPASS == 1 || LANES == 1), "one thread per partial slot and tile-lane");
         __shared__ int s_last;
         // Release: every wave's partial stores are performed at workgroup scope before the barrier (they sit in this XCD's
         // L2), then ONE thread makes them visible device-wide (L2 write-back) and takes the ticket.  A device-scope fence
@@ -1197,11 +1212,15 @@ namespace mbavo
             s_last = last;
         }
         __syncthreads();
-        if (!s_last) return;
+        if (!s_last) return false;
         MBAVO_STAMP(2);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int t0 = oa.bf_tile_begin[bf], t1 = oa.bf_tile_begin[bf + 1];
-        const int e = threadIdx.x % EPAD, l = threadIdx.x / EPAD;
+        const bool to_host = oa.host_flag != nullptr;
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass)
+        {
+        const int e = pass * EPAD + threadIdx.x % EPAD, l = threadIdx.x / EPAD;
         const bool mine = l < LANES && e <= E && (WITH_J || e == 0 || e == E);
         double acc = 0.0;
         if (mine)
@@ -1223,17 +1242,17 @@ namespace mbavo
             if (mine && l == 0)
                 for (int j = 1; j < LANES; ++j) acc += scratch[j * EPAD + e];
         }
-        const bool to_host = oa.host_flag != nullptr;
         if (mine && l == 0)
         {
             if (e == 0) { if (oa.valid_out) oa.valid_out[bf] = acc; }
             else if (e == E) oa.frame_blocks[(size_t)bf * E] = acc; // cost: patch costs are already scaled
             else oa.frame_blocks[(size_t)bf * E + e] = acc * inv; // (the caller's copy: the scale may live in host memory)
         }
+        }
         // the frame block (pinned host memory) must land before the completion word does: every wave's stores are performed
         // at workgroup scope before the barrier, ONE thread then fences at system scope (a system-scope fence by all 768
         // threads was 3 of the 4.8 us this epilogue took inside the persistent kernel)
-        if (to_host)
+        if (to_host || oa.lm)
         {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave's frame-block stores are acknowledged
@@ -1241,6 +1260,22 @@ namespace mbavo
         __syncthreads();
         if (threadIdx.x == 0)
         {
+            if (oa.lm)
+            { // the slot's frame block (device memory) is released device-wide before the slot counts as finished; the workgroup
+              // that finishes the LAST slot acquires the others' and goes on as the evaluation's leader (lm_leader)
+                __hip_atomic_store(&oa.tickets[bf], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const int fin = atomicAdd(oa.slots_done, 1) == oa.nbf - 1 ? 1 : 0;
+                if (fin)
+                {
+                    __hip_atomic_store(oa.slots_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                s_last = 1 + fin;
+            }
+            else
+            {
             oa.tickets[bf] = 0; // ready for the next launch (stream order)
             if (to_host) __threadfence_system(); // THIS slot's frame block is on its way to the host before the slot counts as done
             if (to_host && atomicAdd(oa.slots_done, 1) == oa.nbf - 1)
@@ -1254,7 +1289,14 @@ namespace mbavo
 #endif
                 __hip_atomic_store(oa.host_flag, oa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            }
         }
+        if (oa.lm)
+        {
+            __syncthreads();
+            return s_last == 2;
+        }
+        return false;
     }
 
     // ------------------------------------------------------------------ fused kernel, sample-parallel variant
@@ -1266,7 +1308,7 @@ namespace mbavo
     // shuffles in sample order (bit-identical residuals and Huber costs), and the 64 / S finished rows of a wave go
     // through the same MFMA outer product.  The pose entry of a lane is per lane now (vector loads, L1-resident).
 #ifndef MBAVO_SP_WAVES
-#define MBAVO_SP_WAVES 12
+#define MBAVO_SP_WAVES 8 // (12 until round 3: trackFrame 0.422 -> 0.382 ms per frame with 8 -- two waves per SIMD walk their dependent chains faster than three --, 6: 0.381, 4: 0.390; the semi-dense 4-level evaluation 18.2 us with 12 and with 8, 18.7 with 6, 26.0 with 4)
 #endif
     constexpr int kSpWaves = MBAVO_SP_WAVES;
     // LDS of k_fused_sp: the slabs, the cost / valid-count scratch, and -- when it fits the 160 KB -- the frame's S pose
@@ -1295,7 +1337,7 @@ namespace mbavo
 
     // the body of k_fused_sp (one tile of one evaluation); also run, evaluation after evaluation, by the persistent kernel
     template <int KD, bool WITH_J, bool HALF_GRAD, int LOGS, bool ONE, bool PERSIST = false>
-    __device__ __forceinline__ void sp_tile_body(double *lds, const ProblemDesc *__restrict__ descs,
+    __device__ __forceinline__ bool sp_tile_body(double *lds, const ProblemDesc *__restrict__ descs,
                                                  const TileDesc *__restrict__ tiles,
                                                  const PoseEntry<KD> *__restrict__ table,
                                                  double *__restrict__ rho_out,
@@ -1317,7 +1359,7 @@ namespace mbavo
         const int tile_id = xcd_tile_of_block((int)blockIdx.x, (int)gridDim.x);
         const TileDesc tile = tiles[tile_id];
         const ProblemDesc &d = descs[tile.prob];
-        if (d.active != nullptr && (*d.active & (WITH_J ? 2 : 1)) == 0) return; // device-side LM: problem sits this pass out
+        if (d.active != nullptr && (*d.active & (WITH_J ? 2 : 1)) == 0) return false; // device-side LM: problem sits this pass out
         const int S = d.S, K = d.K, P = d.P, frame = tile.frame;
         Camera cam;
         cam.fx = d.fx; cam.fy = d.fy; cam.cx = d.cx; cam.cy = d.cy; cam.H = d.H; cam.W = d.W;
@@ -1535,9 +1577,10 @@ namespace mbavo
             double *scratch = WITH_J ? rows : stage + SS * (int)(sizeof(PoseEntry<KD>) / sizeof(double));
             MBAVO_STAMP(1);
 #if !defined(MBAVO_EXP_ONE_NOTICKET) // timing experiment: no finalize at all
-            ticket_finalize<KD, WITH_J, kThreads>(d, d.bf_base + frame, partials, oa, scratch, inv);
+            return ticket_finalize<KD, WITH_J, kThreads>(d, d.bf_base + frame, partials, oa, scratch, inv);
 #endif
         }
+        return false;
     }
 
     template <int KD, bool WITH_J, bool HALF_GRAD, int LOGS, bool ONE>
@@ -1550,7 +1593,7 @@ namespace mbavo
                                                         double *__restrict__ partials, const OneArgs oa)
     {
         extern __shared__ __attribute__((aligned(16))) double lds[];
-        sp_tile_body<KD, WITH_J, HALF_GRAD, LOGS, ONE>(lds, descs, tiles, table, rho_out, patch_cost, patch_blocks_strided, partials, oa);
+        (void)sp_tile_body<KD, WITH_J, HALF_GRAD, LOGS, ONE>(lds, descs, tiles, table, rho_out, patch_cost, patch_blocks_strided, partials, oa);
     }
 
     // ------------------------------------------------------------------ persistent evaluation (host-driven LM loop)
@@ -1623,10 +1666,350 @@ namespace mbavo
             oa.t_seen = __builtin_amdgcn_s_memrealtime();
 #endif
             if (mode == 2)
-                sp_tile_body<KD, true, false, LOGS, true, true>(lds, descs, tiles, nullptr, rho_out, patch_cost, nullptr, partials, oa, kn, kn + 3 * d0.N);
+                (void)sp_tile_body<KD, true, false, LOGS, true, true>(lds, descs, tiles, nullptr, rho_out, patch_cost, nullptr, partials, oa, kn, kn + 3 * d0.N);
             else
-                sp_tile_body<KD, false, false, LOGS, true, true>(lds, descs, tiles, nullptr, rho_out, patch_cost, nullptr, partials, oa, kn, kn + 3 * d0.N);
+                (void)sp_tile_body<KD, false, false, LOGS, true, true>(lds, descs, tiles, nullptr, rho_out, patch_cost, nullptr, partials, oa, kn, kn + 3 * d0.N);
             __syncthreads(); // LDS (and s_seq / s_mode) are reused by the next command
+        }
+    }
+
+
+    // ------------------------------------------------------------------ resident LM loop of one pyramid level (round 3)
+    // optimizePyramidLevel (ba_tracker/blur_aware_direct_tracker.cpp:590-637) for ONE small problem entirely on the device:
+    // the level's workgroups stay resident as in k_sp_persist, but the commands come from the workgroup that FINISHES an
+    // evaluation (the one that draws the last ticket of the last slot -- the "leader" of that evaluation): its wave 0 does
+    // what the host did between two evaluations -- merge (merge_hessian_gradient_cost.cpp:39-86), damping, solve
+    // (solve_normal_equation.h:10-35), model change, candidate knots (Spline.h:307-330), step quality and accept / reject
+    // (:890-924), outlier statistics (:639-699), LM radius and step-evaluator updates -- and publishes the next evaluation's
+    // knots, residual scale, outlier flags and mode in DEVICE memory, which the other workgroups poll.  The host launches the
+    // levels' kernels back to back (the knots and the trace count are carried from level to level in device memory) and
+    // waits ONCE per tracked frame for the last level's completion word; no PCIe round trip per evaluation (4.4 us of a
+    // 14.4 us evaluation) and no host wake-ups.
+    // Hand-over rules (MI355X: per-XCD L2s, a CU's L1 is never refreshed by other CUs' stores): tile partials, frame blocks
+    // and patch costs go leader-wards as plain stores + agent-scope release / ticket / agent-scope acquire (ticket_finalize);
+    // everything a leader publishes or leaves for the next leader (knots, scale, flag words, LmState, H, g) is written AND
+    // read with 8- / 4-byte agent-scope atomics (write-through stores, cache-bypassing loads), ordered by vmcnt(0) before
+    // the mode and the sequence word -- no cache-wide fence on the command path.
+    struct LmLevelArgs
+    {
+        unsigned long long *seq;   // phase counter, bumped by every leader AFTER everything else of its command is out
+        int *mode;                 // next phase: 0 = exit, 1 = cost-only pass at eval_knots, 2 = H/g pass
+        double *inv;               // 1 / ((K - bad) F P)                 (ProblemDesc::inv_ptr points here)
+        double *eval_knots;        // [7 N] knots of the next evaluation   (t (3N) | R (4N))
+        unsigned *flag_words;      // outlier flags, 4 keypoints per word  (ProblemDesc::outlier points here)
+        unsigned long long *state; // LmState as 8-byte words: leader to leader
+        double *H, *g;             // damped system (n x n, column-major) and gradient: leader to leader
+        double *cur_knots;         // [7 N] accepted point; carried from level to level (the first evaluation's knots)
+        int *carry_ntrace;         // trace records written by the coarser levels
+        const int *start_idx;      // [F] knot segment of every frame
+        double *frame_blocks;      // [F E] finalize output (device)
+        const double *patch_cost;  // [F K] per-patch costs of the last evaluation (device)
+        mbavo_trace_rec *trace;    // pinned host memory, `o.trace_cap` records
+        double *host_out;          // pinned host memory, LAST level only (else null): [knots 7N | final cost | ntrace | status]
+        unsigned long long *host_flag; unsigned long long host_seq; // completion word of the last level
+        LmOpts o;
+        int level, N, F, K, P;
+    };
+
+    __device__ __forceinline__ double ld_fresh(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void st_fresh(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+    // wave 0 of the leader workgroup, all 64 lanes.  mode_done: the evaluation that has just completed (2 = H/g, 1 = cost).
+    template <int KD>
+    __device__ __forceinline__ void lm_leader(const LmLevelArgs &a, int mode_done, unsigned long long seq_now, double *lds, int lane)
+    {
+        constexpr int M6 = 6 * KD, ND = M6 + 1, E = ND * (ND + 1) / 2;
+        const int N = a.N, n = 6 * N, F = a.F, ld = n + 1;
+        // LDS (the tile's row slabs are free now): H | g | x | tmp | y | order | G (also the LDL^T work copy) | V
+        double *H = lds, *g = H + n * n, *x = g + n, *tmp = x + n, *y = tmp + n;
+        int *order = (int *)(y + n);
+        double *G = y + n + (n + 1) / 2 + 1, *V = G + n * ld;
+        const LmOpts &o = a.o;
+        LmState s;
+        {
+            unsigned long long *w = (unsigned long long *)&s;
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(LmState) / 8); ++i) w[i] = __hip_atomic_load(a.state + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (s.ntrace < 0) s.ntrace = *a.carry_ntrace; // first leader of the level: the coarser levels' count (kernel boundary)
+        const double *fb = a.frame_blocks;
+        double cost = 0.0;
+        for (int f = 0; f < F; ++f) cost += fb[(size_t)f * E];
+        int next_mode = -1;
+        bool solve = false;
+        if (mode_done == 2)
+        { // the H/g pass at the current point has completed: its cost is the evaluation-point cost
+            s.eval_cost = cost;
+            if (s.pending_accept)
+            { // handleSuccessfulStep (:896-903)
+                lm_accepted(s, s.quality);
+                tr_accepted(s, s.eval_cost, s.model, o.max_nonmono);
+                trace_push(s, a.trace, o.trace_cap, lane, a.level, 1, s.cand_cost, s.model, s.quality);
+                ++s.n_accept;
+            }
+            else
+            { // iteration 0 of the level (:590-606)
+                s.initial_cost = cost;
+                lm_reset(s);
+                tr_reset(s, cost);
+                trace_push(s, a.trace, o.trace_cap, lane, a.level, 0, 0.0, 0.0, 0.0);
+            }
+            // merge_hessian_gradient_cost.cpp:39-86, frames in order
+            for (int i = lane; i < n * n; i += 64) H[i] = 0.0;
+            for (int i = lane; i < n; i += 64) g[i] = 0.0;
+            MBAVO_SOLVER_SYNC();
+            for (int f = 0; f < F; ++f)
+            {
+                const double *blk = fb + (size_t)f * E;
+                const int st = a.start_idx[f];
+                for (int j = lane; j < M6; j += 64)
+                {
+                    const int gi = j < 3 * KD ? 3 * st + j : 3 * (N + st) + (j - 3 * KD);
+                    g[gi] += blk[1 + j];
+                }
+                for (int e = lane; e < M6 * (M6 + 1) / 2; e += 64)
+                {
+                    int r, c;
+                    tri_decode(e, M6, r, c);
+                    const int R = r < 3 * KD ? 3 * st + r : 3 * (N + st) + (r - 3 * KD);
+                    const int C = c < 3 * KD ? 3 * st + c : 3 * (N + st) + (c - 3 * KD);
+                    const double v = blk[ND + e];
+                    H[C * n + R] += v;
+                    if (R != C) H[R * n + C] += v;
+                }
+                MBAVO_SOLVER_SYNC();
+            }
+            for (int i = lane; i < n; i += 64) st_fresh(a.g + i, g[i]);
+            s.fresh = 0;
+            s.pending_accept = 0;
+            solve = true;
+        }
+        else
+        { // the cost-only pass at the candidate: step quality, accept / reject (k_lm_decide)
+            s.cand_cost = cost;
+            s.abs_dec = s.eval_cost - s.cand_cost; // recorded before the accept test (:624)
+            s.quality = tr_quality(s, s.cand_cost, s.model);
+            if (s.quality > o.min_q && s.cand_cost < s.eval_cost)
+            { // isStepSuccessful (:890-894) -> detectOutliersAndUploadToGpu (:639-699): patch costs of frame 0
+                const double *pc = a.patch_cost;
+                const int K = a.K;
+                double sum = 0.0, cnt = 0.0;
+                for (int i = lane; i < K; i += 64)
+                {
+                    const double c = pc[i];
+                    if (c < 1e-8) continue;
+                    sum += c;
+                    cnt += 1.0;
+                }
+                sum = wsum(sum);
+                cnt = wsum(cnt);
+                const double mu = sum / cnt;
+                double var = 0.0;
+                for (int i = lane; i < K; i += 64)
+                {
+                    const double c = pc[i];
+                    if (c < 1e-8) continue;
+                    var += (c - mu) * (c - mu);
+                }
+                var = wsum(var) / cnt;
+                const double bound = o.chi * (double)sqrtf((float)var);
+                double nbad = 0.0;
+                for (int w0 = lane; w0 * 4 < K; w0 += 64)
+                { // four keypoints per flag word; flags are only ever set within a level (:686-693)
+                    unsigned word = __hip_atomic_load(a.flag_words + w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), add = 0;
+                    for (int j = 0; j < 4; ++j)
+                    {
+                        const int i = 4 * w0 + j;
+                        if (i < K && fabs(pc[i] - mu) > bound) { add |= 1u << (8 * j); nbad += 1.0; }
+                    }
+                    if (add) __hip_atomic_store(a.flag_words + w0, (word & 0xfefefefeu) | add | (word & 0x01010101u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                s.num_bad = (int)wsum(nbad);
+                const long long num_residuals = (long long)(K - s.num_bad) * F * a.P;
+                if (lane == 0) st_fresh(a.inv, num_residuals > 0 ? 1.0 / (double)num_residuals : 0.0);
+                // accept: the candidate (= the knots just evaluated) becomes the current point, the next pass re-evaluates H/g there
+                for (int i = lane; i < 7 * N; i += 64) st_fresh(a.cur_knots + i, ld_fresh(a.eval_knots + i));
+                s.fresh = 1;
+                s.pending_accept = 1;
+                next_mode = 2;
+            }
+            else
+            {
+                lm_rejected(s); // handleUnsuccessfulStep
+                trace_push(s, a.trace, o.trace_cap, lane, a.level, 2, s.cand_cost, s.model, s.quality);
+                ++s.n_reject;
+                for (int i = lane; i < n * n; i += 64) H[i] = ld_fresh(a.H + i);
+                for (int i = lane; i < n; i += 64) g[i] = ld_fresh(a.g + i);
+                MBAVO_SOLVER_SYNC();
+                solve = true;
+            }
+        }
+        bool damped = false;
+        while (solve)
+        {
+            // finalizeIterationAndCheckIfMinimizerCanContinue (:910-924)
+            ++s.iter;
+            if (s.iter > o.max_it || s.abs_dec < o.min_dec)
+            {
+                s.done = 1;
+                --s.iter;
+                next_mode = 0;
+                break;
+            }
+            // computeTrustRegionStep (:799-831): the damping is applied in place and accumulates over rejected steps
+            const double iradius = 1. / s.radius;
+            for (int i = lane; i < n; i += 64) H[i * n + i] = H[i * n + i] + H[i * n + i] * iradius;
+            damped = true;
+            MBAVO_SOLVER_SYNC();
+            bool have = false;
+            if (o.solver == 1 || o.fast_ratio > 0.0)
+            { // pivoted LDL^T: solver 1 as is; solver 0 when every pivot is positive and the pivot ratio small (host_math.cpp:solve_spd_fast)
+                for (int i = lane; i < n * n; i += 64) G[i] = H[i];
+                MBAVO_SOLVER_SYNC();
+                ldlt_solve(G, g, x, y, order, n, lane);
+                have = o.solver == 1;
+                if (!have)
+                {
+                    double dmax = 0.0, dmin = DBL_MAX;
+                    bool pos = true;
+                    for (int i = 0; i < n; ++i)
+                    {
+                        const double dd = G[i * n + i];
+                        pos = pos && dd > 0.0;
+                        dmax = fmax(dmax, dd);
+                        dmin = fmin(dmin, dd);
+                    }
+                    have = pos && dmax <= o.fast_ratio * dmin;
+                }
+                MBAVO_SOLVER_SYNC();
+            }
+            if (!have)
+            {
+                for (int i = lane; i < n * n; i += 64) G[(i / n) * ld + i % n] = H[i];
+                MBAVO_SOLVER_SYNC();
+                svd_solve(G, V, g, x, tmp, n, ld, lane);
+            }
+            for (int i = lane; i < n; i += 64) x[i] = -x[i];
+            MBAVO_SOLVER_SYNC();
+            double gx = 0.0, xHx = 0.0;
+            for (int r = lane; r < n; r += 64)
+            {
+                gx += g[r] * x[r];
+                double acc = 0.0;
+                for (int c = 0; c < n; ++c) acc += H[c * n + r] * x[c];
+                xHx += x[r] * acc;
+            }
+            gx = wsum(gx);
+            xHx = wsum(xHx);
+            s.model = -(gx + 0.5 * xHx);
+            if (s.model < 0)
+            { // handleInvalidStep
+                lm_rejected(s);
+                trace_push(s, a.trace, o.trace_cap, lane, a.level, 3, 0.0, s.model, 0.0);
+                ++s.n_invalid;
+                continue;
+            }
+            // computeCandidatePointAndEvaluateCost (:833-883): candidate = current (+) step
+            for (int i = lane; i < 3 * N; i += 64) st_fresh(a.eval_knots + i, ld_fresh(a.cur_knots + i) + x[i]);
+            for (int i = lane; i < N; i += 64)
+            {
+                const double *cr = a.cur_knots + 3 * N + 4 * i;
+                const Quat c0{ld_fresh(cr), ld_fresh(cr + 1), ld_fresh(cr + 2), ld_fresh(cr + 3)};
+                const Quat q = qmul(c0, so3_exp(x + 3 * N + 3 * i)); // Spline.h:317-330, not re-normalised
+                double *wr = a.eval_knots + 3 * N + 4 * i;
+                st_fresh(wr, q.x); st_fresh(wr + 1, q.y); st_fresh(wr + 2, q.z); st_fresh(wr + 3, q.w);
+            }
+            next_mode = 1;
+            break;
+        }
+        if (damped && next_mode == 1) // (the next leader re-damps and re-solves only after a rejected candidate)
+            for (int i = lane; i < n * n; i += 64) st_fresh(a.H + i, H[i]);
+        {
+            const unsigned long long *w = (const unsigned long long *)&s;
+            if (lane < (int)(sizeof(LmState) / 8)) __hip_atomic_store(a.state + lane, w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (next_mode == 0)
+        { // the level is over: the accepted point stays in cur_knots for the next level; the last level reports to the host
+            if (lane == 0) __hip_atomic_store(a.carry_ntrace, s.ntrace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.host_out)
+            {
+                for (int i = lane; i < 7 * N; i += 64) a.host_out[i] = ld_fresh(a.cur_knots + i);
+                if (lane == 0)
+                {
+                    a.host_out[7 * N] = s.eval_cost;
+                    a.host_out[7 * N + 1] = (double)s.ntrace;
+                    a.host_out[7 * N + 2] = 1.0;
+                }
+            }
+        }
+        // everything of this command is out (write-through stores acknowledged) before the mode, the mode before the sequence word
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+        {
+            __hip_atomic_store(a.mode, next_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(a.seq, seq_now + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (next_mode == 0 && a.host_flag)
+            {
+                __threadfence_system(); // host_out and the trace records (pinned host memory) ahead of the completion word
+                __hip_atomic_store(a.host_flag, a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+
+    template <int KD, int LOGS>
+    __global__ __launch_bounds__((kSpWaves * 64)) void k_lm_level(const ProblemDesc *__restrict__ descs, const TileDesc *__restrict__ tiles,
+                                                                double *__restrict__ rho_out, double *__restrict__ patch_cost,
+                                                                double *__restrict__ partials, OneArgs oa, LmLevelArgs a)
+    {
+        extern __shared__ __attribute__((aligned(16))) double lds[];
+        __shared__ unsigned long long s_seq;
+        __shared__ int s_mode;
+        __shared__ double knots_lds[7 * 16];
+        unsigned long long last_seq = 0; // (the control block's sequence word starts at 0: the first evaluation needs no command)
+        int mode = 2;
+        const int N = a.N;
+        for (bool first = true;; first = false)
+        {
+            if (!first)
+            {
+                if (threadIdx.x == 0)
+                {
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    unsigned long long q;
+                    int m = 0;
+                    for (;;)
+                    {
+                        q = __hip_atomic_load(a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (q != last_seq)
+                        {
+                            m = __hip_atomic_load(a.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) { m = 0; break; } // ~1 s without a command: give up
+                        __builtin_amdgcn_s_sleep(MBAVO_PERSIST_SLEEP);
+                    }
+                    s_seq = q;
+                    s_mode = m;
+                }
+                __syncthreads();
+                mode = s_mode;
+                last_seq = s_seq;
+                if (mode == 0) return;
+                asm volatile("" ::: "memory");
+            }
+            double *kn = knots_lds;
+            const double *src = first ? a.cur_knots : a.eval_knots;
+            for (int i = threadIdx.x; i < 7 * N; i += kSpWaves * 64) kn[i] = ld_fresh(src + i);
+            __syncthreads();
+            oa.seq = last_seq;
+            bool leader;
+            if (mode == 2)
+                leader = sp_tile_body<KD, true, false, LOGS, true, true>(lds, descs, tiles, nullptr, rho_out, patch_cost, nullptr, partials, oa, kn, kn + 3 * N);
+            else
+                leader = sp_tile_body<KD, false, false, LOGS, true, true>(lds, descs, tiles, nullptr, rho_out, patch_cost, nullptr, partials, oa, kn, kn + 3 * N);
+            if (leader && threadIdx.x < 64) lm_leader<KD>(a, mode, last_seq, lds, (int)threadIdx.x);
+            __syncthreads(); // LDS (and s_seq / s_mode) are reused by the next phase
         }
     }
 

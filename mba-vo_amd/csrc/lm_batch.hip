@@ -20,6 +20,7 @@
 #include "pixel_math.h"
 #include "se3_math.h"
 #include "lm_solvers.h"
+#include "lm_state.h"
 
 #include <cfloat>
 #include <cmath>
@@ -29,88 +30,6 @@
 
 namespace mbavo
 {
-    struct LmState
-    {
-        double radius, decrease_factor;                                                        // LM strategy
-        double minimum_cost, current_cost, reference_cost, candidate_cost, acc_ref, acc_cand;  // step evaluator
-        double eval_cost, cand_cost, model, abs_dec, quality, initial_cost;
-        int num_nonmono, iter, done, fresh, pending_accept, num_bad, n_accept, n_reject, n_invalid, ntrace;
-    };
-
-    struct LmOpts
-    {
-        int max_it, max_nonmono, solver, trace_cap, max_n, max_N;
-        double min_q, min_dec, chi;
-    };
-
-    namespace
-    {
-        __device__ void lm_clamp(LmState &s) { s.radius = fmax(fmin(1e32, s.radius), 10.0); }
-        __device__ void lm_reset(LmState &s) { s.radius = 1e4; s.decrease_factor = 2.0; }
-        __device__ void lm_accepted(LmState &s, double q)
-        {
-            s.radius = s.radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * q - 1.0, 3.0));
-            lm_clamp(s);
-            s.decrease_factor = 2.0;
-        }
-        __device__ void lm_rejected(LmState &s)
-        {
-            s.radius = s.radius / s.decrease_factor;
-            lm_clamp(s);
-            s.decrease_factor *= 2.0;
-        }
-        __device__ void tr_reset(LmState &s, double c)
-        {
-            s.minimum_cost = s.current_cost = s.reference_cost = s.candidate_cost = c;
-            s.acc_ref = s.acc_cand = 0.0;
-            s.num_nonmono = 0;
-        }
-        __device__ double tr_quality(const LmState &s, double cost, double mcc)
-        {
-            if (cost >= DBL_MAX) return -DBL_MAX;
-            const double now = (s.current_cost - cost) / mcc;
-            const double hist = (s.reference_cost - cost) / (s.acc_ref + mcc);
-            return fmax(now, hist);
-        }
-        __device__ void tr_accepted(LmState &s, double cost, double mcc, int max_nonmono)
-        {
-            s.current_cost = cost;
-            s.acc_cand += mcc;
-            s.acc_ref += mcc;
-            if (s.current_cost < s.minimum_cost)
-            {
-                s.minimum_cost = s.candidate_cost = s.current_cost;
-                s.num_nonmono = 0;
-                s.acc_cand = 0.0;
-            }
-            else
-            {
-                ++s.num_nonmono;
-                if (s.current_cost > s.candidate_cost)
-                {
-                    s.candidate_cost = s.current_cost;
-                    s.acc_cand = 0.0;
-                }
-            }
-            if (s.num_nonmono == max_nonmono)
-            {
-                s.reference_cost = s.candidate_cost;
-                s.acc_ref = s.acc_cand;
-            }
-        }
-        __device__ void trace_push(LmState &s, mbavo_trace_rec *trace, int cap, int lane, int kind, double cc, double model, double q)
-        {
-            if (trace && s.ntrace < cap && lane == 0)
-            {
-                mbavo_trace_rec &r = trace[s.ntrace];
-                r.level = 0; r.iter = s.iter; r.kind = kind; r.num_outliers = s.num_bad;
-                r.radius = s.radius; r.eval_cost = s.eval_cost; r.candidate_cost = cc; r.model_change = model; r.quality = q;
-            }
-            ++s.ntrace;
-        }
-
-    } // namespace
-
     // One wave per problem: finish the previous accepted step, loop control, damping, solve, model change, candidate.
     template <int KD>
     __global__ __launch_bounds__(64) void k_lm_solve(const ProblemDesc *__restrict__ descs, LmState *__restrict__ states, LmOpts o,
@@ -145,7 +64,7 @@ namespace mbavo
             { // handleSuccessfulStep (:896-903)
                 lm_accepted(s, s.quality);
                 tr_accepted(s, s.eval_cost, s.model, o.max_nonmono);
-                trace_push(s, tr, o.trace_cap, lane, 1, s.cand_cost, s.model, s.quality);
+                trace_push(s, tr, o.trace_cap, lane, 0, 1, s.cand_cost, s.model, s.quality);
                 ++s.n_accept;
             }
             else
@@ -153,7 +72,7 @@ namespace mbavo
                 s.initial_cost = cost;
                 lm_reset(s);
                 tr_reset(s, cost);
-                trace_push(s, tr, o.trace_cap, lane, 0, 0.0, 0.0, 0.0);
+                trace_push(s, tr, o.trace_cap, lane, 0, 0, 0.0, 0.0, 0.0);
             }
             // merge_hessian_gradient_cost.cpp:39-86, frames in order
             for (int i = lane; i < n * n; i += 64) H[i] = 0.0;
@@ -248,7 +167,7 @@ namespace mbavo
         if (s.model < 0)
         { // handleInvalidStep
             lm_rejected(s);
-            trace_push(s, tr, o.trace_cap, lane, 3, 0.0, s.model, 0.0);
+            trace_push(s, tr, o.trace_cap, lane, 0, 3, 0.0, s.model, 0.0);
             ++s.n_invalid;
             if (lane == 0) { active[b] = 0; states[b] = s; }
             return;
@@ -327,7 +246,7 @@ namespace mbavo
             return;
         }
         lm_rejected(s); // handleUnsuccessfulStep
-        trace_push(s, tr, o.trace_cap, lane, 2, s.cand_cost, s.model, s.quality);
+        trace_push(s, tr, o.trace_cap, lane, 0, 2, s.cand_cost, s.model, s.quality);
         ++s.n_reject;
         if (lane == 0) { active[b] = 0; states[b] = s; }
     }
@@ -386,6 +305,7 @@ namespace mbavo
         o.max_it = opt.max_num_iterations; o.max_nonmono = opt.max_consecutive_nonmonotonic_steps; o.solver = opt.solver_type;
         o.trace_cap = trace ? trace_cap : 0; o.max_n = max_n; o.max_N = max_N;
         o.min_q = opt.min_step_quality; o.min_dec = opt.min_abs_cost_decrease; o.chi = opt.max_chi_square_error;
+        o.fast_ratio = 0.0;
         const size_t lds = ((size_t)2 * max_n * (max_n + 1) + 6 * max_n) * sizeof(double) + (size_t)max_n * sizeof(int);
         if (lds > 160 * 1024) return MBAVO_E_ARG;
 

@@ -50,6 +50,13 @@
 #define MBAVO_LDLT_FN MBAVO_SOLVER_FN
 #endif
 
+// The solvers are written for ONE wave; between their steps the wave's LDS writes must be visible to its other lanes.
+// In a one-wave workgroup (lm_batch.hip, the solver check) that is a workgroup barrier; a wave working alone inside a larger
+// workgroup (the resident LM kernel of engine.hip) defines MBAVO_SOLVER_SYNC as a wave-level fence before including this.
+#ifndef MBAVO_SOLVER_SYNC
+#define MBAVO_SOLVER_SYNC() __syncthreads()
+#endif
+
 namespace mbavo
 {
     namespace
@@ -134,7 +141,7 @@ namespace mbavo
                             }
                         }
                     }
-                    __syncthreads();
+                    MBAVO_SOLVER_SYNC();
                 }
                 if (__ballot(rotated) == 0ull) return true;
             }
@@ -144,7 +151,7 @@ namespace mbavo
         MBAVO_SVD_FN void svd_solve(double *G, double *V, const double *b, double *x, double *tmp, int n, int ld, int lane)
         {
             for (int i = lane; i < n * n; i += 64) V[(i / n) * ld + i % n] = (i / n == i % n) ? 1.0 : 0.0;
-            __syncthreads();
+            MBAVO_SOLVER_SYNC();
             const double eps = DBL_EPSILON;
             // lanes per column pair: as many as fit the wave and have a six-row group to work on
             const int half = n / 2, N6 = n / 6;
@@ -173,7 +180,7 @@ namespace mbavo
                 }
                 tmp[j] = dot;
             }
-            __syncthreads();
+            MBAVO_SOLVER_SYNC();
             for (int i = lane; i < n; i += 64)
             {
                 double acc = 0.0;
@@ -181,14 +188,14 @@ namespace mbavo
                     if (tmp[j] != 0.0) acc += V[j * ld + i] * tmp[j];
                 x[i] = acc;
             }
-            __syncthreads();
+            MBAVO_SOLVER_SYNC();
         }
 
         // x = A^-1 b by LDL^T with diagonal pivoting (host_math.cpp:solve_ldlt); M holds A on entry
         MBAVO_LDLT_FN void ldlt_solve(double *M, const double *b, double *x, double *y, int *order, int n, int lane)
         {
             for (int i = lane; i < n; i += 64) order[i] = i;
-            __syncthreads();
+            MBAVO_SOLVER_SYNC();
             for (int k = 0; k < n; ++k)
             {
                 // pivot: the largest |diagonal| of the trailing block, the first one on ties
@@ -211,49 +218,49 @@ namespace mbavo
                 if (piv != k)
                 {
                     for (int c = lane; c < n; c += 64) { const double t = M[c * n + k]; M[c * n + k] = M[c * n + piv]; M[c * n + piv] = t; }
-                    __syncthreads();
+                    MBAVO_SOLVER_SYNC();
                     for (int r = lane; r < n; r += 64) { const double t = M[k * n + r]; M[k * n + r] = M[piv * n + r]; M[piv * n + r] = t; }
                     if (lane == 0) { const int t = order[k]; order[k] = order[piv]; order[piv] = t; }
-                    __syncthreads();
+                    MBAVO_SOLVER_SYNC();
                 }
                 const double d = M[k * n + k];
                 if (d == 0.0) continue;
                 for (int i = k + 1 + lane; i < n; i += 64) M[k * n + i] /= d; // column k of L
-                __syncthreads();
+                MBAVO_SOLVER_SYNC();
                 const int m = n - k - 1;
                 for (int idx = lane; idx < m * m; idx += 64)
                 { // lower triangle of the trailing block in place (each entry reads itself and column k only) ...
                     const int i = k + 1 + idx / m, j = k + 1 + idx % m;
                     if (i >= j) M[j * n + i] -= M[k * n + i] * (M[k * n + j] * d);
                 }
-                __syncthreads();
+                MBAVO_SOLVER_SYNC();
                 for (int idx = lane; idx < m * m; idx += 64)
                 { // ... then mirrored, so that later pivots see a full symmetric block
                     const int i = k + 1 + idx / m, j = k + 1 + idx % m;
                     if (i > j) M[i * n + j] = M[j * n + i];
                 }
-                __syncthreads();
+                MBAVO_SOLVER_SYNC();
             }
             for (int i = lane; i < n; i += 64) y[i] = b[order[i]];
-            __syncthreads();
+            MBAVO_SOLVER_SYNC();
             for (int c = 0; c < n; ++c)
             {
                 const double yc = y[c];
                 for (int r = c + 1 + lane; r < n; r += 64) y[r] -= M[c * n + r] * yc;
-                __syncthreads();
+                MBAVO_SOLVER_SYNC();
             }
             for (int i = lane; i < n; i += 64) y[i] = fabs(M[i * n + i]) > DBL_MIN ? y[i] / M[i * n + i] : 0.0;
-            __syncthreads();
+            MBAVO_SOLVER_SYNC();
             for (int c = n - 1; c >= 0; --c)
             {
                 double part = 0.0;
                 for (int r = c + 1 + lane; r < n; r += 64) part += M[c * n + r] * y[r];
                 part = wsum(part);
                 if (lane == 0) y[c] -= part;
-                __syncthreads();
+                MBAVO_SOLVER_SYNC();
             }
             for (int i = lane; i < n; i += 64) x[order[i]] = y[i];
-            __syncthreads();
+            MBAVO_SOLVER_SYNC();
         }
     } // namespace
 } // namespace mbavo
