@@ -1264,13 +1264,17 @@ namespace mbavo
             { // the slot's frame block (device memory) is released device-wide before the slot counts as finished; the workgroup
               // that finishes the LAST slot acquires the others' and goes on as the evaluation's leader (lm_leader)
                 __hip_atomic_store(&oa.tickets[bf], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const int fin = atomicAdd(oa.slots_done, 1) == oa.nbf - 1 ? 1 : 0;
-                if (fin)
+                int fin = 1; // one slot (one frame): its last workgroup IS the leader and reads its own block back through the L2
+                if (oa.nbf > 1)
                 {
-                    __hip_atomic_store(oa.slots_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    fin = atomicAdd(oa.slots_done, 1) == oa.nbf - 1 ? 1 : 0;
+                    if (fin)
+                    {
+                        __hip_atomic_store(oa.slots_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
                 }
                 s_last = 1 + fin;
             }
@@ -1709,15 +1713,31 @@ namespace mbavo
         unsigned long long *host_flag; unsigned long long host_seq; // completion word of the last level
         LmOpts o;
         int level, N, F, K, P;
+        unsigned long long *stamps; // (timing experiment MBAVO_LM_STAMPS) [last publish | sum evaluation | sum leader | phases | first entry], 100 MHz ticks
     };
 
     __device__ __forceinline__ double ld_fresh(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ __forceinline__ void st_fresh(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
     // wave 0 of the leader workgroup, all 64 lanes.  mode_done: the evaluation that has just completed (2 = H/g, 1 = cost).
+    // (a real call, its arguments behind one pointer: inlined into the resident kernel it drove that kernel to 56-113 vector
+    // spills and ~300 scalar spills -- the tile body runs at the 256-register budget of two waves per SIMD already)
+#if defined(MBAVO_LM_LEADER_INLINE)
+#define MBAVO_LM_LEADER_FN __device__ __forceinline__
+#else
+#define MBAVO_LM_LEADER_FN __device__ __noinline__
+#endif
     template <int KD>
-    __device__ __forceinline__ void lm_leader(const LmLevelArgs &a, int mode_done, unsigned long long seq_now, double *lds, int lane)
+    MBAVO_LM_LEADER_FN void lm_leader(const LmLevelArgs *__restrict__ ap, int mode_done, unsigned long long seq_now, double *lds, int lane)
     {
+        const LmLevelArgs &a = *ap;
+#if defined(MBAVO_LM_STAMPS)
+        const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+        unsigned long long t_seg[5] = {t_in, t_in, t_in, t_in, t_in};
+#define MBAVO_LM_SEG(i) t_seg[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define MBAVO_LM_SEG(i) do { } while (0)
+#endif
         constexpr int M6 = 6 * KD, ND = M6 + 1, E = ND * (ND + 1) / 2;
         const int N = a.N, n = 6 * N, F = a.F, ld = n + 1;
         // LDS (the tile's row slabs are free now): H | g | x | tmp | y | order | G (also the LDL^T work copy) | V
@@ -1732,11 +1752,12 @@ namespace mbavo
             for (int i = 0; i < (int)(sizeof(LmState) / 8); ++i) w[i] = __hip_atomic_load(a.state + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (s.ntrace < 0) s.ntrace = *a.carry_ntrace; // first leader of the level: the coarser levels' count (kernel boundary)
-        const double *fb = a.frame_blocks;
+        const double *fb = a.frame_blocks; // (cache-bypassing loads: the blocks were stored by this or by other workgroups)
         double cost = 0.0;
-        for (int f = 0; f < F; ++f) cost += fb[(size_t)f * E];
+        for (int f = 0; f < F; ++f) cost += ld_fresh(fb + (size_t)f * E);
         int next_mode = -1;
         bool solve = false;
+        MBAVO_LM_SEG(1); // state and cost loaded
         if (mode_done == 2)
         { // the H/g pass at the current point has completed: its cost is the evaluation-point cost
             s.eval_cost = cost;
@@ -1765,7 +1786,7 @@ namespace mbavo
                 for (int j = lane; j < M6; j += 64)
                 {
                     const int gi = j < 3 * KD ? 3 * st + j : 3 * (N + st) + (j - 3 * KD);
-                    g[gi] += blk[1 + j];
+                    g[gi] += ld_fresh(blk + 1 + j);
                 }
                 for (int e = lane; e < M6 * (M6 + 1) / 2; e += 64)
                 {
@@ -1773,7 +1794,7 @@ namespace mbavo
                     tri_decode(e, M6, r, c);
                     const int R = r < 3 * KD ? 3 * st + r : 3 * (N + st) + (r - 3 * KD);
                     const int C = c < 3 * KD ? 3 * st + c : 3 * (N + st) + (c - 3 * KD);
-                    const double v = blk[ND + e];
+                    const double v = ld_fresh(blk + ND + e);
                     H[C * n + R] += v;
                     if (R != C) H[R * n + C] += v;
                 }
@@ -1845,6 +1866,7 @@ namespace mbavo
             }
         }
         bool damped = false;
+        MBAVO_LM_SEG(2); // merged / decided
         while (solve)
         {
             // finalizeIterationAndCheckIfMinimizerCanContinue (:910-924)
@@ -1862,26 +1884,20 @@ namespace mbavo
             damped = true;
             MBAVO_SOLVER_SYNC();
             bool have = false;
-            if (o.solver == 1 || o.fast_ratio > 0.0)
-            { // pivoted LDL^T: solver 1 as is; solver 0 when every pivot is positive and the pivot ratio small (host_math.cpp:solve_spd_fast)
+            if (o.solver == 0 && o.fast_ratio > 0.0)
+            { // LDL^T in registers stands in for the Jacobi SVD when every pivot is positive and the pivot ratio small
+              // (host_math.cpp:solve_spd_fast is the host loop's twin)
+                if (n == 12) have = spd_solve_regs<12>(H, g, x, lane, o.fast_ratio);
+                else if (n == 18) have = spd_solve_regs<18>(H, g, x, lane, o.fast_ratio);
+                else if (n == 24) have = spd_solve_regs<24>(H, g, x, lane, o.fast_ratio);
+                MBAVO_SOLVER_SYNC();
+            }
+            else if (o.solver == 1)
+            { // pivoted LDL^T (solve_normal_equation.h:27-30)
                 for (int i = lane; i < n * n; i += 64) G[i] = H[i];
                 MBAVO_SOLVER_SYNC();
                 ldlt_solve(G, g, x, y, order, n, lane);
-                have = o.solver == 1;
-                if (!have)
-                {
-                    double dmax = 0.0, dmin = DBL_MAX;
-                    bool pos = true;
-                    for (int i = 0; i < n; ++i)
-                    {
-                        const double dd = G[i * n + i];
-                        pos = pos && dd > 0.0;
-                        dmax = fmax(dmax, dd);
-                        dmin = fmin(dmin, dd);
-                    }
-                    have = pos && dmax <= o.fast_ratio * dmin;
-                }
-                MBAVO_SOLVER_SYNC();
+                have = true;
             }
             if (!have)
             {
@@ -1922,6 +1938,7 @@ namespace mbavo
             next_mode = 1;
             break;
         }
+        MBAVO_LM_SEG(3); // solved
         if (damped && next_mode == 1) // (the next leader re-damps and re-solves only after a rejected candidate)
             for (int i = lane; i < n * n; i += 64) st_fresh(a.H + i, H[i]);
         {
@@ -1942,6 +1959,31 @@ namespace mbavo
                 }
             }
         }
+#if defined(MBAVO_LM_STAMPS)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MBAVO_LM_SEG(4); // state / H / outputs stored and acknowledged
+        if (lane == 0)
+        {
+            unsigned long long st[12];
+            for (int i = 0; i < 12; ++i) st[i] = __hip_atomic_load(a.stamps + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long t_out = __builtin_amdgcn_s_memrealtime();
+            if (st[0]) st[1] += t_in - st[0]; else st[4] = t_in;
+            st[2] += t_out - t_in;
+            st[3] += 1;
+            st[0] = t_out;
+            for (int i = 0; i < 4; ++i) st[5 + i] += t_seg[i + 1] - t_seg[i];
+            if (mode_done == 2) { st[9] += t_out - t_in; st[10] += 1; }
+            for (int i = 0; i < 12; ++i) __hip_atomic_store(a.stamps + i, st[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (next_mode == 0 && a.host_out)
+            {
+                a.host_out[7 * N + 3] = (double)st[1] * 0.01;
+                a.host_out[7 * N + 4] = (double)st[2] * 0.01;
+                a.host_out[7 * N + 5] = (double)st[3];
+                a.host_out[7 * N + 6] = (double)(t_out - st[4]) * 0.01;
+                for (int i = 0; i < 6; ++i) a.host_out[7 * N + 7 + i] = (double)st[5 + i] * (i == 5 ? 1.0 : 0.01);
+            }
+        }
+#endif
         // everything of this command is out (write-through stores acknowledged) before the mode, the mode before the sequence word
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0)
@@ -1960,7 +2002,8 @@ namespace mbavo
     template <int KD, int LOGS>
     __global__ __launch_bounds__((kSpWaves * 64)) void k_lm_level(const ProblemDesc *__restrict__ descs, const TileDesc *__restrict__ tiles,
                                                                 double *__restrict__ rho_out, double *__restrict__ patch_cost,
-                                                                double *__restrict__ partials, OneArgs oa, LmLevelArgs a)
+                                                                double *__restrict__ partials, OneArgs oa,
+                                                                const LmLevelArgs *__restrict__ ap)
     {
         extern __shared__ __attribute__((aligned(16))) double lds[];
         __shared__ unsigned long long s_seq;
@@ -1968,7 +2011,7 @@ namespace mbavo
         __shared__ double knots_lds[7 * 16];
         unsigned long long last_seq = 0; // (the control block's sequence word starts at 0: the first evaluation needs no command)
         int mode = 2;
-        const int N = a.N;
+        const int N = ap->N;
         for (bool first = true;; first = false)
         {
             if (!first)
@@ -1980,10 +2023,10 @@ namespace mbavo
                     int m = 0;
                     for (;;)
                     {
-                        q = __hip_atomic_load(a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        q = __hip_atomic_load(ap->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (q != last_seq)
                         {
-                            m = __hip_atomic_load(a.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            m = __hip_atomic_load(ap->mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;
                         }
                         if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) { m = 0; break; } // ~1 s without a command: give up
@@ -1999,7 +2042,7 @@ namespace mbavo
                 asm volatile("" ::: "memory");
             }
             double *kn = knots_lds;
-            const double *src = first ? a.cur_knots : a.eval_knots;
+            const double *src = first ? ap->cur_knots : ap->eval_knots;
             for (int i = threadIdx.x; i < 7 * N; i += kSpWaves * 64) kn[i] = ld_fresh(src + i);
             __syncthreads();
             oa.seq = last_seq;
@@ -2008,7 +2051,7 @@ namespace mbavo
                 leader = sp_tile_body<KD, true, false, LOGS, true, true>(lds, descs, tiles, nullptr, rho_out, patch_cost, nullptr, partials, oa, kn, kn + 3 * N);
             else
                 leader = sp_tile_body<KD, false, false, LOGS, true, true>(lds, descs, tiles, nullptr, rho_out, patch_cost, nullptr, partials, oa, kn, kn + 3 * N);
-            if (leader && threadIdx.x < 64) lm_leader<KD>(a, mode, last_seq, lds, (int)threadIdx.x);
+            if (leader && threadIdx.x < 64) lm_leader<KD>(ap, mode, last_seq, lds, (int)threadIdx.x);
             __syncthreads(); // LDS (and s_seq / s_mode) are reused by the next phase
         }
     }
@@ -2731,6 +2774,203 @@ namespace mbavo
         }
         flag_pending_ = false;
         return (int)hipStreamSynchronize(stream_);
+    }
+
+
+    // ------------------------------------------------------------------ resident LM loop: host side
+    // is `p` a problem the single-launch sample-parallel kernel takes (rebuild_layout's rule for a list of one)?
+    static bool sp_single_launch_applies(const mbavo_problem &p, int kdeg, int num_cus)
+    {
+        int lg = 0;
+        while ((1 << lg) < p.S) ++lg;
+        if ((1 << lg) != p.S || lg < 2 || lg > 5 || !sp_one_fits(kdeg, lg) || p.grad_fp16 || p.K < 1 || p.F < 1) return false;
+        const long long round_px = (long long)kSpWaves * (64 >> lg), pixels = (long long)p.F * p.K * p.P;
+        const int force = env_int("MBAVO_SP", -1);
+        return force != 0 && (force == 1 || pixels <= 2 * round_px * num_cus) && env_int("MBAVO_ONE", 1) != 0;
+    }
+
+    int Engine::lm_device(int num_levels, const mbavo_problem *probs, const int *pyr_level, int kdeg, const LmDeviceOpts &o,
+                          double *h_knots_t, double *h_knots_R, int N, const int *h_start_idx, int F, double *h_final_cost,
+                          mbavo_trace_rec *h_trace, int trace_cap, int *h_ntrace)
+    {
+        constexpr int kTraceCap = 4096;
+        if (num_levels < 1 || num_levels > 8 || !probs || (kdeg != 2 && kdeg != 4) || !h_knots_t || !h_knots_R || !h_start_idx) return MBAVO_E_ARG;
+        // MBAVO_DEVICE_LM: 0 (default) = the host-driven loop, 1 = this loop where the solve has its fast path (k = 2: cond(H) ~ 1e6
+        // on plane scenes; the cubic spline's systems sit at 1e9 and take the Jacobi sweeps, which one wave walks far slower than
+        // the host), 2 = always.  Measured on trackFrame (640x480, 4 levels, k = 2; profiles/r03_device_lm.txt): 0.546 ms per
+        // frame against 0.393 for the host-driven loop -- an evaluation costs 16.1 us between two leaders (the host sees 14.4 us
+        // INCLUDING its PCIe round trip: the cross-XCD hand-overs of a command cost what the bus does) and the leader 10.9 us
+        // (state in, merge, solve, state out: a chain of device-memory round trips) against 1.5 us of host work.  Kept as a
+        // tested option, not as the default.
+        const int want = env_int("MBAVO_DEVICE_LM", 0);
+        if (want == 0 || (want == 1 && (kdeg != 2 || o.fast_ratio <= 0.0) && o.solver == 0)) return 1;
+        if (N < kdeg || N > 4 || F < 1 || F > 16 || trace_cap > kTraceCap || persist_mask_) return 1;
+        for (int li = 0; li < num_levels; ++li)
+            if (!sp_single_launch_applies(probs[li], kdeg, num_cus_) || probs[li].N != N || probs[li].F != F) return 1;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != device_) HIP_TRY(hipSetDevice(device_));
+        PhaseScope ps_all(PhaseTimers::kLevel);
+
+        // device memory: [carry: cur_knots 7N | ntrace] [per level, initialised by ONE copy: seq | mode | inv | LmState | start_idx F |
+        // flag words] [per level, work: eval_knots 7N | g n | H n*n]; the patch costs in their own buffer
+        const int n = 6 * N, E = kdeg == 2 ? Pack<2>::E : Pack<4>::E;
+        auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+        const size_t o_carry = 0, carry_bytes = al(sizeof(double) * 7 * N + 8 + 12 * 8); // knots | ntrace | (timing experiment) stamps
+        size_t o_init[8], o_flags[8], o_work[8], off = carry_bytes;
+        int maxK = 1;
+        for (int li = 0; li < num_levels; ++li)
+        {
+            o_init[li] = off;
+            const size_t head = 24 + sizeof(LmState) + al(sizeof(int) * F) + al(sizeof(LmLevelArgs)); // (LmState is 8-aligned, 24 + it too)
+            o_flags[li] = off + al(head);
+            off = o_flags[li] + al(((size_t)probs[li].K + 3) / 4 * 4);
+            maxK = probs[li].K > maxK ? probs[li].K : maxK;
+        }
+        const size_t init_bytes = off;
+        for (int li = 0; li < num_levels; ++li)
+        {
+            o_work[li] = off;
+            off += al(sizeof(double) * (7 * N + n + (size_t)n * n));
+        }
+        char *dev = (char *)named_scratch(12, off);
+        double *d_pc = (double *)named_scratch(13, sizeof(double) * (size_t)F * maxK);
+        double *d_fb = (double *)named_scratch(14, sizeof(double) * (size_t)F * E);
+        char *stage = (char *)pinned_scratch(5, init_bytes);
+        const size_t out_doubles = 7 * (size_t)N + 16;
+        char *hout = (char *)pinned_scratch(6, sizeof(double) * out_doubles + sizeof(mbavo_trace_rec) * (size_t)(trace_cap > 0 ? trace_cap : 1));
+        if (!dev || !d_pc || !d_fb || !stage || !hout) return (int)hipErrorOutOfMemory;
+        if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 64, hipHostMallocDefault) != hipSuccess) { h_flag_ = nullptr; return (int)hipErrorOutOfMemory; }
+        double *host_out = (double *)hout;
+        mbavo_trace_rec *host_trace = (mbavo_trace_rec *)(hout + sizeof(double) * out_doubles);
+        host_out[7 * N + 2] = 0.0;
+
+        memset(stage, 0, init_bytes);
+        memcpy(stage + o_carry, h_knots_t, sizeof(double) * 3 * N);
+        memcpy(stage + o_carry + sizeof(double) * 3 * N, h_knots_R, sizeof(double) * 4 * N);
+        const unsigned long long done_seq = ++flag_seq_;
+        const size_t o_args = 24 + sizeof(LmState) + al(sizeof(int) * F); // inside a level's initialised block
+        for (int li = 0; li < num_levels; ++li)
+        {
+            char *b = stage + o_init[li];
+            *(int *)(b + 8) = 2; // mode of the first evaluation (not polled: informational)
+            const long long nres = (long long)probs[li].K * F * probs[li].P; // spline_update_step.cpp:116-117, no outliers yet (:601)
+            *(double *)(b + 16) = nres > 0 ? 1.0 / (double)nres : 0.0;
+            LmState st;
+            memset(&st, 0, sizeof(st));
+            st.radius = 1e4; st.decrease_factor = 2.0; st.abs_dec = 1e10; st.fresh = 1;
+            st.ntrace = li == 0 ? 0 : -1; // finer levels: taken from the carry word when their kernel starts
+            memcpy(b + 24, &st, sizeof(st));
+            memcpy(b + 24 + sizeof(LmState), h_start_idx, sizeof(int) * F);
+            // the kernel's arguments live in the level's control block: the resident loop keeps ONE pointer in registers
+            char *ib = dev + o_init[li], *wb = dev + o_work[li];
+            LmLevelArgs &a = *(LmLevelArgs *)(b + o_args);
+            a.seq = (unsigned long long *)ib; a.mode = (int *)(ib + 8); a.inv = (double *)(ib + 16);
+            a.state = (unsigned long long *)(ib + 24);
+            a.start_idx = (const int *)(ib + 24 + sizeof(LmState));
+            a.flag_words = (unsigned *)(dev + o_flags[li]);
+            a.eval_knots = (double *)wb; a.g = (double *)wb + 7 * N; a.H = a.g + n;
+            a.cur_knots = (double *)(dev + o_carry); a.carry_ntrace = (int *)(dev + o_carry + sizeof(double) * 7 * N);
+            a.frame_blocks = d_fb; a.patch_cost = d_pc;
+            a.stamps = (unsigned long long *)(dev + o_carry + sizeof(double) * 7 * N + 8);
+            a.trace = h_trace ? host_trace : nullptr;
+            const bool last = li + 1 == num_levels;
+            a.host_out = last ? host_out : nullptr;
+            a.host_flag = last ? (unsigned long long *)h_flag_ : nullptr;
+            a.host_seq = done_seq;
+            a.o.max_it = o.max_it; a.o.max_nonmono = o.max_nonmono; a.o.solver = o.solver; a.o.trace_cap = h_trace ? trace_cap : 0;
+            a.o.max_n = n; a.o.max_N = N; a.o.min_q = o.min_q; a.o.min_dec = o.min_dec; a.o.chi = o.chi; a.o.fast_ratio = o.fast_ratio;
+            a.level = pyr_level ? pyr_level[li] : li; a.N = N; a.F = F; a.K = probs[li].K; a.P = probs[li].P;
+        }
+        HIP_TRY(hipMemcpyAsync(dev, stage, init_bytes, hipMemcpyHostToDevice, stream_));
+
+        for (int li = 0; li < num_levels; ++li)
+        {
+            char *ib = dev + o_init[li], *wb = dev + o_work[li];
+            mbavo_problem p = probs[li];
+            p.d_knots_t = (const double *)wb; p.d_knots_R = (const double *)wb + 3 * N;
+            p.d_outlier = (const unsigned char *)(dev + o_flags[li]); p.num_bad = 0; p.num_residuals = 0;
+            int rc = rebuild_layout(1, &p, kdeg, nullptr, (const double *)(ib + 16));
+            if (rc) return rc;
+            const int ntiles = (int)h_tiles_.size();
+            if (sp_logs_ <= 0 || ntiles < 1 || ntiles > num_cus_ || empty_slots_) return MBAVO_E_ARG; // (checked above: cannot happen)
+            OneArgs oa;
+            memset(&oa, 0, sizeof(oa));
+            oa.bf_tile_begin = (const int *)d_bf_tile_begin_;
+            oa.tickets = (int *)d_tickets_;
+            oa.slots_done = (int *)d_tickets_ + total_bf_;
+            oa.frame_blocks = d_fb; oa.valid_out = nullptr; oa.status = (int *)d_status_;
+            oa.nbf = total_bf_;
+            oa.lm = 1;
+            const LmLevelArgs *d_args = (const LmLevelArgs *)(ib + o_args);
+            hipStream_t st = stream_;
+#define MBAVO_LM_LAUNCH(KD, LG)                                                                                                    \
+    do                                                                                                                            \
+    {                                                                                                                             \
+        if constexpr (SpLds<KD, true, LG, true>::kFits)                                                                           \
+        {                                                                                                                         \
+            size_t lds_sp = SpLds<KD, true, LG, true>::kBytes > SpLds<KD, false, LG, true>::kBytes                                \
+                                ? SpLds<KD, true, LG, true>::kBytes : SpLds<KD, false, LG, true>::kBytes;                          \
+            const size_t need = sizeof(double) * ((size_t)n * n + 4 * (size_t)n + (n + 1) / 2 + 2 + 2 * (size_t)n * (n + 1));      \
+            if (need > lds_sp) lds_sp = need; /* the leader's solver work areas */                                                 \
+            HIP_TRY(ensure_lds((const void *)k_lm_level<KD, LG>, lds_sp));                                                        \
+            hipLaunchKernelGGL((k_lm_level<KD, LG>), dim3(ntiles), dim3(kSpWaves * 64), lds_sp, st, (const ProblemDesc *)d_descs_, \
+                               (const TileDesc *)d_tiles_, (double *)d_rho_, d_pc, (double *)d_partials_, oa, d_args);             \
+        }                                                                                                                         \
+    } while (0)
+#define MBAVO_LM_K(KD)                                     \
+    switch (sp_logs_)                                      \
+    {                                                      \
+    case 2: MBAVO_LM_LAUNCH(KD, 2); break;                  \
+    case 3: MBAVO_LM_LAUNCH(KD, 3); break;                  \
+    case 4: MBAVO_LM_LAUNCH(KD, 4); break;                  \
+    default: MBAVO_LM_LAUNCH(KD, 5); break;                 \
+    }
+            if (kdeg == 4) { MBAVO_LM_K(4) } else { MBAVO_LM_K(2) }
+#undef MBAVO_LM_K
+#undef MBAVO_LM_LAUNCH
+            HIP_TRY(hipGetLastError());
+            last_kernel_id_[0] = kdeg; last_kernel_id_[1] = 1; last_kernel_id_[2] = 0; last_kernel_id_[3] = sp_logs_; last_kernel_id_[4] = 1;
+        }
+        ps_all.stop();
+        {
+            PhaseScope ps_wait(PhaseTimers::kWait);
+            const auto t0 = std::chrono::steady_clock::now();
+            volatile unsigned long long *f = (volatile unsigned long long *)h_flag_;
+            bool ok = false;
+            for (long spins = 1;; ++spins)
+            {
+                if (*f == done_seq) { ok = true; break; }
+                host_spin_pause();
+                if ((spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(4)) break;
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            if (!ok || host_out[7 * N + 2] != 1.0)
+            {
+                fprintf(stderr, "mbavo: resident LM loop timed out\n");
+                (void)hipStreamSynchronize(stream_); // (the kernels give up by themselves after ~1 s without a command)
+                (void)hipMemsetAsync(d_tickets_, 0, cap_tickets_, stream_);
+                return (int)hipErrorLaunchTimeOut;
+            }
+        }
+#if defined(MBAVO_LM_STAMPS)
+        {
+            static double ev = 0, ld = 0, ph = 0, tot = 0, seg[6] = {0, 0, 0, 0, 0, 0}; static long calls = 0;
+            ev += host_out[7 * N + 3]; ld += host_out[7 * N + 4]; ph += host_out[7 * N + 5]; tot += host_out[7 * N + 6];
+            for (int i = 0; i < 6; ++i) seg[i] += host_out[7 * N + 7 + i];
+            if (++calls % 9 == 0)
+                fprintf(stderr, "lm_device: per call %.1f phases, evaluation (publish -> next leader's entry) %.2f us each, leader %.2f us each "
+                                "[load %.2f | merge/decide %.2f | solve %.2f | store %.2f], after an H/g pass %.2f us (%.1f per call); first leader's entry -> end %.1f us (mean of %ld calls)\n",
+                        ph / calls, ev / (ph - calls * num_levels > 0 ? ph - calls * num_levels : 1), ld / ph, seg[0] / ph, seg[1] / ph, seg[2] / ph,
+                        seg[3] / ph, seg[4] / (seg[5] > 0 ? seg[5] : 1), seg[5] / calls, tot / calls, calls);
+        }
+#endif
+        memcpy(h_knots_t, host_out, sizeof(double) * 3 * N);
+        memcpy(h_knots_R, host_out + 3 * N, sizeof(double) * 4 * N);
+        if (h_final_cost) *h_final_cost = host_out[7 * N];
+        const int ntrace = (int)host_out[7 * N + 1];
+        if (h_ntrace) *h_ntrace = ntrace;
+        if (h_trace && trace_cap > 0) memcpy(h_trace, host_trace, sizeof(mbavo_trace_rec) * (size_t)(ntrace < trace_cap ? ntrace : trace_cap));
+        return 0;
     }
 
     const char *Engine::last_kernel()

@@ -381,7 +381,7 @@ namespace mbavo
         return true;
     }
 
-    static double fast_solve_ratio()
+    double fast_solve_ratio()
     { // MBAVO_FAST_SOLVE=0 always takes the Jacobi SVD; a number sets the admitted pivot ratio (default 1e8)
         static const double v = [] {
             const char *e = getenv("MBAVO_FAST_SOLVE");

@@ -19,6 +19,8 @@ namespace mbavo
 
     // x = -pinv(A) b (type 0) or -A^{-1} b via LDL^T (type 1); returns rank, or -1 for an unknown type
     int solve_normal_equation_host(const double *A_colmajor, const double *b, int n, int solver_type, double *x);
+    // pivot ratio up to which LDL^T stands in for the Jacobi SVD (solver type 0); 0 = never (MBAVO_FAST_SOLVE, default 1e8)
+    double fast_solve_ratio();
 } // namespace mbavo
 
 namespace SLAM

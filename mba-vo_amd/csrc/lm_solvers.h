@@ -191,6 +191,66 @@ namespace mbavo
             MBAVO_SOLVER_SYNC();
         }
 
+
+        // ---- small SPD systems in registers (n = NN <= 24, one wave): x = A^-1 b by LDL^T WITHOUT pivoting, lane i holding row i of
+        // the (symmetric, fully updated) trailing matrix in NN registers.  Every index is a compile-time constant: the pivot row is
+        // broadcast with v_readlane (constant lane), no LDS traffic and no barrier inside -- ~NN^2 / 2 x 3 instructions against
+        // ~2 000 cycles per elimination step of ldlt_solve above (shuffle pivot search, row / column swaps and three LDS passes
+        // with barriers: 27 us for a 12 x 12 system inside the resident LM kernel, ~1.5 us with this form).
+        // Unpivoted LDL^T is backward stable for positive definite A; `ok` = every pivot positive and max / min pivot <= max_ratio
+        // (the guard of host_math.cpp:solve_spd_fast; its pivots come in diagonal-pivoting order, so the two guards can disagree
+        // next to the threshold -- both paths compute the same x to rounding x cond(A)).  A: column-major n x n in LDS (symmetric).
+        __device__ __forceinline__ double bcast_lane(double v, int src) // src: compile-time constant after unrolling
+        {
+            const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
+            return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        }
+        template <int NN>
+        __device__ __forceinline__ bool spd_solve_regs(const double *A, const double *b, double *x, int lane, double max_ratio)
+        {
+            const int i = lane < NN ? lane : NN - 1; // lanes past the matrix shadow the last row (results unused)
+            double a[NN];
+#pragma unroll
+            for (int j = 0; j < NN; ++j) a[j] = A[j * NN + i];
+            double rhs = b[i];
+            double dmax = 0.0, dmin = DBL_MAX;
+            bool pos = true;
+#pragma unroll
+            for (int k = 0; k < NN; ++k)
+            {
+                const double d = bcast_lane(a[k], k);
+                pos = pos && d > 0.0;
+                dmax = fmax(dmax, d);
+                dmin = fmin(dmin, d);
+                const double rd = 1.0 / d;
+                const double l = a[k] * rd; // L[i][k] for the lanes i > k
+#pragma unroll
+                for (int j = k + 1; j < NN; ++j)
+                {
+                    const double rkj = bcast_lane(a[j], k); // A(k)[k][j] = d * L[j][k]
+                    if (lane > k) a[j] -= l * rkj;
+                }
+                // forward substitution rides along: y_k is final once rows 0 .. k-1 were eliminated
+                const double yk = bcast_lane(rhs, k);
+                if (lane > k) { rhs -= l * yk; a[k] = l; }
+            }
+            // z = D^-1 y; then x = L^-T z from the last unknown up: lane k holds d_k L[j][k] in a[j], j > k (its final row)
+            double diag = 1.0; // d_i sits in a[i]: a dynamic register index, resolved through selects
+#pragma unroll
+            for (int j = 0; j < NN; ++j) diag = lane == j ? a[j] : diag;
+            const double rdi = 1.0 / diag;
+            double xv = rhs * rdi;
+#pragma unroll
+            for (int j = NN - 1; j >= 1; --j)
+            {
+                const double xj = bcast_lane(xv, j);
+                if (lane < j) xv -= (a[j] * rdi) * xj;
+            }
+            if (lane < NN) x[lane] = xv;
+            return pos && dmax <= max_ratio * dmin;
+        }
+
         // x = A^-1 b by LDL^T with diagonal pivoting (host_math.cpp:solve_ldlt); M holds A on entry
         MBAVO_LDLT_FN void ldlt_solve(double *M, const double *b, double *x, double *y, int *order, int n, int lane)
         {

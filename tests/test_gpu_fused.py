@@ -226,7 +226,9 @@ def test_non_finite_and_wild_knots_do_not_fault(mbavo, gpu_ctx):
 def test_many_small_problems_flat_finalize(orc, mbavo, gpu_ctx):
     """70 small problems in one call (>= 64 slots of <= 4 tiles each: the one-block-per-slot finalize kernel) against the
     same problems evaluated alone (the tree finalize kernel): the tiles are added in the same order, so the blocks of a
-    problem whose tiling is the same in both calls are identical bit for bit; all of them match the oracle."""
+    problem whose tiling is the same in both calls are identical bit for bit (a problem of at most one sample-parallel
+    round, 64 pixels since round 3, is one tile either way); otherwise only the grouping of the sum differs (1e-13); all
+    of them match the oracle."""
     rng = np.random.default_rng(77)
     scs = [scenes.Scene(S=8, F=1 + (i % 2), k=4, P=8, K=int(rng.integers(5, 40)), seed=500 + i) for i in range(70)]
     ds = [scenes.DeviceScene(s) for s in scs]
@@ -238,10 +240,18 @@ def test_many_small_problems_flat_finalize(orc, mbavo, gpu_ctx):
             ro = orc.evaluate(p)
             assert _rel(fb[row:row + sc.F], ro["frame_blocks"]) < RTOL
         row += sc.F
-    # one tile per slot in both calls for these sizes -> identical sums
-    one, _, _ = scenes.gpu_eval_batch(gpu_ctx, [ds[3]], 4)
-    r3 = sum(s.F for s in scs[:3])
-    assert np.array_equal(one, fb[r3:r3 + scs[3].F])
+    row = 0
+    exact = 0
+    for i, sc in enumerate(scs):
+        if i % 9 == 3 or sc.K * sc.P <= 64:
+            one, _, _ = scenes.gpu_eval_batch(gpu_ctx, [ds[i]], 4)
+            got = fb[row:row + sc.F]
+            assert np.abs(one - got).max() <= 1e-13 * np.abs(got).max()
+            if sc.K * sc.P <= 64:  # one tile per slot in both calls -> identical sums
+                assert np.array_equal(one, got)
+                exact += 1
+        row += sc.F
+    assert exact >= 3
 
 
 @pytest.mark.parametrize("sp", ["0", "1"])
