@@ -72,7 +72,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_workload(name, frames=1, seed=1, ctx=None, dev="cuda:0"):
+def build_workload(name, frames=1, seed=1, ctx=None, dev="cuda:0", grad_fp16=False):
     """(list of Prob or a device-resident RenderedPairBatch, description, sharding mode at N > 1)"""
     from mba_vo_amd import workloads as wl
     if name == "c2_dense":
@@ -88,7 +88,7 @@ def build_workload(name, frames=1, seed=1, ctx=None, dev="cuda:0"):
             "640x480 pair, 1 level, S=1 (sharp degenerate case), dense (configs[0])", "frames"
     if name in ("c3_batch64", "c4_batch512"):
         B = 64 if name == "c3_batch64" else 512
-        return wl.RenderedPairBatch(ctx, B, S=8, k=4, device=dev, seed=seed), \
+        return wl.RenderedPairBatch(ctx, B, S=8, k=4, device=dev, seed=seed, grad_fp16=grad_fp16), \
             "batch of %d independent 640x480 pairs = %d consecutive frames of ONE GPU-rendered synthetic blurred sequence " \
             "(textured plane, camera on a ground-truth spline; generate_synthetic_data.cpp:127-214): every pair has its OWN " \
             "keyframe (sharp rendering), gradient image, grid-selected keypoints x 8-pixel pattern with depths from its own " \
@@ -246,11 +246,13 @@ class Runner:
     def __init__(self, M, ctx, name, dev, rank, world, sharded, grad_fp16=False, shard_mode=None, sequential=False):
         from mba_vo_amd import shard, workloads as wl
         self.M, self.ctx, self.name, self.world, self.rank = M, ctx, name, world, rank
-        built, self.desc, self.mode = build_workload(name, frames=world if sharded else 1, ctx=ctx, dev=dev)
+        built, self.desc, self.mode = build_workload(name, frames=world if sharded else 1, ctx=ctx, dev=dev, grad_fp16=grad_fp16)
         if shard_mode is not None:
             self.mode = shard_mode
         if isinstance(built, wl.RenderedPairBatch):
             self.dw, self.probs = built, built.probs
+            if grad_fp16:
+                self.desc += ", fp16 gradient images"
         else:
             self.probs = built
             if grad_fp16:
@@ -604,6 +606,18 @@ def main():
                              "note": "compulsory bytes only; compute-bound kernel, low by construction; traffic = "
                                      "(2*FETCH_SIZE + WRITE_SIZE) KiB from the committed TCC counter passes"},
         }
+        if args.workload in ("c3_batch64", "c4_batch512"):
+            # pairs with their own images: the tap gather binds (no-taps ablation: 47 % of the 512-pair kernel, profiles/
+            # r03_kfused_experiments.txt 3.), so the HBM figure leads and the FP64 one rides along
+            out["roofline_fp64"] = out["roofline"]
+            h = out.pop("roofline_hbm")
+            h.update(kernel=kernel, kernel_ms=round(k_ms, 6), launches_timed=int(nlaunch[0]), traffic_source=traffic_src,
+                     frac_of_traffic=round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and k_ms > 0 else None,
+                     note="achieved = compulsory bytes by the gather bound of SURVEY.md 8(d) (36 B per pixel-sample + the current "
+                          "pixel; keypoints, pose tables, packed blocks) over the kernel's duration; traffic = (2*FETCH_SIZE + "
+                          "WRITE_SIZE) KiB from the committed TCC counter pass -- every touched 128-byte line of a sparse gather in "
+                          "row-major images, fetched about once; frac_of_traffic = traffic / duration / peak")
+            out["roofline"] = h
         if d2h_ms is not None:
             out["ms_per_step_incl_d2h"] = round(d2h_ms, 5)
             out["d2h_note"] = "step + copy of the %d packed doubles to pinned host memory + wait (what a host LM loop pays per " \

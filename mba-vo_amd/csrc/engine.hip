@@ -508,6 +508,12 @@ namespace mbavo
 
 #endif
 
+    // Device-scope, cache-bypassing accesses (global_load / global_store ... sc1): a store is written through to memory, a load
+    // is served from there -- what one workgroup hands to a workgroup on another CU / XCD without a cache-wide fence on either side
+    // (MI355X: per-XCD L2s, a CU's L1 is never refreshed by other CUs' stores).  Ordered by s_waitcnt vmcnt(0) before the flag.
+    __device__ __forceinline__ double ld_fresh(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void st_fresh(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
     // 1 / ((K - bad) F P) of a problem.  Device-side LM and the host-driven loop keep it outside the descriptor (inv_ptr:
     // device memory -- for the host-driven loop a word of the CPU-writable push block, see Engine::push_block): read FRESH
     // by one lane per wave (a scalar load could hit a stale scalar-cache line inside the persistent kernel) and broadcast.
@@ -1190,25 +1196,25 @@ namespace mbavo
         constexpr int NPASS = (EFULL + EPAD - 1) / EPAD;
         static_assert(E + 1 <= EFULL && LANES >= 1 && (NPASS == 1 || LANES == 1), "one thread per partial slot and tile-lane");
         __shared__ int s_last;
-        // Release: every wave's partial stores are performed at workgroup scope before the barrier (they sit in this XCD's
-        // L2), then ONE thread makes them visible device-wide (L2 write-back) and takes the ticket.  A device-scope fence
-        // by all 768 threads costs 9 us here (measured, tools/ab_run.sh).
+        // Release: every wave's partial stores are acknowledged before the barrier (vmcnt(0): a workgroup-scope release emits no
+        // wait outside tgsplit mode), then ONE thread makes them visible device-wide (agent-scope release: L2 write-back) and
+        // takes the ticket; the last workgroup acquires.  A device-scope fence by all 768 threads costs 9 us here (measured).
+        // Round 3 tried the hand-over WITHOUT the two cache-wide fences (partials stored and loaded with sc1 accesses, vmcnt(0),
+        // ticket): 27 parity tests failed and trackFrame was no longer reproducible run to run -- and it was not faster
+        // (0.384 vs 0.376 ms per frame; profiles/r03_kfused_experiments.txt 4.).  -DMBAVO_NO_TICKET_FENCES rebuilds that form.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        // (a workgroup-scope release emits no vmcnt wait outside tgsplit mode, and thread 0's agent-scope release below waits
-        // for wave 0's stores only: every wave waits for the acknowledgement of its own partial / patch-cost stores here)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0)
         {
-            // (device scope also when the per-patch costs go to pinned host memory: the fence waits until this workgroup's
-            // stores are acknowledged, i.e. on their way to the host ahead of the completion word the LAST workgroup
-            // publishes after its own system-scope fence; a system-scope fence here costs 40 us per evaluation)
-            // release only (L2 write-back); the acquire -- an invalidation of this XCD's L2 -- is the LAST workgroup's
-            // business: done by every workgroup it threw the pyramid out of the L2s once per evaluation
+#if !defined(MBAVO_NO_TICKET_FENCES)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
             const int n = oa.bf_tile_begin[bf + 1] - oa.bf_tile_begin[bf];
             const int last = atomicAdd(&oa.tickets[bf], 1) == n - 1 ? 1 : 0;
+#if !defined(MBAVO_NO_TICKET_FENCES)
             if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the other workgroups' partials (other XCDs' L2s) are read from memory
+#endif
             s_last = last;
         }
         __syncthreads();
@@ -1225,15 +1231,15 @@ namespace mbavo
         double acc = 0.0;
         if (mine)
         {
-            const MBAVO_GLOBAL double *pp = (const MBAVO_GLOBAL double *)partials;
+            const double *pp = partials;
             int t = t0 + l;
             for (; t + 3 * LANES < t1; t += 4 * LANES)
             { // four loads in flight, added in tile order
-                const double a = pp[(size_t)t * PS + e], b = pp[(size_t)(t + LANES) * PS + e];
-                const double c = pp[(size_t)(t + 2 * LANES) * PS + e], dd = pp[(size_t)(t + 3 * LANES) * PS + e];
+                const double a = ld_fresh(pp + (size_t)t * PS + e), b = ld_fresh(pp + (size_t)(t + LANES) * PS + e);
+                const double c = ld_fresh(pp + (size_t)(t + 2 * LANES) * PS + e), dd = ld_fresh(pp + (size_t)(t + 3 * LANES) * PS + e);
                 acc += a; acc += b; acc += c; acc += dd;
             }
-            for (; t < t1; t += LANES) acc += pp[(size_t)t * PS + e];
+            for (; t < t1; t += LANES) acc += ld_fresh(pp + (size_t)t * PS + e);
         }
         if (LANES > 1)
         {
@@ -1280,11 +1286,11 @@ namespace mbavo
             }
             else
             {
-            oa.tickets[bf] = 0; // ready for the next launch (stream order)
+            __hip_atomic_store(&oa.tickets[bf], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next evaluation
             if (to_host) __threadfence_system(); // THIS slot's frame block is on its way to the host before the slot counts as done
             if (to_host && atomicAdd(oa.slots_done, 1) == oa.nbf - 1)
             {
-                *oa.slots_done = 0;
+                __hip_atomic_store(oa.slots_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(MBAVO_PERSIST_STAMPS) // timing experiment: when this workgroup saw the command / finished (100 MHz ticks)
                 oa.host_flag[1] = __builtin_amdgcn_s_memrealtime();
                 oa.host_flag[2] = oa.t_seen;
@@ -1558,12 +1564,17 @@ namespace mbavo
         if (WITH_J) acc.store(slab, lane);
         __syncthreads();
         double *out = partials + (size_t)tile_id * PS;
+#if defined(MBAVO_NO_TICKET_FENCES)
+        auto put = [&](int e, double v) { if constexpr (ONE) st_fresh(out + e, v); else out[e] = v; };
+#else
+        auto put = [&](int e, double v) { out[e] = v; };
+#endif
         if (threadIdx.x == 0)
         {
             double c = 0.0, v = 0.0;
             for (int i = 0; i < kWavesPerGroup; ++i) { c += red[i]; v += red[kWavesPerGroup + i]; }
-            out[0] = v;
-            out[E] = c;
+            put(0, v);
+            put(E, c);
         }
         if (WITH_J)
         {
@@ -1571,7 +1582,7 @@ namespace mbavo
             {
                 int i, j;
                 tri_decode(e, ND, i, j);
-                out[e] = OuterAcc<ND>::gather(rows, i, j, kWavesPerGroup);
+                put(e, OuterAcc<ND>::gather(rows, i, j, kWavesPerGroup));
             }
         }
         if constexpr (ONE)
@@ -1716,8 +1727,6 @@ namespace mbavo
         unsigned long long *stamps; // (timing experiment MBAVO_LM_STAMPS) [last publish | sum evaluation | sum leader | phases | first entry], 100 MHz ticks
     };
 
-    __device__ __forceinline__ double ld_fresh(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ __forceinline__ void st_fresh(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
     // wave 0 of the leader workgroup, all 64 lanes.  mode_done: the evaluation that has just completed (2 = H/g, 1 = cost).
     // (a real call, its arguments behind one pointer: inlined into the resident kernel it drove that kernel to 56-113 vector
@@ -2491,6 +2500,7 @@ namespace mbavo
             }
             else if (fused_pose)
             {
+                if constexpr (KD == 4) // (k = 2 never takes the prologue, see above: its instantiations are not compiled)
                 {
                     // cost-only: the pose prologue's segments need LDS of their own (there are no slabs to borrow)
                     const size_t lds = lds_plain + (WITH_J ? 0 : (size_t)kPoseSPB * (KD - 1) * sizeof(SplineSeg));

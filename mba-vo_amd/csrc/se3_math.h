@@ -43,6 +43,85 @@ namespace mbavo
         o[0] = v.x; o[1] = v.y; o[2] = v.z;
     }
 
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_POSE_LIBM)
+#define MBAVO_POSE_FASTMATH 1
+    // Device forms of the four library calls on the pose chain (round 3).  A sample's pose entries are ONE dependent chain per
+    // lane -- 2.9 us of stage A on configs[1], every evaluation waits for it -- and the runtime's sqrt / division / atan / sin /
+    // cos are general-purpose sequences (argument reduction for any double, special values): 31, 18, 95, 189 and 189
+    // instructions.  The arguments here are a rotation's half-angle and the tangent of one: finite, moderate.  Each form
+    // below is within one or two units in the last place of the correctly rounded value (the runtime's own bound for sin /
+    // cos / atan); polynomial coefficients and reduction constants are those of fdlibm's k_sin.c / k_cos.c / s_atan.c /
+    // e_rem_pio2.c.  -DMBAVO_POSE_LIBM builds the chain on the runtime's functions again (A/B switch).
+    namespace fastm
+    {
+        __device__ __forceinline__ double rcp(double x) // 1 / x: v_rcp_f64 (2^-23) + two Newton steps; x finite, normal, non-zero
+        {
+            double r = __builtin_amdgcn_rcp(x);
+            r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+            r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+            return r;
+        }
+        // s = sqrt(x), r = 1 / sqrt(x) from ONE v_rsq_f64 + two Newton steps (the chain needs both everywhere it takes a norm)
+        __device__ __forceinline__ void sqrt_rsqrt(double x, double &s, double &r)
+        {
+            double y = __builtin_amdgcn_rsq(x);
+            const double h = 0.5 * x;
+            y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
+            y = __builtin_fma(y, __builtin_fma(-(h * y), y, 0.5), y);
+            double t = x * y;
+            t = __builtin_fma(__builtin_fma(-t, t, x), 0.5 * y, t); // one correction of the root itself
+            s = t;
+            r = y;
+        }
+        // sin and cos of a moderate argument (two-constant Cody-Waite reduction: good to |x| ~ 1e5; the chain's arguments are
+        // half of c * |log(q)| <= pi / 2 -- no large-argument path, a NaN stays a NaN)
+        __device__ __forceinline__ void sincos(double x, double &sn, double &cs)
+        {
+            const double k = rint(x * 6.36619772367581382433e-01);
+            double r = __builtin_fma(-k, 1.57079632673412561417e+00, x); // exact: the constant holds 33 bits of pi/2
+            r = __builtin_fma(-k, 6.07710050650619224932e-11, r);
+            const double z = r * r;
+            const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                              z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+            const double ks = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+            const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                              z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+            const double hz = 0.5 * z, w = 1.0 - hz;
+            const double kc = w + (((1.0 - w) - hz) + z * pc);
+            const int q = (int)k & 3;
+            sn = (q & 1) ? kc : ks;
+            cs = (q & 1) ? ks : kc;
+            if (q == 1 || q == 2) cs = -cs;
+            if (q >= 2) sn = -sn;
+        }
+        // atan(num / den) for finite num, den (den != 0 where num != 0: the callers branch on |den| < 1e-10 first)
+        __device__ __forceinline__ double atan_ratio(double num, double den)
+        {
+            const double x0 = num * rcp(den);
+            const double ax = fabs(x0);
+            double x = ax, hi = 0.0, lo = 0.0;
+            if (ax >= 0.4375)
+            {
+                if (ax < 1.1875)
+                {
+                    if (ax < 0.6875) { x = (2.0 * ax - 1.0) * rcp(2.0 + ax); hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
+                    else { x = (ax - 1.0) * rcp(ax + 1.0); hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
+                }
+                else if (ax < 2.4375) { x = (ax - 1.5) * rcp(1.0 + 1.5 * ax); hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
+                else { x = ax < 1e300 ? -rcp(ax) : 0.0; hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
+            }
+            const double z = x * x, w = z * z;
+            const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
+                              w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+            const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 +
+                              w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+            const double r = ax < 0.4375 ? x - x * (s1 + s2) : hi - ((x * (s1 + s2) - lo) - x);
+            return x0 < 0 ? -r : r;
+        }
+    } // namespace fastm
+#endif
+
     // A 4x3 Jacobian block d(quaternion)/d(3-vector), stored as its columns.  Every operation below acts on the
     // columns independently, so a block can also be processed one column at a time (NC = 1: the pose-table kernel
     // gives each column of a block its own lane).
@@ -77,7 +156,12 @@ namespace mbavo
         }
         else
         {
+#if defined(MBAVO_POSE_FASTMATH)
+            double n, n_rcp;
+            fastm::sqrt_rsqrt(sn, n, n_rcp);
+#else
             const double n = sqrt(sn);
+#endif
             if (fabs(w) < 1e-10)
             {
                 const double pi = 3.14159265358979323846;
@@ -94,8 +178,13 @@ namespace mbavo
                 // device: ONE reciprocal of n and products where the reference divides by n four times (an IEEE fp64
                 // division is ~13 dependent instructions, and a pose lane walks this chain alone on its SIMD); the results
                 // differ from the quotients in the last place at most
+#if defined(MBAVO_POSE_FASTMATH)
+                const double rn = n_rcp;
+                lam = 2.0 * fastm::atan_ratio(n, w) * rn;
+#else
                 const double rn = 1.0 / n; // (v_rsq_f64 + Newton instead of sqrt + division: no measurable difference)
                 lam = 2.0 * atan(n / w) * rn;
+#endif
                 if (WITH_J)
                 {
                     const double dn = (2 * w - lam) * rn * rn;
@@ -142,11 +231,19 @@ namespace mbavo
         }
         else
         {
+#if defined(MBAVO_POSE_FASTMATH) && !defined(MBAVO_POSE_IEEE_DIV)
+            double th, rth, hs, hc;
+            fastm::sqrt_rsqrt(th2, th, rth);
+            fastm::sincos(0.5 * th, hs, hc);
+#else
             const double th = sqrt(th2);
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_POSE_IEEE_DIV)
+#if !defined(MBAVO_POSE_FASTMATH)
             // (sincos() for the pair measured 2 us SLOWER per evaluation: its results come back through private memory)
             const double hs = sin(0.5 * th), hc = cos(0.5 * th);
             const double rth = 1.0 / th; // (device: one reciprocal instead of six divisions by theta, see qlog)
+#endif
             im = hs * rth;
             re = hc;
             if (WITH_J)
@@ -488,8 +585,18 @@ namespace mbavo
             return g == 0 ? 5 * s + 0.5 * u - 0.5 * uu + s * uuu : (g == 1 ? s + 0.5 * u + 0.5 * uu - 2 * s * uuu : s * uuu);
         }
     }
+    // On the device a REAL call (round 3): inlined into the fused kernels, which sit at their register budget, the shorter
+    // chain of the fastm forms came back as 6 vector spills in k_fused<4, .., POSE> (+0.5 us per dense evaluation); as a call the
+    // kernel keeps its 166 registers and the semi-dense single-launch kernel drops from 172 to 150 with no scalar spill
+    // (configs[1] dense step 37.44 -> 36.68 us, semi-dense evaluation 18.26 -> 17.58, trackFrame 0.407 -> 0.394 ms per frame;
+    // A/B in one call, profiles/r03_kfused_experiments.txt).  -DMBAVO_SEG_INLINE restores the inlined form.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_SEG_INLINE)
+#define MBAVO_SEG_FN __device__ __noinline__
+#else
+#define MBAVO_SEG_FN MBAVO_HD
+#endif
     template <bool WITH_J>
-    MBAVO_HD void spline_segment_eval(const double *Ra4, const double *Rb4, double c, SplineSeg &out)
+    MBAVO_SEG_FN void spline_segment_eval(const double *Ra4, const double *Rb4, double c, SplineSeg &out)
     {
         double om[3];
         qlog<WITH_J>(qmul(qconj(load_quat(Ra4)), load_quat(Rb4)), om, &out.dl);

@@ -148,7 +148,7 @@ class RenderedPairBatch:
     tests.  Same interface as DeviceWorkload (array, step, frame_blocks, valid, probs)."""
 
     def __init__(self, ctx, B, H=480, W=640, S=8, k=4, device="cuda:0", seed=1, huber=10.0, D=7.5, frame_dt=0.1, exp=0.04,
-                 cell=30, thresh=4.0, perturb=2e-3, pairs=None):
+                 cell=30, thresh=4.0, perturb=2e-3, pairs=None, grad_fp16=False):
         import torch
         L = ctx.lib
         rng = np.random.default_rng(seed)
@@ -186,8 +186,12 @@ class RenderedPairBatch:
                 capi.check(L.mbavo_synthesize_blur(base.data_ptr(), H, W, float(D), capi.dp(intr), 4, t0w, dtk, capi.dp(ktw),
                                                    capi.dp(kRw), n_world, float(t), float(e), ns, dst.data_ptr(), None),
                            "mbavo_synthesize_blur")
-            grad = torch.empty(H * W * 2, dtype=torch.float32, device=device)
-            capi.check(L.mbavo_image_gradients_u8(ref.data_ptr(), H, W, grad.data_ptr(), None), "mbavo_image_gradients_u8")
+            if grad_fp16:  # IEEE half pairs (lossless for central differences of an 8-bit image)
+                grad = torch.empty(H * W * 2, dtype=torch.float16, device=device)
+                capi.check(L.mbavo_image_gradients_u8_half(ref.data_ptr(), H, W, grad.data_ptr(), None), "mbavo_image_gradients_u8_half")
+            else:
+                grad = torch.empty(H * W * 2, dtype=torch.float32, device=device)
+                capi.check(L.mbavo_image_gradients_u8(ref.data_ptr(), H, W, grad.data_ptr(), None), "mbavo_image_gradients_u8")
             # z-depth of the plane z = D (plane frame) in the keyframe camera (camera -> plane pose (qk, pk))
             x, y, z, w = qk
             r2 = (2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y))
@@ -233,7 +237,7 @@ class RenderedPairBatch:
             q.d_cap_time, q.d_exp_time, q.t0, q.dt = capt.data_ptr(), expt.data_ptr(), t0, dtk
             q.d_knots_t, q.d_knots_R = dkt.data_ptr(), dkR.data_ptr()
             q.h_start_idx = start.ctypes.data_as(C.POINTER(C.c_int))
-            q.huber_a, q.grad_fp16 = huber, 0
+            q.huber_a, q.grad_fp16 = huber, 1 if grad_fp16 else 0
             self.probs.append(_PairInfo(S, k, 4, 1, K, 8, H, W))
             self._host.append(dict(ref=ref, cur=cur, grad=grad, xy=xy, kz=kz, kt=kt, kR=kR, kt_gt=kt_gt, t0=t0, cap=tc, exp=exp,
                                    huber=huber, pk=pk, qk=qk, dkt=dkt, dkR=dkR))
@@ -258,7 +262,7 @@ class RenderedPairBatch:
         return Prob(h["ref"].cpu().numpy().reshape(H, W), [h["cur"].cpu().numpy().reshape(H, W)],
                     h["xy"].cpu().numpy().reshape(-1, 2), h["kz"].cpu().numpy(), synth.PATTERN8, self.intr, self.S, self.k, 4,
                     [h["cap"]], [h["exp"]], h["t0"], 0.5, h["kt"], h["kR"], h["huber"],
-                    grad=h["grad"].cpu().numpy().reshape(H, W, 2))
+                    grad=h["grad"].float().cpu().numpy().reshape(H, W, 2))
 
     def step(self, ctx, with_hessian=True, out=None):
         fb = self.frame_blocks if out is None else out

@@ -188,3 +188,48 @@ def test_synthetic_blur_generator_on_device(orc, mbavo, gpu_ctx):
         g = d_out.cpu().numpy().reshape(H, W)
         assert np.array_equal(g, o)
         assert g.std() > 5 and np.abs(g.astype(int) - ref.astype(int)).max() > 0   # non-trivial image, actually warped
+
+
+@pytest.mark.parametrize("k", [2, 4])
+def test_pose_chain_over_the_whole_range_of_rotations(orc, mbavo, gpu_ctx, k):
+    """The device pose chain takes its square roots, reciprocals, atan, sin and cos from short forms written for a rotation's
+    half-angle (se3_math.h fastm, round 3) instead of the runtime's general ones; the oracle runs glibc's.  Random knot
+    rotations whose RELATIVE angles cover every branch of those forms -- 1e-9 rad (next to the series branches of the
+    quaternion log / exp) up to 3.1 rad (the atan's reduction ranges, w of either sign) -- at random blur-sample times:
+    poses and both pose-to-knot Jacobians within 1e-12 of the oracle's (observed 1e-15: the forms are good to 1-2 ulp)."""
+    import torch
+    L, O = mbavo.load(), orc.lib()
+    rng = np.random.default_rng(40 + k)
+    worst = 0.0
+    for angle in (1e-9, 3e-6, 1e-3, 0.05, 0.4, 0.8, 1.1, 1.6, 2.2, 2.9, 3.1):
+        F, S, N = 3, 16, 3 + k
+        q = np.zeros((N, 4))
+        q[0] = rng.normal(size=4)
+        q[0] /= np.linalg.norm(q[0])
+        for i in range(1, N):  # knot i = knot i-1 * (a rotation by `angle` about a random axis)
+            ax = rng.normal(size=3)
+            ax /= np.linalg.norm(ax)
+            a = angle * rng.uniform(0.7, 1.0)
+            d = np.r_[np.sin(a / 2) * ax, np.cos(a / 2)]
+            x1, y1, z1, w1 = q[i - 1]
+            x2, y2, z2, w2 = d
+            q[i] = [w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2,
+                    w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2]
+        kt = rng.normal(size=(N, 3))
+        cap = np.ascontiguousarray(0.2 + 0.5 * np.arange(F) + rng.uniform(0, 0.2, F))
+        exp = np.full(F, 0.15)
+        nJt, nJR = 9 * k, 12 * k
+        o_p, o_Jt, o_JR = np.zeros(F * S * 7), np.zeros(F * S * nJt), np.zeros(F * S * nJR)
+        O.orc_compute_virtual_camera_poses(S, F, orc.dp(cap), orc.dp(exp), k, 0.0, 0.5, orc.dp(kt.ravel().copy()),
+                                           orc.dp(q.ravel().copy()), orc.dp(o_p), orc.dp(o_Jt), orc.dp(o_JR), None)
+        d_p = torch.zeros(F * S * 7, dtype=torch.float64, device="cuda:0")
+        d_Jt = torch.zeros(F * S * nJt, dtype=torch.float64, device="cuda:0")
+        d_JR = torch.zeros(F * S * nJR, dtype=torch.float64, device="cuda:0")
+        assert L.mbavo_compute_virtual_camera_poses(S, F, _t(cap).data_ptr(), _t(exp).data_ptr(), k, 0.0, 0.5, _t(kt.ravel()).data_ptr(),
+                                                    _t(q.ravel()).data_ptr(), d_p.data_ptr(), d_Jt.data_ptr(), d_JR.data_ptr()) == 0
+        assert np.isfinite(o_JR).all()
+        for got, want in ((d_p, o_p), (d_JR, o_JR)):
+            r = _rel(got.cpu().numpy(), want)
+            worst = max(worst, r)
+            assert r < 1e-12, (angle, r)
+    assert worst < 1e-12

@@ -2,7 +2,7 @@
 # HBM traffic of the fused kernel from the TCC counters, one counter per pass (MI355X_MICROARCH.md, HBM section),
 # with a calibration run on a streaming copy of known size so the gfx950 FETCH_SIZE under-count can be corrected.
 export TMPDIR=/tmp
-OUT=gpurun_out/hbm
+OUT=${PROF_SCRATCH:-gpurun_out}/hbm
 rm -rf "$OUT"; mkdir -p "$OUT"
 cat > /tmp/calib.py <<'PY'
 import torch

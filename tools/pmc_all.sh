@@ -3,7 +3,7 @@
 # into profiles/<tag>_pmc_sq.json.  Usage (GPU box): bash tools/pmc_all.sh r01
 TAG=${1:-r01}
 export TMPDIR=/tmp
-OUT=gpurun_out/pmc_all
+OUT=${PROF_SCRATCH:-gpurun_out}/pmc_all
 rm -rf "$OUT"; mkdir -p "$OUT" profiles
 i=0
 for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" \

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 mkdir -p profiles gpurun_out
 rocprofv3 -L 2>/dev/null | grep -o "SQ_INSTS_VALU[A-Z0-9_]*\|SQ_[A-Z_]*F64[A-Z0-9_]*" | sort -u > gpurun_out/sq_valu_counters.txt
 for W in $WL; do
-  OUT=gpurun_out/pmc_fp64_$W
+  OUT=${PROF_SCRATCH:-gpurun_out}/pmc_fp64_$W
   rm -rf "$OUT"; mkdir -p "$OUT"
   for C in SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU SQ_INSTS_MFMA; do
     rocprofv3 --pmc $C --output-format csv -d "$OUT/$C" -o p -- python bench.py --steps 10 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-configs --workload $W > /dev/null 2> "$OUT/err_$C.txt" || echo "pass $C failed: $(tail -1 $OUT/err_$C.txt)"

@@ -2,6 +2,8 @@
 # All committed profiler artefacts of a round, on the GPU box: bash tools/profile_round.sh r02
 TAG=${1:-r02}
 export TMPDIR=/tmp
+# raw rocprofv3 output stays on the box (gpurun merges at most 64 MiB back): only the extracts travel, through gpurun_out/profiles_<tag>
+export PROF_SCRATCH=${PROF_SCRATCH:-/tmp/mbavo_prof}; mkdir -p $PROF_SCRATCH
 mkdir -p profiles gpurun_out
 bash tools/profile.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1; tail -12 gpurun_out/${TAG}_profile.log | cut -c1-160
 for W in c2_dense c3_batch64 c4_batch512; do
