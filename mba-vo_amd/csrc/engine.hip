@@ -1993,7 +1993,10 @@ namespace mbavo
             }
         }
 #endif
-        // everything of this command is out (write-through stores acknowledged) before the mode, the mode before the sequence word
+        // everything of this command is out (write-through stores acknowledged, and -- belt and braces after the ticket experiment
+        // of profiles/r03_kfused_experiments.txt 4. -- an agent-scope release) before the mode, the mode before the sequence word
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0)
         {
@@ -2043,6 +2046,7 @@ namespace mbavo
                     }
                     s_seq = q;
                     s_mode = m;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // ONE poll, ONE acquire: the leader's command is visible
                 }
                 __syncthreads();
                 mode = s_mode;
