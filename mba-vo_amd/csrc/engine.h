@@ -212,6 +212,7 @@ namespace mbavo
         unsigned persist_mask_ = 0;                    // slots with a persistent kernel enqueued and not ended
         unsigned long long pending_seq_ = 0;           // sequence number of the evaluation posted last
         int persist_gen_ = 0;
+        int persist_gen_of_[kPushSlots] = {};          // generation of the kernel enqueued on each slot
         int status_seen_ = 0;
         void *h_fb_ = nullptr; size_t cap_hfb_ = 0;
         static constexpr int kPinnedSlots = 8; // 0-4 host-driven LM loop (tracker.cpp), 5-6 resident LM loop (lm_device)

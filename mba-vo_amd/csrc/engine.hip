@@ -1288,16 +1288,17 @@ namespace mbavo
             {
             __hip_atomic_store(&oa.tickets[bf], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next evaluation
             if (to_host) __threadfence_system(); // THIS slot's frame block is on its way to the host before the slot counts as done
-            if (to_host && atomicAdd(oa.slots_done, 1) == oa.nbf - 1)
+            // (one slot -- one frame, the tracker's case -- needs no count: a device-memory round trip less before the word)
+            if (to_host && (oa.nbf == 1 || atomicAdd(oa.slots_done, 1) == oa.nbf - 1))
             {
-                __hip_atomic_store(oa.slots_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (oa.nbf > 1) __hip_atomic_store(oa.slots_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #if defined(MBAVO_PERSIST_STAMPS) // timing experiment: when this workgroup saw the command / finished (100 MHz ticks)
                 oa.host_flag[1] = __builtin_amdgcn_s_memrealtime();
                 oa.host_flag[2] = oa.t_seen;
                 for (int i = 0; i < 4; ++i) oa.host_flag[3 + i] = stamp_area()[i];
                 __threadfence_system();
 #endif
-                __hip_atomic_store(oa.host_flag, oa.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(oa.host_flag, oa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (ordered by the fence above)
             }
             }
         }
@@ -1622,13 +1623,19 @@ namespace mbavo
 #ifndef MBAVO_PERSIST_SLEEP
 #define MBAVO_PERSIST_SLEEP 8
 #endif
+    // ONE 8-byte word carries the whole command (round 3: sequence number, mode and generation used to be three words, i.e. two
+    // more dependent device-memory round trips before a workgroup could start): the host stores it AFTER the inputs are in place.
+    //   bits 16..63 sequence number   bits 4..15 generation: which launch the command is for (workgroups of an earlier launch
+    //   that have not seen their exit command yet leave when they meet a command of a later generation)
+    //   bits 0..3 mode: 0 = exit, 1 = cost-only evaluation, 2 = H/g evaluation
     struct PersistCmd
     {
-        unsigned long long seq; // incremented by the host AFTER mode and the inputs are in place
-        int mode;               // 0 = exit, 1 = cost-only evaluation, 2 = H/g evaluation
-        int gen;                // which launch the command is for: workgroups of an earlier launch that have not seen their
-                                // exit command yet leave when they meet a command of a later generation
+        unsigned long long word;
     };
+    static inline unsigned long long persist_word(unsigned long long seq, int gen, int mode)
+    {
+        return (seq << 16) | ((unsigned long long)(gen & 0xfff) << 4) | (unsigned long long)(mode & 0xf);
+    }
     template <int KD, int LOGS>
     __global__ __launch_bounds__((kSpWaves * 64)) void k_sp_persist(const ProblemDesc *__restrict__ descs, const TileDesc *__restrict__ tiles,
                                                                   double *__restrict__ rho_out, double *__restrict__ patch_cost,
@@ -1648,11 +1655,12 @@ namespace mbavo
                 int m = 0;
                 for (;;)
                 { // relaxed: an acquire here would invalidate the caches on every poll
-                    q = __hip_atomic_load(&cmd->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const unsigned long long w = __hip_atomic_load(&cmd->word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    q = w >> 16;
                     if (q != last_seq)
                     {
-                        m = __hip_atomic_load(&cmd->mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        if (__hip_atomic_load(&cmd->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != gen) m = 0;
+                        m = (int)(w & 0xf);
+                        if ((int)((w >> 4) & 0xfff) != (gen & 0xfff)) m = 0;
                         break;
                     }
                     if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { m = 0; break; } // ~2 s: give up
@@ -2321,17 +2329,39 @@ namespace mbavo
             const int force = env_int("MBAVO_SP", -1);
             if (ok && force != 0 && (force == 1 || pixels <= 2 * round_px * num_cus_)) sp_logs = lg;
         }
-        sp_logs_ = sp_logs;
-        long long lo = sp_logs ? (long long)kSpWaves * (64 >> sp_logs) : env_int("MBAVO_MIN_TILE_PX", 256), hi = pixels > lo ? pixels : lo;
-        if (count_tiles(lo) > target_tiles)
-        {
-            while (lo < hi)
+        auto tile_px = [&](int logs) {
+            long long lo = logs ? (long long)kSpWaves * (64 >> logs) : env_int("MBAVO_MIN_TILE_PX", 256), hi = pixels > lo ? pixels : lo;
+            if (count_tiles(lo) > target_tiles)
             {
-                const long long mid = (lo + hi) / 2;
-                if (count_tiles(mid) <= target_tiles) hi = mid; else lo = mid + 1;
+                while (lo < hi)
+                {
+                    const long long mid = (lo + hi) / 2;
+                    if (count_tiles(mid) <= target_tiles) hi = mid; else lo = mid + 1;
+                }
+            }
+            return lo;
+        };
+        long long px_per_tile = tile_px(sp_logs);
+        if (sp_logs && env_int("MBAVO_SP", -1) != 1)
+        { // The single-launch form ends with ONE workgroup summing its slot's partials (ticket_finalize): fine for the handful of
+          // tiles of a semi-dense level, slow for a slot of hundreds (a dense 160 x 120 level alone: 253 tiles, 38.1 us against 20.5
+          // for the lane-per-pixel kernel + finalize kernel; tools/level_bench.py).  Such lists take the lane-per-pixel kernel.
+            long long worst = 0;
+            for (int b = 0; b < B; ++b)
+            {
+                long long kpt = px_per_tile / descs[b].P;
+                if (kpt < 1) kpt = 1;
+                worst = std::max(worst, (descs[b].K + kpt - 1) / kpt);
+            }
+            // (the summing workgroup has threads / padded-entries tile-lanes: 4 for k = 2, 1 for k = 4; 64 partials per lane at most)
+            const int lanes = kdeg == 2 ? kSpWaves * 64 / 128 : (kSpWaves * 64 >= 384 ? kSpWaves * 64 / 384 : 1);
+            if (worst > (long long)env_int("MBAVO_SP_MAX_SLOT_TILES", 64) * lanes)
+            {
+                sp_logs = 0;
+                px_per_tile = tile_px(0);
             }
         }
-        const long long px_per_tile = lo;
+        sp_logs_ = sp_logs;
         std::vector<TileDesc> tiles;
         std::vector<int> bf_tile_begin, bf_prob;
         for (int b = 0; b < B; ++b)
@@ -2669,10 +2699,7 @@ namespace mbavo
         if (sp_logs_ <= 0 || !sp_one_fits(kdeg, sp_logs_) || ntiles < 1 || ntiles > num_cus_ || h_descs_[0].grad_fp16 || p.N > 16) return 1;
         if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 64, hipHostMallocDefault) != hipSuccess) { h_flag_ = nullptr; return (int)hipErrorOutOfMemory; }
         volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
-        cmd->mode = 0;
-        cmd->gen = ++persist_gen_;
-        host_store_fence();
-        cmd->seq = flag_seq_;
+        cmd->word = persist_word(flag_seq_, ++persist_gen_, 0);
         host_store_fence();
         OneArgs oa;
         memset(&oa, 0, sizeof(oa));
@@ -2709,6 +2736,7 @@ namespace mbavo
 #undef MBAVO_PERSIST_LAUNCH
         HIP_TRY(hipGetLastError());
         persist_mask_ |= 1u << slot;
+        persist_gen_of_[slot] = persist_gen_;
         last_kernel_id_[0] = kdeg; last_kernel_id_[1] = 1; last_kernel_id_[2] = 0; last_kernel_id_[3] = sp_logs_; last_kernel_id_[4] = 1;
         return 0;
     }
@@ -2718,10 +2746,9 @@ namespace mbavo
         if (!persistent_active(slot)) return MBAVO_E_ARG;
         volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
         const unsigned long long seq = ++flag_seq_;
-        cmd->mode = with_hessian ? 2 : 1;
-        host_store_fence(); // the inputs (knots, flags, scale: the push block, write-combining) and the mode are out ...
-        cmd->seq = seq;
-        host_store_fence(); // ... before the sequence number, which leaves the write-combining buffer now
+        host_store_fence(); // the inputs (knots, flags, scale: the push block, write-combining) are out ...
+        cmd->word = persist_word(seq, persist_gen_of_[slot], with_hessian ? 2 : 1);
+        host_store_fence(); // ... before the command word, which leaves the write-combining buffer now
         pending_seq_ = seq;
         return 0;
     }
@@ -2763,9 +2790,8 @@ namespace mbavo
     {
         if (!persistent_active(slot)) return 0;
         volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
-        cmd->mode = 0;
         host_store_fence();
-        cmd->seq = ++flag_seq_;
+        cmd->word = persist_word(++flag_seq_, persist_gen_of_[slot], 0);
         host_store_fence();
         persist_mask_ &= ~(1u << slot);
         return 0;
@@ -2894,6 +2920,17 @@ namespace mbavo
             a.o.max_it = o.max_it; a.o.max_nonmono = o.max_nonmono; a.o.solver = o.solver; a.o.trace_cap = h_trace ? trace_cap : 0;
             a.o.max_n = n; a.o.max_N = N; a.o.min_q = o.min_q; a.o.min_dec = o.min_dec; a.o.chi = o.chi; a.o.fast_ratio = o.fast_ratio;
             a.level = pyr_level ? pyr_level[li] : li; a.N = N; a.F = F; a.K = probs[li].K; a.P = probs[li].P;
+        }
+        for (int li = 0; li < num_levels; ++li)
+        { // every level's layout first (they park): a level that does not take the single-launch kernel after all (tiles per slot)
+          // must be known before anything is enqueued
+            char *ib = dev + o_init[li], *wb = dev + o_work[li];
+            mbavo_problem p = probs[li];
+            p.d_knots_t = (const double *)wb; p.d_knots_R = (const double *)wb + 3 * N;
+            p.d_outlier = (const unsigned char *)(dev + o_flags[li]); p.num_bad = 0; p.num_residuals = 0;
+            const int rc = rebuild_layout(1, &p, kdeg, nullptr, (const double *)(ib + 16));
+            if (rc) return rc;
+            if (sp_logs_ <= 0 || h_tiles_.empty() || (int)h_tiles_.size() > num_cus_ || empty_slots_) return 1;
         }
         HIP_TRY(hipMemcpyAsync(dev, stage, init_bytes, hipMemcpyHostToDevice, stream_));
 
