@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c2_dense", choices=WORKLOADS)
-    ap.add_argument("--shard", default=None, choices=["pairs", "keypoints", "frames"],
+    ap.add_argument("--shard", default=None, choices=["pairs", "keypoints", "frames", "frame_blocks"],
                     help="N > 1 sharding (default: the workload's own -- frames for a single pair, pairs for a batch of pairs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the bounded runs of the other BASELINE configs")
@@ -249,6 +249,8 @@ class Runner:
         built, self.desc, self.mode = build_workload(name, frames=world if sharded else 1, ctx=ctx, dev=dev, grad_fp16=grad_fp16)
         if shard_mode is not None:
             self.mode = shard_mode
+        elif self.mode == "frames":
+            self.mode = "frame_blocks"  # (the packed blocks are summed, no merge kernel in the step; --shard frames: merged systems)
         if isinstance(built, wl.RenderedPairBatch):
             self.dw, self.probs = built, built.probs
             if grad_fp16:
@@ -317,7 +319,7 @@ class Runner:
         for px, S, p in counts:
             E = synth.packed_len(p.k)
             flops += px * S * (363 + 48 * p.k) + px * (2 * E + 12 * p.k + 13)
-        nbytes = self.wl.algorithmic_bytes(self.probs, None if self.se is None else (self.mode, self.rank, self.world))
+        nbytes = self.wl.algorithmic_bytes(self.probs, None if self.se is None else (self.mode.replace("frame_blocks", "frames"), self.rank, self.world))
         ach_tf = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         ach_gbs = nbytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         return flops, nbytes, ach_tf, ach_gbs
@@ -480,7 +482,7 @@ def main():
         ref = run.se.reference()
         scale = float(ref.abs().max())
         diff = float((got - ref).abs().max()) / (scale if scale > 0 else 1.0)
-        obj = {"frames": "merged [cost | g | H] systems", "keypoints": "packed frame blocks (partial sums over the ranks' keypoint bands)",
+        obj = {"frames": "merged [cost | g | H] systems", "frame_blocks": "packed frame blocks (every rank's frames in its slice, rank-major)", "keypoints": "packed frame blocks (partial sums over the ranks' keypoint bands)",
                "pairs": "packed frame blocks (disjoint slices, rank-major)"}[run.mode]
         return {"object": obj, "doubles": int(run.se.count), "max_rel_diff_vs_single_gpu": diff,
                 "ok": bool(diff <= 1e-12), "bit_exact": bool(torch.equal(got, ref)), "sharding": run.mode}
@@ -580,7 +582,7 @@ def main():
                        "parallelism": ("workload sharded by %s over %d rank(s): evaluation -> %sONE mbavo_allreduce_blocks%s "
                                        "(RCCL, context's own communicator) of %d doubles per step"
                                        % (run.mode, world, "device merge -> " if run.mode == "frames" else "",
-                                          "_to" if run.mode == "pairs" else "", run.se.count))
+                                          "_to" if run.mode in ("pairs", "frame_blocks") else "", run.se.count))
                        if run.se is not None else "1 GPU"},
             "roofline": {"bound": "fp64", "achieved": round(ach_tf, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach_tf / FP64_PEAK_TFLOPS, 5),

@@ -9,6 +9,9 @@ equations (the reference's reduction point is merge_hessian_gradie
     evaluates its pairs into ITS contiguous slice of a B*F*E send buffer whose other slices are zero and stay zero
     (`pair_layout`), and ONE out-of-place all-reduce (`mbavo_allreduce_blocks_to`) leaves every pair's blocks on every
     rank -- disjoint slices, so the sum is exact and bit-identical to a single-GPU evaluation.
+  * ONE joint problem, frames sharded, packed blocks summed ('frame_blocks', bench.py's default for a single pair): as
+    'frames' below, but every rank's frame blocks go into its slice of a zero send buffer and the all-reduce carries the
+    packed blocks; the scatter into the 6N x 6N system is the consumer's (no merge kernel in the step).
   * ONE joint problem, frames sharded (`mbavo_shard_frames`): rank r owns a contiguous frame range; every rank scatters
     its frames' blocks into the 6N x 6N system on the device (`mbavo_merge_device`) and the partial systems
     [cost | g | H] are summed: one all-reduce of 1 + 6N + 36N^2 doubles per problem.
@@ -110,13 +113,16 @@ class ShardedEvaluation:
 
     def __init__(self, ctx, whole, k, rank, world, mode, device):
         import torch
-        assert mode in ("keypoints", "frames", "pairs")
+        assert mode in ("keypoints", "frames", "frame_blocks", "pairs")
         self.ctx, self.whole, self.k, self.rank, self.world, self.mode = ctx, whole, k, rank, world, mode
         self.B = len(whole)
         lib = ctx.lib
         self.E = lib.mbavo_packed_len(k)
         if mode == "pairs":
             self._init_pairs(device)
+            return
+        if mode == "frame_blocks":
+            self._init_frame_blocks(device)
             return
         self.shards, self.first = shard_array(lib, whole, rank, world, mode)
         live = [b for b in range(self.B) if self.shards[b].F > 0]
@@ -131,6 +137,40 @@ class ShardedEvaluation:
         self.reduced = self.systems if mode == "frames" else self.frame_blocks
         self.count = self.sys_len if mode == "frames" else self.nbf * self.E
         self._ref_fb, self._ref_sys = z(self.nbf_whole * self.E), z(self.sys_len)
+
+    def _init_frame_blocks(self, device):
+        """Frames sharded as in 'frames', but what is summed over the ranks are the PACKED FRAME BLOCKS themselves: rank r's
+        frames occupy a contiguous slice (rank-major rows) of a zero send buffer its evaluation writes straight into, ONE
+        out-of-place all-reduce leaves every frame's block on every rank, and the 6N x 6N scatter
+        (merge_hessian_gradient_cost.cpp:39-86) is the consumer's, as on one GPU -- no merge kernel in the step (one launch,
+        ~3 us, less than 'frames'; F*E instead of 1 + 6N + 36N^2 doubles per problem on the wire, latency-bound either way)."""
+        import torch
+        lib, whole, rank, world = self.ctx.lib, self.whole, self.rank, self.world
+        self.shards, self.first = shard_array(lib, whole, rank, world, "frames")
+        live = [b for b in range(self.B) if self.shards[b].F > 0]
+        self.live = (capi.Problem * max(len(live), 1))(*[self.shards[b] for b in live])
+        self.n_live = len(live)
+        self.nbf = sum(self.shards[b].F for b in range(self.B))
+        self.nbf_whole = sum(whole[b].F for b in range(self.B))
+        bf_base = np.cumsum([0] + [whole[b].F for b in range(self.B)])
+        perm, self.row_base = [], [0]
+        for r in range(world):
+            for b in range(self.B):
+                f0, f1 = frame_range_of_rank(whole[b].F, r, world)
+                perm += [int(bf_base[b]) + f for f in range(f0, f1)]
+            self.row_base.append(len(perm))
+        assert sorted(perm) == list(range(self.nbf_whole)) and self.row_base[rank + 1] - self.row_base[rank] == self.nbf
+        self.sys_len = 0
+        z = lambda n: torch.zeros(max(n, 1), dtype=torch.float64, device=device)
+        self.send = z(self.nbf_whole * self.E)
+        self.frame_blocks = self.send[self.row_base[rank] * self.E:self.row_base[rank + 1] * self.E] if self.nbf else z(1)
+        self.valid = z(self.nbf)
+        self.systems = None
+        self.reduced = z(self.nbf_whole * self.E) if world > 1 else self.send  # (one rank: its slice is the whole buffer)
+        self.count = self.nbf_whole * self.E
+        self._ref_fb, self._ref_sys = z(self.nbf_whole * self.E), None
+        self._perm = torch.from_numpy(np.array(perm, np.int64)).to(device)
+        self.row_of_frame = {int(p): i for i, p in enumerate(perm)}  # problem-major frame slot -> row of `reduced`
 
     def _init_pairs(self, device):
         import torch
@@ -155,7 +195,7 @@ class ShardedEvaluation:
             if self.nbf else z(1)
         self.valid = z(self.nbf)
         self.systems = None
-        self.reduced = z(self.nbf_whole * self.E)  # rank-major rows (pair_layout)
+        self.reduced = z(self.nbf_whole * self.E) if world > 1 else self.send  # rank-major rows (pair_layout); one rank: the send buffer
         self.count = self.nbf_whole * self.E
         self._ref_fb, self._ref_sys = z(self.nbf_whole * self.E), None
         # rows of the whole workload in problem order -> rank-major rows
@@ -186,7 +226,7 @@ class ShardedEvaluation:
 
     def _reduce(self):
         reduce = True
-        if reduce and self.mode == "pairs":
+        if reduce and self.mode in ("pairs", "frame_blocks"):
             capi.check(self.ctx.lib.mbavo_allreduce_blocks_to(self.ctx.handle, None, self.send.data_ptr(),
                                                               self.reduced.data_ptr(), self.count), "mbavo_allreduce_blocks_to")
         elif reduce:
@@ -203,7 +243,7 @@ class ShardedEvaluation:
             capi.check(lib.mbavo_merge_device(ctx.handle, self.B, self.whole, self.k, self._ref_fb.data_ptr(),
                                               self._ref_sys.data_ptr()), "mbavo_merge_device")
         torch.cuda.synchronize()
-        if self.mode == "pairs":  # the same rows in the rank-major order of the reduced buffer
+        if self.mode in ("pairs", "frame_blocks"):  # the same rows in the rank-major order of the reduced buffer
             return self._ref_fb.view(self.nbf_whole, self.E)[self._perm].reshape(-1).clone()
         return (self._ref_sys if self.mode == "frames" else self._ref_fb).clone()
 

@@ -77,6 +77,24 @@ def rank_body(rank, world, local_rank, port, out_path):
     res["device_merge_equals_host_merge"] = bool(exact)
     res["frames_vs_oracle"] = worst_oracle
 
+    # ---- frame_blocks mode (bench.py's default for a single pair): the same frame shards, but the packed blocks themselves are
+    # summed from every rank's slice of a zero send buffer -- no merge kernel; rows in rank-major order
+    se_fb = shard.ShardedEvaluation(ctx, dw.array, 4, rank, world, "frame_blocks", dev)
+    for _ in range(2):
+        se_fb.step(True)
+    torch.cuda.synchronize()
+    got_fb, ref_fb = se_fb.reduced.clone(), se_fb.reference()
+    res["frame_blocks_vs_single_gpu"] = rel(got_fb, ref_fb)
+    lo_fb, hi_fb = se_fb.row_base[rank] * se_fb.E, se_fb.row_base[rank + 1] * se_fb.E
+    res["frame_blocks_foreign_slices_zero"] = bool(float(se_fb.send[:lo_fb].abs().sum() + se_fb.send[hi_fb:].abs().sum()) == 0.0)
+    # the consumer's merge of the reduced blocks == the 'frames' mode's reduced systems
+    blocks_pm = torch.empty_like(got_fb).view(se_fb.nbf_whole, se_fb.E)
+    blocks_pm[se_fb._perm] = got_fb.view(se_fb.nbf_whole, se_fb.E)  # back to problem-major rows
+    sys_fb = torch.zeros_like(got)
+    assert ctx.lib.mbavo_merge_device(ctx.handle, len(probs), dw.array, 4, blocks_pm.data_ptr(), sys_fb.data_ptr()) == 0
+    torch.cuda.synchronize()
+    res["frame_blocks_merged_vs_frames_mode"] = rel(sys_fb, got)
+
     # ---- keypoints mode: 5 semi-dense pairs, every pair's keypoints sharded, packed blocks summed
     pb = wl.pair_batch(5, H=240, W=320, S=8, k=4, N=4, mode="semidense", seed=3)
     dw2 = wl.DeviceWorkload(pb, device=dev)
@@ -124,6 +142,8 @@ def check(res, world):
     assert res["world"] == world and res["rccl_ranks"] == world
     assert res["nonzero"] and res["ranks_agree"] and res["device_merge_equals_host_merge"]
     assert res["frames_vs_single_gpu"] <= 1e-12 and res["keypoints_vs_single_gpu"] <= 1e-12
+    assert res["frame_blocks_vs_single_gpu"] <= 1e-12 and res["frame_blocks_foreign_slices_zero"]
+    assert res["frame_blocks_merged_vs_frames_mode"] <= 1e-12
     assert res["frames_vs_oracle"] <= 1e-9 and res["pairs_vs_oracle"] <= 1e-9
     assert res["pairs_vs_single_gpu"] <= 1e-12 and res["pairs_own_slice_exact"] and res["pairs_foreign_slices_zero"]
 
@@ -177,7 +197,7 @@ def test_frame_shards_of_every_rank_add_up_on_one_gpu(mbavo, world):
     try:
         probs = wl.pyramid_pair(240, 320, 3, S=8, k=4, N=4, mode="dense", seed=11, frames=world)
         dw = wl.DeviceWorkload(probs, device=dev)
-        total, ref = None, None
+        total, ref, total_fb, ref_fb = None, None, None, None
         for r in range(world):
             se = shard.ShardedEvaluation(ctx, dw.array, 4, r, world, "frames", dev)
             assert sum(se.shards[b].F for b in range(se.B)) == len(probs)  # one frame of every pyramid level
@@ -185,9 +205,15 @@ def test_frame_shards_of_every_rank_add_up_on_one_gpu(mbavo, world):
             torch.cuda.synchronize()
             part = se.reduced.clone()
             total = part if total is None else total + part
+            # the default of bench.py: the packed blocks in the rank's slice of the zero send buffer, no merge kernel
+            sb = shard.ShardedEvaluation(ctx, dw.array, 4, r, world, "frame_blocks", dev)
+            sb.step(True, reduce=False)
+            torch.cuda.synchronize()
+            total_fb = sb.send.clone() if total_fb is None else total_fb + sb.send
             if r == world - 1:
-                ref = se.reference()
-        assert float(ref.abs().max()) > 0
+                ref, ref_fb = se.reference(), sb.reference()
+        assert float(ref.abs().max()) > 0 and float(ref_fb.abs().max()) > 0
         assert float((total - ref).abs().max() / ref.abs().max()) <= 1e-12
+        assert float((total_fb - ref_fb).abs().max() / ref_fb.abs().max()) <= 1e-12
     finally:
         ctx.close()
