@@ -88,6 +88,12 @@ namespace mbavo
         static constexpr int kPushSlots = 8;
         int persistent_begin(int slot, const mbavo_problem &p, int kdeg, double *h_frame_blocks, double *h_patch_cost, const double *h_inv,
                              bool cached_only = false);
+        // ONE kernel for a list of B problems that share their knot buffer (round 3: the pyramid levels of a tracked frame -- one
+        // launch per frame instead of one per level): a command names the problem it evaluates (persistent_post's `prob`), the
+        // workgroups of the other problems' tiles skip it.  h_inv: B consecutive words (problem b's scale at h_inv[b]); frame
+        // blocks / patch costs of problem b at its rows of the list (frames / patches of the problems before it first).
+        int persistent_begin(int slot, int B, const mbavo_problem *probs, int kdeg, double *h_frame_blocks, double *h_patch_cost,
+                             const double *h_inv, bool cached_only = false);
         // Fine-grained DEVICE memory the CPU writes directly through the PCIe BAR (write-combining: stores + sfence; never
         // read it from the CPU): a slot's command block (its first 64 bytes, owned by the engine) and the per-evaluation
         // inputs the caller lays out behind it (knots, residual scale, outlier flags).  Pushing the inputs costs the GPU
@@ -96,9 +102,9 @@ namespace mbavo
         // nullptr when the platform cannot do it (or the blocks would have to grow while a persistent kernel runs).
         void *push_block(int slot, size_t bytes);
         static constexpr size_t kPushHeader = 64;
-        int persistent_post(int slot, bool with_hessian);
+        int persistent_post(int slot, bool with_hessian, int prob = 0);
         int persistent_wait();
-        int persistent_eval(int slot, bool with_hessian) { const int r = persistent_post(slot, with_hessian); return r ? r : persistent_wait(); }
+        int persistent_eval(int slot, bool with_hessian, int prob = 0) { const int r = persistent_post(slot, with_hessian, prob); return r ? r : persistent_wait(); }
         int persistent_end(int slot);
         int persistent_end_all();
         bool persistent_active(int slot) const { return slot >= 0 && slot < kPushSlots && (persist_mask_ >> slot & 1u) != 0; }

@@ -1625,16 +1625,17 @@ namespace mbavo
 #endif
     // ONE 8-byte word carries the whole command (round 3: sequence number, mode and generation used to be three words, i.e. two
     // more dependent device-memory round trips before a workgroup could start): the host stores it AFTER the inputs are in place.
-    //   bits 16..63 sequence number   bits 4..15 generation: which launch the command is for (workgroups of an earlier launch
+    //   bits 20..63 sequence number   bits 8..19 generation: which launch the command is for (workgroups of an earlier launch
     //   that have not seen their exit command yet leave when they meet a command of a later generation)
+    //   bits 4..7 problem of the kernel's list the command is for (the pyramid level when one kernel serves all levels)
     //   bits 0..3 mode: 0 = exit, 1 = cost-only evaluation, 2 = H/g evaluation
     struct PersistCmd
     {
         unsigned long long word;
     };
-    static inline unsigned long long persist_word(unsigned long long seq, int gen, int mode)
+    static inline unsigned long long persist_word(unsigned long long seq, int gen, int mode, int prob = 0)
     {
-        return (seq << 16) | ((unsigned long long)(gen & 0xfff) << 4) | (unsigned long long)(mode & 0xf);
+        return (seq << 20) | ((unsigned long long)(gen & 0xfff) << 8) | ((unsigned long long)(prob & 0xf) << 4) | (unsigned long long)(mode & 0xf);
     }
     template <int KD, int LOGS>
     __global__ __launch_bounds__((kSpWaves * 64)) void k_sp_persist(const ProblemDesc *__restrict__ descs, const TileDesc *__restrict__ tiles,
@@ -1646,22 +1647,27 @@ namespace mbavo
         __shared__ unsigned long long s_seq;
         __shared__ int s_mode;
         __shared__ double knots_lds[7 * 16]; // this command's control knots [t (3N) | R (4N)], N <= 16
+        // One kernel may serve SEVERAL problems (round 3: the pyramid levels of a tracked frame, one launch per frame instead of
+        // one per level): a command names its problem, the workgroups of the other problems' tiles skip it.
+        const int my_prob = tiles[xcd_tile_of_block((int)blockIdx.x, (int)gridDim.x)].prob;
         for (;;)
         {
             if (threadIdx.x == 0)
             {
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned long long q;
-                int m = 0;
+                int m = 0, pr = 0;
                 for (;;)
                 { // relaxed: an acquire here would invalidate the caches on every poll
                     const unsigned long long w = __hip_atomic_load(&cmd->word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    q = w >> 16;
+                    q = w >> 20;
                     if (q != last_seq)
                     {
                         m = (int)(w & 0xf);
-                        if ((int)((w >> 4) & 0xfff) != (gen & 0xfff)) m = 0;
-                        break;
+                        pr = (int)((w >> 4) & 0xf);
+                        if ((int)((w >> 8) & 0xfff) != (gen & 0xfff)) m = 0;
+                        if (m == 0 || pr == my_prob) break;
+                        last_seq = q; // another problem's evaluation: not for this workgroup
                     }
                     if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { m = 0; break; } // ~2 s: give up
                     __builtin_amdgcn_s_sleep(MBAVO_PERSIST_SLEEP);
@@ -1676,14 +1682,15 @@ namespace mbavo
             // nothing read from memory may be carried over from the previous command, and nothing should be: values
             // hoisted out of this loop stay live across both bodies and spill
             asm volatile("" ::: "memory");
-            // The inputs the host rewrote (it wrote them BEFORE the sequence number, sfence in between): the knots go into
+            // The inputs the host rewrote (it wrote them BEFORE the command word, sfence in between): the knots go into
             // LDS through cache-bypassing loads, the residual scale and the outlier flags are read the same way where they
             // are used.  No acquire fence: the images, keypoints and descriptors stay in the caches across commands.
-            const ProblemDesc &d0 = descs[0];
+            const ProblemDesc &d0 = descs[my_prob];
             double *kn = knots_lds;
             for (int i = threadIdx.x; i < 7 * d0.N; i += kSpWaves * 64)
                 kn[i] = __hip_atomic_load(i < 3 * d0.N ? d0.knots_t + i : d0.knots_R + (i - 3 * d0.N), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
+            oa.nbf = d0.F; // the slots of THIS problem's evaluation
             oa.seq = last_seq;
 #if defined(MBAVO_PERSIST_STAMPS)
             oa.t_seen = __builtin_amdgcn_s_memrealtime();
@@ -2686,17 +2693,27 @@ namespace mbavo
     int Engine::persistent_begin(int slot, const mbavo_problem &p, int kdeg, double *h_frame_blocks, double *h_patch_cost,
                                  const double *h_inv, bool cached_only)
     {
+        return persistent_begin(slot, 1, &p, kdeg, h_frame_blocks, h_patch_cost, h_inv, cached_only);
+    }
+
+    int Engine::persistent_begin(int slot, int B, const mbavo_problem *probs, int kdeg, double *h_frame_blocks, double *h_patch_cost,
+                                 const double *h_inv, bool cached_only)
+    {
+        if (B < 1 || B > 15 || !probs) return MBAVO_E_ARG;
+        const mbavo_problem &p = probs[0];
         if (slot < 0 || slot >= kPushSlots || persistent_active(slot) || !h_frame_blocks || !h_inv || (kdeg != 2 && kdeg != 4)) return MBAVO_E_ARG;
         if (env_int("MBAVO_PERSIST", 1) == 0 || env_int("MBAVO_ONE", 1) == 0) return 1;
         if (!d_push_ || push_stride_ == 0) return 1; // no CPU-writable device memory: the caller takes the per-evaluation launches
         if (cached_only && env_int("MBAVO_PRELAUNCH", 1) == 0) return 1;
         int cur = -1;
         if (hipGetDevice(&cur) != hipSuccess || cur != device_) HIP_TRY(hipSetDevice(device_));
-        int rc = rebuild_layout(1, &p, kdeg, nullptr, h_inv, cached_only);
+        int rc = rebuild_layout(B, probs, kdeg, nullptr, h_inv, cached_only);
         if (rc == 2) return 1;
         if (rc) return rc;
         const int ntiles = (int)h_tiles_.size();
-        if (sp_logs_ <= 0 || !sp_one_fits(kdeg, sp_logs_) || ntiles < 1 || ntiles > num_cus_ || h_descs_[0].grad_fp16 || p.N > 16) return 1;
+        if (sp_logs_ <= 0 || !sp_one_fits(kdeg, sp_logs_) || ntiles < 1 || ntiles > num_cus_ || h_descs_[0].grad_fp16 || p.N > 16 || empty_slots_) return 1;
+        for (int b = 1; b < B; ++b) // (one knot buffer for all the problems of a persistent kernel)
+            if (probs[b].N != p.N || probs[b].d_knots_t != p.d_knots_t || probs[b].d_knots_R != p.d_knots_R) return 1;
         if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 64, hipHostMallocDefault) != hipSuccess) { h_flag_ = nullptr; return (int)hipErrorOutOfMemory; }
         volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
         cmd->word = persist_word(flag_seq_, ++persist_gen_, 0);
@@ -2741,13 +2758,13 @@ namespace mbavo
         return 0;
     }
 
-    int Engine::persistent_post(int slot, bool with_hessian)
+    int Engine::persistent_post(int slot, bool with_hessian, int prob)
     {
-        if (!persistent_active(slot)) return MBAVO_E_ARG;
+        if (!persistent_active(slot) || prob < 0 || prob > 15) return MBAVO_E_ARG;
         volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
         const unsigned long long seq = ++flag_seq_;
         host_store_fence(); // the inputs (knots, flags, scale: the push block, write-combining) are out ...
-        cmd->word = persist_word(seq, persist_gen_of_[slot], with_hessian ? 2 : 1);
+        cmd->word = persist_word(seq, persist_gen_of_[slot], with_hessian ? 2 : 1, prob);
         host_store_fence(); // ... before the command word, which leaves the write-combining buffer now
         pending_seq_ = seq;
         return 0;

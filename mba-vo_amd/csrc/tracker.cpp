@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -121,6 +122,7 @@ namespace mbavo
         double eval_cost = 0.0;
 
         int maxK = 0;
+        size_t sumK = 0;
         for (int l = 0; l < o.num_levels; ++l) maxK = levels[l].K > maxK ? levels[l].K : maxK;
         double *d_cap = nullptr, *d_exp = nullptr, *d_kt = nullptr, *d_kR = nullptr, *d_pc = nullptr;
         unsigned char *d_flags = nullptr;
@@ -138,11 +140,13 @@ namespace mbavo
         // the per-patch costs land in pinned host memory (written by the fused kernel, read by detect_outliers after the
         // evaluation's synchronisation: no D2H copy); the flags are staged in pinned memory so that their upload is a
         // truly asynchronous copy
-        d_pc = (double *)eng.pinned_scratch(0, sizeof(double) * (size_t)F * (maxK > 0 ? maxK : 1));
+        // (sized for ALL levels side by side: one persistent kernel may serve every level of the call, see `joint` below)
+        for (int l = 0; l < o.num_levels; ++l) sumK += (size_t)(levels[l].K > 0 ? levels[l].K : 1);
+        d_pc = (double *)eng.pinned_scratch(0, sizeof(double) * (size_t)F * sumK);
         flags = (unsigned char *)eng.pinned_scratch(1, maxK > 0 ? maxK : 1);
         d_flags = (unsigned char *)eng.named_scratch(6, maxK > 0 ? maxK : 1);
-        h_pin = eng.host_frame_blocks((size_t)F * E); // device-visible pinned host memory
-        if (h_pin) memset(h_pin, 0, sizeof(double) * (size_t)F * E);
+        h_pin = eng.host_frame_blocks((size_t)F * E * o.num_levels); // device-visible pinned host memory
+        if (h_pin) memset(h_pin, 0, sizeof(double) * (size_t)F * E * o.num_levels);
         h_inv = (double *)eng.pinned_scratch(3, sizeof(double));
         if (!h_inv || !d_cap || !d_exp || !d_kt || !d_kR || !d_pc || !d_flags || !flags || !h_pin) { rc_ = (int)hipErrorOutOfMemory; goto done; }
         { // capture / exposure times: one asynchronous copy from pinned staging [cap F | exp F] (:701-719)
@@ -246,18 +250,64 @@ namespace mbavo
             return pr;
         };
 
+        // ONE persistent kernel for ALL levels of the call where they fit one list (round 3: a launch and a level set-up cost the
+        // host ~14 us each, only partly hidden behind evaluations; trackFrame 0.366 -> see profiles/r03_kfused_experiments.txt 7.):
+        // the levels are the problems of one layout, they share the knot buffer of slot 0's push block, every level has its own
+        // scale word and flag bytes there, and a command names its level.  MBAVO_PERSIST_LEVELS=0 keeps one kernel per level.
+        bool joint = false;
+        size_t joint_pc_off[8] = {};
+        const char *env_joint = getenv("MBAVO_PERSIST_LEVELS");
+        if (o.num_levels > 1 && (env_joint == nullptr || atoi(env_joint) != 0))
+        {
+            size_t flag_bytes = 0;
+            for (int l = 0; l < o.num_levels; ++l) flag_bytes += ((size_t)(levels[l].K > 0 ? levels[l].K : 1) + 63) & ~(size_t)63;
+            char *push = (char *)eng.push_block(0, Engine::kPushHeader + 64 + sizeof(double) * 7 * N + flag_bytes + 64);
+            if (push)
+            {
+                double *b = (double *)(push + Engine::kPushHeader);
+                mbavo_problem lp[8];
+                unsigned char *fl = (unsigned char *)(b + 8 + 7 * N);
+                size_t pc_off = 0;
+                bool ok = true;
+                for (int li = 0; li < o.num_levels && ok; ++li)
+                {
+                    if ((rc_ = prepare(li)) != 0) goto done;
+                    LevelRun &R = runs[li];
+                    const mbavo_level &L = levels[o.num_levels - li - 1];
+                    R.w_inv = b + li; R.w_kt = b + 8; R.w_kR = R.w_kt + 3 * N; R.w_flags = fl;
+                    R.p.d_knots_t = R.w_kt; R.p.d_knots_R = R.w_kR; R.p.d_outlier = R.w_flags;
+                    memset(R.w_flags, 0, L.K > 0 ? L.K : 1);
+                    const long long nres = (long long)L.K * F * L.P;
+                    *R.w_inv = nres > 0 ? 1.0 / (double)nres : 0.0;
+                    fl += ((size_t)(L.K > 0 ? L.K : 1) + 63) & ~(size_t)63;
+                    joint_pc_off[li] = pc_off;
+                    pc_off += (size_t)F * L.K;
+                    lp[li] = R.p;
+                }
+                PhaseScope ps_level(PhaseTimers::kLevel);
+                const int pr = eng.persistent_begin(0, o.num_levels, lp, k, h_pin, d_pc, b, false);
+                if (pr == 0) joint = true;
+                else if (pr < 0 || pr > 1) { rc_ = pr; goto done; }
+                else
+                    for (int li = 0; li < o.num_levels; ++li) runs[li].prepared = false; // per-level kernels: their own slots
+            }
+        }
+
         for (int li = 0; li < o.num_levels; ++li)
         {
             const int lv = o.num_levels - li - 1; // coarse to fine (:571-575)
             const mbavo_level &L = levels[lv];
             memset(flags, 0, L.K > 0 ? L.K : 1); // :601 (the device copy below, where it is used)
-            if ((rc_ = prepare(li)) != 0) goto done;
+            if (!joint)
             {
+                if ((rc_ = prepare(li)) != 0) goto done;
                 const int pr = launch(li, false);
                 if (pr < 0 || pr > 1) { rc_ = pr; goto done; }
             }
             LevelRun &R = runs[li];
-            const bool persistent = R.launched;
+            const bool persistent = joint || R.launched;
+            double *const lvl_pin = h_pin + (joint ? (size_t)li * F * E : 0);  // this level's frame blocks / patch costs
+            double *const lvl_pc = d_pc + (joint ? joint_pc_off[li] : 0);
             mbavo_problem p = R.p;
             // The outlier count changes with every accepted step; it reaches the kernels through a word (inv_ptr) instead of the
             // problem descriptor, so the engine's cached layout stays valid for the whole level
@@ -275,7 +325,7 @@ namespace mbavo
                 p.d_knots_t = d_kt; p.d_knots_R = d_kR; p.d_outlier = d_flags; // per-evaluation launches read the device copy
                 TRK_HIP(hipMemsetAsync(d_flags, 0, L.K > 0 ? L.K : 1, st));
             }
-            bool want_prelaunch = persistent && li + 1 < o.num_levels;
+            bool want_prelaunch = persistent && !joint && li + 1 < o.num_levels;
             // one evaluation at the given knots: knots into the pinned buffer, ONE launch for these problem sizes (pose
             // prologue + fused + last-workgroup finalize) whose frame blocks land in pinned host memory (h_pin), then a
             // spin on the kernel's completion word: no copies, no stream synchronisation
@@ -286,7 +336,7 @@ namespace mbavo
                     memcpy(w_kt, kt, sizeof(double) * 3 * N);
                     memcpy(w_kR, kR, sizeof(double) * 4 * N);
                     if (!persistent) r = eng.evaluate(1, &p, k, with_h, h_pin, d_pc, nullptr, nullptr, nullptr, h_inv, true);
-                    else r = eng.persistent_post(li, with_h);
+                    else r = joint ? eng.persistent_post(0, with_h, li) : eng.persistent_post(li, with_h);
                 }
                 if (r) return r;
                 if (want_prelaunch)
@@ -307,7 +357,7 @@ namespace mbavo
                 if (r) return r;
                 PhaseScope ps(PhaseTimers::kMerge);
 
-                merge_blocks_host(F, k, h_pin, start_idx.data(), N, cost, with_h ? H.data() : nullptr,
+                merge_blocks_host(F, k, lvl_pin, start_idx.data(), N, cost, with_h ? H.data() : nullptr,
                                   with_h ? g.data() : nullptr);
                 return 0;
             };
@@ -365,7 +415,7 @@ namespace mbavo
                     {
                         PhaseScope ps(PhaseTimers::kOutliers);
                         const int bad_before = num_bad;
-                        num_bad = detect_outliers(d_pc, L.K, o.max_chi_square_error, w_flags); // frame 0's costs, just written
+                        num_bad = detect_outliers(lvl_pc, L.K, o.max_chi_square_error, w_flags); // frame 0's costs, just written
                         if (PhaseTimers::get().on) ++PhaseTimers::get().calls[num_bad != bad_before ? PhaseTimers::kFlagsChanged : PhaseTimers::kFlagsSame];
                         set_inv();
                         if (!persistent) TRK_HIP(hipMemcpyAsync(d_flags, w_flags, L.K, hipMemcpyHostToDevice, st));
@@ -380,7 +430,7 @@ namespace mbavo
                 lm.step_rejected(); // handleUnsuccessfulStep
                 record(iter, 2, cand_cost, model, quality);
             }
-            (void)eng.persistent_end(li); // the level's resident workgroups exit; the next level's kernel is already queued behind them
+            if (!joint) (void)eng.persistent_end(li); // the level's resident workgroups exit; the next level's kernel is already queued behind them
         }
         }
         memcpy(knots_t, spline.get_knot_data_t(), sizeof(double) * 3 * N);
