@@ -25,33 +25,42 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 namespace mbavo
 {
-    // One wave per problem: finish the previous accepted step, loop control, damping, solve, model change, candidate.
-    template <int KD>
-    __global__ __launch_bounds__(64) void k_lm_solve(const ProblemDesc *__restrict__ descs, LmState *__restrict__ states, LmOpts o,
-                                                     const double *__restrict__ fb, const int *__restrict__ start_idx,
-                                                     double *__restrict__ Hst, double *__restrict__ gst,
-                                                     double *__restrict__ cur_t, double *__restrict__ cur_R,
-                                                     int *__restrict__ active, mbavo_trace_rec *__restrict__ trace,
-                                                     int *__restrict__ num_done)
+    // One workgroup of T threads per problem: finish the previous accepted step, loop control, damping, solve, model change,
+    // candidate.  T = 64 (one wave: the one-sided Jacobi SVD / pivoted LDL^T of lm_solvers.h, any n up to 96) or T = kEigT
+    // (solver 0 with n <= kEigMaxN: the workgroup-parallel eigenvalue Jacobi, eig_solve).  The scalar state of the loop is
+    // computed redundantly by every thread (same inputs, same arithmetic); thread 0 stores it.
+    template <int KD, int T>
+    __global__ __launch_bounds__(T) void k_lm_solve(const ProblemDesc *__restrict__ descs, LmState *__restrict__ states, LmOpts o,
+                                                    const double *__restrict__ fb, const int *__restrict__ start_idx,
+                                                    double *__restrict__ Hst, double *__restrict__ gst,
+                                                    double *__restrict__ cur_t, double *__restrict__ cur_R,
+                                                    int *__restrict__ active, mbavo_trace_rec *__restrict__ trace,
+                                                    int *__restrict__ num_done)
     {
         constexpr int M6 = 6 * KD, ND = M6 + 1, E = ND * (ND + 1) / 2;
         extern __shared__ __attribute__((aligned(16))) double lds[];
-        const int b = blockIdx.x, lane = threadIdx.x;
+        const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
         const ProblemDesc &d = descs[b];
         const int N = d.N, n = 6 * N, F = d.F;
         LmState s = states[b];
         if (s.done) return;
-        // LDS: V and G (n x (n + 1) each) + vectors; the damped system H itself lives in global memory (it persists
-        // across iterations anyway), which leaves room for the reference's maximum of 16 control knots (n = 96)
-        double *V = lds, *g = V + n * (n + 1), *x = g + n, *tmp = x + n;
-        int *order = (int *)(tmp + n);
+        // LDS, T = 64: V and G (n x (n + 1) each) + vectors; the damped system H itself lives in global memory (it persists
+        // across iterations anyway), which leaves room for the reference's maximum of 16 control knots (n = 96).
+        // T = kEigT: the four n x eig_ld(n) areas of eig_solve first (16-byte aligned), then the vectors.
+        // T = kEigT additionally keeps the system itself in LDS for the length of the kernel (merge, damping, model change:
+        // ~25 dependent global round trips otherwise); global memory holds it between launches.
+        constexpr bool eig = T == kEigT; // the host launches this form only for solver 0 with every n <= kEigMaxN
+        double *V = lds, *g = V + (eig ? eig_lds_doubles(n) : (size_t)n * (n + 1)), *x = g + n, *tmp = x + n;
+        double *Hl = tmp + n;                                        // T = kEigT: n x n
+        int *order = eig ? (int *)(Hl + n * n) : (int *)(tmp + n);   // T = kEigT: eig_solve's 4 + 2 n ints
         double *Hg = Hst + (size_t)b * o.max_n * o.max_n, *gg = gst + (size_t)b * o.max_n;
-        double *H = Hg;
+        double *H = eig ? Hl : Hg;
         double *Ct = cur_t + (size_t)b * 3 * o.max_N, *CR = cur_R + (size_t)b * 4 * o.max_N;
         mbavo_trace_rec *tr = trace ? trace + (size_t)b * o.trace_cap : nullptr;
 
@@ -64,7 +73,7 @@ namespace mbavo
             { // handleSuccessfulStep (:896-903)
                 lm_accepted(s, s.quality);
                 tr_accepted(s, s.eval_cost, s.model, o.max_nonmono);
-                trace_push(s, tr, o.trace_cap, lane, 0, 1, s.cand_cost, s.model, s.quality);
+                trace_push(s, tr, o.trace_cap, tid, 0, 1, s.cand_cost, s.model, s.quality);
                 ++s.n_accept;
             }
             else
@@ -72,22 +81,22 @@ namespace mbavo
                 s.initial_cost = cost;
                 lm_reset(s);
                 tr_reset(s, cost);
-                trace_push(s, tr, o.trace_cap, lane, 0, 0, 0.0, 0.0, 0.0);
+                trace_push(s, tr, o.trace_cap, tid, 0, 0, 0.0, 0.0, 0.0);
             }
             // merge_hessian_gradient_cost.cpp:39-86, frames in order
-            for (int i = lane; i < n * n; i += 64) H[i] = 0.0;
-            for (int i = lane; i < n; i += 64) g[i] = 0.0;
+            for (int i = tid; i < n * n; i += T) H[i] = 0.0;
+            for (int i = tid; i < n; i += T) g[i] = 0.0;
             __syncthreads();
             for (int f = 0; f < F; ++f)
             {
                 const double *blk = fb + (size_t)(d.bf_base + f) * E;
                 const int st = start_idx[d.bf_base + f];
-                for (int j = lane; j < M6; j += 64)
+                for (int j = tid; j < M6; j += T)
                 {
                     const int gi = j < 3 * KD ? 3 * st + j : 3 * (N + st) + (j - 3 * KD);
                     g[gi] += blk[1 + j];
                 }
-                for (int e = lane; e < M6 * (M6 + 1) / 2; e += 64)
+                for (int e = tid; e < M6 * (M6 + 1) / 2; e += T)
                 {
                     int r, c;
                     tri_decode(e, M6, r, c);
@@ -99,13 +108,15 @@ namespace mbavo
                 }
                 __syncthreads();
             }
-            for (int i = lane; i < n; i += 64) gg[i] = g[i];
+            for (int i = tid; i < n; i += T) gg[i] = g[i];
             s.fresh = 0;
             s.pending_accept = 0;
         }
         else
         {
-            for (int i = lane; i < n; i += 64) g[i] = gg[i];
+            for (int i = tid; i < n; i += T) g[i] = gg[i];
+            if (eig)
+                for (int i = tid; i < n * n; i += T) Hl[i] = Hg[i];
         }
         __syncthreads();
 
@@ -115,7 +126,7 @@ namespace mbavo
         {
             s.done = 1;
             --s.iter;
-            if (lane == 0)
+            if (tid == 0)
             {
                 active[b] = 0;
                 states[b] = s;
@@ -123,21 +134,35 @@ namespace mbavo
             }
             // leave the accepted point in the caller's knot buffers
             double *Wt = const_cast<double *>(d.knots_t), *WR = const_cast<double *>(d.knots_R);
-            for (int i = lane; i < 3 * N; i += 64) Wt[i] = Ct[i];
-            for (int i = lane; i < 4 * N; i += 64) WR[i] = CR[i];
+            for (int i = tid; i < 3 * N; i += T) Wt[i] = Ct[i];
+            for (int i = tid; i < 4 * N; i += T) WR[i] = CR[i];
             return;
         }
 
         // computeTrustRegionStep (:799-831): the damping is applied in place and accumulates over rejected steps
         const double iradius = 1. / s.radius;
-        for (int i = lane; i < n; i += 64)
+        for (int i = tid; i < n; i += T)
         {
             const double v = H[i * n + i] + H[i * n + i] * iradius;
             H[i * n + i] = v;
         }
         __syncthreads();
-        // the solvers destroy their matrix: work on a copy in V's place (LDLT) or keep H in V and rotate a copy (SVD)
-        if (o.solver == 1)
+        if (eig)
+            for (int i = tid; i < n * n; i += T) Hg[i] = Hl[i]; // the damped system, for the next launch
+        // the solvers destroy their matrix: work on a copy in V's place (LDLT, eigenvalue Jacobi) or keep H in V and rotate a
+        // copy (one-sided SVD)
+        if constexpr (T == kEigT)
+        {
+            const int info = eig_solve(V, Hl, g, x, tmp, order, n, tid);
+            if (tid == 0)
+            { // solver statistics in the spare words behind num_done (MBAVO_LM_STATS=1 prints them)
+                atomicAdd(num_done + 1, 1);
+                atomicAdd(num_done + 2, info & 255);
+                atomicMax(num_done + 3, info & 255);
+                atomicAdd(num_done + 4, info >> 8);
+            }
+        }
+        else if (o.solver == 1)
         {
             for (int i = lane; i < n * n; i += 64) V[i] = H[i];
             __syncthreads();
@@ -151,9 +176,9 @@ namespace mbavo
             __syncthreads();
             svd_solve(G, V, g, x, tmp, n, ld, lane);
         }
-        for (int i = lane; i < n; i += 64) x[i] = -x[i];
+        for (int i = tid; i < n; i += T) x[i] = -x[i];
         __syncthreads();
-        double gx = 0.0, xHx = 0.0;
+        double gx = 0.0, xHx = 0.0; // every wave sums the whole vectors
         for (int r = lane; r < n; r += 64)
         {
             gx += g[r] * x[r];
@@ -167,20 +192,20 @@ namespace mbavo
         if (s.model < 0)
         { // handleInvalidStep
             lm_rejected(s);
-            trace_push(s, tr, o.trace_cap, lane, 0, 3, 0.0, s.model, 0.0);
+            trace_push(s, tr, o.trace_cap, tid, 0, 3, 0.0, s.model, 0.0);
             ++s.n_invalid;
-            if (lane == 0) { active[b] = 0; states[b] = s; }
+            if (tid == 0) { active[b] = 0; states[b] = s; }
             return;
         }
         // computeCandidatePointAndEvaluateCost (:833-883): candidate = current (+) step, into the evaluated buffers
         double *Wt = const_cast<double *>(d.knots_t), *WR = const_cast<double *>(d.knots_R);
-        for (int i = lane; i < 3 * N; i += 64) Wt[i] = Ct[i] + x[i];
-        for (int i = lane; i < N; i += 64)
+        for (int i = tid; i < 3 * N; i += T) Wt[i] = Ct[i] + x[i];
+        for (int i = tid; i < N; i += T)
         {
             const Quat q = qmul(load_quat(CR + 4 * i), so3_exp(x + 3 * N + 3 * i)); // Spline.h:317-330, not re-normalised
             WR[4 * i] = q.x; WR[4 * i + 1] = q.y; WR[4 * i + 2] = q.z; WR[4 * i + 3] = q.w;
         }
-        if (lane == 0) { active[b] = 1; states[b] = s; }
+        if (tid == 0) { active[b] = 1; states[b] = s; }
     }
 
     // One wave per problem, after the cost-only pass on the candidates: step quality, accept / reject, outliers.
@@ -306,7 +331,12 @@ namespace mbavo
         o.trace_cap = trace ? trace_cap : 0; o.max_n = max_n; o.max_N = max_N;
         o.min_q = opt.min_step_quality; o.min_dec = opt.min_abs_cost_decrease; o.chi = opt.max_chi_square_error;
         o.fast_ratio = 0.0;
-        const size_t lds = ((size_t)2 * max_n * (max_n + 1) + 6 * max_n) * sizeof(double) + (size_t)max_n * sizeof(int);
+        // solver 0 with every system within the workgroup-parallel eigenvalue Jacobi's reach (k_lm_solve<KD, kEigT>);
+        // MBAVO_LM_EIG=0 keeps the one-wave one-sided sweeps
+        const char *eig_env = getenv("MBAVO_LM_EIG");
+        const bool eig = opt.solver_type == 0 && max_n <= kEigMaxN && !(eig_env && eig_env[0] == '0');
+        const size_t lds = eig ? (eig_lds_doubles(max_n) + 3 * max_n + (size_t)max_n * max_n) * sizeof(double) + (size_t)(4 + 2 * max_n) * sizeof(int)
+                               : ((size_t)2 * max_n * (max_n + 1) + 6 * max_n) * sizeof(double) + (size_t)max_n * sizeof(int);
         if (lds > 160 * 1024) return MBAVO_E_ARG;
 
         // one allocation for all LM state (freed at the end: this is a per-level call, not a per-iteration one)
@@ -315,7 +345,7 @@ namespace mbavo
         const size_t o_state = take(sizeof(LmState) * B), o_H = take(sizeof(double) * (size_t)B * max_n * max_n),
                      o_g = take(sizeof(double) * (size_t)B * max_n), o_ct = take(sizeof(double) * (size_t)B * 3 * max_N),
                      o_cR = take(sizeof(double) * (size_t)B * 4 * max_N), o_inv = take(sizeof(double) * B),
-                     o_act = take(sizeof(int) * B), o_done = take(sizeof(int)), o_start = take(sizeof(int) * nbf),
+                     o_act = take(sizeof(int) * B), o_done = take(sizeof(int) * 8), o_start = take(sizeof(int) * nbf),
                      o_flags = take((size_t)total_K), o_fb = take(sizeof(double) * (size_t)nbf * E),
                      o_pc = take(sizeof(double) * (size_t)(total_patches + 1)),
                      o_trace = take(sizeof(mbavo_trace_rec) * (size_t)B * (trace ? trace_cap : 0));
@@ -362,18 +392,22 @@ namespace mbavo
             bool range_checked = false;
             if (lds > 48 * 1024)
             { // more than 8 control knots: the three n x n areas need the large-LDS attribute
-                if (k == 4) LM_HIP(hipFuncSetAttribute((const void *)k_lm_solve<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                if (k == 4) LM_HIP(hipFuncSetAttribute(eig ? (const void *)k_lm_solve<4, kEigT> : (const void *)k_lm_solve<4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #if !defined(MBAVO_LM_K4_ONLY) // reproducer variant (tools/micro/lm_solve_calls.sh): one kernel only reaches the solvers
-                else LM_HIP(hipFuncSetAttribute((const void *)k_lm_solve<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                else LM_HIP(hipFuncSetAttribute(eig ? (const void *)k_lm_solve<2, kEigT> : (const void *)k_lm_solve<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
             }
             for (int slot = 0; slot <= o.max_it + 1; ++slot)
             {
-                if (k == 4)
-                    hipLaunchKernelGGL((k_lm_solve<4>), dim3(B), dim3(64), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
+                if (k == 4 && eig)
+                    hipLaunchKernelGGL((k_lm_solve<4, kEigT>), dim3(B), dim3(kEigT), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
+                else if (k == 4)
+                    hipLaunchKernelGGL((k_lm_solve<4, 64>), dim3(B), dim3(64), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
 #if !defined(MBAVO_LM_K4_ONLY)
+                else if (eig)
+                    hipLaunchKernelGGL((k_lm_solve<2, kEigT>), dim3(B), dim3(kEigT), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
                 else
-                    hipLaunchKernelGGL((k_lm_solve<2>), dim3(B), dim3(64), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
+                    hipLaunchKernelGGL((k_lm_solve<2, 64>), dim3(B), dim3(64), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
 #endif
                 if (slot % sync_every == sync_every - 1 || slot == o.max_it + 1)
                 {
@@ -398,6 +432,13 @@ namespace mbavo
             {
                 LM_HIP(hipMemcpy(&h_done, num_done, sizeof(int), hipMemcpyDeviceToHost));
                 if (h_done < B) { rc = MBAVO_E_RANGE; goto done; }
+            }
+            if (const char *e = getenv("MBAVO_LM_STATS"); e && e[0] == '1' && eig)
+            {
+                int st4[5] = {0, 0, 0, 0, 0};
+                LM_HIP(hipMemcpy(st4, num_done, sizeof(st4), hipMemcpyDeviceToHost));
+                fprintf(stderr, "mbavo lm_batch: %d eigenvalue-Jacobi solves, %.2f sweeps on average, %d at most, %d preconditioned (L^T L)\n", st4[1],
+                        st4[1] ? (double)st4[2] / st4[1] : 0.0, st4[3], st4[4]);
             }
             if (results)
                 for (int b = 0; b < B; ++b)

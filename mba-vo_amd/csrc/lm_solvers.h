@@ -192,6 +192,416 @@ namespace mbavo
         }
 
 
+        // ---- x = pinv(A) b for SYMMETRIC A (the damped normal equations: positive semi-definite) by the two-sided (eigenvalue)
+        // Jacobi method, for a whole WORKGROUP of kEigT threads (n even, n <= kEigMaxN).  The one-sided sweeps above spend a
+        // round on three dot products per column pair, a dependent chain of two square roots and two divisions and two LDS
+        // passes behind barriers (~2 400 cycles per round on one wave whatever n is); here
+        //  * a rotation's parameters come from three matrix entries (no dot products);
+        //  * the n/2 disjoint rotations of a round are applied as one congruence A <- J^T A J, V <- V J whose (n/2)^2
+        //    independent 2 x 2 blocks are the work items: thread (i, j) turns block (i, j) of A and of V and writes the
+        //    rotated blocks into the OTHER buffer -- one barrier per round;
+        //  * the tournament is run Brent-Luk fashion: the pairs of a round are always the neighbours (2i, 2i + 1), and the
+        //    write side moves every row / column to the slot where it meets its next opponent (one fixed permutation for
+        //    all rounds), so that every read is an aligned 16-byte pair;
+        //  * the DIRECTION of a rotation needs no more than single precision to annihilate an entry to working accuracy over
+        //    the sweeps, only its normalisation has to be exact: (c, s) = (u, +-o) / sqrt(u^2 + o^2) with o = 2 a_pq,
+        //    u = |a_qq - a_pp| + hypot(a_qq - a_pp, o) -- the hypot from the hardware's approximate square root, the
+        //    normalisation from v_rsq_f64 and two Newton steps: two transcendental instructions per rotation, ~100 cycles.
+        // What a round costs was measured piece by piece (tools/micro/eig_round.hip, one workgroup alone on a CU, 2.39 GHz):
+        // a barrier 40 cycles, a dependent LDS read 72, a dependent v_fma_f64 4.9, a transcendental f64 instruction ~21 -- and
+        // the LDS pipe: 128 bytes a cycle for the whole CU whatever the exec mask says (a wave's ds_read_b128 is 8 cycles of
+        // it), so four b128 reads and four b64 writes per thread take 300 / 440 / 690 cycles per round with 64 / 256 / 512
+        // threads.  The first forms of this solver (every thread reading both diagonal blocks and deriving both rotations, or
+        // separate threads for A and V each reading a diagonal block) sat at ~1 100 cycles per round for that reason.  Hence:
+        // one thread turns the A block AND the V block (no second set of diagonal reads), it reads three entries of ITS row
+        // pair's diagonal block (16 + 8 bytes, issued first: the block reads ride behind the parameter chain), derives that
+        // rotation and takes the column pair's from a lane of its own wave that has derived it (ds_bpermute: 4 bytes a lane);
+        // waves without live items skip the round; the leading dimension is padded so that the half-wave groups of a b128
+        // read fall on complementary banks.
+        // Convergence as in the one-sided form: a pair is left alone when |a_pq| <= eps sqrt(a_pp a_qq) (the RELATIVE test:
+        // on the graded systems of a cubic spline, cond 1e9, it keeps the small eigenvalues accurate to ~1e-12 where a test
+        // against the largest diagonal entry gives 1e-7); the sweeps end when a sweep rotated nothing, or nothing above
+        // 1e-7 (quadratic convergence: what is left after such a sweep is ~1e-14 of sqrt(a_pp a_qq), a second-order 1e-28 on the
+        // eigenvalues; numpy prototype on the oracle's systems: the same solution errors as with 1e-9, one sweep fewer on some).
+        // Threshold of the pseudo-inverse as solve_svd: n eps max|lambda|.  A is PSD, so |lambda_j| are its singular values.
+        // Layout: bufs = A0 | A1 | V0 | V1, each n columns of eig_ld(n) doubles; A0 holds A on entry (destroyed).
+#ifndef MBAVO_EIG_ABL
+#define MBAVO_EIG_ABL 0
+#endif
+        struct JacobiRot { double c, s; };
+        __device__ __forceinline__ JacobiRot jacobi_rot(double app, double aqq, double apq, bool &big)
+        {
+#pragma clang fp contract(off)
+            const double lim2 = fabs(app * aqq), a2 = apq * apq;
+            const bool rot = a2 > (DBL_EPSILON * DBL_EPSILON) * lim2;
+            big = a2 > 1e-14 * lim2;
+            const double d = aqq - app, o = apq + apq, o2 = o * o;
+            const double h = __builtin_amdgcn_sqrt(__builtin_fma(d, d, o2)); // ~ hypot(d, o)
+            const double u = fabs(d) + h, so = __builtin_copysign(o, __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, o) ^ __builtin_bit_cast(unsigned long long, d)));
+            const double w = __builtin_fma(u, u, o2);
+            double y = __builtin_amdgcn_rsq(w);
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+            { // y <- y + y/2 (1 - w y^2)
+                const double e = __builtin_fma(-(w * y), y, 1.0);
+                y = __builtin_fma(0.5 * y, e, y);
+            }
+            JacobiRot r; // tan = sign(d) o / u
+            r.c = rot ? u * y : 1.0;
+            r.s = rot ? so * y : 0.0;
+            return r;
+        }
+        // (u, w) <- (c u - s w, s u + c w)
+        __device__ __forceinline__ void jacobi_apply(const JacobiRot &r, double &u, double &w)
+        {
+#pragma clang fp contract(off)
+            const double nu = __builtin_fma(r.c, u, -(r.s * w)), nw = __builtin_fma(r.s, u, r.c * w);
+            u = nu;
+            w = nw;
+        }
+        struct __attribute__((aligned(16))) D2 { double x, y; };
+        constexpr int kEigMaxN = 48, kEigT = 256;
+        // leading dimension: even (16-byte pairs), and = n/2 (mod 16) where that is even, so that the groups of n/2 lanes that
+        // read 16-byte pairs of consecutive rows from columns 2 ld doubles apart tile the 64 banks
+        __host__ __device__ inline int eig_ld(int n)
+        {
+            const int h = n / 2;
+            if (h & 1) return n;
+            int ld = n;
+            while ((ld & 15) != (h & 15)) ld += 2;
+            return ld;
+        }
+        __host__ __device__ inline size_t eig_lds_doubles(int n) { return (size_t)4 * n * eig_ld(n); }
+        __device__ __forceinline__ double shfl_f64(double v, int src)
+        {
+            const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+            const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)(unsigned)u);
+            const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)(unsigned)(u >> 32));
+            return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        }
+        // up to MAXI work items per thread: (n/2)^2 <= kEigT * MAXI.  Returns the buffer the result is in.
+        template <int MAXI>
+        __device__ __forceinline__ int eig_sweeps(double *bufs, int *flags, int n, int ld, int tid)
+        {
+            const int half = n / 2, hh = half * half, sz = n * ld; // A0 | V0 prepared, flags[0..2] zero (visible after the barrier below)
+            // slot -> slot of the next round: top row 2i, bottom row 2i + 1; top_0 stays, the others go round
+            auto next_slot = [half](int sl) {
+                const int i = sl >> 1;
+                if ((sl & 1) == 0)
+                {
+                    if (i == 0) return 0;
+                    return i == half - 1 ? 2 * i + 1 : 2 * (i + 1);
+                }
+                return i == 0 ? (half > 1 ? 2 : 1) : 2 * (i - 1) + 1;
+            };
+            const int wave_base = tid & ~63;
+            // The items of a thread never change: their offsets are computed once.  Item (i, j) rotates the block (I, J) =
+            // (min, max) of A -- the two threads either side of the diagonal compute the SAME block from the same entries, one
+            // writes it as it stands and the other transposed, so A stays symmetric bit for bit and no thread branches on its
+            // side of the diagonal -- and rows (2i, 2i + 1) x columns (2j, 2j + 1) of V.  i runs fastest over the lanes:
+            // neighbouring lanes read neighbouring rows, and the first n/2 lanes of every wave own all the row pairs.
+            int o_d[MAXI], o_b[MAXI], o_v[MAXI], w00[MAXI], w01[MAXI], w10[MAXI], w11[MAXI], wv0[MAXI], wv1[MAXI], src[MAXI], kind[MAXI];
+#pragma unroll
+            for (int q = 0; q < MAXI; ++q)
+            {
+                const int it = tid + q * kEigT;
+                const bool live = it < hh;
+                const int j = live ? it / half : 0, i = it % half; // i: valid for every lane (its rotation may be asked for)
+                const bool swap = i > j;
+                const int I2 = 2 * (swap ? j : i), J2 = 2 * (swap ? i : j);
+                o_d[q] = 2 * i * ld + 2 * i; o_b[q] = J2 * ld + I2; o_v[q] = 2 * j * ld + 2 * i;
+                const int pI0 = next_slot(I2), pI1 = next_slot(I2 + 1), pJ0 = next_slot(J2), pJ1 = next_slot(J2 + 1);
+                // element (row I + a, column J + b) of the rotated block goes to (pI_a, pJ_b), transposed for the lower side
+                w00[q] = swap ? pI0 * ld + pJ0 : pJ0 * ld + pI0; w01[q] = swap ? pI1 * ld + pJ0 : pJ0 * ld + pI1;
+                w10[q] = swap ? pI0 * ld + pJ1 : pJ1 * ld + pI0; w11[q] = swap ? pI1 * ld + pJ1 : pJ1 * ld + pI1;
+                wv0[q] = next_slot(2 * j) * ld + 2 * i; wv1[q] = next_slot(2 * j + 1) * ld + 2 * i;
+                src[q] = ((j - wave_base) % half + half) % half; // the lane of this wave whose FIRST item has row pair j
+                // bit 0: live, bit 1: the thread's own rotation is the COLUMN pair's (lower side), bit 2: diagonal block,
+                // bit 3: reports the state of its row pair
+                kind[q] = (live ? 1 : 0) | (swap ? 2 : 0) | (live && i == j ? 4 : 0) | (live && j == 0 ? 8 : 0);
+            }
+            // a wave takes part in item q as a whole (the shuffle needs the lanes that own the row pairs) or not at all
+            bool wave_live[MAXI];
+#pragma unroll
+            for (int q = 0; q < MAXI; ++q) wave_live[q] = wave_base + q * kEigT < hh;
+            __syncthreads();
+            int cur = 0;
+            for (int sweep = 0; sweep < 30; ++sweep)
+            {
+                int *flag = flags + sweep % 3;
+                if (tid == 0) flags[(sweep + 1) % 3] = 0; // last read two sweeps ago, many barriers back
+                for (int r = 0; r < n - 1; ++r)
+                {
+                    const double *As = bufs + (cur ? sz : 0), *Vs = As + 2 * sz;
+                    double *Ad = bufs + (cur ? 0 : sz), *Vd = Ad + 2 * sz;
+                    if (wave_live[0])
+                    {
+                        D2 d0[MAXI], b0[MAXI], b1[MAXI], v0[MAXI], v1[MAXI];
+                        double dqq[MAXI];
+#pragma unroll
+                        for (int q = 0; q < MAXI; ++q)
+                        { // (a_pp, a_qp) and a_qq of the row pair first: the parameter chain starts as soon as they are in
+                            if (!wave_live[q]) continue;
+                            d0[q] = *(const D2 *)(As + o_d[q]);
+                            dqq[q] = As[o_d[q] + ld + 1];
+                        }
+#pragma unroll
+                        for (int q = 0; q < MAXI; ++q)
+                        {
+                            if (!wave_live[q]) continue;
+                            b0[q] = *(const D2 *)(As + o_b[q]); b1[q] = *(const D2 *)(As + o_b[q] + ld);
+                            v0[q] = *(const D2 *)(Vs + o_v[q]); v1[q] = *(const D2 *)(Vs + o_v[q] + ld);
+                        }
+                        JacobiRot first;
+#pragma unroll
+                        for (int q = 0; q < MAXI; ++q)
+                        {
+                            if (!wave_live[q]) continue;
+                            bool big;
+#if MBAVO_EIG_ABL == 2 // ablation: no parameter chain
+                            JacobiRot ri; ri.c = d0[q].x; ri.s = dqq[q] + d0[q].y; big = true;
+#else
+                            const JacobiRot ri = jacobi_rot(d0[q].x, dqq[q], d0[q].y, big);
+#endif
+                            if (q == 0) first = ri;
+#if MBAVO_EIG_ABL != 3 // ablation 3: no convergence flag
+                            if ((kind[q] & 8) && big) *flag = 1; // every writer stores the same word
+#endif
+                            JacobiRot rj;
+#if MBAVO_EIG_ABL == 1 // ablation (tools/micro/eig_round.hip): no shuffle
+                            rj = first;
+#else
+                            rj.c = shfl_f64(first.c, src[q]);
+                            rj.s = shfl_f64(first.s, src[q]);
+#endif
+                            const bool lower = kind[q] & 2;
+                            JacobiRot rI, rJ;
+                            rI.c = lower ? rj.c : ri.c; rI.s = lower ? rj.s : ri.s;
+                            rJ.c = lower ? ri.c : rj.c; rJ.s = lower ? ri.s : rj.s;
+                            // rows by J_I, then columns by J_J
+                            jacobi_apply(rI, b0[q].x, b0[q].y);
+                            jacobi_apply(rI, b1[q].x, b1[q].y);
+                            jacobi_apply(rJ, b0[q].x, b1[q].x);
+                            jacobi_apply(rJ, b0[q].y, b1[q].y);
+                            if (kind[q] & 4) b0[q].y = b1[q].x; // the diagonal block stays exactly symmetric
+                            jacobi_apply(rj, v0[q].x, v1[q].x);
+                            jacobi_apply(rj, v0[q].y, v1[q].y);
+#if MBAVO_EIG_ABL == 4 // ablation: one write instead of six
+                            if (kind[q] & 1) Ad[w00[q]] = b0[q].x + b0[q].y + b1[q].x + b1[q].y + v0[q].x + v0[q].y + v1[q].x + v1[q].y;
+#else
+                            if (kind[q] & 1)
+#endif
+#if MBAVO_EIG_ABL != 4
+                            {
+                                Ad[w00[q]] = b0[q].x; Ad[w01[q]] = b0[q].y;
+                                Ad[w10[q]] = b1[q].x; Ad[w11[q]] = b1[q].y;
+                                *(D2 *)(Vd + wv0[q]) = v0[q]; // the rows of V stay where they are
+                                *(D2 *)(Vd + wv1[q]) = v1[q];
+                            }
+#endif
+                        }
+                    }
+                    cur ^= 1;
+                    __syncthreads();
+                }
+                if (tid == 0) flags[3] = sweep + 1; // sweeps taken (read by the solver check)
+                if (*flag == 0) break; // nothing rotated, or nothing above 1e-7: converged
+            }
+            return cur;
+        }
+
+        // A = L D L^T -> L (see eig_solve): lower triangle of A in place, the strict upper triangle zeroed.  false: a pivot
+        // was not positive (A is left half-factored).
+        template <int MAXE>
+        __device__ __forceinline__ bool eig_factor(double *A1, int n, int ld, int tid)
+        {
+            int er[MAXE], ec[MAXE];
+            bool on_e[MAXE];
+#pragma unroll
+            for (int q = 0; q < MAXE; ++q)
+            { // entry e of the lower triangle, row-major: e = r (r + 1) / 2 + c
+                const int e = tid + q * kEigT;
+                int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                r += (r + 1) * (r + 2) / 2 <= e ? 1 : 0;
+                r -= r * (r + 1) / 2 > e ? 1 : 0;
+                on_e[q] = r < n;
+                er[q] = on_e[q] ? r : 0;
+                ec[q] = on_e[q] ? e - r * (r + 1) / 2 : 0;
+            }
+            for (int k = 0; k < n; ++k)
+            {
+                const double d = A1[k * ld + k];
+                double own[MAXE], rk[MAXE], ck[MAXE];
+#pragma unroll
+                for (int q = 0; q < MAXE; ++q)
+                { // idle entries (column <= k, or past the matrix) read valid words and are not written
+                    own[q] = A1[ec[q] * ld + er[q]];
+                    rk[q] = A1[k * ld + er[q]];
+                    ck[q] = A1[k * ld + ec[q]];
+                }
+                if (!(d > 0.0)) return false; // the same word in every thread
+                double rd = __builtin_amdgcn_rcp(d);
+                rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
+                rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
+#pragma unroll
+                for (int q = 0; q < MAXE; ++q)
+                    if (on_e[q] && ec[q] > k) A1[ec[q] * ld + er[q]] = own[q] - rk[q] * (ck[q] * rd);
+                __syncthreads();
+            }
+            // l_rc = (d_c l_rc) / sqrt(d_c) below the diagonal, sqrt(d_c) on it, zero above
+            double lv[MAXE];
+#pragma unroll
+            for (int q = 0; q < MAXE; ++q)
+            {
+                const double dc = A1[ec[q] * ld + ec[q]], v = A1[ec[q] * ld + er[q]];
+                double y = __builtin_amdgcn_rsq(dc);
+#pragma unroll
+                for (int it = 0; it < 2; ++it) y = __builtin_fma(0.5 * y, __builtin_fma(-(dc * y), y, 1.0), y);
+                lv[q] = er[q] == ec[q] ? dc * y : v * y;
+            }
+            __syncthreads(); // every diagonal entry has been read
+#pragma unroll
+            for (int q = 0; q < MAXE; ++q)
+                if (on_e[q])
+                {
+                    A1[ec[q] * ld + er[q]] = lv[q];
+                    if (er[q] != ec[q]) A1[er[q] * ld + ec[q]] = 0.0;
+                }
+            __syncthreads();
+            return true;
+        }
+
+        // Preconditioning (Veselic / Hari): for positive definite A the sweeps run on L^T L instead of A = L L^T (L the Cholesky
+        // factor of A with its rows / columns sorted by falling diagonal: the stand-in for pivoting), accumulating G = L J_1 J_2 ...
+        // in V's place.  L^T L is one step of the LR iteration closer to diagonal: 5 sweeps where A itself takes 9 on the
+        // cubic spline's systems (cond 1e9), to the same accuracy.  With L^T L = W diag(lambda) W^T the columns of G = L W are
+        // sqrt(lambda_j) u_j, u_j the eigenvectors of A and lambda_j its eigenvalues: x = sum_j g_j (g_j . b) / lambda_j^2.
+        // A pivot that is not positive (semi-definite or indefinite A) sends the system down the plain path: sweeps on A, V = I.
+        // Hs: the system, dense n x n column-major in LDS (kept); bufs: eig_lds_doubles(n) doubles of scratch; iwork: 4 + 2 n ints.
+#if defined(MBAVO_EIG_STAMPS) // phase stamps of the LAST solve (tests/harness/solver_check.hip, -DMBAVO_EIG_STAMPS)
+        __device__ long long g_eig_stamps[8];
+#define MBAVO_EIG_STAMP(k) do { if (tid == 0) g_eig_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MBAVO_EIG_STAMP(k) do { } while (0)
+#endif
+        // Returns the number of sweeps taken, + 256 when the system went down the preconditioned path.
+        __device__ __forceinline__ int eig_solve(double *bufs, const double *Hs, const double *b, double *x, double *tmp, int *iwork, int n, int tid)
+        {
+            constexpr int T = kEigT;
+            const int ld = eig_ld(n), sz = n * ld, nn = n * n;
+            int *flags = iwork, *ord = iwork + 4;
+            double *A0 = bufs, *A1 = bufs + sz, *V0 = bufs + 2 * sz;
+            if (tid < 3) flags[tid] = 0;
+            MBAVO_EIG_STAMP(0);
+#if !defined(MBAVO_EIG_NO_PRECONDITION)
+            // sorted position of every index: falling diagonal, ties in index order -- n^2 comparisons over all threads, counted
+            // in LDS (one thread per index walking the diagonal took 3 000 cycles)
+            int *rank = ord + n;
+            for (int i = tid; i < n; i += T) rank[i] = 0;
+            __syncthreads();
+            for (int e = tid; e < nn; e += T)
+            {
+                const int i = e / n, k = e % n;
+                const double di = Hs[i * n + i], dk = Hs[k * n + k];
+                if (dk > di || (dk == di && k < i)) atomicAdd(rank + i, 1);
+            }
+            __syncthreads();
+            for (int i = tid; i < n; i += T) ord[rank[i]] = i;
+            __syncthreads();
+            MBAVO_EIG_STAMP(1); // sorted
+            for (int e = tid; e < nn; e += T) A1[(e / n) * ld + e % n] = Hs[ord[e / n] * n + ord[e % n]];
+            __syncthreads();
+            MBAVO_EIG_STAMP(2); // gathered
+            // A1 = L D L^T in place (lower triangle; column k ends up holding d_k l_rk), right-looking with ONE barrier per
+            // column: a thread updates its entries of the trailing triangle straight from the unscaled column and the pivot,
+            //     a_rc <- a_rc - a_rk a_ck / d_k        (r >= c > k),
+            // so nobody waits for a scaled column to be written first (the textbook form took three barriers a column,
+            // ~1 000 cycles each; a single wave walking the columns alone took 2 800 for a 24 x 24 system's 276 dependent
+            // LDS reads).  The entries of a thread are fixed: decoded once; idle entries read entry (0, 0) instead of
+            // branching round their loads.  Every thread reads the pivot: the verdict (all pivots positive) is uniform.
+            const bool spd = n * (n + 1) / 2 <= 2 * T ? eig_factor<2>(A1, n, ld, tid) : eig_factor<(kEigMaxN * (kEigMaxN + 1) / 2 + T - 1) / T>(A1, n, ld, tid);
+            MBAVO_EIG_STAMP(4); // factored and scaled
+            if (spd)
+            { // A0 <- L^T L (upper triangle computed, mirrored: symmetric bit for bit), V0 <- L.  The strict upper triangle of A1
+              // is zero, so the sums run over whole columns: six pairs of entries in flight
+                for (int e = tid; e < nn; e += T)
+                {
+                    const int c = e / n, r = e % n;
+                    V0[c * ld + r] = A1[c * ld + r];
+                    if (r <= c)
+                    {
+                        double acc = 0.0;
+                        for (int m0 = 0; m0 < n; m0 += 6)
+                        {
+                            D2 u[3], w[3];
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) { u[q] = *(const D2 *)(A1 + r * ld + m0 + 2 * q); w[q] = *(const D2 *)(A1 + c * ld + m0 + 2 * q); }
+#pragma unroll
+                            for (int q = 0; q < 3; ++q) acc += u[q].x * w[q].x + u[q].y * w[q].y;
+                        }
+                        A0[c * ld + r] = acc;
+                        A0[r * ld + c] = acc;
+                    }
+                }
+            }
+            else
+#else
+            const bool spd = false;
+#endif
+            { // the plain path: sweeps on A itself, V = I
+                for (int e = tid; e < nn; e += T)
+                {
+                    A0[(e / n) * ld + e % n] = Hs[e];
+                    V0[(e / n) * ld + e % n] = (e / n == e % n) ? 1.0 : 0.0;
+                }
+                for (int i = tid; i < n; i += T) ord[i] = i;
+            }
+            MBAVO_EIG_STAMP(5); // L^T L
+            // one work item per thread wherever the blocks allow it
+            const int cur = (n / 2) * (n / 2) <= T ? eig_sweeps<1>(bufs, flags, n, ld, tid)
+                                                   : eig_sweeps<((kEigMaxN / 2) * (kEigMaxN / 2) + T - 1) / T>(bufs, flags, n, ld, tid);
+            MBAVO_EIG_STAMP(6); // sweeps
+            const double *Af = bufs + (cur ? sz : 0), *Vf = Af + 2 * sz;
+            // coefficients (g_j . b) / lambda_j^p and x = sum_j g_j coef_j: four lanes per dot product, the quarters meet by
+            // xor-shuffles (4 n <= 192 threads: whole waves take part)
+            const int jj = tid >> 2, part = tid & 3, q4 = n / 4 + (n % 4 ? 1 : 0), lo = part * q4, hi = lo + q4 < n ? lo + q4 : n;
+            double lmax = 0.0;
+            for (int j0 = 0; j0 < n; j0 += 6)
+            {
+                double dj[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) dj[u] = Af[(j0 + u) * ld + j0 + u];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) lmax = fmax(lmax, fabs(dj[u]));
+            }
+            const double thr = fmax((double)n * DBL_EPSILON * lmax, DBL_MIN);
+            if (tid < ((4 * n + 63) & ~63))
+            {
+                const int j = jj < n ? jj : n - 1;
+                double dot = 0.0;
+                for (int i = lo; i < hi; ++i) dot += Vf[j * ld + i] * b[ord[i]];
+                dot += __shfl_xor(dot, 1, 64);
+                dot += __shfl_xor(dot, 2, 64);
+                const double lam = Af[j * ld + j];
+                const bool keep = fabs(lam) >= thr && lam != 0.0;
+                if (part == 0 && jj < n) tmp[j] = keep ? dot / (spd ? lam * lam : lam) : 0.0;
+            }
+            __syncthreads();
+            if (tid < ((4 * n + 63) & ~63))
+            {
+                const int i = jj < n ? jj : n - 1;
+                double acc = 0.0;
+                for (int j = lo; j < hi; ++j) acc += Vf[j * ld + i] * tmp[j];
+                acc += __shfl_xor(acc, 1, 64);
+                acc += __shfl_xor(acc, 2, 64);
+                if (part == 0 && jj < n) x[ord[i]] = acc;
+            }
+            const int info = flags[3] + (spd ? 256 : 0);
+            __syncthreads();
+            MBAVO_EIG_STAMP(7); // solved
+            return info;
+        }
+
         // ---- small SPD systems in registers (n = NN <= 24, one wave): x = A^-1 b by LDL^T WITHOUT pivoting, lane i holding row i of
         // the (symmetric, fully updated) trailing matrix in NN registers.  Every index is a compile-time constant: the pivot row is
         // broadcast with v_readlane (constant lane), no LDS traffic and no barrier inside -- ~NN^2 / 2 x 3 instructions against

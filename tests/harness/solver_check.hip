@@ -33,18 +33,44 @@ __global__ __launch_bounds__(64) void k_solve(const double *A, const double *b, 
     for (int i = lane; i < n; i += 64) x[i] = -xx[i];
 }
 
+// the workgroup-parallel two-sided Jacobi (lm_solvers.h: eig_solve) in the LDS layout of k_lm_solve
+__global__ __launch_bounds__(mbavo::kEigT) void k_solve_eig(const double *A, const double *b, double *x, int n, long long *cycles, int reps)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    double *bufs = lds, *g = bufs + mbavo::eig_lds_doubles(n), *xx = g + n, *tmp = xx + n, *Hs = tmp + n;
+    int *flags = (int *)(Hs + n * n);
+    long long best = 0x7fffffffffffffffll;
+    for (int rep = 0; rep < reps; ++rep)
+    { // the same solve `reps` times: the shortest is the one at full clock
+        for (int i = tid; i < n; i += mbavo::kEigT) g[i] = b[i];
+        for (int i = tid; i < n * n; i += mbavo::kEigT) Hs[i] = A[i];
+        __syncthreads();
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        mbavo::eig_solve(bufs, Hs, g, xx, tmp, flags, n, tid);
+        const long long t1 = __builtin_amdgcn_s_memtime();
+        best = t1 - t0 < best ? t1 - t0 : best;
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += mbavo::kEigT) x[i] = -xx[i];
+    if (tid == 0 && cycles) { cycles[0] = best; cycles[1] = flags[3]; }
+}
+
 int main()
 {
     int bad = 0;
     srand(3);
     for (int N = 2; N <= 16; N += (N < 8 ? 1 : 4)) // up to the reference's max_num_ctrl_knots = 16 (n = 96)
         for (int solver = 0; solver < 2; ++solver)
-            for (int rankdef = 0; rankdef < 2; ++rankdef)
-            {
+            for (int rankdef = 0; rankdef < 3; ++rankdef)
+            { // 2: full rank with graded columns (cond ~1e9: the cubic spline's damped normal equations look like this)
                 if (solver == 1 && rankdef) continue; // LDLT is for full-rank systems
-                const int n = 6 * N, m = rankdef ? n - 6 : n + 8;
+                const int n = 6 * N, m = rankdef == 1 ? n - 6 : n + 8;
                 std::vector<double> J((size_t)m * n), A((size_t)n * n, 0.0), b(n), xh(n), xd(n);
                 for (auto &v : J) v = rand() / (double)RAND_MAX - 0.5;
+                if (rankdef == 2)
+                    for (int r = 0; r < m; ++r)
+                        for (int c = 0; c < n; ++c) J[(size_t)r * n + c] *= pow(10.0, -4.5 * ((c * 7) % n) / (double)(n - 1));
                 for (int r = 0; r < n; ++r)
                     for (int c = 0; c < n; ++c)
                     {
@@ -66,9 +92,34 @@ int main()
                 double err = 0, nrm = 0;
                 for (int i = 0; i < n; ++i) { err = fmax(err, fabs(xd[i] - xh[i])); nrm = fmax(nrm, fabs(xh[i])); }
                 const bool ok = e == hipSuccess && err <= 1e-8 * fmax(nrm, 1.0);
-                printf("n=%3d %s %s  max|x_dev - x_host| = %.3e (|x| %.3e) %s\n", n, solver ? "LDLT" : "SVD ", rankdef ? "rank-deficient" : "full rank     ",
+                printf("n=%3d %s %s  max|x_dev - x_host| = %.3e (|x| %.3e) %s\n", n, solver ? "LDLT" : "SVD ", rankdef == 1 ? "rank-deficient" : rankdef ? "graded        " : "full rank     ",
                        err, nrm, ok ? "ok" : "FAIL");
                 bad += !ok;
+                if (solver == 0 && n <= mbavo::kEigMaxN)
+                { // the same system through the workgroup-parallel eigenvalue Jacobi
+                    long long *dcyc, cyc[2] = {0, 0};
+                    hipMalloc(&dcyc, 16);
+                    const size_t lds2 = (mbavo::eig_lds_doubles(n) + 3 * n + n * n) * 8 + (4 + 2 * n) * 4; // + four flag words and the sorted order
+                    hipFuncSetAttribute((const void *)k_solve_eig, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                    hipMemset(dx, 0, n * 8);
+                    hipLaunchKernelGGL(k_solve_eig, dim3(1), dim3(mbavo::kEigT), lds2, 0, dA, db, dx, n, dcyc, 40);
+                    e = hipDeviceSynchronize();
+                    hipMemcpy(xd.data(), dx, n * 8, hipMemcpyDeviceToHost);
+                    hipMemcpy(cyc, dcyc, 16, hipMemcpyDeviceToHost);
+                    err = 0;
+                    for (int i = 0; i < n; ++i) err = fmax(err, fabs(xd[i] - xh[i]));
+                    const bool ok2 = e == hipSuccess && err <= 1e-8 * fmax(nrm, 1.0);
+                    printf("n=%3d EIG  %s  max|x_dev - x_host| = %.3e (|x| %.3e) %s  [%lld sweeps, %lld cycles (best of 40): %.0f per round]\n", n,
+                           rankdef == 1 ? "rank-deficient" : rankdef ? "graded        " : "full rank     ", err, nrm, ok2 ? "ok" : "FAIL", cyc[1], cyc[0], (double)cyc[0] / (double)(cyc[1] * (n - 1)));
+                    bad += !ok2;
+#if defined(MBAVO_EIG_STAMPS)
+                    long long st[8];
+                    hipMemcpyFromSymbol(st, HIP_SYMBOL(mbavo::g_eig_stamps), sizeof(st));
+                    printf("        stamps: sort %lld gather %lld factor %lld scale %lld LtL %lld sweeps %lld solve %lld\n", st[1] - st[0], st[2] - st[1],
+                           st[3] - st[2], st[4] - st[3], st[5] - st[4], st[6] - st[5], st[7] - st[6]);
+#endif
+                    hipFree(dcyc);
+                }
                 hipFree(dA); hipFree(db); hipFree(dx);
             }
     printf("%s\n", bad ? "SOLVER CHECK FAILED" : "SOLVER CHECK PASSED");
