@@ -60,7 +60,8 @@ def _host_lm(mbavo, ctx, dw, b, p, solver, trace_cap=64):
                                      for r in trace[:n]]
 
 
-@pytest.mark.parametrize("k,N,F,solver", [(4, 4, 1, 0), (4, 6, 2, 0), (2, 3, 2, 1), (4, 4, 1, 1), (2, 2, 1, 0), (4, 16, 2, 0)])
+@pytest.mark.parametrize("k,N,F,solver", [(4, 4, 1, 0), (4, 6, 2, 0), (2, 3, 2, 1), (4, 4, 1, 1), (2, 2, 1, 0), (4, 16, 2, 0),
+                                              (4, 8, 2, 0)])  # n = 24, 36 (three blocks per thread), 12: eigenvalue Jacobi; 96: one-wave sweeps; 48: its largest
 def test_lm_batch_matches_host_loop(mbavo, gpu_ctx, k, N, F, solver):
     import torch
     capi = mbavo.capi
@@ -100,6 +101,34 @@ def test_lm_batch_matches_host_loop(mbavo, gpu_ctx, k, N, F, solver):
         if r.accepted > 0:
             assert np.abs(kt_d - p.knots_t).max() > 1e-9  # the knots really moved
     assert 1 in kinds_seen and (2 in kinds_seen or 3 in kinds_seen)
+
+
+def test_lm_batch_eigenvalue_jacobi_matches_one_wave_sweeps(mbavo, gpu_ctx, monkeypatch):
+    """Solver type 0 through the workgroup-parallel eigenvalue Jacobi (default for n <= 48) and through the one-wave one-sided
+    sweeps (MBAVO_LM_EIG=0): the same records, costs to 1e-6 relative (both solve to rounding x cond(H), cond ~1e9)."""
+    import torch
+    capi = mbavo.capi
+    B, k, N, F = 8, 4, 4, 1
+    out = {}
+    for eig in ("1", "0"):
+        monkeypatch.setenv("MBAVO_LM_EIG", eig)
+        probs = _scene(B, k, N, F, seed=23)
+        dw = workloads.DeviceWorkload(probs)
+        o = capi.LmBatchOpts()
+        o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, OPTS["max_it"], OPTS["max_nonmono"]
+        o.solver_type, o.sync_every = 0, 4
+        o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
+        cap = 64
+        res = (capi.LmBatchResult * B)()
+        trace = (capi.TraceRec * (B * cap))()
+        assert gpu_ctx.lib.mbavo_lm_batch(gpu_ctx.handle, B, dw.array, C.byref(o), res, trace, cap) == 0
+        torch.cuda.synchronize()
+        out[eig] = [[(t.iter, t.kind, t.num_outliers, t.eval_cost, t.candidate_cost) for t in trace[b * cap:b * cap + res[b].num_trace]]
+                    for b in range(B)]
+    for a, b in zip(out["1"], out["0"]):
+        assert [t[:3] for t in a] == [t[:3] for t in b]
+        for ta, tb in zip(a, b):
+            assert abs(ta[3] - tb[3]) <= 1e-6 * max(1.0, abs(tb[3])) and abs(ta[4] - tb[4]) <= 1e-6 * max(1.0, abs(tb[4]))
 
 
 def test_lm_batch_against_oracle(orc, mbavo, gpu_ctx):
