@@ -50,6 +50,10 @@ namespace mbavo
         const int N = d.N, n = 6 * N, F = d.F;
         LmState s = states[b];
         if (s.done) return;
+#if defined(MBAVO_EIG_STAMPS) // development aid: where the kernel's time goes (block 0 prints at its end)
+        const long long ts0 = __builtin_amdgcn_s_memtime();
+        long long ts1 = 0, ts2 = 0, ts3 = 0;
+#endif
         // LDS, T = 64: V and G (n x (n + 1) each) + vectors; the damped system H itself lives in global memory (it persists
         // across iterations anyway), which leaves room for the reference's maximum of 16 control knots (n = 96).
         // T = kEigT: the four n x eig_ld(n) areas of eig_solve first (16-byte aligned), then the vectors.
@@ -139,6 +143,9 @@ namespace mbavo
             return;
         }
 
+#if defined(MBAVO_EIG_STAMPS)
+        ts1 = __builtin_amdgcn_s_memtime();
+#endif
         // computeTrustRegionStep (:799-831): the damping is applied in place and accumulates over rejected steps
         const double iradius = 1. / s.radius;
         for (int i = tid; i < n; i += T)
@@ -151,6 +158,9 @@ namespace mbavo
             for (int i = tid; i < n * n; i += T) Hg[i] = Hl[i]; // the damped system, for the next launch
         // the solvers destroy their matrix: work on a copy in V's place (LDLT, eigenvalue Jacobi) or keep H in V and rotate a
         // copy (one-sided SVD)
+#if defined(MBAVO_EIG_STAMPS)
+        ts2 = __builtin_amdgcn_s_memtime();
+#endif
         if constexpr (T == kEigT)
         {
             const int info = eig_solve(V, Hl, g, x, tmp, order, n, tid);
@@ -176,6 +186,9 @@ namespace mbavo
             __syncthreads();
             svd_solve(G, V, g, x, tmp, n, ld, lane);
         }
+#if defined(MBAVO_EIG_STAMPS)
+        ts3 = __builtin_amdgcn_s_memtime();
+#endif
         for (int i = tid; i < n; i += T) x[i] = -x[i];
         __syncthreads();
         double gx = 0.0, xHx = 0.0; // every wave sums the whole vectors
@@ -206,6 +219,11 @@ namespace mbavo
             WR[4 * i] = q.x; WR[4 * i + 1] = q.y; WR[4 * i + 2] = q.z; WR[4 * i + 3] = q.w;
         }
         if (tid == 0) { active[b] = 1; states[b] = s; }
+#if defined(MBAVO_EIG_STAMPS)
+        if (tid == 0 && b == 0)
+            printf("k_lm_solve<%d,%d> block 0: merge %lld | damp + store %lld | solve %lld | model + candidate %lld cycles\n", KD, T, ts1 - ts0,
+                   ts2 - ts1, ts3 - ts2, (long long)__builtin_amdgcn_s_memtime() - ts3);
+#endif
     }
 
     // One wave per problem, after the cost-only pass on the candidates: step quality, accept / reject, outliers.

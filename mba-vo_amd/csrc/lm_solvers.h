@@ -324,85 +324,115 @@ namespace mbavo
             bool wave_live[MAXI];
 #pragma unroll
             for (int q = 0; q < MAXI; ++q) wave_live[q] = wave_base + q * kEigT < hh;
+            // One round, from buffer X into buffer Y.  Every address of a round is a register: the two directions (0 -> 1 and
+            // 1 -> 0) keep their own sets and the rounds are unrolled in pairs (with the buffer chosen by a parity inside the loop
+            // every access paid a shift and an addition: 16 vector + 8 scalar instructions of ~115 per round, and a lone wave
+            // issues one every ~7 cycles).  Rejected variants (tools/micro/eig_round.hip, cycles per round at n = 24 against 990):
+            // both roles of a rotation by shuffle instead of the selects 1 068; the column pair's rotation derived locally
+            // instead of shuffled 1 109.
+            struct Dir
+            {
+                const double *d[MAXI], *b[MAXI], *v[MAXI];
+                double *w00[MAXI], *w01[MAXI], *w10[MAXI], *w11[MAXI], *wv0[MAXI], *wv1[MAXI];
+            };
+            Dir fw, bw; // reads buffer 0 / writes buffer 1, and the other way round
+#pragma unroll
+            for (int q = 0; q < MAXI; ++q)
+            {
+                const double *A0 = bufs, *A1 = bufs + sz, *V0 = bufs + 2 * sz, *V1 = bufs + 3 * sz;
+                fw.d[q] = A0 + o_d[q]; fw.b[q] = A0 + o_b[q]; fw.v[q] = V0 + o_v[q];
+                bw.d[q] = A1 + o_d[q]; bw.b[q] = A1 + o_b[q]; bw.v[q] = V1 + o_v[q];
+                double *W1 = bufs + sz, *W0 = bufs, *X1 = bufs + 3 * sz, *X0 = bufs + 2 * sz;
+                fw.w00[q] = W1 + w00[q]; fw.w01[q] = W1 + w01[q]; fw.w10[q] = W1 + w10[q]; fw.w11[q] = W1 + w11[q];
+                fw.wv0[q] = X1 + wv0[q]; fw.wv1[q] = X1 + wv1[q];
+                bw.w00[q] = W0 + w00[q]; bw.w01[q] = W0 + w01[q]; bw.w10[q] = W0 + w10[q]; bw.w11[q] = W0 + w11[q];
+                bw.wv0[q] = X0 + wv0[q]; bw.wv1[q] = X0 + wv1[q];
+            }
+            auto round = [&](const Dir &a, int *flag) {
+                if (!wave_live[0]) return;
+                D2 d0[MAXI], b0[MAXI], b1[MAXI], v0[MAXI], v1[MAXI];
+                double dqq[MAXI];
+#pragma unroll
+                for (int q = 0; q < MAXI; ++q)
+                { // (a_pp, a_qp) and a_qq of the row pair first: the parameter chain starts as soon as they are in
+                    if (!wave_live[q]) continue;
+                    d0[q] = *(const D2 *)a.d[q];
+                    dqq[q] = a.d[q][ld + 1];
+                }
+#pragma unroll
+                for (int q = 0; q < MAXI; ++q)
+                {
+                    if (!wave_live[q]) continue;
+                    b0[q] = *(const D2 *)a.b[q]; b1[q] = *(const D2 *)(a.b[q] + ld);
+                    v0[q] = *(const D2 *)a.v[q]; v1[q] = *(const D2 *)(a.v[q] + ld);
+                }
+                JacobiRot first;
+#pragma unroll
+                for (int q = 0; q < MAXI; ++q)
+                {
+                    if (!wave_live[q]) continue;
+                    bool big;
+#if MBAVO_EIG_ABL == 2 // ablation (tools/micro/eig_round.hip): no parameter chain
+                    JacobiRot ri; ri.c = d0[q].x; ri.s = dqq[q] + d0[q].y; big = true;
+#else
+                    const JacobiRot ri = jacobi_rot(d0[q].x, dqq[q], d0[q].y, big);
+#endif
+                    if (q == 0) first = ri;
+#if MBAVO_EIG_ABL != 3 // ablation 3: no convergence flag
+                    if ((kind[q] & 8) && big) *flag = 1; // every writer stores the same word
+#endif
+                    JacobiRot rj;
+#if MBAVO_EIG_ABL == 1 // ablation: no shuffle
+                    rj = first;
+#else
+                    rj.c = shfl_f64(first.c, src[q]);
+                    rj.s = shfl_f64(first.s, src[q]);
+#endif
+                    const bool lower = kind[q] & 2;
+                    JacobiRot rI, rJ;
+                    rI.c = lower ? rj.c : ri.c; rI.s = lower ? rj.s : ri.s;
+                    rJ.c = lower ? ri.c : rj.c; rJ.s = lower ? ri.s : rj.s;
+                    // rows by J_I, then columns by J_J
+                    jacobi_apply(rI, b0[q].x, b0[q].y);
+                    jacobi_apply(rI, b1[q].x, b1[q].y);
+                    jacobi_apply(rJ, b0[q].x, b1[q].x);
+                    jacobi_apply(rJ, b0[q].y, b1[q].y);
+                    if (kind[q] & 4) b0[q].y = b1[q].x; // the diagonal block stays exactly symmetric
+                    jacobi_apply(rj, v0[q].x, v1[q].x);
+                    jacobi_apply(rj, v0[q].y, v1[q].y);
+#if MBAVO_EIG_ABL == 4 // ablation: one write instead of six
+                    if (kind[q] & 1) *a.w00[q] = b0[q].x + b0[q].y + b1[q].x + b1[q].y + v0[q].x + v0[q].y + v1[q].x + v1[q].y;
+#else
+                    if (kind[q] & 1)
+                    {
+                        *a.w00[q] = b0[q].x; *a.w01[q] = b0[q].y;
+                        *a.w10[q] = b1[q].x; *a.w11[q] = b1[q].y;
+                        *(D2 *)a.wv0[q] = v0[q]; // the rows of V stay where they are
+                        *(D2 *)a.wv1[q] = v1[q];
+                    }
+#endif
+                }
+            };
             __syncthreads();
-            int cur = 0;
+            int cur = 0; // the buffer the next round reads
             for (int sweep = 0; sweep < 30; ++sweep)
             {
                 int *flag = flags + sweep % 3;
                 if (tid == 0) flags[(sweep + 1) % 3] = 0; // last read two sweeps ago, many barriers back
-                for (int r = 0; r < n - 1; ++r)
+                int r = 0;
+                for (; r + 1 < n - 1; r += 2)
                 {
-                    const double *As = bufs + (cur ? sz : 0), *Vs = As + 2 * sz;
-                    double *Ad = bufs + (cur ? 0 : sz), *Vd = Ad + 2 * sz;
-                    if (wave_live[0])
-                    {
-                        D2 d0[MAXI], b0[MAXI], b1[MAXI], v0[MAXI], v1[MAXI];
-                        double dqq[MAXI];
-#pragma unroll
-                        for (int q = 0; q < MAXI; ++q)
-                        { // (a_pp, a_qp) and a_qq of the row pair first: the parameter chain starts as soon as they are in
-                            if (!wave_live[q]) continue;
-                            d0[q] = *(const D2 *)(As + o_d[q]);
-                            dqq[q] = As[o_d[q] + ld + 1];
-                        }
-#pragma unroll
-                        for (int q = 0; q < MAXI; ++q)
-                        {
-                            if (!wave_live[q]) continue;
-                            b0[q] = *(const D2 *)(As + o_b[q]); b1[q] = *(const D2 *)(As + o_b[q] + ld);
-                            v0[q] = *(const D2 *)(Vs + o_v[q]); v1[q] = *(const D2 *)(Vs + o_v[q] + ld);
-                        }
-                        JacobiRot first;
-#pragma unroll
-                        for (int q = 0; q < MAXI; ++q)
-                        {
-                            if (!wave_live[q]) continue;
-                            bool big;
-#if MBAVO_EIG_ABL == 2 // ablation: no parameter chain
-                            JacobiRot ri; ri.c = d0[q].x; ri.s = dqq[q] + d0[q].y; big = true;
-#else
-                            const JacobiRot ri = jacobi_rot(d0[q].x, dqq[q], d0[q].y, big);
-#endif
-                            if (q == 0) first = ri;
-#if MBAVO_EIG_ABL != 3 // ablation 3: no convergence flag
-                            if ((kind[q] & 8) && big) *flag = 1; // every writer stores the same word
-#endif
-                            JacobiRot rj;
-#if MBAVO_EIG_ABL == 1 // ablation (tools/micro/eig_round.hip): no shuffle
-                            rj = first;
-#else
-                            rj.c = shfl_f64(first.c, src[q]);
-                            rj.s = shfl_f64(first.s, src[q]);
-#endif
-                            const bool lower = kind[q] & 2;
-                            JacobiRot rI, rJ;
-                            rI.c = lower ? rj.c : ri.c; rI.s = lower ? rj.s : ri.s;
-                            rJ.c = lower ? ri.c : rj.c; rJ.s = lower ? ri.s : rj.s;
-                            // rows by J_I, then columns by J_J
-                            jacobi_apply(rI, b0[q].x, b0[q].y);
-                            jacobi_apply(rI, b1[q].x, b1[q].y);
-                            jacobi_apply(rJ, b0[q].x, b1[q].x);
-                            jacobi_apply(rJ, b0[q].y, b1[q].y);
-                            if (kind[q] & 4) b0[q].y = b1[q].x; // the diagonal block stays exactly symmetric
-                            jacobi_apply(rj, v0[q].x, v1[q].x);
-                            jacobi_apply(rj, v0[q].y, v1[q].y);
-#if MBAVO_EIG_ABL == 4 // ablation: one write instead of six
-                            if (kind[q] & 1) Ad[w00[q]] = b0[q].x + b0[q].y + b1[q].x + b1[q].y + v0[q].x + v0[q].y + v1[q].x + v1[q].y;
-#else
-                            if (kind[q] & 1)
-#endif
-#if MBAVO_EIG_ABL != 4
-                            {
-                                Ad[w00[q]] = b0[q].x; Ad[w01[q]] = b0[q].y;
-                                Ad[w10[q]] = b1[q].x; Ad[w11[q]] = b1[q].y;
-                                *(D2 *)(Vd + wv0[q]) = v0[q]; // the rows of V stay where they are
-                                *(D2 *)(Vd + wv1[q]) = v1[q];
-                            }
-#endif
-                        }
-                    }
-                    cur ^= 1;
+                    round(fw, flag);
                     __syncthreads();
+                    round(bw, flag);
+                    __syncthreads();
+                }
+                if (r < n - 1)
+                { // n - 1 is odd: one more round, and the two directions change names for the next sweep
+                    round(fw, flag);
+                    __syncthreads();
+                    const Dir t = fw; fw = bw; bw = t;
+                    cur ^= 1;
                 }
                 if (tid == 0) flags[3] = sweep + 1; // sweeps taken (read by the solver check)
                 if (*flag == 0) break; // nothing rotated, or nothing above 1e-7: converged
