@@ -254,13 +254,13 @@ class Runner:
         if isinstance(built, wl.RenderedPairBatch):
             self.dw, self.probs = built, built.probs
             if grad_fp16:
-                self.desc += ", fp16 gradient images"
+                self.desc += ", packed keyframes (one word per pixel: intensity + both differences)" if int(grad_fp16) == 2 else ", fp16 gradient images"
         else:
             self.probs = built
             if grad_fp16:
                 for p in self.probs:
-                    p.grad_fp16 = True
-                self.desc += ", fp16 gradient pyramid"
+                    p.grad_fp16 = int(grad_fp16)
+                self.desc += ", packed keyframe pyramid (one word per pixel: intensity + both differences)" if int(grad_fp16) == 2 else ", fp16 gradient pyramid"
             self.dw = wl.DeviceWorkload(self.probs, device=dev)
         self.se = shard.ShardedEvaluation(ctx, self.dw.array, self.dw.k, rank, world, self.mode, dev) if sharded else None
         self.wl = wl
@@ -677,9 +677,11 @@ def main():
         todo = [(n, False, False) for n in SIDE_CONFIGS if n != args.workload] + [("c5_1080p", True, False)]
         if args.workload == "c2_dense":
             todo.insert(0, ("c2_dense", False, True))
-        todo += [("c3_batch64_shared", False, False)]
+        # named extras: the keyframe in the two lossless compact formats (mbavo_problem.grad_fp16 = 1: half pairs, 2: packed words)
+        todo += [("c3_batch64_shared", False, False), ("c4_batch512", 1, False), ("c4_batch512", 2, False), ("c3_batch64", 2, False),
+                 ("c2_dense", 2, False)]
         for name, half, seq_levels in todo:
-            key = name + ("_fp16grad" if half else "") + ("_sequential" if seq_levels else "")
+            key = name + ("_packed" if int(half) == 2 else "_fp16grad" if half else "") + ("_sequential" if seq_levels else "")
             try:
                 r = Runner(M, ctx, name, dev, 0, 1, False, half, sequential=seq_levels)
                 n, dt, kms, kname = bounded_run(M, ctx, r)

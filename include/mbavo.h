@@ -60,6 +60,8 @@ typedef struct mbavo_problem {
                                              1: d_ref_dIxy is IEEE half [dx,dy] per pixel (4 B/pixel, BASELINE configs[4]).
                                              Central differences of an 8-bit image are multiples of 0.5 in [-127.5, 127.5],
                                              exactly representable in fp16, so both formats see identical tap values (results agree to rounding).
+                                             2: d_ref_dIxy is the packed keyframe of mbavo_pack_keyframe_u8 (4 B/pixel: intensity and both
+                                             differences in one word; H/g passes read nothing else of the keyframe, cost-only passes d_ref_img).
                                              All problems of one mbavo_eval_batch call must use the same format. */
     long long num_residuals;              /* 0: the blocks are scaled by 1/((K - num_bad)*F*P) of THIS problem
                                              (inv_num_residuals, spline_update_step.cpp:116-117).  > 0: by 1/num_residuals --
@@ -207,6 +209,10 @@ int mbavo_pyramid_down_u8(const unsigned char *d_src, int H, int W, unsigned cha
 int mbavo_image_gradients_u8(const unsigned char *d_src, int H, int W, float *d_dIxy, void *hip_stream);
 /* same gradient image stored as IEEE half pairs (fp16 pyramid, mbavo_problem.grad_fp16 = 1) */
 int mbavo_image_gradients_u8_half(const unsigned char *d_src, int H, int W, void *d_dIxy_half, void *hip_stream);
+/* packed keyframe (mbavo_problem.grad_fp16 = 2): ONE 32-bit word per pixel -- bits 0-7 the intensity, bits 8-16 and 23-31 the
+ * doubled central differences 2 dI/dx, 2 dI/dy of Gradient.h:16-75 as 9-bit two's complement (zero on the 1-pixel border).  Holds
+ * exactly what the u8 image and its float gradient image hold (4 bytes per pixel instead of 9); d_ref_dIxy then points at it. */
+int mbavo_pack_keyframe_u8(const unsigned char *d_src, int H, int W, void *d_packed /* H*W uint32 */, void *hip_stream);
 
 /* gradient magnitude image (Gradient.h:56-71, the detector's score) */
 int mbavo_gradient_magnitude_u8(const unsigned char *d_src, int H, int W, float *d_mag, void *hip_stream);

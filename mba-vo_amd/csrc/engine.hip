@@ -577,7 +577,7 @@ namespace mbavo
     // more chunk for one wave, i.e. 7 chunks on its SIMD against 6 on the others (+5 us measured against a tile of
     // exactly two rounds).
     // LOGS_CT >= 0: S is the compile-time 2^LOGS_CT (the exchange loops over the samples unroll); -1: run-time `logs_rt`.
-    template <int KD, bool WITH_J, bool HALF_GRAD, int NWAVES, int LOGS_CT = -1, int MS = 1>
+    template <int KD, bool WITH_J, int HALF_GRAD, int NWAVES, int LOGS_CT = -1, int MS = 1>
     __device__ __forceinline__ void sp_round_rt(const ProblemDesc &d, const TileDesc &tile, const Camera &cam,
                                                 const PoseEntry<KD> *__restrict__ ftab, const PoseEntry<KD> &mid,
                                                 const unsigned char *__restrict__ I_cur, int logs_rt, int base, int npx,
@@ -638,7 +638,7 @@ namespace mbavo
                         SampleInFlight f;
                         sample_issue<KD, WITH_J, HALF_GRAD>(pe[0], ray, kz, iz, cam, d.ref_img, d.ref_dIxy, f);
                         ok_l = f.taps.ok;
-                        sample_retire<KD, WITH_J>(pe[0], f, ray, kz, iz, cam, vals[0], Jc);
+                        sample_retire<KD, WITH_J, false, HALF_GRAD>(pe[0], f, ray, kz, iz, cam, vals[0], Jc);
                     }
                     else
                     {
@@ -647,8 +647,8 @@ namespace mbavo
                         sample_issue<KD, WITH_J, HALF_GRAD>(pe[0], ray, kz, iz, cam, d.ref_img, d.ref_dIxy, fa);
                         sample_issue<KD, WITH_J, HALF_GRAD>(pe[1], ray, kz, iz, cam, d.ref_img, d.ref_dIxy, fb);
                         ok_l = fa.taps.ok && fb.taps.ok;
-                        sample_retire<KD, WITH_J>(pe[0], fa, ray, kz, iz, cam, vals[0], Jc);
-                        sample_retire<KD, WITH_J>(pe[1], fb, ray, kz, iz, cam, vals[MS - 1], Jc);
+                        sample_retire<KD, WITH_J, false, HALF_GRAD>(pe[0], fa, ray, kz, iz, cam, vals[0], Jc);
+                        sample_retire<KD, WITH_J, false, HALF_GRAD>(pe[1], fb, ray, kz, iz, cam, vals[MS - 1], Jc);
                     }
                 };
                 if (staged)
@@ -767,7 +767,7 @@ namespace mbavo
     // k_pose_table, segments in the not-yet-used row slabs) into its own S entries of `table_w`, which the host passes as
     // `table` too: the sample loop needs the entries behind wave-uniform SCALAR loads from read-only memory (through LDS it
     // was 1.5x slower), so they go out through the L2 and come back through the scalar cache.
-    template <int KD, bool WITH_J, bool HALF_GRAD, bool POSE = false>
+    template <int KD, bool WITH_J, int HALF_GRAD, bool POSE = false> // HALF_GRAD: 0 float pairs, 1 IEEE half pairs, 2 packed keyframe words
     __global__ __launch_bounds__((waves_of<KD, WITH_J>() * 64)) MBAVO_FUSED_OCC void k_fused(const ProblemDesc *__restrict__ descs,
                                                         const TileDesc *__restrict__ tiles,
                                                         const PoseEntry<KD> *__restrict__ table,
@@ -1347,7 +1347,7 @@ namespace mbavo
     }
 
     // the body of k_fused_sp (one tile of one evaluation); also run, evaluation after evaluation, by the persistent kernel
-    template <int KD, bool WITH_J, bool HALF_GRAD, int LOGS, bool ONE, bool PERSIST = false>
+    template <int KD, bool WITH_J, int HALF_GRAD, int LOGS, bool ONE, bool PERSIST = false>
     __device__ __forceinline__ bool sp_tile_body(double *lds, const ProblemDesc *__restrict__ descs,
                                                  const TileDesc *__restrict__ tiles,
                                                  const PoseEntry<KD> *__restrict__ table,
@@ -1455,7 +1455,7 @@ namespace mbavo
                         SampleInFlight f;
                         sample_issue<KD, WITH_J, HALF_GRAD>(pe, ray, kz, iz, cam, d.ref_img, d.ref_dIxy, f);
                         ok_l = f.taps.ok;
-                        sample_retire<KD, WITH_J>(pe, f, ray, kz, iz, cam, val, Jc);
+                        sample_retire<KD, WITH_J, false, HALF_GRAD>(pe, f, ray, kz, iz, cam, val, Jc);
                     };
                     if constexpr (STAGE)
                         one_sample(((const PoseEntry<KD> *)stage)[sidx]); // LDS
@@ -1599,7 +1599,7 @@ namespace mbavo
         return false;
     }
 
-    template <int KD, bool WITH_J, bool HALF_GRAD, int LOGS, bool ONE>
+    template <int KD, bool WITH_J, int HALF_GRAD, int LOGS, bool ONE>
     __global__ __launch_bounds__((kSpWaves * 64)) void k_fused_sp(const ProblemDesc *__restrict__ descs,
                                                         const TileDesc *__restrict__ tiles,
                                                         const PoseEntry<KD> *__restrict__ table,
@@ -2276,7 +2276,7 @@ namespace mbavo
             const long long num_residuals = p.num_residuals > 0 ? p.num_residuals : (long long)(p.K - p.num_bad) * p.F * p.P;
             d.inv_num_residuals = num_residuals > 0 ? 1.0 / (double)num_residuals : 0.0; // empty problem: all-zero blocks
             d.S = p.S; d.F = p.F; d.K = p.K; d.P = p.P; d.N = p.N; d.H = p.H; d.W = p.W; d.kp_stride = p.kp_stride;
-            d.grad_fp16 = p.grad_fp16 ? 1 : 0;
+            d.grad_fp16 = p.grad_fp16 == 2 ? 2 : (p.grad_fp16 ? 1 : 0);
             d.active = d_active ? d_active + b : nullptr;
             d.inv_ptr = d_inv ? d_inv + b : nullptr;
             d.pose_base = entries; d.bf_base = bf; d.pixel_base = pixels; d.patch_base = patches;
@@ -2467,7 +2467,7 @@ namespace mbavo
     } while (0)
 
     template <int KD, bool WITH_J>
-    static int launch_all(Engine *eng, hipStream_t st, int max_S, bool half_grad, int sp_logs, bool one, bool flat_finalize, const ProblemDesc *descs, const int *entry_prob, int entries, const TileDesc *tiles, int ntiles,
+    static int launch_all(Engine *eng, hipStream_t st, int max_S, int grad_mode, int sp_logs, bool one, bool flat_finalize, const ProblemDesc *descs, const int *entry_prob, int entries, const TileDesc *tiles, int ntiles,
                           const int *bf_prob, const int *bf_tile_begin, int nbf, void *poses, double *rho,
                           double *patch_cost, double *patch_blocks_strided, double *partials, int *status,
                           double *frame_blocks, double *valid, const OneArgs &oa, bool fused_pose_ok)
@@ -2516,10 +2516,17 @@ namespace mbavo
             const size_t lds = lds_plain;
             (void)max_S;
             // the large-LDS attribute is per device and per kernel: remembered per engine (= per device)
-            if (half_grad)
-                HIP_TRY(eng->ensure_lds((const void *)k_fused<KD, WITH_J, true>, lds));
-            else
-                HIP_TRY(eng->ensure_lds((const void *)k_fused<KD, WITH_J, false>, lds));
+            // gradient format of the instantiation: cost-only passes of the packed format tap the u8 image like format 0
+            // (and are format 0's instantiation); MBAVO_GRAD_CASE runs its statement with G = the compile-time format
+            const int gm = (!WITH_J && grad_mode == 2) ? 0 : grad_mode;
+#define MBAVO_GRAD_CASE(...)                                                       \
+    do                                                                             \
+    {                                                                              \
+        if (gm == 1) { constexpr int G = 1; __VA_ARGS__; }                         \
+        else if (gm == 2) { constexpr int G = WITH_J ? 2 : 0; __VA_ARGS__; }       \
+        else { constexpr int G = 0; __VA_ARGS__; }                                 \
+    } while (0)
+            MBAVO_GRAD_CASE(HIP_TRY(eng->ensure_lds((const void *)k_fused<KD, WITH_J, G>, lds)));
             if (sp_logs > 0)
             {
 #define MBAVO_SP_LAUNCH(LG)                                                                                                    \
@@ -2545,26 +2552,15 @@ namespace mbavo
                 {
                     // cost-only: the pose prologue's segments need LDS of their own (there are no slabs to borrow)
                     const size_t lds = lds_plain + (WITH_J ? 0 : (size_t)kPoseSPB * (KD - 1) * sizeof(SplineSeg));
-                    if (half_grad)
-                    {
-                        HIP_TRY(eng->ensure_lds((const void *)k_fused<KD, WITH_J, true, true>, lds));
-                        MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, true, true>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho,
-                                           patch_cost, patch_blocks_strided, partials, table, status, max_S);
-                    }
-                    else
-                    {
-                        HIP_TRY(eng->ensure_lds((const void *)k_fused<KD, WITH_J, false, true>, lds));
-                        MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, false, true>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho,
-                                           patch_cost, patch_blocks_strided, partials, table, status, max_S);
-                    }
+                    MBAVO_GRAD_CASE(HIP_TRY(eng->ensure_lds((const void *)k_fused<KD, WITH_J, G, true>, lds));
+                                    MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, G, true>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho,
+                                                       patch_cost, patch_blocks_strided, partials, table, status, max_S));
                 }
             }
-            else if (half_grad)
-                MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, true>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho, patch_cost,
-                                   patch_blocks_strided, partials, table, status, max_S);
             else
-                MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, false>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho, patch_cost,
-                                   patch_blocks_strided, partials, table, status, max_S);
+                MBAVO_GRAD_CASE(MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, G>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho, patch_cost,
+                                                   patch_blocks_strided, partials, table, status, max_S));
+#undef MBAVO_GRAD_CASE
         }
         static_assert(Pack<KD>::E + 1 <= 384, "one thread per partial slot");
         if (flat_finalize)
@@ -2600,9 +2596,9 @@ namespace mbavo
         int max_S = 1;
         for (const ProblemDesc &pd : h_descs_) max_S = pd.S > max_S ? pd.S : max_S;
         // the gradient storage format selects the kernel instantiation, so it must be the same for the whole batch
-        const bool half_grad = h_descs_[0].grad_fp16 != 0;
+        const int half_grad = h_descs_[0].grad_fp16; // 0 float pairs, 1 IEEE half pairs, 2 packed keyframe words
         for (const ProblemDesc &pd : h_descs_)
-            if ((pd.grad_fp16 != 0) != half_grad) return MBAVO_E_ARG;
+            if (pd.grad_fp16 != half_grad) return MBAVO_E_ARG;
         // small problems: ONE launch (pose entries in the fused kernel's prologue, finalize by the last workgroup of a slot)
         // (profiles/r02_single_launch_ab.txt: with the two-stage pose prologue it wins for every spline degree and mode;
         // before it, the k = 4 H/g prologue was a 2 600-instruction chain with vector spills and lost to three launches).
@@ -3048,7 +3044,7 @@ namespace mbavo
         else if (k[3] > 0)
             snprintf(last_kernel_, sizeof(last_kernel_), "k_fused_sp<%d,%s,false,%d,%s>", k[0], k[1] ? "true" : "false", k[3], k[4] ? "true" : "false");
         else
-            snprintf(last_kernel_, sizeof(last_kernel_), "k_fused<%d,%s,%s,%s>", k[0], k[1] ? "true" : "false", k[2] ? "true" : "false", k[5] ? "true" : "false");
+            snprintf(last_kernel_, sizeof(last_kernel_), "k_fused<%d,%s,%s,%s>", k[0], k[1] ? "true" : "false", k[2] == 2 && k[1] ? "packed" : k[2] == 1 ? "true" : "false", k[5] ? "true" : "false");
         return last_kernel_;
     }
 

@@ -51,6 +51,20 @@ namespace mbavo
         }
         g[i] = __floats2half2_rn(dx, dy);
     }
+    // intensity and both doubled differences in one word per pixel (pixel_math.h: pack_keyframe_word)
+    __global__ void k_pack_keyframe(const unsigned char *__restrict__ src, int H, int W, unsigned *__restrict__ out)
+    {
+        const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+        if (x >= W || y >= H) return;
+        const size_t i = (size_t)y * W + x;
+        int kx = 0, ky = 0;
+        if (!(x == 0 || y == 0 || x == W - 1 || y == H - 1))
+        {
+            kx = (int)src[i + 1] - (int)src[i - 1];
+            ky = (int)src[i + W] - (int)src[i - W];
+        }
+        out[i] = pack_keyframe_word((int)src[i], kx, ky);
+    }
     // Synthetic motion blur (generate_synthetic_data.cpp:127-214): every output pixel is warped into the sharp
     // image through each of the n sampled poses, every warp is truncated to 8 bits as warp_image() stores it, the n
     // images are averaged in float and rounded to nearest even like cv::Mat::convertTo(CV_8U).
@@ -129,6 +143,13 @@ extern "C" int mbavo_image_gradients_u8_half(const unsigned char *d_src, int H, 
     if (!d_src || !d_dIxy_half || H < 1 || W < 1) return MBAVO_E_ARG;
     hipLaunchKernelGGL(mbavo::k_gradients_half, dim3((W + 255) / 256, H), dim3(256), 0, (hipStream_t)stream, d_src, H, W,
                        (__half2 *)d_dIxy_half);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mbavo_pack_keyframe_u8(const unsigned char *d_src, int H, int W, void *d_packed, void *stream)
+{
+    if (!d_src || !d_packed || H < 1 || W < 1) return MBAVO_E_ARG;
+    hipLaunchKernelGGL(mbavo::k_pack_keyframe, dim3((W + 255) / 256, H), dim3(256), 0, (hipStream_t)stream, d_src, H, W, (unsigned *)d_packed);
     return (int)hipGetLastError();
 }
 

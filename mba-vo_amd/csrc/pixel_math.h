@@ -263,13 +263,23 @@ namespace mbavo
         float w00, w01, w10, w11;
         unsigned short r0, r1; // image rows y, y+1: bytes (x, x+1)
         float g0[4], g1[4];    // gradient rows: [dx(x) dy(x) dx(x+1) dy(x+1)]
+        unsigned pk[4];        // packed keyframe (GRAD == 2): words of (x, y), (x+1, y), (x, y+1), (x+1, y+1)
         bool ok;
     };
+
+    // Packed keyframe (mbavo_problem.grad_fp16 = 2, mbavo_pack_keyframe_u8): ONE 32-bit word per pixel holds the intensity and
+    // both central differences of an 8-bit image -- bits 0-7 I, bits 8-16 2 dI/dx and bits 23-31 2 dI/dy as 9-bit two's
+    // complement (|2 d| <= 255) -- so a bilinear tap with gradients is two 8-byte loads from ONE image instead of two 2-byte
+    // loads from the u8 image and two 16-byte loads from the float gradient image (9 bytes per pixel in two images -> 4 in
+    // one; per 8-pixel patch ~10 touched 128-byte lines instead of ~27).  Every value is recovered exactly: the fp32 blend
+    // runs on the doubled differences and its result is halved, which commutes with every rounding of the blend.
+    struct __attribute__((aligned(4))) Word2A4 { unsigned v[2]; };
+    MBAVO_HD unsigned pack_keyframe_word(int I, int kx, int ky) { return (unsigned)I | ((unsigned)kx & 0x1ffu) << 8 | (unsigned)ky << 23; }
 
     // HALF_GRAD: the gradient image holds IEEE half pairs (4 B/pixel) instead of float pairs.  A compile-time
     // switch: a run-time branch around the loads makes the compiler wait for ALL outstanding loads (vmcnt(0)) at
     // the first use, which serialises the sample pipeline.
-    template <bool WITH_GRAD, bool HALF_GRAD = false>
+    template <bool WITH_GRAD, int HALF_GRAD = 0> // 0: float pairs, 1: IEEE half pairs, 2: packed keyframe words
     MBAVO_HD void tap_fetch(const unsigned char *__restrict__ I, const float *__restrict__ G, int H, int W,
                             double x, double y, TapLoads &t)
     {
@@ -316,12 +326,20 @@ namespace mbavo
 #endif
         const unsigned idx1 = idx + (unsigned)W;
         const MBAVO_GLOBAL unsigned char *Ig = (const MBAVO_GLOBAL unsigned char *)I;
+        if (WITH_GRAD && HALF_GRAD == 2)
+        { // everything a tap needs is in the packed image (cost-only passes keep to the u8 image: 2 bytes a row)
+            const MBAVO_GLOBAL unsigned char *Gb = (const MBAVO_GLOBAL unsigned char *)G;
+            const Word2A4 a = *(const MBAVO_GLOBAL Word2A4 *)(Gb + idx * 4u);
+            const Word2A4 b = *(const MBAVO_GLOBAL Word2A4 *)(Gb + idx1 * 4u);
+            t.pk[0] = a.v[0]; t.pk[1] = a.v[1]; t.pk[2] = b.v[0]; t.pk[3] = b.v[1];
+            return;
+        }
         t.r0 = ((const MBAVO_GLOBAL UnalignedU16 *)(Ig + idx))->v;
         t.r1 = ((const MBAVO_GLOBAL UnalignedU16 *)(Ig + idx1))->v;
         if (WITH_GRAD)
         {
             const MBAVO_GLOBAL unsigned char *Gb = (const MBAVO_GLOBAL unsigned char *)G;
-            if (HALF_GRAD)
+            if (HALF_GRAD == 1)
             { // 8 bytes per row pair instead of 16
                 const Half4A4 a = *(const MBAVO_GLOBAL Half4A4 *)(Gb + idx * 4u);
                 const Half4A4 b = *(const MBAVO_GLOBAL Half4A4 *)(Gb + idx1 * 4u);
@@ -337,10 +355,36 @@ namespace mbavo
     }
 
     // float weights, float accumulation, order w11*I11 + w10*I10 + w01*I01 + w00*I00 (:56-68)
-    template <bool WITH_GRAD>
+    template <bool WITH_GRAD, int GRAD = 0>
     MBAVO_HD void tap_blend(const TapLoads &t, double &val, double &gx, double &gy)
     {
 #pragma clang fp contract(off)
+        if (WITH_GRAD && GRAD == 2)
+        { // packed keyframe words: the same blend on the doubled differences, halved at the end (exact)
+            const float i00 = (float)(t.pk[0] & 0xffu), i01 = (float)(t.pk[1] & 0xffu);
+            const float i10 = (float)(t.pk[2] & 0xffu), i11 = (float)(t.pk[3] & 0xffu);
+            float v = t.w11 * i11;
+            v = v + t.w10 * i10;
+            v = v + t.w01 * i01;
+            v = v + t.w00 * i00;
+            val = (double)v;
+            // (9-bit fields: shift the field's top bit to bit 31, arithmetic shift back)
+            const float x00 = (float)((int)(t.pk[0] << 15) >> 23), x01 = (float)((int)(t.pk[1] << 15) >> 23);
+            const float x10 = (float)((int)(t.pk[2] << 15) >> 23), x11 = (float)((int)(t.pk[3] << 15) >> 23);
+            const float y00 = (float)((int)t.pk[0] >> 23), y01 = (float)((int)t.pk[1] >> 23);
+            const float y10 = (float)((int)t.pk[2] >> 23), y11 = (float)((int)t.pk[3] >> 23);
+            float a = t.w11 * x11;
+            a = a + t.w10 * x10;
+            a = a + t.w01 * x01;
+            a = a + t.w00 * x00;
+            float b = t.w11 * y11;
+            b = b + t.w10 * y10;
+            b = b + t.w01 * y01;
+            b = b + t.w00 * y00;
+            gx = (double)(0.5f * a);
+            gy = (double)(0.5f * b);
+            return;
+        }
         const float i00 = (float)(t.r0 & 0xff), i01 = (float)(t.r0 >> 8);
         const float i10 = (float)(t.r1 & 0xff), i11 = (float)(t.r1 >> 8);
         float v = t.w11 * i11;
@@ -571,7 +615,7 @@ namespace mbavo
         TapLoads taps;
     };
 
-    template <int KDEG, bool WITH_J, bool HALF_GRAD = false>
+    template <int KDEG, bool WITH_J, int HALF_GRAD = 0>
     MBAVO_HD void sample_issue(const PoseEntry<KDEG> &pe, const double ray[3], double D, double iz, const Camera &cam,
                                const unsigned char *__restrict__ I, const float *__restrict__ G, SampleInFlight &f)
     {
@@ -620,12 +664,12 @@ namespace mbavo
 
     // FIRST: the pixel's first sample SETS isum and Jrow instead of adding to them (no zero-initialisation of the 6k
     // accumulators per pixel).
-    template <int KDEG, bool WITH_J, bool FIRST = false>
+    template <int KDEG, bool WITH_J, bool FIRST = false, int GRAD = 0>
     MBAVO_HD void sample_retire(const PoseEntry<KDEG> &pe, const SampleInFlight &f, const double ray[3], double D, double iz,
                                 const Camera &cam, double &isum, double *Jrow)
     {
         double val, gx = 0, gy = 0;
-        tap_blend<WITH_J>(f.taps, val, gx, gy);
+        tap_blend<WITH_J, GRAD>(f.taps, val, gx, gy);
         isum = FIRST ? val : isum + val;
         if (WITH_J)
         {
@@ -684,7 +728,7 @@ namespace mbavo
     // of sample s+1 are issued before sample s is consumed.
     // (pixel_row_sum: the sum of the S interpolated intensities and the current image's pixel; pixel_row below forms the
     // residual from them)
-    template <int KDEG, bool WITH_J, bool HALF_GRAD = false>
+    template <int KDEG, bool WITH_J, int HALF_GRAD = 0>
     MBAVO_HD bool pixel_row_sum(const PoseEntry<KDEG> *__restrict__ table, int S, const Camera &cam,
                                 const unsigned char *__restrict__ I_ref, const float *__restrict__ G_ref,
                                 const unsigned char *__restrict__ I_cur, double centre_x, double centre_y,
@@ -715,28 +759,28 @@ namespace mbavo
             sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(0), ray, depth, iz, cam, I_ref, G_ref, fa);
             sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(1), ray, depth, iz, cam, I_ref, G_ref, fb);
             ok = fa.taps.ok && fb.taps.ok;
-            sample_retire<KDEG, WITH_J, true>(MBAVO_TAB(0), fa, ray, depth, iz, cam, isum, Jrow);
-            sample_retire<KDEG, WITH_J>(MBAVO_TAB(1), fb, ray, depth, iz, cam, isum, Jrow);
+            sample_retire<KDEG, WITH_J, true, HALF_GRAD>(MBAVO_TAB(0), fa, ray, depth, iz, cam, isum, Jrow);
+            sample_retire<KDEG, WITH_J, false, HALF_GRAD>(MBAVO_TAB(1), fb, ray, depth, iz, cam, isum, Jrow);
             for (s = 2; s + 1 < S; s += 2)
             {
                 sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s), ray, depth, iz, cam, I_ref, G_ref, fa);
                 sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s + 1), ray, depth, iz, cam, I_ref, G_ref, fb);
                 ok = ok && fa.taps.ok && fb.taps.ok;
-                sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, depth, iz, cam, isum, Jrow);
-                sample_retire<KDEG, WITH_J>(MBAVO_TAB(s + 1), fb, ray, depth, iz, cam, isum, Jrow);
+                sample_retire<KDEG, WITH_J, false, HALF_GRAD>(MBAVO_TAB(s), fa, ray, depth, iz, cam, isum, Jrow);
+                sample_retire<KDEG, WITH_J, false, HALF_GRAD>(MBAVO_TAB(s + 1), fb, ray, depth, iz, cam, isum, Jrow);
             }
             if (s < S)
             { // odd S
                 sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(s), ray, depth, iz, cam, I_ref, G_ref, fa);
                 ok = ok && fa.taps.ok;
-                sample_retire<KDEG, WITH_J>(MBAVO_TAB(s), fa, ray, depth, iz, cam, isum, Jrow);
+                sample_retire<KDEG, WITH_J, false, HALF_GRAD>(MBAVO_TAB(s), fa, ray, depth, iz, cam, isum, Jrow);
             }
         }
         else
         { // the sharp case S = 1
             sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(0), ray, depth, iz, cam, I_ref, G_ref, fa);
             ok = fa.taps.ok;
-            sample_retire<KDEG, WITH_J, true>(MBAVO_TAB(0), fa, ray, depth, iz, cam, isum, Jrow);
+            sample_retire<KDEG, WITH_J, true, HALF_GRAD>(MBAVO_TAB(0), fa, ray, depth, iz, cam, isum, Jrow);
         }
         if (!ok) return false;
         isum_out = isum;
@@ -744,7 +788,7 @@ namespace mbavo
         return true;
     }
 
-    template <int KDEG, bool WITH_J, bool HALF_GRAD = false>
+    template <int KDEG, bool WITH_J, int HALF_GRAD = 0>
     MBAVO_HD bool pixel_row(const PoseEntry<KDEG> *__restrict__ table, int S, const Camera &cam,
                             const unsigned char *__restrict__ I_ref, const float *__restrict__ G_ref,
                             const unsigned char *__restrict__ I_cur, double centre_x, double centre_y,
@@ -763,7 +807,7 @@ namespace mbavo
     // The same with the sample count's constants handed in: fS = (double)(float)S, rS = quotient_recip(fS), both kept in
     // scalar registers by the caller (formed per call they are hoisted into VGPR pairs that stay live through the whole
     // kernel).  The mean's factor 1 / fS is the caller's business.
-    template <int KDEG, bool WITH_J, bool HALF_GRAD = false>
+    template <int KDEG, bool WITH_J, int HALF_GRAD = 0>
     MBAVO_HD bool pixel_row(const PoseEntry<KDEG> *__restrict__ table, int S, const Camera &cam,
                             const unsigned char *__restrict__ I_ref, const float *__restrict__ G_ref,
                             const unsigned char *__restrict__ I_cur, double centre_x, double centre_y,

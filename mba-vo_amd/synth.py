@@ -165,3 +165,16 @@ def packed_len(k):
 def segment_start_index(t, t0, dt):
     """(int)((t - t0)/dt), truncation toward zero (SplineFunctor.h:13-19)."""
     return int((t - t0) / dt)
+
+
+def pack_keyframe(img):
+    """The packed keyframe of mbavo_pack_keyframe_u8 (mbavo_problem.grad_fp16 = 2) on the host: one uint32 per pixel, bits 0-7 the
+    intensity, bits 8-16 / 23-31 the doubled central differences (Gradient.h:16-75: zero on the 1-pixel border) as 9-bit two's
+    complement."""
+    I = img.astype(np.int64)
+    kx = np.zeros_like(I)
+    ky = np.zeros_like(I)
+    kx[1:-1, 1:-1] = I[1:-1, 2:] - I[1:-1, :-2]
+    ky[1:-1, 1:-1] = I[2:, 1:-1] - I[:-2, 1:-1]
+    w = I | ((kx & 0x1ff) << 8) | ((ky & 0x1ff) << 23)
+    return np.ascontiguousarray(w.astype(np.uint32))

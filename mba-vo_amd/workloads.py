@@ -31,7 +31,7 @@ class Prob:
         self.knots_t, self.knots_R = np.ascontiguousarray(knots_t, np.float64).ravel(), np.ascontiguousarray(knots_R, np.float64).ravel()
         self.start_idx = np.array([synth.segment_start_index(c, t0, dt) for c in self.cap], np.int32)
         self.outlier, self.num_bad = None, 0
-        self.grad_fp16 = False  # upload the gradient image as IEEE half pairs (BASELINE configs[4])
+        self.grad_fp16 = False  # True / 1: upload the gradient image as IEEE half pairs (BASELINE configs[4]); 2: the packed keyframe
 
     @property
     def pixel_samples(self):
@@ -186,7 +186,10 @@ class RenderedPairBatch:
                 capi.check(L.mbavo_synthesize_blur(base.data_ptr(), H, W, float(D), capi.dp(intr), 4, t0w, dtk, capi.dp(ktw),
                                                    capi.dp(kRw), n_world, float(t), float(e), ns, dst.data_ptr(), None),
                            "mbavo_synthesize_blur")
-            if grad_fp16:  # IEEE half pairs (lossless for central differences of an 8-bit image)
+            if int(grad_fp16) == 2:  # packed keyframe: intensity + both differences in one word per pixel
+                grad = torch.empty(H * W, dtype=torch.int32, device=device)
+                capi.check(L.mbavo_pack_keyframe_u8(ref.data_ptr(), H, W, grad.data_ptr(), None), "mbavo_pack_keyframe_u8")
+            elif grad_fp16:  # IEEE half pairs (lossless for central differences of an 8-bit image)
                 grad = torch.empty(H * W * 2, dtype=torch.float16, device=device)
                 capi.check(L.mbavo_image_gradients_u8_half(ref.data_ptr(), H, W, grad.data_ptr(), None), "mbavo_image_gradients_u8_half")
             else:
@@ -237,7 +240,7 @@ class RenderedPairBatch:
             q.d_cap_time, q.d_exp_time, q.t0, q.dt = capt.data_ptr(), expt.data_ptr(), t0, dtk
             q.d_knots_t, q.d_knots_R = dkt.data_ptr(), dkR.data_ptr()
             q.h_start_idx = start.ctypes.data_as(C.POINTER(C.c_int))
-            q.huber_a, q.grad_fp16 = huber, 1 if grad_fp16 else 0
+            q.huber_a, q.grad_fp16 = huber, int(grad_fp16)
             self.probs.append(_PairInfo(S, k, 4, 1, K, 8, H, W))
             self._host.append(dict(ref=ref, cur=cur, grad=grad, xy=xy, kz=kz, kt=kt, kR=kR, kt_gt=kt_gt, t0=t0, cap=tc, exp=exp,
                                    huber=huber, pk=pk, qk=qk, dkt=dkt, dkR=dkR))
@@ -292,7 +295,9 @@ class DeviceWorkload:
         self.array = (capi.Problem * B)()
         for b, p in enumerate(probs):
             ref = up(p.ref)
-            if p.grad_fp16:
+            if int(p.grad_fp16) == 2:
+                grad = up(synth.pack_keyframe(p.ref))
+            elif p.grad_fp16:
                 if not hasattr(p, "_grad_half"):
                     p._grad_half = np.ascontiguousarray(p.grad.astype(np.float16))
                 grad = up(p._grad_half)
@@ -315,7 +320,7 @@ class DeviceWorkload:
             q.d_knots_t, q.d_knots_R = kt.data_ptr(), kR.data_ptr()
             q.h_start_idx = p.start_idx.ctypes.data_as(C.POINTER(C.c_int))
             q.huber_a = p.huber
-            q.grad_fp16 = 1 if p.grad_fp16 else 0
+            q.grad_fp16 = int(p.grad_fp16)
             self._knots.append((kt, kR))
         self.B = B
         self.k = probs[0].k

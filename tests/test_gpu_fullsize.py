@@ -237,3 +237,54 @@ def test_c4_batch512_rendered_pairs_full_size(orc, mbavo, gpu_ctx):
         got = total.cpu().numpy().reshape(512, batch.E)
         order = np.array(se.row_of_pair)
         assert np.abs(got[order] - fb).max() <= 1e-12 * np.abs(fb).max()
+
+
+def test_packed_keyframe_matches_float_gradients(orc, mbavo, gpu_ctx):
+    """mbavo_problem.grad_fp16 = 2: the keyframe as ONE word per pixel (intensity + both doubled central differences,
+    mbavo_pack_keyframe_u8).  Every tap value is recovered exactly and the fp32 blend on the doubled differences, halved, rounds
+    like the blend on the differences themselves -- so the results differ from the float-gradient instantiation only where the
+    compiler contracts the fp64 chains differently: 1e-13 relative on the packed blocks, exact valid-pixel counts; 1e-9 against
+    the oracle.  Dense tiles with a sample-parallel remainder (S = 8, 16), 8-pixel patches (k = 2 and 4), cost-only passes (which
+    keep to the u8 image), and the device producer against the host one."""
+    import torch
+    from mba_vo_amd import synth
+    for S in (8, 16):
+        probs = wl.pyramid_pair(20, 40, 1, S=S, k=4, N=4, mode="dense", seed=4)
+        fb32, v32 = _run(gpu_ctx, probs)
+        p = probs[0]
+        op, keep = orc.make_problem(p.S, p.F, p.K, p.P, p.k, p.N, p.H, p.W, p.ref, p.grad, p.cur, p.kp_xy, p.kp_z,
+                                    p.pattern, p.intr, p.cap, p.exp, p.t0, p.dt, p.knots_t, p.knots_R, p.start_idx, p.huber)
+        ro = orc.evaluate(op)
+        for q in probs:
+            q.grad_fp16 = 2
+        fbp, vp = _run(gpu_ctx, probs)
+        assert np.abs(fbp - fb32).max() <= 1e-13 * np.abs(fb32).max() and np.array_equal(vp, v32) and v32.sum() > 0
+        assert np.abs(ro["frame_blocks"][0] - fbp[0]).max() <= 1e-9 * np.abs(fbp[0]).max()
+    for k in (2, 4):
+        probs = wl.pair_batch(6, H=120, W=160, S=8, k=k, N=4 if k == 4 else 2, mode="semidense", seed=7)
+        fb32, v32 = _run(gpu_ctx, probs)
+        c32, _ = _run(gpu_ctx, probs, False)
+        for q in probs:
+            q.grad_fp16 = 2
+        fbp, vp = _run(gpu_ctx, probs)
+        assert np.abs(fbp - fb32).max() <= 1e-13 * np.abs(fb32).max() and np.array_equal(vp, v32) and v32.sum() > 0
+        cp, _ = _run(gpu_ctx, probs, False)
+        # cost-only passes tap the u8 image in both formats (the float list may take the sample-parallel kernel: another order of sums)
+        assert np.abs(cp[:, 0] - c32[:, 0]).max() <= 1e-13 * np.abs(c32[:, 0]).max()
+    big = wl.pyramid_pair(480, 640, 2, S=8, k=4, N=4, mode="dense", seed=3)
+    fb32, v32 = _run(gpu_ctx, big)
+    for q in big:
+        q.grad_fp16 = 2
+    fbp, vp = _run(gpu_ctx, big)
+    assert np.abs(fbp - fb32).max() <= 1e-13 * np.abs(fb32).max() and np.array_equal(vp, v32)
+    src = torch.from_numpy(big[0].ref).to("cuda:0")
+    H, W = big[0].ref.shape
+    out = torch.zeros(H * W, dtype=torch.int32, device="cuda:0")
+    assert gpu_ctx.lib.mbavo_pack_keyframe_u8(src.data_ptr(), H, W, out.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    host = synth.pack_keyframe(big[0].ref)
+    assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(H, W), host)
+    # the words hold the float gradient image exactly
+    kx = ((host.astype(np.int64) << 47) >> 55).astype(np.float32) * 0.5
+    ky = (host.astype(np.int32) >> 23).astype(np.float32) * 0.5
+    assert np.array_equal(kx, big[0].grad[..., 0]) and np.array_equal(ky, big[0].grad[..., 1]) and np.array_equal(host & 0xff, big[0].ref)

@@ -15,8 +15,8 @@ lib = ctx.lib
 lib.mbavo_debug_fused_stamps.argtypes = [C.c_void_p, C.c_int]
 names = sys.argv[1:] or ["c2_dense", "c3_batch64"]
 for name in names:
-    probs = bench.build_workload(name, 1)[0]
-    dw = wl.DeviceWorkload(probs)
+    probs = bench.build_workload(name, 1, ctx=ctx)[0]
+    dw = probs if hasattr(probs, "step") else wl.DeviceWorkload(probs)  # rendered pair batches are device workloads already
     for _ in range(30): dw.step(ctx, True)
     torch.cuda.synchronize()
     res = []

@@ -83,6 +83,10 @@ def bench_line(M, ctx, dev, B=64, iterations=10, host_pairs=8):
         out["device_" + name] = device_lm(M, ctx, batch, solver, iterations)
     if host_pairs > 0:
         out["host_svd"] = host_lm(M, ctx, batch, 0, iterations, host_pairs)
+    del batch
+    # the same pairs with packed keyframes (mbavo_problem.grad_fp16 = 2: one word per pixel, identical tap values)
+    packed = workloads.RenderedPairBatch(ctx, B, S=8, k=4, device=dev, seed=1, grad_fp16=2)
+    out["device_svd_packed_keyframes"] = device_lm(M, ctx, packed, 0, iterations)
     return out
 
 
