@@ -644,10 +644,10 @@ def main():
     # N > 1: BASELINE configs[3] (512 pairs over the ranks) in both shardings, bounded -- the driver's scaling run only
     # launches the default workload, so the batch's scaling points ride in its line
     if use_dist and not args.no_configs and args.workload == "c2_dense":
-        for mode in ("pairs", "keypoints"):
-            key = "c4_batch512_" + mode
+        for mode, fmt in (("pairs", 0), ("keypoints", 0), ("pairs", 2)):  # (2: packed keyframes, mbavo_problem.grad_fp16 = 2)
+            key = "c4_batch512_" + mode + ("_packed" if fmt == 2 else "")
             try:
-                r = Runner(M, ctx, "c4_batch512", dev, rank, world, True, shard_mode=mode)
+                r = Runner(M, ctx, "c4_batch512", dev, rank, world, True, fmt, shard_mode=mode)
                 n, dt, kms, kname = bounded_run(M, ctx, r, min_steps=60, sync=sync)
                 dt = max_over_ranks(dt)
                 chk = reduction_check(r)
