@@ -125,12 +125,14 @@ def loop_spline(n_knots, dt=0.5, amp=(0.5, 0.35, 0.04), period=(2.1, 1.7, 3.3), 
 class _PairInfo:
     """What bench.py's accounting needs to know about one device-resident pair (no host copies of the images)."""
 
-    def __init__(self, S, k, N, F, K, P, H, W):
+    def __init__(self, S, k, N, F, K, P, H, W, fmt=0):
         self.S, self.k, self.N, self.F, self.K, self.P, self.H, self.W = S, k, N, F, K, P, H, W
         # SURVEY.md 8(d), semi-dense: the compulsory bytes are the taps of the distinct tap locations, bounded above by the
         # gather figure 36 B per pixel-sample (2 x 2 u8 + 2 x 2 x 8 B gradient taps) + the current pixel -- and by the
         # whole images (keyframe u8 + gradient 2 x f32 + current u8), all of them this pair's own
-        self.image_bytes = min(H * W * (1 + 8) + F * H * W, F * K * P * (S * 36 + 1))
+        # (keyframe formats 1 / 2: half pairs 1 + 4 bytes per pixel, 20 per tap; packed words 4 and 16)
+        img, tap = {0: (9, 36), 1: (5, 20), 2: (4, 16)}[int(fmt)]
+        self.image_bytes = min(H * W * img + F * H * W, F * K * P * (S * tap + 1))
 
     @property
     def pixel_samples(self):
@@ -173,7 +175,7 @@ class RenderedPairBatch:
         cap_kp = (H // cell + 1) * (W // cell + 1)
         for b in range(B):
             if b not in own:
-                self.probs.append(_PairInfo(S, k, 4, 1, 0, 8, H, W))
+                self.probs.append(_PairInfo(S, k, 4, 1, 0, 8, H, W, grad_fp16))
                 self._host.append(None)
                 continue
             tk, tc = t_first + b * frame_dt, t_first + (b + 1) * frame_dt
@@ -241,7 +243,7 @@ class RenderedPairBatch:
             q.d_knots_t, q.d_knots_R = dkt.data_ptr(), dkR.data_ptr()
             q.h_start_idx = start.ctypes.data_as(C.POINTER(C.c_int))
             q.huber_a, q.grad_fp16 = huber, int(grad_fp16)
-            self.probs.append(_PairInfo(S, k, 4, 1, K, 8, H, W))
+            self.probs.append(_PairInfo(S, k, 4, 1, K, 8, H, W, grad_fp16))
             self._host.append(dict(ref=ref, cur=cur, grad=grad, xy=xy, kz=kz, kt=kt, kR=kR, kt_gt=kt_gt, t0=t0, cap=tc, exp=exp,
                                    huber=huber, pk=pk, qk=qk, dkt=dkt, dkR=dkR))
         self.nbf = B
