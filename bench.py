@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip the bounded runs of the other BASELINE configs")
     ap.add_argument("--grad-fp16", action="store_true",
                     help="gradient pyramid stored as IEEE half pairs (BASELINE configs[4]: lossless for 8-bit images)")
+    ap.add_argument("--packed-keyframes", action="store_true",
+                    help="keyframes as one word per pixel: intensity + both central differences (mbavo_problem.grad_fp16 = 2, lossless)")
     ap.add_argument("--time-every", type=int, default=8,
                     help="HIP-event pair around the dominant kernel on every n-th timed step (events cost launch gaps)")
     ap.add_argument("--min-seconds", type=float, default=0.3, help="repeat the K-step region until this much was timed")
@@ -508,7 +510,7 @@ def main():
         red = statistics.median(b.elapsed_time(c) for a, b, c in ev)
         return loc, red
 
-    run = Runner(M, ctx, args.workload, dev, rank, world, use_dist, args.grad_fp16, shard_mode=args.shard)
+    run = Runner(M, ctx, args.workload, dev, rank, world, use_dist, 2 if args.packed_keyframes else int(args.grad_fp16), shard_mode=args.shard)
 
     for _ in range(args.warmup):
         run.step()
