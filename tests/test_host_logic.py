@@ -180,3 +180,36 @@ def test_triangular_index_decode_closed_form():
     for nd in (1, 2, 12, 13, 24, 25, 36, 37, 49, 96, 97, 200):
         for e in range(nd * (nd + 1) // 2):
             assert closed(e, nd) == search(e, nd), (nd, e)
+
+
+def test_packed_keyframe_holds_image_and_gradients_exactly(orc):
+    """The packed keyframe word (mbavo_problem.grad_fp16 = 2: intensity | 2 dI/dx | 2 dI/dy, 8 + 9 + 9 bits) decodes to the u8
+    image and to the oracle's gradient image (Gradient.h:16-75) bit for bit, extreme differences (+-255) and the zero border
+    included; the halved blend on doubled differences rounds like the blend on the differences."""
+    from mba_vo_amd import synth
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    img[5, 4:9] = [0, 7, 255, 9, 0]        # differences of +255 and -255 in x ...
+    img[10:15, 20] = [0, 7, 255, 9, 0]     # ... and in y
+    w = synth.pack_keyframe(img)
+    assert w.dtype == np.uint32 and w.shape == img.shape
+    I = (w & 0xff).astype(np.uint8)
+    kx = ((w.astype(np.int64) << 47) >> 55).astype(np.int32)     # bits 8-16, sign-extended
+    ky = (w.view(np.int32) >> 23)                                # bits 23-31, arithmetic shift
+    g = np.zeros(img.shape + (2,), np.float32)
+    mag = np.zeros(img.shape, np.float32)
+    orc.lib().orc_image_gradients_u8(orc.u8p(img), img.shape[0], img.shape[1], orc.fp(g), orc.fp(mag))
+    assert np.array_equal(I, img)
+    assert np.array_equal(kx.astype(np.float32) * np.float32(0.5), g[..., 0]) and np.array_equal(ky.astype(np.float32) * np.float32(0.5), g[..., 1])
+    assert kx.min() == -255 and kx.max() == 255 and ky.min() == -255 and ky.max() == 255
+    assert (kx[0] == 0).all() and (kx[:, -1] == 0).all() and (ky[-1] == 0).all() and (ky[:, 0] == 0).all()
+    # fp32 blend in the reference's order on the differences, and on the doubled differences then halved: the same bits
+    wts = rng.random((1000, 4)).astype(np.float32)
+    pick = rng.integers(0, kx.size, (1000, 4))
+    k4 = kx.ravel()[pick].astype(np.float32)
+    a = wts[:, 3] * (np.float32(0.5) * k4[:, 3])
+    b = wts[:, 3] * k4[:, 3]
+    for j in (2, 1, 0):
+        a = a + wts[:, j] * (np.float32(0.5) * k4[:, j])
+        b = b + wts[:, j] * k4[:, j]
+    assert np.array_equal(a, np.float32(0.5) * b)
