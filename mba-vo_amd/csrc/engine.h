@@ -225,7 +225,7 @@ namespace mbavo
         void *pinned_[kPinnedSlots] = {};
         size_t pinned_cap_[kPinnedSlots] = {};
 
-        static constexpr int kSlots = 16; // 0-6 LM loop (tracker.cpp), 8-10 keyframe detection (keyframe_ops.hip), 7 / 11 merge_device, 12-13 lm_device
+        static constexpr int kSlots = 16; // 0-6 LM loop (tracker.cpp), 8-10 keyframe detection (keyframe_ops.hip), 7 / 11 merge_device, 12-14 lm_device, 15 lm_batch
         void *slots_[kSlots] = {};
         size_t slot_cap_[kSlots] = {};
 

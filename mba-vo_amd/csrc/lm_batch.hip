@@ -357,7 +357,7 @@ namespace mbavo
                                : ((size_t)2 * max_n * (max_n + 1) + 6 * max_n) * sizeof(double) + (size_t)max_n * sizeof(int);
         if (lds > 160 * 1024) return MBAVO_E_ARG;
 
-        // one allocation for all LM state (freed at the end: this is a per-level call, not a per-iteration one)
+        // one arena for all LM state
         size_t off = 0;
         auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
         const size_t o_state = take(sizeof(LmState) * B), o_H = take(sizeof(double) * (size_t)B * max_n * max_n),
@@ -375,7 +375,9 @@ namespace mbavo
         std::vector<int> h_act(B);
         int h_done = 0;
         LM_HIP(hipSetDevice(eng.device()));
-        LM_HIP(hipMalloc((void **)&base, off));
+        // the engine's scratch slot 15, grown on demand and kept: no hipMalloc / hipFree per call (~90 us of a 64-pair call)
+        base = (char *)eng.named_scratch(15, off);
+        if (!base) { rc = (int)hipErrorOutOfMemory; goto done; }
         LM_HIP(hipMemsetAsync(base, 0, off, st));
         {
             LmState *states = (LmState *)(base + o_state);
@@ -469,7 +471,6 @@ namespace mbavo
                 }
         }
     done:
-        if (base) (void)hipFree(base);
         return rc > 0 ? -1000 - rc : rc;
     }
 } // namespace mbavo
