@@ -394,6 +394,19 @@ namespace mbavo
         val = (double)v;
         if (WITH_GRAD)
         {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_NO_PK_BLEND)
+            // the two gradient blends are the same four steps on (dx, dy) pairs that sit in adjacent registers as loaded:
+            // packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32, the weight broadcast by op_sel) round each half exactly
+            // like the scalar ones -- 7 instructions instead of 14
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 g11 = {t.g1[2], t.g1[3]}, g10 = {t.g1[0], t.g1[1]}, g01 = {t.g0[2], t.g0[3]}, g00 = {t.g0[0], t.g0[1]};
+            f32x2 ab = t.w11 * g11;
+            ab = ab + t.w10 * g10;
+            ab = ab + t.w01 * g01;
+            ab = ab + t.w00 * g00;
+            gx = (double)ab.x;
+            gy = (double)ab.y;
+#else
             float a = t.w11 * t.g1[2];
             a = a + t.w10 * t.g1[0];
             a = a + t.w01 * t.g0[2];
@@ -404,6 +417,7 @@ namespace mbavo
             b = b + t.w00 * t.g0[1];
             gx = (double)a;
             gy = (double)b;
+#endif
         }
     }
 
