@@ -373,6 +373,17 @@ namespace mbavo
             const float x10 = (float)((int)(t.pk[2] << 15) >> 23), x11 = (float)((int)(t.pk[3] << 15) >> 23);
             const float y00 = (float)((int)t.pk[0] >> 23), y01 = (float)((int)t.pk[1] >> 23);
             const float y10 = (float)((int)t.pk[2] >> 23), y11 = (float)((int)t.pk[3] >> 23);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_NO_PK_BLEND)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 g11 = {x11, y11}, g10 = {x10, y10}, g01 = {x01, y01}, g00 = {x00, y00};
+            f32x2 ab = t.w11 * g11;
+            ab = ab + t.w10 * g10;
+            ab = ab + t.w01 * g01;
+            ab = ab + t.w00 * g00;
+            ab = 0.5f * ab;
+            gx = (double)ab.x;
+            gy = (double)ab.y;
+#else
             float a = t.w11 * x11;
             a = a + t.w10 * x10;
             a = a + t.w01 * x01;
@@ -383,6 +394,7 @@ namespace mbavo
             b = b + t.w00 * y00;
             gx = (double)(0.5f * a);
             gy = (double)(0.5f * b);
+#endif
             return;
         }
         const float i00 = (float)(t.r0 & 0xff), i01 = (float)(t.r0 >> 8);
