@@ -206,6 +206,9 @@ int mbavo_lm_batch(mbavo_ctx *ctx, int B, const mbavo_problem *h_problems, const
 /* ---- keyframe input producers on device (core/measurements/ImagePyramid.h:59-99,
  * core/image_proc/Gradient.h:16-75) */
 int mbavo_pyramid_down_u8(const unsigned char *d_src, int H, int W, unsigned char *d_dst, void *hip_stream);
+/* levels 1 .. num_levels-1 (level l: (H0 >> l) x (W0 >> l)) below h_level_ptrs[0] on the context's stream, three levels per launch:
+ * the same 2 x 2 box with truncation per level (ImagePyramid.h:59-99); h_level_ptrs: host array of device pointers, num_levels <= 8 */
+int mbavo_pyramid_levels_u8(mbavo_ctx *ctx, unsigned char *const *h_level_ptrs, int H0, int W0, int num_levels);
 int mbavo_image_gradients_u8(const unsigned char *d_src, int H, int W, float *d_dIxy, void *hip_stream);
 /* same gradient image stored as IEEE half pairs (fp16 pyramid, mbavo_problem.grad_fp16 = 1) */
 int mbavo_image_gradients_u8_half(const unsigned char *d_src, int H, int W, void *d_dIxy_half, void *hip_stream);

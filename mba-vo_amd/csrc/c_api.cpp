@@ -258,6 +258,14 @@ extern "C"
                                        cap, h_count);
     }
 
+    int mbavo_pyramid_levels_u8(mbavo_ctx *ctx, unsigned char *const *h_level_ptrs, int H0, int W0, int num_levels)
+    {
+        if (!ctx || !h_level_ptrs || num_levels < 1 || num_levels > 8) return MBAVO_E_ARG;
+        for (int l = 0; l < num_levels; ++l)
+            if (!h_level_ptrs[l]) return MBAVO_E_ARG;
+        return mbavo::pyramid_enqueue(*ctx->engine, h_level_ptrs, H0, W0, num_levels);
+    }
+
     int mbavo_se3_exp(const double a[6], double pose[7])
     {
         if (!a || !pose) return MBAVO_E_ARG;

@@ -16,6 +16,7 @@
 #include "engine.h"
 #include "vo_frontend.h"
 #include <cmath>
+#include <cstring>
 #include <hip/hip_runtime.h>
 
 namespace mbavo
@@ -49,12 +50,10 @@ namespace mbavo
     }
 
     // one wave per grid cell
-    __global__ __launch_bounds__(64) void k_detect_cells(const unsigned char *__restrict__ src, int H, int W, int cell_h,
-                                                         int cell_w, int cells_w, float thr,
-                                                         const float *__restrict__ depth, int W0, double scale,
-                                                         CellPick *__restrict__ picks)
+    __device__ __forceinline__ void detect_cell(const unsigned char *__restrict__ src, int H, int W, int cell_h, int cell_w, int cells_w,
+                                                float thr, const float *__restrict__ depth, int W0, double scale, int ci, int lane,
+                                                CellPick *__restrict__ picks)
     {
-        const int ci = blockIdx.x, lane = threadIdx.x;
         const int y0 = (ci / cells_w) * cell_h, x0 = (ci % cells_w) * cell_w;
         float best = 0.f; // cv::KeyPoint() has response 0: a pixel must beat it strictly
         int best_idx = 0x7fffffff;
@@ -84,6 +83,89 @@ namespace mbavo
             }
             picks[ci] = p;
         }
+    }
+    __global__ __launch_bounds__(64) void k_detect_cells(const unsigned char *__restrict__ src, int H, int W, int cell_h,
+                                                         int cell_w, int cells_w, float thr,
+                                                         const float *__restrict__ depth, int W0, double scale,
+                                                         CellPick *__restrict__ picks)
+    {
+        detect_cell(src, H, W, cell_h, cell_w, cells_w, thr, depth, W0, scale, (int)blockIdx.x, (int)threadIdx.x, picks);
+    }
+
+    // ---- a keyframe's levels in ONE launch each (round 3): the per-level kernels are latency-bound (4-10 us each whatever the
+    // level's size), and a keyframe ran 3 of them per level back to back -- 11 launches at four levels, ~100 us of the 150 us a
+    // keyframe cost.  The levels' parameters travel by value; a workgroup finds its level from the prefix sums.
+    struct PyramidLevels
+    {
+        const unsigned char *img[8];
+        float2 *grad[8];
+        int H[8], W[8];
+        int row0[9];                         // gradients: first grid row of every level
+        int ch[8], cw[8], cells_w[8], cell0[9]; // grid selection: cell size, cells per row, first cell of every level
+        double scale[8];
+        int n;
+    };
+    // 2 x 2 box with truncation (ImagePyramid.h:59-99), up to three levels below `src` in one launch: a workgroup takes a
+    // 32 x 32 tile of the source down to 16 x 16, 8 x 8 and 4 x 4 through LDS -- the same integer operations per level
+    __global__ __launch_bounds__(256) void k_pyr_down_multi(const unsigned char *__restrict__ src, int Hs, int Ws, unsigned char *__restrict__ d1,
+                                                            unsigned char *__restrict__ d2, unsigned char *__restrict__ d3, int n)
+    {
+        __shared__ int t1[16][17], t2[8][9];
+        const int tid = threadIdx.x;
+        const int H1 = Hs / 2, W1 = Ws / 2, H2 = H1 / 2, W2 = W1 / 2, H3 = H2 / 2, W3 = W2 / 2;
+        {
+            const int ty = tid >> 4, tx = tid & 15, h = blockIdx.y * 16 + ty, w = blockIdx.x * 16 + tx;
+            int v = 0;
+            if (h < H1 && w < W1)
+            {
+                const unsigned char *r0 = src + (size_t)(2 * h) * Ws + 2 * w, *r1 = r0 + Ws;
+                v = ((int)r0[0] + (int)r0[1] + (int)r1[0] + (int)r1[1]) >> 2;
+                d1[(size_t)h * W1 + w] = (unsigned char)v;
+            }
+            t1[ty][tx] = v;
+        }
+        if (n < 2) return;
+        __syncthreads();
+        if (tid < 64)
+        {
+            const int ty = tid >> 3, tx = tid & 7, h = blockIdx.y * 8 + ty, w = blockIdx.x * 8 + tx;
+            const int v = (t1[2 * ty][2 * tx] + t1[2 * ty][2 * tx + 1] + t1[2 * ty + 1][2 * tx] + t1[2 * ty + 1][2 * tx + 1]) >> 2;
+            if (h < H2 && w < W2) d2[(size_t)h * W2 + w] = (unsigned char)v; // (its four sources are inside level 1 whenever it is inside level 2)
+            t2[ty][tx] = v;
+        }
+        if (n < 3) return;
+        __syncthreads();
+        if (tid < 16)
+        {
+            const int ty = tid >> 2, tx = tid & 3, h = blockIdx.y * 4 + ty, w = blockIdx.x * 4 + tx;
+            const int v = (t2[2 * ty][2 * tx] + t2[2 * ty][2 * tx + 1] + t2[2 * ty + 1][2 * tx] + t2[2 * ty + 1][2 * tx + 1]) >> 2;
+            if (h < H3 && w < W3) d3[(size_t)h * W3 + w] = (unsigned char)v;
+        }
+    }
+    // interleaved [dx, dy] central differences of every level (image_ops.hip: k_gradients)
+    __global__ __launch_bounds__(256) void k_gradients_multi(const PyramidLevels lv)
+    {
+        int l = 0;
+        while (l + 1 < lv.n && (int)blockIdx.y >= lv.row0[l + 1]) ++l;
+        const int H = lv.H[l], W = lv.W[l], y = (int)blockIdx.y - lv.row0[l], x = blockIdx.x * blockDim.x + threadIdx.x;
+        if (x >= W || y >= H) return;
+        const unsigned char *src = lv.img[l];
+        const size_t i = (size_t)y * W + x;
+        float2 v = make_float2(0.f, 0.f);
+        if (!(x == 0 || y == 0 || x == W - 1 || y == H - 1))
+        {
+            v.x = 0.5f * ((float)src[i + 1] - (float)src[i - 1]);
+            v.y = 0.5f * ((float)src[i + W] - (float)src[i - W]);
+        }
+        lv.grad[l][i] = v;
+    }
+    // grid selection of every level: one wave per cell, the cells of all levels in one grid (picks in level order)
+    __global__ __launch_bounds__(64) void k_detect_cells_multi(const PyramidLevels lv, float thr, int W0, CellPick *__restrict__ picks)
+    {
+        int l = 0;
+        while (l + 1 < lv.n && (int)blockIdx.x >= lv.cell0[l + 1]) ++l;
+        detect_cell(lv.img[l], lv.H[l], lv.W[l], lv.ch[l], lv.cw[l], lv.cells_w[l], thr, nullptr, W0, lv.scale[l],
+                    (int)blockIdx.x - lv.cell0[l], (int)threadIdx.x, picks + lv.cell0[l]);
     }
 
     // ordered compaction of the kept cells: single block, chunked exclusive scan
@@ -247,6 +329,52 @@ namespace mbavo
         hipLaunchKernelGGL(k_detect_cells, dim3(nc), dim3(64), 0, eng.stream(), d_img, H, W, ch, cw, cells_w, thr, (const float *)nullptr,
                            im_W0, std::pow(2, level), d_picks);
         *num_cells = nc;
+        return (int)hipGetLastError();
+    }
+    int pyramid_enqueue(Engine &eng, unsigned char *const *d_levels, int H0, int W0, int L)
+    { // levels 1 .. L-1 from level 0, three per launch
+        if (!d_levels || L < 1 || L > 8 || H0 < 1 || W0 < 1) return MBAVO_E_ARG;
+        for (int l = 0; l + 1 < L; l += 3)
+        {
+            const int n = L - 1 - l < 3 ? L - 1 - l : 3, Hs = H0 >> l, Ws = W0 >> l;
+            if (Hs < 2 || Ws < 2) return MBAVO_E_ARG;
+            hipLaunchKernelGGL(k_pyr_down_multi, dim3((Ws / 2 + 15) / 16, (Hs / 2 + 15) / 16), dim3(256), 0, eng.stream(), d_levels[l], Hs, Ws,
+                               d_levels[l + 1], n >= 2 ? d_levels[l + 2] : nullptr, n >= 3 ? d_levels[l + 3] : nullptr, n);
+        }
+        return (int)hipGetLastError();
+    }
+
+    int keyframe_levels_enqueue(Engine &eng, unsigned char *const *d_levels, float *const *d_grads, int H0, int W0, int L, int cell_H, int cell_W,
+                                float thr, CellPick *d_picks, int *cells_per_level)
+    {
+        if (!d_levels || !d_grads || L < 1 || L > 8) return MBAVO_E_ARG;
+        int rc = pyramid_enqueue(eng, d_levels, H0, W0, L);
+        if (rc != 0) return rc;
+        PyramidLevels lv;
+        memset(&lv, 0, sizeof(lv));
+        lv.n = L;
+        const bool grid = d_picks != nullptr;
+        for (int l = 0; l < L; ++l)
+        {
+            lv.img[l] = d_levels[l]; lv.grad[l] = (float2 *)d_grads[l];
+            lv.H[l] = H0 >> l; lv.W[l] = W0 >> l;
+            lv.row0[l + 1] = lv.row0[l] + lv.H[l];
+            lv.scale[l] = std::pow(2, l);
+            if (grid)
+            { // FeatureDetectorBase.cpp:56-64 (as in detect_semidense)
+                const int sf = (int)std::pow(2, l);
+                const int Hl = H0 / sf, Wl = W0 / sf;
+                const int ch = (int)(cell_H / std::pow(1.414, l)), cw = (int)(cell_W / std::pow(1.414, l));
+                if (ch < 1 || cw < 1) return MBAVO_E_ARG;
+                const int cells_h = Hl / ch + 1, cells_w = Wl / cw + 1;
+                if ((lv.H[l] - 1) / ch >= cells_h || (lv.W[l] - 1) / cw >= cells_w) return MBAVO_E_RANGE;
+                lv.ch[l] = ch; lv.cw[l] = cw; lv.cells_w[l] = cells_w;
+                lv.cell0[l + 1] = lv.cell0[l] + cells_h * cells_w;
+                if (cells_per_level) cells_per_level[l] = cells_h * cells_w;
+            }
+        }
+        hipLaunchKernelGGL(k_gradients_multi, dim3((W0 + 255) / 256, lv.row0[L]), dim3(256), 0, eng.stream(), lv);
+        if (grid) hipLaunchKernelGGL(k_detect_cells_multi, dim3(lv.cell0[L]), dim3(64), 0, eng.stream(), lv, thr, W0, d_picks);
         return (int)hipGetLastError();
     }
 } // namespace mbavo

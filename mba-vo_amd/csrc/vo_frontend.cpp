@@ -7,6 +7,7 @@
 #include "tracker.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 
@@ -231,6 +232,17 @@ namespace SLAM
               // pinned staging -- the 4 H x W bytes of depth never cross the bus
                 int rc = ensureGridBuffers();
                 if (rc != 0) return rc;
+                static const bool levels_at_once = [] { const char *e = getenv("MBAVO_KF_MULTI"); return !(e && e[0] == '0'); }();
+                if (levels_at_once)
+                { // pyramid, gradient images and grid selection of ALL levels: three launches (MBAVO_KF_MULTI=0: three per level)
+                    int ncell[8] = {};
+                    rc = mbavo::keyframe_levels_enqueue(mEngine, mRef, mGrad, H, W, L, mOptions.grid_selection_cell_H, mOptions.grid_selection_cell_W,
+                                                        mOptions.score_threshold, mPicksDev, ncell);
+                    if (rc != 0) return rc;
+                    for (int l = 0; l < L; ++l)
+                        if (ncell[l] != mKpCap[l]) return MBAVO_E_ARG;
+                }
+                else
                 for (int l = 0; l < L; ++l)
                 {
                     const int Hl = H >> l, Wl = W >> l;
@@ -300,6 +312,13 @@ namespace SLAM
             const int H = mOptions.im_size_HW[0], W = mOptions.im_size_HW[1];
             hipStream_t st = mEngine.stream();
             VO_HIP(hipMemcpyAsync(mCur[0], f.image, (size_t)H * W, hipMemcpyHostToDevice, st));
+            static const bool levels_at_once = [] { const char *e = getenv("MBAVO_KF_MULTI"); return !(e && e[0] == '0'); }();
+            if (levels_at_once)
+            {
+                const int rc = mbavo::pyramid_enqueue(mEngine, mCur, H, W, mOptions.num_pyramid_levels);
+                if (rc != 0) return rc;
+            }
+            else
             for (int l = 1; l < mOptions.num_pyramid_levels; ++l)
             {
                 const int rc = mbavo_pyramid_down_u8(mCur[l - 1], H >> (l - 1), W >> (l - 1), mCur[l], st);

@@ -33,7 +33,12 @@ namespace mbavo
     // them.  The front end's keyframe path: depth test + ordered compaction of the few hundred picks happen on the host, so
     // the depth map is never uploaded and a keyframe costs ONE stream synchronisation.
     int detect_cells_enqueue(Engine &eng, const unsigned char *d_img, int H, int W, int level, int im_H0, int im_W0, int cell_H,
-                             int cell_W, float thr, CellPick *d_picks, int *num_cells);
+                             int cell_W, float thr, CellPick *d_picks, int *num_cells);    // A keyframe's (or a frame's) levels in one launch each: the pyramid below d_levels[0] (three levels per launch), and with
+    // keyframe_levels_enqueue also every level's gradient image and -- d_picks non-null -- every level's grid selection (picks in
+    // level order, cells_per_level[l] of them).  Same integer / fp32 operations as the per-level kernels.
+    int pyramid_enqueue(Engine &eng, unsigned char *const *d_levels, int H0, int W0, int L);
+    int keyframe_levels_enqueue(Engine &eng, unsigned char *const *d_levels, float *const *d_grads, int H0, int W0, int L, int cell_H, int cell_W,
+                                float thr, CellPick *d_picks, int *cells_per_level);
 }
 
 namespace SLAM

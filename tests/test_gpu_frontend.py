@@ -203,3 +203,23 @@ def test_product_sequence_module_matches_oracle_rendering(orc, mbavo, gpu_ctx):
         assert x["is_keyframe"] == y["is_keyframe"] and x["num_trace"] == y["num_trace"] and x["K0"] == y["K"][0]
         assert np.abs(x["T"] - y["T"]).max() < 1e-6
         assert x["seconds"] > 0
+
+
+def test_pyramid_levels_in_one_launch_match_level_by_level(mbavo, gpu_ctx):
+    """mbavo_pyramid_levels_u8 (three levels per launch through LDS) against mbavo_pyramid_down_u8 level by level: identical
+    bytes, odd sizes and seven levels (two and a half launches) included."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(5)
+    for H, W, L in ((480, 640, 4), (97, 131, 5), (1080, 1920, 7), (33, 47, 2)):
+        img = torch.from_numpy(rng.integers(0, 256, (H, W), dtype=np.uint8)).to("cuda:0")
+        a = [img] + [torch.zeros((H >> l) * (W >> l), dtype=torch.uint8, device="cuda:0") for l in range(1, L)]
+        b = [img] + [torch.full(((H >> l) * (W >> l),), 7, dtype=torch.uint8, device="cuda:0") for l in range(1, L)]
+        for l in range(1, L):
+            assert gpu_ctx.lib.mbavo_pyramid_down_u8(a[l - 1].data_ptr(), H >> (l - 1), W >> (l - 1), a[l].data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream) == 0
+        ptrs = (C.c_void_p * L)(*[t.data_ptr() for t in b])
+        assert gpu_ctx.lib.mbavo_pyramid_levels_u8(gpu_ctx.handle, ptrs, H, W, L) == 0
+        torch.cuda.synchronize()
+        for l in range(1, L):
+            assert torch.equal(a[l], b[l]), (H, W, l)
