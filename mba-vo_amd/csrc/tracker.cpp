@@ -34,7 +34,10 @@ namespace mbavo
         }                                                                                \
     } while (0)
 
-    static int detect_outliers(const double *patch_cost, int K, double chi, unsigned char *flags)
+    // `shadow` (may be null): the flags in ordinary host memory (the persistent kernels' flag bytes live in write-combined device
+    // memory, which the host cannot read back at speed); *newly = how many patches this call flagged for the first time
+    static int detect_outliers(const double *patch_cost, int K, double chi, unsigned char *flags, unsigned char *shadow = nullptr,
+                               int *newly = nullptr)
     { // :639-699
         double sum = 0.0;
         std::vector<double> kept;
@@ -51,9 +54,15 @@ namespace mbavo
         for (double c : kept) var += (c - mu) * (c - mu);
         var = var / kept.size();
         const double bound = chi * (double)sqrtf((float)var);
-        int n = 0;
+        int n = 0, fresh = 0;
         for (int i = 0; i < K; ++i)
-            if (std::fabs(patch_cost[i] - mu) > bound) { flags[i] = 1; ++n; }
+            if (std::fabs(patch_cost[i] - mu) > bound)
+            {
+                flags[i] = 1;
+                ++n;
+                if (shadow) { fresh += shadow[i] == 0; shadow[i] = 1; }
+            }
+        if (newly) *newly = shadow ? fresh : n;
         return n;
     }
 
@@ -117,6 +126,17 @@ namespace mbavo
         if (start_idx_out) memcpy(start_idx_out, start_idx.data(), sizeof(int) * F);
 
         std::vector<double> H((size_t)n * n), g(n), step(n), cand_t(3 * N), cand_R(4 * N);
+        // Speculation (MBAVO_SPECULATE=1): the candidate is evaluated WITH H / g.  An accepted step is followed by an H / g evaluation
+        // at the very same knots (:896-903); it differs from the candidate's only through the outlier flags and the residual scale
+        // detectOutliers may have changed in between (:639-699) -- where it changed neither, the candidate's H, g and cost ARE that
+        // evaluation's, bit for bit, and it is skipped.
+        // Worth it where an evaluation is latency-bound and H / g cost little more than the cost alone: the levels that run on
+        // persistent kernels (trackFrame 0.330 -> 0.322 ms per frame, 172 -> 154 evaluations of 12.8 / 14.2 us over 8 tracked
+        // frames, identical records and poses); dense levels pay twice the cost-only pass for a one-in-three hit.
+        // MBAVO_SPECULATE=0 / 1: never / on every level.
+        static const int speculate_env = [] { const char *e = getenv("MBAVO_SPECULATE"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1; }();
+        std::vector<double> Hs(speculate_env != 0 ? (size_t)n * n : 0), gs(speculate_env != 0 ? n : 0);
+        std::vector<unsigned char> shadow;
         SLAM::VO::LevenbergMarquardtStrategy lm;
         SLAM::VO::TrustRegionStepEvaluator evaluator(o.max_consecutive_nonmonotonic_steps);
         double eval_cost = 0.0;
@@ -298,6 +318,7 @@ namespace mbavo
             const int lv = o.num_levels - li - 1; // coarse to fine (:571-575)
             const mbavo_level &L = levels[lv];
             memset(flags, 0, L.K > 0 ? L.K : 1); // :601 (the device copy below, where it is used)
+            shadow.assign((size_t)(L.K > 0 ? L.K : 1), 0);
             if (!joint)
             {
                 if ((rc_ = prepare(li)) != 0) goto done;
@@ -325,11 +346,13 @@ namespace mbavo
                 p.d_knots_t = d_kt; p.d_knots_R = d_kR; p.d_outlier = d_flags; // per-evaluation launches read the device copy
                 TRK_HIP(hipMemsetAsync(d_flags, 0, L.K > 0 ? L.K : 1, st));
             }
+            const bool speculate = speculate_env == 1 || (speculate_env < 0 && persistent);
             bool want_prelaunch = persistent && !joint && li + 1 < o.num_levels;
             // one evaluation at the given knots: knots into the pinned buffer, ONE launch for these problem sizes (pose
             // prologue + fused + last-workgroup finalize) whose frame blocks land in pinned host memory (h_pin), then a
             // spin on the kernel's completion word: no copies, no stream synchronisation
-            auto evaluate = [&](const double *kt, const double *kR, bool with_h, double *cost) -> int {
+            auto evaluate = [&](const double *kt, const double *kR, bool with_h, double *cost, double *Hout = nullptr, double *gout = nullptr) -> int {
+                if (!Hout) { Hout = H.data(); gout = g.data(); }
                 int r;
                 {
                     PhaseScope ps(PhaseTimers::kEnqueue);
@@ -357,8 +380,7 @@ namespace mbavo
                 if (r) return r;
                 PhaseScope ps(PhaseTimers::kMerge);
 
-                merge_blocks_host(F, k, lvl_pin, start_idx.data(), N, cost, with_h ? H.data() : nullptr,
-                                  with_h ? g.data() : nullptr);
+                merge_blocks_host(F, k, lvl_pin, start_idx.data(), N, cost, with_h ? Hout : nullptr, with_h ? gout : nullptr);
                 return 0;
             };
             auto record = [&](int iter, int kind, double cc, double model, double q) {
@@ -406,22 +428,31 @@ namespace mbavo
                 spline.Plus_t(step.data(), cand_t.data());
                 spline.Plus_R(step.data() + 3 * N, cand_R.data());
                 double cand_cost = 0.0;
-                if ((rc_ = evaluate(cand_t.data(), cand_R.data(), false, &cand_cost))) goto done;
+                if ((rc_ = evaluate(cand_t.data(), cand_R.data(), speculate, &cand_cost, Hs.data(), gs.data()))) goto done;
 
                 abs_dec = eval_cost - cand_cost;
                 const double quality = evaluator.StepQuality(cand_cost, model);
                 if (quality > o.min_step_quality && cand_cost < eval_cost)
                 { // isStepSuccessful (:890-894) -> detectOutliers + handleSuccessfulStep (:896-903)
+                    bool same_inputs = false;
                     {
                         PhaseScope ps(PhaseTimers::kOutliers);
                         const int bad_before = num_bad;
-                        num_bad = detect_outliers(lvl_pc, L.K, o.max_chi_square_error, w_flags); // frame 0's costs, just written
-                        if (PhaseTimers::get().on) ++PhaseTimers::get().calls[num_bad != bad_before ? PhaseTimers::kFlagsChanged : PhaseTimers::kFlagsSame];
+                        int newly = 0;
+                        num_bad = detect_outliers(lvl_pc, L.K, o.max_chi_square_error, w_flags, shadow.data(), &newly); // frame 0's costs, just written
+                        same_inputs = newly == 0 && num_bad == bad_before; // flags and residual scale as the candidate's evaluation saw them
+                        if (PhaseTimers::get().on) ++PhaseTimers::get().calls[!same_inputs ? PhaseTimers::kFlagsChanged : PhaseTimers::kFlagsSame];
                         set_inv();
                         if (!persistent) TRK_HIP(hipMemcpyAsync(d_flags, w_flags, L.K, hipMemcpyHostToDevice, st));
                     }
                     spline.InvalidParameter(cand_t.data(), cand_R.data());
-                    if ((rc_ = evaluate(spline.get_knot_data_t(), spline.get_knot_data_R(), true, &eval_cost))) goto done;
+                    if (speculate && same_inputs)
+                    { // the candidate's evaluation IS the accepted point's
+                        H.swap(Hs);
+                        g.swap(gs);
+                        eval_cost = cand_cost;
+                    }
+                    else if ((rc_ = evaluate(spline.get_knot_data_t(), spline.get_knot_data_R(), true, &eval_cost))) goto done;
                     lm.step_accepted(quality);
                     evaluator.StepAccepted(eval_cost, model);
                     record(iter, 1, cand_cost, model, quality);
