@@ -162,7 +162,7 @@ namespace SLAM
 
         BlurAwareDirectTracker::BlurAwareDirectTracker(mbavo::Engine &engine, const BlurAwareDirectTrackerOptions &options)
             : mEngine(engine), mOptions(options), mPrevTimestamp(0), mEvaluationPointCost(0), mIsFirstFrame(true),
-              mCurCap(0), mCurExp(0), mStatus(0), mDepth(nullptr), mPicksDev(nullptr), mPicksHost(nullptr), mKpStage(nullptr)
+              mCurCap(0), mCurExp(0), mStatus(0), mDepth(nullptr), mKpArena(nullptr), mPicksDev(nullptr), mPicksHost(nullptr), mKpStage(nullptr)
         { // blur_aware_direct_tracker.cpp:14-34; the shared storages are the engine's
             for (int i = 0; i < 6; ++i) mNeighFrameVelocity[i] = mSplineVelocity[i] = 0;
             for (int l = 0; l < 8; ++l)
@@ -184,7 +184,6 @@ namespace SLAM
                 if (mKpCap[l] < 1) { mStatus = MBAVO_E_ARG; return; }
                 alloc((void **)&mRef[l], n); alloc((void **)&mCur[l], n); alloc((void **)&mGrad[l], n * 2 * sizeof(float));
                 alloc((void **)&mCurPtr[l], sizeof(void *));
-                alloc((void **)&mKpXY[l], sizeof(double) * 2 * mKpCap[l]); alloc((void **)&mKpZ[l], sizeof(double) * mKpCap[l]);
                 const int P = mOptions.patch_size[l];
                 if (P < 1 || !mOptions.local_patch_pattern_xy[l]) { mStatus = MBAVO_E_ARG; return; }
                 alloc((void **)&mPattern[l], sizeof(int) * 2 * P);
@@ -196,6 +195,12 @@ namespace SLAM
                     if (e == hipSuccess) e = hipMemcpy(mCurPtr[l], &mCur[l], sizeof(void *), hipMemcpyHostToDevice);
                     if (e != hipSuccess) mStatus = (int)e;
                 }
+            }
+            alloc((void **)&mKpArena, sizeof(double) * mStageOff[L]);
+            for (int l = 0; l < L && mStatus == 0; ++l)
+            {
+                mKpXY[l] = mKpArena + mStageOff[l];
+                mKpZ[l] = mKpXY[l] + 2 * (size_t)mKpCap[l];
             }
         }
 
@@ -211,12 +216,12 @@ namespace SLAM
 
         BlurAwareDirectTracker::~BlurAwareDirectTracker()
         {
-            (void)hipFree(mDepth);
+            (void)hipFree(mDepth); (void)hipFree(mKpArena);
             (void)hipFree(mPicksDev); (void)hipHostFree(mPicksHost); (void)hipHostFree(mKpStage);
             for (int l = 0; l < 8; ++l)
             {
                 (void)hipFree(mRef[l]); (void)hipFree(mCur[l]); (void)hipFree(mGrad[l]); (void)hipFree(mCurPtr[l]);
-                (void)hipFree(mKpXY[l]); (void)hipFree(mKpZ[l]); (void)hipFree(mPattern[l]);
+                (void)hipFree(mPattern[l]);
             }
         }
 
@@ -272,12 +277,9 @@ namespace SLAM
                         ++n;
                     }
                     mNumKeypoints[l] = n;
-                    if (n > 0)
-                    {
-                        VO_HIP(hipMemcpyAsync(mKpXY[l], xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
-                        VO_HIP(hipMemcpyAsync(mKpZ[l], z, sizeof(double) * n, hipMemcpyHostToDevice, st));
-                    }
                 }
+                // ONE upload for all levels: the device arena has the staging's layout (eight small copies cost ~4 us of host time each)
+                VO_HIP(hipMemcpyAsync(mKpArena, mKpStage, sizeof(double) * mStageOff[L], hipMemcpyHostToDevice, st));
                 mHostKpXY0.assign(mKpStage, mKpStage + 2 * (size_t)mNumKeypoints[0]);
                 mHostKpZ0.assign(mKpStage + 2 * (size_t)mKpCap[0], mKpStage + 2 * (size_t)mKpCap[0] + mNumKeypoints[0]);
                 return 0;

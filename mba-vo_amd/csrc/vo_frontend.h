@@ -140,6 +140,7 @@ namespace SLAM
             // device-resident pyramids (keyframe: image + gradient; current frame: image) and keypoints
             unsigned char *mRef[8], *mCur[8];
             float *mGrad[8], *mDepth;
+            double *mKpArena; // every level's keypoints [xy (2 cap) | z (cap)] back to back, in the layout of the pinned staging: one upload per keyframe
             const unsigned char **mCurPtr[8]; // device array of 1 device pointer per level
             double *mKpXY[8], *mKpZ[8];
             int *mPattern[8];
