@@ -82,13 +82,15 @@ class Scene:
 class DeviceScene:
     """Device-resident copy of a Scene + its mbavo_problem."""
 
-    def __init__(self, sc, vec2d=False):
+    def __init__(self, sc, vec2d=False, packed=False):
         import torch
         dev = "cuda:0"
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.sc = sc
         self.ref = t(sc.ref)
-        self.grad = t(sc.grad)
+        # packed: the keyframe as one word per pixel (mbavo_problem.grad_fp16 = 2) instead of the float gradient image
+        self.packed = packed
+        self.grad = t(synth.pack_keyframe(sc.ref).view(np.int32)) if packed else t(sc.grad)
         self.cur = [t(c) for c in sc.cur]
         self.cur_ptrs = torch.tensor([c.data_ptr() for c in self.cur], dtype=torch.int64, device=dev)
         if vec2d:  # Core::Vector2d array: {int nDim; pad; double x; double y} = 3 doubles
@@ -134,6 +136,7 @@ class DeviceScene:
         p.d_knots_R = self.knots_R.data_ptr()
         p.h_start_idx = self.start_idx.ctypes.data_as(C.POINTER(C.c_int))
         p.huber_a = sc.huber
+        p.grad_fp16 = 2 if self.packed else 0
         return p
 
 

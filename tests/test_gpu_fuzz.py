@@ -62,6 +62,33 @@ def test_random_problem_matches_oracle(orc, mbavo, gpu_ctx, seed):
     assert np.abs(fc[:, 0] - fb[:, 0]).max() <= 1e-11 * max(np.abs(fb[:, 0]).max(), 1e-300), kw
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_problem_packed_keyframe_matches_float(mbavo, gpu_ctx, seed):
+    """The same random problems with the keyframe handed over packed (one word per pixel, mbavo_problem.grad_fp16 = 2) and as the
+    u8 image + float gradient image: every tap value is the same, so the two agree to 1e-12 relative on the packed blocks (small
+    lists take the sample-parallel kernel with the float image and the lane-per-pixel kernel with the packed one: another order
+    of sums), with identical valid-pixel counts; border keypoints (taps next to the zero-gradient border) included."""
+    rng = np.random.default_rng(7000 + seed)
+    k = int(rng.choice([2, 4]))
+    S = int(rng.choice([1, 2, 3, 4, 5, 8, 16]))
+    P = int(rng.choice([1, 1, 3, 8, 8, 13]))
+    F = int(rng.choice([1, 1, 2, 3]))
+    dense = P == 1 and rng.random() < 0.6
+    kw = dict(S=S, F=F, k=k, P=P, seed=seed + 90)
+    if dense:
+        kw.update(H=int(rng.integers(12, 60)), W=int(rng.integers(16, 90)), kp="dense", margin=int(rng.integers(0, 3)))
+    else:
+        kw.update(K=int(rng.integers(1, 700)), kp=str(rng.choice(["random", "border"])))
+    if rng.random() < 0.3:
+        kw.update(outlier_frac=0.15)
+    sc = scenes.Scene(**kw)
+    fb0, pc0, v0 = scenes.gpu_eval_batch(gpu_ctx, [scenes.DeviceScene(sc)], k)
+    fb2, pc2, v2 = scenes.gpu_eval_batch(gpu_ctx, [scenes.DeviceScene(sc, packed=True)], k)
+    assert np.array_equal(v0, v2), kw
+    assert _rel(fb2, fb0) < 1e-12, kw
+    assert np.abs(pc2 - pc0).max() <= 1e-12 * max(np.abs(pc0).max(), 1e-300), kw
+
+
 def _random_scene_kwargs(rng, k, seed, S=None):
     S = int(rng.choice([1, 2, 3, 4, 8, 16])) if S is None else S
     P = int(rng.choice([1, 2, 3, 4, 8, 16]))
