@@ -164,6 +164,15 @@ namespace SLAM
                                             double *total_costs,
                                             double *cpu_hessian_tR,
                                             double *cpu_gradient_tR);
+
+        // ---- extension (not in the reference): the PACKED keyframe, one 32-bit word per pixel holding the intensity and both
+        // central differences of Gradient.h:16-75 (include/mbavo.h: mbavo_pack_keyframe_u8; exact for 8-bit images, 4 instead of
+        // 9 bytes per pixel).  A caller with many keyframes in flight packs each once,
+        //     pack_keyframe(cuda_ref_img, H, W, cuda_packed);          set_keyframe_format(storages, 2);
+        // and hands cuda_packed to evaluate_cost_hessian_gradient in cuda_dIxy_ref's place (cuda_ref_img stays valid: cost-only
+        // evaluations tap it).  Format 0 (the default) is the reference's float [dx, dy] image.
+        void pack_keyframe(const unsigned char *cuda_img, const int H, const int W, unsigned int *cuda_packed);
+        void set_keyframe_format(const CudaSharedStorages &storages, const int format);
     } // namespace VO
 } // namespace SLAM
 

@@ -361,6 +361,7 @@ namespace SLAM
         {
             std::mutex g_reg_mutex;
             std::map<const void *, Engine *> g_engines; // keyed by storages.cuda_frame_cost_gradient_hessian_tR
+            std::map<const void *, int> g_formats;      // keyframe format of the storages' evaluations (set_keyframe_format; default 0)
 
             template <class T>
             void dev_alloc(T *&p, size_t count)
@@ -419,6 +420,7 @@ namespace SLAM
                 std::lock_guard<std::mutex> lk(g_reg_mutex);
                 auto it = g_engines.find(st.cuda_frame_cost_gradient_hessian_tR);
                 if (it != g_engines.end()) { delete it->second; g_engines.erase(it); }
+                g_formats.erase(st.cuda_frame_cost_gradient_hessian_tR);
             }
             void *ptrs[] = {st.cuda_img_cap_time, st.cuda_img_exp_time, st.cuda_keypoint_depth_z,
                             st.cuda_local_patch_pattern_xy, st.cuda_cur_images, st.cuda_keypoint_xy,
@@ -447,10 +449,13 @@ namespace SLAM
                                             double *cpu_hessian_tR, double *cpu_gradient_tR)
         {
             Engine *eng = nullptr;
+            int format = 0;
             {
                 std::lock_guard<std::mutex> lk(g_reg_mutex);
                 auto it = g_engines.find(st.cuda_frame_cost_gradient_hessian_tR);
                 if (it != g_engines.end()) eng = it->second;
+                auto fi = g_formats.find(st.cuda_frame_cost_gradient_hessian_tR);
+                if (fi != g_formats.end()) format = fi->second;
             }
             if (!eng)
             {
@@ -474,6 +479,7 @@ namespace SLAM
             p.d_knots_t = st.cuda_spline_ctrl_knots_data_t; p.d_knots_R = st.cuda_spline_ctrl_knots_data_R;
             p.h_start_idx = cpu_ctrl_knot_start_indices;
             p.huber_a = huber_a;
+            p.grad_fp16 = format;
             const bool with_h = cpu_hessian_tR != nullptr;
             int rc = eng->evaluate(1, &p, spline_deg_k, with_h, st.cuda_frame_cost_gradient_hessian_tR, nullptr, nullptr,
                                    st.cuda_patch_cost_gradient_hessian_tR);
@@ -485,6 +491,20 @@ namespace SLAM
             HIP_OR_DIE(hipStreamSynchronize(eng->stream()));
             merge_hessian_gradient_cost(F, spline_deg_k, st.cuda_frame_cost_gradient_hessian_tR,
                                         cpu_ctrl_knot_start_indices, N, total_costs, cpu_hessian_tR, cpu_gradient_tR);
+        }
+
+        void pack_keyframe(const unsigned char *cuda_img, const int H, const int W, unsigned int *cuda_packed)
+        {
+            const int rc = mbavo_pack_keyframe_u8(cuda_img, H, W, cuda_packed, nullptr);
+            if (rc != 0) { fprintf(stderr, "ba_tracker: pack_keyframe failed (%d)\n", rc); abort(); }
+            HIP_OR_DIE(hipStreamSynchronize(nullptr));
+        }
+
+        void set_keyframe_format(const CudaSharedStorages &st, const int format)
+        {
+            if (format < 0 || format > 2) { fprintf(stderr, "ba_tracker: keyframe format %d (0 float pairs, 1 half pairs, 2 packed words)\n", format); abort(); }
+            std::lock_guard<std::mutex> lk(g_reg_mutex);
+            g_formats[st.cuda_frame_cost_gradient_hessian_tR] = format;
         }
     } // namespace VO
 } // namespace SLAM

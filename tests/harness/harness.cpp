@@ -414,6 +414,22 @@ static void test_evaluate_cost_hessian_gradient(Fixture &fx)
     // cost-only mode: nullptr, nullptr
     evaluate_cost_hessian_gradient(S, F, fx.d_img, fx.d_grad, K, P, fx.intr, fx.hw, k, 0.0, 0.5, start, N, st, huber, &c3, nullptr, nullptr);
     CHECK(fabs(c3 - c1) <= 1e-12 * fabs(c1), "cost-only %.15g vs %.15g", c3, c1);
+    // extension: the keyframe handed over packed (one word per pixel: intensity + both central differences) -- the same system
+    {
+        unsigned int *d_packed = dev_alloc<unsigned int>((size_t)fx.hw.values[0] * fx.hw.values[1]);
+        pack_keyframe(fx.d_img, fx.hw.values[0], fx.hw.values[1], d_packed);
+        set_keyframe_format(st, 2);
+        std::vector<double> H4((size_t)n * n), g4(n);
+        double c4 = 0, c5 = 0;
+        evaluate_cost_hessian_gradient(S, F, fx.d_img, (const float *)d_packed, K, P, fx.intr, fx.hw, k, 0.0, 0.5, start, N, st, huber, &c4, H4.data(), g4.data());
+        CHECK(fabs(c4 - c1) <= 1e-12 * fabs(c1), "packed keyframe: cost %.15g vs %.15g", c4, c1);
+        CHECK(maxdiff(H4.data(), H1.data(), (size_t)n * n) <= 1e-12 * hs, "packed keyframe: H rel diff %g", maxdiff(H4.data(), H1.data(), (size_t)n * n) / hs);
+        CHECK(maxdiff(g4.data(), g1.data(), n) <= 1e-12 * gs, "packed keyframe: g rel diff %g", maxdiff(g4.data(), g1.data(), n) / gs);
+        evaluate_cost_hessian_gradient(S, F, fx.d_img, (const float *)d_packed, K, P, fx.intr, fx.hw, k, 0.0, 0.5, start, N, st, huber, &c5, nullptr, nullptr);
+        CHECK(fabs(c5 - c1) <= 1e-12 * fabs(c1), "packed keyframe, cost-only: %.15g vs %.15g", c5, c1);
+        set_keyframe_format(st, 0);
+        HIPOK(hipFree(d_packed));
+    }
     free_shared_cuda_storages(st);
     CHECK(st.cuda_frame_cost_gradient_hessian_tR == nullptr, "storages reset");
 }
