@@ -131,6 +131,35 @@ def test_lm_batch_eigenvalue_jacobi_matches_one_wave_sweeps(mbavo, gpu_ctx, monk
             assert abs(ta[3] - tb[3]) <= 1e-6 * max(1.0, abs(tb[3])) and abs(ta[4] - tb[4]) <= 1e-6 * max(1.0, abs(tb[4]))
 
 
+def test_lm_batch_packed_keyframes_same_records(mbavo, gpu_ctx):
+    """The batched LM on packed keyframes (mbavo_problem.grad_fp16 = 2) against the float-gradient form of the same pairs: the
+    same records, costs to 1e-5 relative (the stated tolerance of the batched LM against the host loop: rounding x cond(H))."""
+    import torch
+    capi = mbavo.capi
+    B, k, N, F = 6, 4, 4, 1
+    out = {}
+    for fmt in (0, 2):
+        probs = _scene(B, k, N, F, seed=31)
+        for p in probs:
+            p.grad_fp16 = fmt
+        dw = workloads.DeviceWorkload(probs)
+        o = capi.LmBatchOpts()
+        o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, OPTS["max_it"], OPTS["max_nonmono"]
+        o.solver_type, o.sync_every = 0, 4
+        o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
+        cap = 64
+        res = (capi.LmBatchResult * B)()
+        trace = (capi.TraceRec * (B * cap))()
+        assert gpu_ctx.lib.mbavo_lm_batch(gpu_ctx.handle, B, dw.array, C.byref(o), res, trace, cap) == 0
+        torch.cuda.synchronize()
+        out[fmt] = [[(t.iter, t.kind, t.num_outliers, t.eval_cost, t.candidate_cost) for t in trace[b * cap:b * cap + res[b].num_trace]]
+                    for b in range(B)]
+    for a, b in zip(out[2], out[0]):
+        assert [t[:3] for t in a] == [t[:3] for t in b]
+        for ta, tb in zip(a, b):
+            assert abs(ta[3] - tb[3]) <= 1e-5 * max(1.0, abs(tb[3])) and abs(ta[4] - tb[4]) <= 1e-5 * max(1.0, abs(tb[4]))
+
+
 def test_lm_batch_against_oracle(orc, mbavo, gpu_ctx):
     """The same loop on the CPU oracle (orc_optimize_trajectory, one level) for a few problems."""
     import torch
