@@ -186,7 +186,8 @@ int mbavo_optimize_trajectory(mbavo_ctx *ctx, const mbavo_track_opts *opts, cons
 /* ---- device-side LM over a batch of independent problems (one pyramid level each): optimizePyramidLevel
  * (ba_tracker/blur_aware_direct_tracker.cpp:590-924) for B problems at once with the packed blocks, the 6N x 6N
  * assembly / damping / solve (solve_normal_equation.h:10-35), the radius and step-evaluator state and the outlier
- * statistics all on the device; the host only polls a done-counter every `sync_every` iterations.
+ * statistics all on the device; the host only reads a done-counter: behind an event, one iteration late, while the next
+ * iteration is already queued (sync_every <= 0, the default), or after draining the stream every `sync_every` iterations.
  * Each problem's knots (d_knots_t / d_knots_R, device) are updated in place; d_outlier / num_bad of the input are
  * ignored (flags start cleared, as at the start of a level).  Trace records as mbavo_optimize_trajectory writes
  * them (level = 0), `trace_cap` per problem.  At most 16 control knots per problem (the reference's

@@ -368,6 +368,7 @@ namespace mbavo
                      o_pc = take(sizeof(double) * (size_t)(total_patches + 1)),
                      o_trace = take(sizeof(mbavo_trace_rec) * (size_t)B * (trace ? trace_cap : 0));
         char *base = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr}; // the done-counter's events (sync_every <= 0), destroyed at `done`
         std::vector<mbavo_problem> work(probs, probs + B);
         std::vector<int> h_start(nbf);
         std::vector<LmState> h_states(B);
@@ -408,7 +409,20 @@ namespace mbavo
             if ((rc = eng.evaluate(B, work.data(), k, true, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
             const ProblemDesc *descs = eng.device_descs();
             hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(64), 0, st, descs, B, states, o, ct, cR);
-            const int sync_every = opt.sync_every > 0 ? opt.sync_every : 4;
+            // sync_every > 0: the host drains the stream and reads the done-counter every that many iterations (round 1's scheme:
+            // up to sync_every - 1 iterations of idle launches after the last problem has finished, and a pipeline bubble at every
+            // read).  sync_every <= 0 (default): the counter of iteration i - 1 is read -- behind an event, not a stream
+            // synchronisation -- while iteration i's solve is already queued: the device never waits for the host and at most one
+            // iteration of idle launches follows the last problem.
+            const int sync_every = opt.sync_every;
+            int *h_lag = nullptr;
+            if (sync_every <= 0)
+            {
+                h_lag = (int *)eng.pinned_scratch(7, 2 * sizeof(int));
+                if (!h_lag) { rc = (int)hipErrorOutOfMemory; goto done; }
+                LM_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+                LM_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+            }
             bool range_checked = false;
             if (lds > 48 * 1024)
             { // more than 8 control knots: the three n x n areas need the large-LDS attribute
@@ -429,7 +443,22 @@ namespace mbavo
                 else
                     hipLaunchKernelGGL((k_lm_solve<2, 64>), dim3(B), dim3(64), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
 #endif
-                if (slot % sync_every == sync_every - 1 || slot == o.max_it + 1)
+                if (sync_every <= 0)
+                {
+                    LM_HIP(hipMemcpyAsync(&h_lag[slot & 1], num_done, sizeof(int), hipMemcpyDeviceToHost, st));
+                    LM_HIP(hipEventRecord(ev[slot & 1], st));
+                    const bool last = slot == o.max_it + 1;
+                    if (slot >= 1 || last)
+                    {
+                        const int look = last ? slot : slot - 1;
+                        LM_HIP(hipEventSynchronize(ev[look & 1]));
+                        if (!range_checked && eng.fetch_status() != 0) { rc = MBAVO_E_RANGE; goto done; }
+                        range_checked = true;
+                        h_done = h_lag[look & 1];
+                        if (h_done >= B || last) break;
+                    }
+                }
+                else if (slot % sync_every == sync_every - 1 || slot == o.max_it + 1)
                 {
                     LM_HIP(hipMemcpyAsync(&h_done, num_done, sizeof(int), hipMemcpyDeviceToHost, st));
                     LM_HIP(hipStreamSynchronize(st));
@@ -471,6 +500,8 @@ namespace mbavo
                 }
         }
     done:
+        if (ev[0]) (void)hipEventDestroy(ev[0]);
+        if (ev[1]) (void)hipEventDestroy(ev[1]);
         return rc > 0 ? -1000 - rc : rc;
     }
 } // namespace mbavo

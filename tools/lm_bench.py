@@ -18,7 +18,7 @@ def device_lm(M, ctx, batch, solver, iterations, reps=3, min_dec=0.0):
     B = batch.B
     o = capi.LmBatchOpts()
     o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = batch.k, iterations, 5
-    o.solver_type, o.sync_every = solver, 4
+    o.solver_type, o.sync_every = solver, int(os.environ.get("MBAVO_LM_SYNC_EVERY", "0"))
     o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = 0.5, min_dec, 3.0  # min_dec 0: run all iterations
     res = (capi.LmBatchResult * B)()
     times = []
