@@ -109,6 +109,16 @@ namespace mbavo
         int persistent_end_all();
         bool persistent_active(int slot) const { return slot >= 0 && slot < kPushSlots && (persist_mask_ >> slot & 1u) != 0; }
         const ProblemDesc *device_descs() const { return (const ProblemDesc *)d_descs_; }
+        // The batched LM (lm_batch.hip) sums the tile partials of a (problem, frame) slot inside its own kernels instead of
+        // reading frame blocks: with set_defer_finalize(true) an evaluate() whose list takes the flat finalize (>= 64 slots of
+        // <= 4 tiles each) launches NO finalize kernel and leaves d_frame_blocks untouched; finalize_deferred() says whether the
+        // last evaluate() did so.  Partial of tile t: doubles [t * stride, (t + 1) * stride) = [valid | g, H sums 1 .. E-1 | cost |
+        // spare] (unscaled: the residual scale is applied by whoever sums); slot bf owns tiles [begin[bf], begin[bf + 1]).
+        void set_defer_finalize(bool on) { defer_finalize_ = on; }
+        bool finalize_deferred() const { return deferred_last_; }
+        const double *device_partials() const { return (const double *)d_partials_; }
+        const int *device_bf_tile_begin() const { return (const int *)d_bf_tile_begin_; }
+        bool defer_finalize_ = false, deferred_last_ = false;
 
         // The WHOLE coarse-to-fine LM loop of one small problem on the device (k_lm_level, round 3): one resident kernel per
         // pyramid level, enqueued back to back; the workgroup that finishes an evaluation solves, decides and publishes the

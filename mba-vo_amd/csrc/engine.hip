@@ -2563,7 +2563,9 @@ namespace mbavo
 #undef MBAVO_GRAD_CASE
         }
         static_assert(Pack<KD>::E + 1 <= 384, "one thread per partial slot");
-        if (flat_finalize)
+        eng->deferred_last_ = flat_finalize && eng->defer_finalize_;
+        if (eng->deferred_last_) {} // the caller's kernels sum the tile partials (engine.h: set_defer_finalize)
+        else if (flat_finalize)
             hipLaunchKernelGGL((k_finalize_flat<KD, WITH_J>), dim3(nbf), dim3(KD == 2 ? 128 : 384), 0, st, descs, bf_prob, bf_tile_begin,
                                partials, frame_blocks, valid);
         else
@@ -2609,6 +2611,7 @@ namespace mbavo
         OneArgs oa;
         memset(&oa, 0, sizeof(oa));
         flag_pending_ = false;
+        deferred_last_ = false; // (launch_all sets it when it leaves the finalize to the caller)
         if (one)
         {
             oa.bf_tile_begin = (const int *)d_bf_tile_begin_;

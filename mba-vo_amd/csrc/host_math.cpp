@@ -381,14 +381,17 @@ namespace mbavo
         return true;
     }
 
-    double fast_solve_ratio()
+    double fast_solve_ratio_env()
     { // MBAVO_FAST_SOLVE=0 always takes the Jacobi SVD; a number sets the admitted pivot ratio (default 1e8)
-        static const double v = [] {
-            const char *e = getenv("MBAVO_FAST_SOLVE");
-            if (!e || !*e) return 1e8;
-            const double r = atof(e);
-            return r > 1.0 ? r : (r == 1.0 ? 1e8 : 0.0);
-        }();
+        const char *e = getenv("MBAVO_FAST_SOLVE");
+        if (!e || !*e) return 1e8;
+        const double r = atof(e);
+        return r > 1.0 ? r : (r == 1.0 ? 1e8 : 0.0);
+    }
+
+    double fast_solve_ratio()
+    { // read once: the host loop asks at every LM iteration
+        static const double v = fast_solve_ratio_env();
         return v;
     }
 

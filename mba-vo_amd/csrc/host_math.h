@@ -21,6 +21,7 @@ namespace mbavo
     int solve_normal_equation_host(const double *A_colmajor, const double *b, int n, int solver_type, double *x);
     // pivot ratio up to which LDL^T stands in for the Jacobi SVD (solver type 0); 0 = never (MBAVO_FAST_SOLVE, default 1e8)
     double fast_solve_ratio();
+    double fast_solve_ratio_env(); // the same, read from the environment at every call (per mbavo_lm_batch call)
 } // namespace mbavo
 
 namespace SLAM

@@ -21,27 +21,66 @@
 #include "se3_math.h"
 #include "lm_solvers.h"
 #include "lm_state.h"
+#include "host_math.h"
 
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <vector>
 
 namespace mbavo
 {
+    // Where the sums of a (problem, frame) slot come from: the frame blocks a finalize kernel wrote, or -- deferred
+    // (engine.h: set_defer_finalize) -- the tile partials themselves, added in k_finalize_flat's order ((t0 + t2) + (t1 + t3),
+    // absent tiles = +0) and scaled by the same residual scale: the same bits, two launches fewer per LM iteration.
+    struct FinSrc
+    {
+        const double *fb;        // frame blocks (E doubles per slot: [cost | g | H packed])
+        const double *partials;  // deferred: tile partials, `stride` doubles each: [valid | g, H sums | cost | spare]
+        const int *tile_begin;   // deferred: slot bf owns tiles [tile_begin[bf], tile_begin[bf + 1])
+        int stride, deferred;
+    };
+    __device__ __forceinline__ double slot_sum(const FinSrc &fs, int bf, int e)
+    {
+        const int t0 = fs.tile_begin[bf], n = fs.tile_begin[bf + 1] - t0;
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < n) t[i] = fs.partials[(size_t)(t0 + i) * fs.stride + e];
+        return (t[0] + t[2]) + (t[1] + t[3]);
+    }
+    template <int E>
+    __device__ __forceinline__ double slot_cost(const FinSrc &fs, int bf)
+    {
+        return fs.deferred ? slot_sum(fs, bf, E) : fs.fb[(size_t)bf * E]; // (patch costs are scaled when they are computed)
+    }
+
+    // The host's view of the loop without a copy or an event in the stream: the last workgroup of a k_lm_solve launch stores
+    // (slot + 1) << 32 | problems done into a pinned host word.  num_done[6] is the launch's ticket counter (zero between launches).
+    __device__ __forceinline__ void slot_publish(int *num_done, unsigned long long *host_word, int slot, int B)
+    {
+        if (!host_word) return;
+        __threadfence();
+        if (atomicAdd(num_done + 6, 1) != B - 1) return;
+        num_done[6] = 0;
+        const unsigned nd = (unsigned)atomicAdd(num_done, 0);
+        __hip_atomic_store(host_word, ((unsigned long long)(slot + 1) << 32) | nd, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+
     // One workgroup of T threads per problem: finish the previous accepted step, loop control, damping, solve, model change,
     // candidate.  T = 64 (one wave: the one-sided Jacobi SVD / pivoted LDL^T of lm_solvers.h, any n up to 96) or T = kEigT
     // (solver 0 with n <= kEigMaxN: the workgroup-parallel eigenvalue Jacobi, eig_solve).  The scalar state of the loop is
     // computed redundantly by every thread (same inputs, same arithmetic); thread 0 stores it.
     template <int KD, int T>
     __global__ __launch_bounds__(T) void k_lm_solve(const ProblemDesc *__restrict__ descs, LmState *__restrict__ states, LmOpts o,
-                                                    const double *__restrict__ fb, const int *__restrict__ start_idx,
+                                                    FinSrc fs, const int *__restrict__ start_idx,
                                                     double *__restrict__ Hst, double *__restrict__ gst,
                                                     double *__restrict__ cur_t, double *__restrict__ cur_R,
                                                     int *__restrict__ active, mbavo_trace_rec *__restrict__ trace,
-                                                    int *__restrict__ num_done)
+                                                    int *__restrict__ num_done, unsigned long long *host_word, int slot, int B)
     {
         constexpr int M6 = 6 * KD, ND = M6 + 1, E = ND * (ND + 1) / 2;
         extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -49,7 +88,11 @@ namespace mbavo
         const ProblemDesc &d = descs[b];
         const int N = d.N, n = 6 * N, F = d.F;
         LmState s = states[b];
-        if (s.done) return;
+        if (s.done)
+        {
+            if (tid == 0) slot_publish(num_done, host_word, slot, B);
+            return;
+        }
 #if defined(MBAVO_EIG_STAMPS) // development aid: where the kernel's time goes (block 0 prints at its end)
         const long long ts0 = __builtin_amdgcn_s_memtime();
         long long ts1 = 0, ts2 = 0, ts3 = 0;
@@ -71,7 +114,7 @@ namespace mbavo
         if (s.fresh)
         { // the H/g pass at the current point has completed: its cost is the evaluation-point cost
             double cost = 0.0;
-            for (int f = 0; f < F; ++f) cost += fb[(size_t)(d.bf_base + f) * E];
+            for (int f = 0; f < F; ++f) cost += slot_cost<E>(fs, d.bf_base + f);
             s.eval_cost = cost;
             if (s.pending_accept)
             { // handleSuccessfulStep (:896-903)
@@ -91,14 +134,16 @@ namespace mbavo
             for (int i = tid; i < n * n; i += T) H[i] = 0.0;
             for (int i = tid; i < n; i += T) g[i] = 0.0;
             __syncthreads();
+            const double inv = fs.deferred ? (d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals) : 0.0;
             for (int f = 0; f < F; ++f)
             {
-                const double *blk = fb + (size_t)(d.bf_base + f) * E;
-                const int st = start_idx[d.bf_base + f];
+                const int bf = d.bf_base + f;
+                const double *blk = fs.fb + (size_t)bf * E;
+                const int st = start_idx[bf];
                 for (int j = tid; j < M6; j += T)
                 {
                     const int gi = j < 3 * KD ? 3 * st + j : 3 * (N + st) + (j - 3 * KD);
-                    g[gi] += blk[1 + j];
+                    g[gi] += fs.deferred ? slot_sum(fs, bf, 1 + j) * inv : blk[1 + j];
                 }
                 for (int e = tid; e < M6 * (M6 + 1) / 2; e += T)
                 {
@@ -106,7 +151,7 @@ namespace mbavo
                     tri_decode(e, M6, r, c);
                     const int R = r < 3 * KD ? 3 * st + r : 3 * (N + st) + (r - 3 * KD);
                     const int C = c < 3 * KD ? 3 * st + c : 3 * (N + st) + (c - 3 * KD);
-                    const double v = blk[ND + e];
+                    const double v = fs.deferred ? slot_sum(fs, bf, ND + e) * inv : blk[ND + e];
                     H[C * n + R] += v;
                     if (R != C) H[R * n + C] += v;
                 }
@@ -135,6 +180,7 @@ namespace mbavo
                 active[b] = 0;
                 states[b] = s;
                 atomicAdd(num_done, 1);
+                slot_publish(num_done, host_word, slot, B);
             }
             // leave the accepted point in the caller's knot buffers
             double *Wt = const_cast<double *>(d.knots_t), *WR = const_cast<double *>(d.knots_R);
@@ -161,7 +207,30 @@ namespace mbavo
 #if defined(MBAVO_EIG_STAMPS)
         ts2 = __builtin_amdgcn_s_memtime();
 #endif
-        if constexpr (T == kEigT)
+        // LDL^T in registers (wave 0) stands in for the Jacobi SVD (solver 0) or the pivoted LDL^T (solver 1) when every pivot is positive and the pivot ratio is
+        // at most fast_ratio -- the host loop's rule (host_math.cpp:solve_spd_fast, MBAVO_FAST_SOLVE) -- and, refined in
+        // double-double, up to refined_ratio when the refinement converges (lm_solvers.h: spd_solve_regs_impl; MBAVO_LM_REFINE=0
+        // switches that off); any other system takes the solver below.  11 000 cycles (22 000 refined) against 138 000 for
+        // the eigenvalue Jacobi or the pivoted LDL^T at n = 24 (tests/harness/solver_check.hip), and a launch lasts as long as
+        // its slowest system: before the refined form, one system of 64 above the ratio held every launch for 75 us.
+        bool have = false;
+        if (o.fast_ratio > 0.0 && (n == 12 || n == 18 || n == 24)) // (solver 1 too: its pivoted LDL^T walks 2 000 cycles per column)
+        {
+            if (tid < 64)
+            {
+                bool ok;
+                if (n == 12) ok = spd_solve_regs_impl<12, true>(H, g, x, lane, o.fast_ratio, o.refined_ratio);
+                else if (n == 18) ok = spd_solve_regs_impl<18, true>(H, g, x, lane, o.fast_ratio, o.refined_ratio);
+                else ok = spd_solve_regs_impl<24, true>(H, g, x, lane, o.fast_ratio, o.refined_ratio);
+                if (tid == 0) order[0] = ok ? 1 : 0;
+            }
+            __syncthreads();
+            have = order[0] != 0;
+            __syncthreads(); // `order` is the Jacobi solvers' work area
+            if (have && tid == 0) atomicAdd(num_done + 5, 1);
+        }
+        if (have) {}
+        else if constexpr (T == kEigT)
         {
             const int info = eig_solve(V, Hl, g, x, tmp, order, n, tid);
             if (tid == 0)
@@ -207,7 +276,7 @@ namespace mbavo
             lm_rejected(s);
             trace_push(s, tr, o.trace_cap, tid, 0, 3, 0.0, s.model, 0.0);
             ++s.n_invalid;
-            if (tid == 0) { active[b] = 0; states[b] = s; }
+            if (tid == 0) { active[b] = 0; states[b] = s; slot_publish(num_done, host_word, slot, B); }
             return;
         }
         // computeCandidatePointAndEvaluateCost (:833-883): candidate = current (+) step, into the evaluated buffers
@@ -218,7 +287,7 @@ namespace mbavo
             const Quat q = qmul(load_quat(CR + 4 * i), so3_exp(x + 3 * N + 3 * i)); // Spline.h:317-330, not re-normalised
             WR[4 * i] = q.x; WR[4 * i + 1] = q.y; WR[4 * i + 2] = q.z; WR[4 * i + 3] = q.w;
         }
-        if (tid == 0) { active[b] = 1; states[b] = s; }
+        if (tid == 0) { active[b] = 1; states[b] = s; slot_publish(num_done, host_word, slot, B); }
 #if defined(MBAVO_EIG_STAMPS)
         if (tid == 0 && b == 0)
             printf("k_lm_solve<%d,%d> block 0: merge %lld | damp + store %lld | solve %lld | model + candidate %lld cycles\n", KD, T, ts1 - ts0,
@@ -229,7 +298,7 @@ namespace mbavo
     // One wave per problem, after the cost-only pass on the candidates: step quality, accept / reject, outliers.
     template <int KD>
     __global__ __launch_bounds__(64) void k_lm_decide(const ProblemDesc *__restrict__ descs, LmState *__restrict__ states, LmOpts o,
-                                                      const double *__restrict__ fb, const double *__restrict__ patch_cost,
+                                                      FinSrc fs, const double *__restrict__ patch_cost,
                                                       double *__restrict__ inv,
                                                       double *__restrict__ cur_t, double *__restrict__ cur_R,
                                                       int *__restrict__ active, mbavo_trace_rec *__restrict__ trace)
@@ -241,7 +310,7 @@ namespace mbavo
         if (s.done || active[b] == 0) return; // finished, or an invalid step: nothing was evaluated
         mbavo_trace_rec *tr = trace ? trace + (size_t)b * o.trace_cap : nullptr;
         double cost = 0.0;
-        for (int f = 0; f < d.F; ++f) cost += fb[(size_t)(d.bf_base + f) * E];
+        for (int f = 0; f < d.F; ++f) cost += slot_cost<E>(fs, d.bf_base + f);
         s.cand_cost = cost;
         s.abs_dec = s.eval_cost - s.cand_cost; // recorded before the accept test (:624)
         s.quality = tr_quality(s, s.cand_cost, s.model);
@@ -332,6 +401,11 @@ namespace mbavo
             return MBAVO_E_ARG;
         int rc = 0;
         hipStream_t st = eng.stream();
+        // MBAVO_LM_STAMPS=1: host-side phases of a call on stderr (development aid)
+        const bool stamps = getenv("MBAVO_LM_STAMPS") && getenv("MBAVO_LM_STAMPS")[0] == '1';
+        std::chrono::steady_clock::time_point tp[6];
+        auto stamp = [&](int i) { if (stamps) tp[i] = std::chrono::steady_clock::now(); };
+        stamp(0);
         const int E = (6 * k + 1) * (6 * k + 2) / 2;
         int max_N = 0, nbf = 0;
         long long total_K = 0, total_patches = 0;
@@ -348,7 +422,12 @@ namespace mbavo
         o.max_it = opt.max_num_iterations; o.max_nonmono = opt.max_consecutive_nonmonotonic_steps; o.solver = opt.solver_type;
         o.trace_cap = trace ? trace_cap : 0; o.max_n = max_n; o.max_N = max_N;
         o.min_q = opt.min_step_quality; o.min_dec = opt.min_abs_cost_decrease; o.chi = opt.max_chi_square_error;
-        o.fast_ratio = 0.0;
+        o.fast_ratio = fast_solve_ratio_env(); // MBAVO_FAST_SOLVE (default 1e8; 0: the Jacobi solvers / the pivoted LDL^T only)
+        {
+            const char *e = getenv("MBAVO_LM_REFINE"); // 0: no refined stand-in; a number > 1: the admitted pivot ratio
+            const double r = e && *e ? atof(e) : 1.0;
+            o.refined_ratio = o.fast_ratio > 0.0 ? (r > 1.0 ? r : (r == 1.0 ? 1e13 : 0.0)) : 0.0;
+        }
         // solver 0 with every system within the workgroup-parallel eigenvalue Jacobi's reach (k_lm_solve<KD, kEigT>);
         // MBAVO_LM_EIG=0 keeps the one-wave one-sided sweeps
         const char *eig_env = getenv("MBAVO_LM_EIG");
@@ -360,26 +439,27 @@ namespace mbavo
         // one arena for all LM state
         size_t off = 0;
         auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+        // head: what the host initialises, contiguous so that ONE copy from pinned memory uploads it (three pageable copies and
+        // a fill of the whole arena cost ~35 us of a 64-pair call: four blit kernels with a ~6 us gap behind each)
+        const size_t o_inv = take(sizeof(double) * B), o_act = take(sizeof(int) * B), o_done = take(sizeof(int) * 8),
+                     o_start = take(sizeof(int) * nbf), o_flags = take((size_t)total_K), head_bytes = off;
         const size_t o_state = take(sizeof(LmState) * B), o_H = take(sizeof(double) * (size_t)B * max_n * max_n),
                      o_g = take(sizeof(double) * (size_t)B * max_n), o_ct = take(sizeof(double) * (size_t)B * 3 * max_N),
-                     o_cR = take(sizeof(double) * (size_t)B * 4 * max_N), o_inv = take(sizeof(double) * B),
-                     o_act = take(sizeof(int) * B), o_done = take(sizeof(int) * 8), o_start = take(sizeof(int) * nbf),
-                     o_flags = take((size_t)total_K), o_fb = take(sizeof(double) * (size_t)nbf * E),
+                     o_cR = take(sizeof(double) * (size_t)B * 4 * max_N), o_fb = take(sizeof(double) * (size_t)nbf * E),
                      o_pc = take(sizeof(double) * (size_t)(total_patches + 1)),
                      o_trace = take(sizeof(mbavo_trace_rec) * (size_t)B * (trace ? trace_cap : 0));
         char *base = nullptr;
-        hipEvent_t ev[2] = {nullptr, nullptr}; // the done-counter's events (sync_every <= 0), destroyed at `done`
         std::vector<mbavo_problem> work(probs, probs + B);
-        std::vector<int> h_start(nbf);
-        std::vector<LmState> h_states(B);
-        std::vector<double> h_inv(B);
-        std::vector<int> h_act(B);
+        const LmState *h_states = nullptr;
+        char *h_stage = nullptr; // pinned: [done word (64 bytes) | head | final states]
         int h_done = 0;
         LM_HIP(hipSetDevice(eng.device()));
         // the engine's scratch slot 15, grown on demand and kept: no hipMalloc / hipFree per call (~90 us of a 64-pair call)
         base = (char *)eng.named_scratch(15, off);
         if (!base) { rc = (int)hipErrorOutOfMemory; goto done; }
-        LM_HIP(hipMemsetAsync(base, 0, off, st));
+        h_stage = (char *)eng.pinned_scratch(7, 64 + head_bytes + sizeof(LmState) * B);
+        if (!h_stage) { rc = (int)hipErrorOutOfMemory; goto done; }
+        h_states = (const LmState *)(h_stage + 64 + head_bytes); // (head_bytes is a multiple of 256)
         {
             LmState *states = (LmState *)(base + o_state);
             double *Hst = (double *)(base + o_H), *gst = (double *)(base + o_g), *ct = (double *)(base + o_ct), *cR = (double *)(base + o_cR);
@@ -387,6 +467,10 @@ namespace mbavo
             int *act = (int *)(base + o_act), *num_done = (int *)(base + o_done), *d_start = (int *)(base + o_start);
             unsigned char *flags = (unsigned char *)(base + o_flags);
             mbavo_trace_rec *d_trace = trace ? (mbavo_trace_rec *)(base + o_trace) : nullptr;
+            char *head = h_stage + 64;
+            memset(head, 0, head_bytes); // done counter, statistics, ticket and outlier flags start at zero
+            double *h_inv = (double *)(head + o_inv);
+            int *h_act = (int *)(head + o_act), *h_start = (int *)(head + o_start);
             size_t fo = 0;
             int bf = 0;
             for (int b = 0; b < B; ++b)
@@ -395,35 +479,40 @@ namespace mbavo
                 work[b].num_bad = 0;
                 fo += work[b].K > 0 ? work[b].K : 1;
                 for (int f = 0; f < work[b].F; ++f) h_start[bf++] = work[b].h_start_idx[f];
-            }
-            LM_HIP(hipMemcpyAsync(d_start, h_start.data(), sizeof(int) * nbf, hipMemcpyHostToDevice, st));
-            for (int b = 0; b < B; ++b)
-            { // num_bad = 0 at the start of a level (:600); every problem takes part in the first H/g pass
+                // num_bad = 0 at the start of a level (:600); every problem takes part in the first H/g pass
                 const long long num_residuals = (long long)work[b].K * work[b].F * work[b].P;
                 h_inv[b] = num_residuals > 0 ? 1.0 / (double)num_residuals : 0.0;
                 h_act[b] = 2;
             }
-            LM_HIP(hipMemcpyAsync(inv, h_inv.data(), sizeof(double) * B, hipMemcpyHostToDevice, st));
-            LM_HIP(hipMemcpyAsync(act, h_act.data(), sizeof(int) * B, hipMemcpyHostToDevice, st));
+            stamp(1);
+            LM_HIP(hipMemcpyAsync(base, head, head_bytes, hipMemcpyHostToDevice, st));
+            stamp(2);
+            // (states: k_lm_init; H, g: the first solve of a problem; patch costs and frame blocks: the passes that are read)
+            if (trace) LM_HIP(hipMemsetAsync(d_trace, 0, sizeof(mbavo_trace_rec) * (size_t)B * trace_cap, st));
+            // sync_every > 0: the host drains the stream and reads the done-counter every that many iterations (round 1's scheme:
+            // up to sync_every - 1 iterations of idle launches after the last problem has finished, and a pipeline bubble at every
+            // read).  sync_every <= 0 (default): the last workgroup of every solve launch stores (slot + 1, problems done) into a
+            // pinned host word (slot_publish); the host enqueues slot i's solve AND its three passes, then spins on that word until
+            // solve i has been published -- nothing but kernels is in the stream (the D2H copy + event of the previous scheme cost a
+            // 4.4 us blit kernel and a 5.8 us gap behind it per slot: tools/lm_timeline.py).
+            const int sync_every = opt.sync_every;
+            volatile unsigned long long *h_word = nullptr;
+            if (sync_every <= 0)
+            {
+                h_word = (volatile unsigned long long *)h_stage;
+                *h_word = 0; // (no kernel that writes it is in flight: every call ends with a stream synchronisation)
+            }
+            // MBAVO_LM_DEFER=0: the engine's finalize kernels write frame blocks and the LM kernels read those
+            eng.set_defer_finalize(!(getenv("MBAVO_LM_DEFER") && getenv("MBAVO_LM_DEFER")[0] == '0'));
             // iteration 0 (:604): also builds the layout (device descriptors) the LM kernels read
             if ((rc = eng.evaluate(B, work.data(), k, true, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
             const ProblemDesc *descs = eng.device_descs();
+            FinSrc fs;
+            fs.fb = fb; fs.partials = eng.device_partials(); fs.tile_begin = eng.device_bf_tile_begin();
+            fs.stride = E + 2; // engine.hip: Pack<k>::PSTRIDE
+            fs.deferred = eng.finalize_deferred() ? 1 : 0;
             hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(64), 0, st, descs, B, states, o, ct, cR);
-            // sync_every > 0: the host drains the stream and reads the done-counter every that many iterations (round 1's scheme:
-            // up to sync_every - 1 iterations of idle launches after the last problem has finished, and a pipeline bubble at every
-            // read).  sync_every <= 0 (default): the counter of iteration i - 1 is read -- behind an event, not a stream
-            // synchronisation -- while iteration i's solve is already queued: the device never waits for the host and at most one
-            // iteration of idle launches follows the last problem.
-            const int sync_every = opt.sync_every;
-            int *h_lag = nullptr;
-            if (sync_every <= 0)
-            {
-                h_lag = (int *)eng.pinned_scratch(7, 2 * sizeof(int));
-                if (!h_lag) { rc = (int)hipErrorOutOfMemory; goto done; }
-                LM_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-                LM_HIP(hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
-            }
-            bool range_checked = false;
+            stamp(3);
             if (lds > 48 * 1024)
             { // more than 8 control knots: the three n x n areas need the large-LDS attribute
                 if (k == 4) LM_HIP(hipFuncSetAttribute(eig ? (const void *)k_lm_solve<4, kEigT> : (const void *)k_lm_solve<4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -431,52 +520,84 @@ namespace mbavo
                 else LM_HIP(hipFuncSetAttribute(eig ? (const void *)k_lm_solve<2, kEigT> : (const void *)k_lm_solve<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 #endif
             }
+            unsigned long long *d_word = const_cast<unsigned long long *>(h_word); // pinned host memory is device-visible at its own address
             for (int slot = 0; slot <= o.max_it + 1; ++slot)
             {
+#define LM_SOLVE_ARGS descs, states, o, fs, d_start, Hst, gst, ct, cR, act, d_trace, num_done, d_word, slot, B
                 if (k == 4 && eig)
-                    hipLaunchKernelGGL((k_lm_solve<4, kEigT>), dim3(B), dim3(kEigT), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
+                    hipLaunchKernelGGL((k_lm_solve<4, kEigT>), dim3(B), dim3(kEigT), lds, st, LM_SOLVE_ARGS);
                 else if (k == 4)
-                    hipLaunchKernelGGL((k_lm_solve<4, 64>), dim3(B), dim3(64), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
+                    hipLaunchKernelGGL((k_lm_solve<4, 64>), dim3(B), dim3(64), lds, st, LM_SOLVE_ARGS);
 #if !defined(MBAVO_LM_K4_ONLY)
                 else if (eig)
-                    hipLaunchKernelGGL((k_lm_solve<2, kEigT>), dim3(B), dim3(kEigT), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
+                    hipLaunchKernelGGL((k_lm_solve<2, kEigT>), dim3(B), dim3(kEigT), lds, st, LM_SOLVE_ARGS);
                 else
-                    hipLaunchKernelGGL((k_lm_solve<2, 64>), dim3(B), dim3(64), lds, st, descs, states, o, fb, d_start, Hst, gst, ct, cR, act, d_trace, num_done);
+                    hipLaunchKernelGGL((k_lm_solve<2, 64>), dim3(B), dim3(64), lds, st, LM_SOLVE_ARGS);
 #endif
+#undef LM_SOLVE_ARGS
                 if (sync_every <= 0)
                 {
-                    LM_HIP(hipMemcpyAsync(&h_lag[slot & 1], num_done, sizeof(int), hipMemcpyDeviceToHost, st));
-                    LM_HIP(hipEventRecord(ev[slot & 1], st));
+                    // the three passes of this slot go in behind the solve BEFORE the host looks at the solve's word: the device
+                    // has ~45 us of work queued while the host waits, and a finished batch costs at most these three idle launches
                     const bool last = slot == o.max_it + 1;
-                    if (slot >= 1 || last)
+                    if (!last)
                     {
-                        const int look = last ? slot : slot - 1;
-                        LM_HIP(hipEventSynchronize(ev[look & 1]));
-                        if (!range_checked && eng.fetch_status() != 0) { rc = MBAVO_E_RANGE; goto done; }
-                        range_checked = true;
-                        h_done = h_lag[look & 1];
-                        if (h_done >= B || last) break;
+                        if ((rc = eng.evaluate(B, work.data(), k, false, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
+                        if (k == 4)
+                            hipLaunchKernelGGL((k_lm_decide<4>), dim3(B), dim3(64), 0, st, descs, states, o, fs, pc, inv, ct, cR, act, d_trace);
+                        else
+                            hipLaunchKernelGGL((k_lm_decide<2>), dim3(B), dim3(64), 0, st, descs, states, o, fs, pc, inv, ct, cR, act, d_trace);
+                        if ((rc = eng.evaluate(B, work.data(), k, true, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
                     }
+                    const unsigned long long want = (unsigned long long)slot + 1;
+                    unsigned long long w = *h_word;
+                    if ((w >> 32) < want)
+                    {
+                        const auto t_spin = std::chrono::steady_clock::now();
+                        for (unsigned long spins = 1; ((w = *h_word) >> 32) < want; ++spins)
+                        {
+#if defined(__x86_64__)
+                            __builtin_ia32_pause();
+#endif
+                            if ((spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t_spin > std::chrono::seconds(10))
+                            { // a launch failed or the device is wedged: let the runtime say which
+                                LM_HIP(hipStreamSynchronize(st));
+                                LM_HIP(hipGetLastError());
+                                rc = MBAVO_E_RANGE;
+                                goto done;
+                            }
+                        }
+                    }
+                    h_done = (int)(unsigned)(w & 0xffffffffull);
+                    if (h_done >= B || last) break;
+                    continue;
                 }
                 else if (slot % sync_every == sync_every - 1 || slot == o.max_it + 1)
                 {
                     LM_HIP(hipMemcpyAsync(&h_done, num_done, sizeof(int), hipMemcpyDeviceToHost, st));
                     LM_HIP(hipStreamSynchronize(st));
-                    if (!range_checked && eng.fetch_status() != 0) { rc = MBAVO_E_RANGE; goto done; }
-                    range_checked = true;
                     if (h_done >= B) break;
                 }
                 if ((rc = eng.evaluate(B, work.data(), k, false, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
                 if (k == 4)
-                    hipLaunchKernelGGL((k_lm_decide<4>), dim3(B), dim3(64), 0, st, descs, states, o, fb, pc, inv, ct, cR, act, d_trace);
+                    hipLaunchKernelGGL((k_lm_decide<4>), dim3(B), dim3(64), 0, st, descs, states, o, fs, pc, inv, ct, cR, act, d_trace);
                 else
-                    hipLaunchKernelGGL((k_lm_decide<2>), dim3(B), dim3(64), 0, st, descs, states, o, fb, pc, inv, ct, cR, act, d_trace);
+                    hipLaunchKernelGGL((k_lm_decide<2>), dim3(B), dim3(64), 0, st, descs, states, o, fs, pc, inv, ct, cR, act, d_trace);
                 if ((rc = eng.evaluate(B, work.data(), k, true, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
             }
+            stamp(4);
             LM_HIP(hipGetLastError());
-            LM_HIP(hipMemcpyAsync(h_states.data(), states, sizeof(LmState) * B, hipMemcpyDeviceToHost, st));
+            LM_HIP(hipMemcpyAsync(const_cast<LmState *>(h_states), states, sizeof(LmState) * B, hipMemcpyDeviceToHost, st)); // pinned: no staging
             if (trace) LM_HIP(hipMemcpyAsync(trace, d_trace, sizeof(mbavo_trace_rec) * (size_t)B * trace_cap, hipMemcpyDeviceToHost, st));
             LM_HIP(hipStreamSynchronize(st));
+            stamp(5);
+            if (stamps)
+            {
+                auto us = [&](int a, int b) { return std::chrono::duration<double, std::micro>(tp[b] - tp[a]).count(); };
+                fprintf(stderr, "mbavo lm_batch: host set-up %.1f us | head upload call %.1f | first evaluation + init enqueued %.1f | LM slots %.1f | results + drain %.1f\n",
+                        us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5));
+            }
+            if (eng.fetch_status() != 0) { rc = MBAVO_E_RANGE; goto done; } // a capture time outside the spline somewhere in the call
             if (h_done < B)
             {
                 LM_HIP(hipMemcpy(&h_done, num_done, sizeof(int), hipMemcpyDeviceToHost));
@@ -484,10 +605,10 @@ namespace mbavo
             }
             if (const char *e = getenv("MBAVO_LM_STATS"); e && e[0] == '1' && eig)
             {
-                int st4[5] = {0, 0, 0, 0, 0};
+                int st4[6] = {0, 0, 0, 0, 0, 0};
                 LM_HIP(hipMemcpy(st4, num_done, sizeof(st4), hipMemcpyDeviceToHost));
-                fprintf(stderr, "mbavo lm_batch: %d eigenvalue-Jacobi solves, %.2f sweeps on average, %d at most, %d preconditioned (L^T L)\n", st4[1],
-                        st4[1] ? (double)st4[2] / st4[1] : 0.0, st4[3], st4[4]);
+                fprintf(stderr, "mbavo lm_batch: %d LDL^T stand-ins; %d eigenvalue-Jacobi solves, %.2f sweeps on average, %d at most, %d preconditioned (L^T L)\n",
+                        st4[5], st4[1], st4[1] ? (double)st4[2] / st4[1] : 0.0, st4[3], st4[4]);
             }
             if (results)
                 for (int b = 0; b < B; ++b)
@@ -500,8 +621,7 @@ namespace mbavo
                 }
         }
     done:
-        if (ev[0]) (void)hipEventDestroy(ev[0]);
-        if (ev[1]) (void)hipEventDestroy(ev[1]);
+        eng.set_defer_finalize(false);
         return rc > 0 ? -1000 - rc : rc;
     }
 } // namespace mbavo

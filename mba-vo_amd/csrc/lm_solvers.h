@@ -646,8 +646,19 @@ namespace mbavo
             const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
             return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
         }
-        template <int NN>
-        __device__ __forceinline__ bool spd_solve_regs(const double *A, const double *b, double *x, int lane, double max_ratio)
+        //
+        // REFINE (the batched LM, where one ill-conditioned system of a batch would otherwise hold its whole launch for the
+        // eigenvalue Jacobi's 70 us): a system whose pivot ratio lies between max_ratio and max_ratio_refined keeps the
+        // factors and takes steps of iterative refinement with the residual b - A x accumulated in double-double (two-product by
+        // FMA, two-sum): while cond(A) eps < 1 the iteration contracts by ~cond(A) eps per step onto the correctly rounded
+        // solution of the system as given -- the centre of the ball of radius ~cond(A) eps |x| in which the reference's Jacobi
+        // SVD (solve_normal_equation.h:10-35; every singular value above Eigen's threshold ~n eps sigma_max: full rank) lands.
+        // Accepted only when the last correction is below 1e-13 |x|_inf; anything else -- a non-positive pivot, a ratio above
+        // max_ratio_refined, no convergence in kRefineSteps -- returns false and the caller takes the Jacobi solver.
+        constexpr int kRefineSteps = 4;
+        template <int NN, bool REFINE>
+        __device__ __forceinline__ bool spd_solve_regs_impl(const double *A, const double *b, double *x, int lane, double max_ratio,
+                                                            double max_ratio_refined)
         {
             const int i = lane < NN ? lane : NN - 1; // lanes past the matrix shadow the last row (results unused)
             double a[NN];
@@ -687,8 +698,55 @@ namespace mbavo
                 const double xj = bcast_lane(xv, j);
                 if (lane < j) xv -= (a[j] * rdi) * xj;
             }
+            bool ok = pos && dmax <= max_ratio * dmin;
+            if constexpr (REFINE)
+            {
+                if (!ok && pos && dmax <= max_ratio_refined * dmin)
+                {
+                    const double bi = b[i];
+                    for (int step = 0; step < kRefineSteps && !ok; ++step)
+                    {
+                        // r_i = b_i - sum_j A_ij x_j as an unevaluated sum hi + lo
+                        double hi = bi, lo = 0.0;
+#pragma unroll
+                        for (int j = 0; j < NN; ++j)
+                        {
+#pragma clang fp contract(off) // the error-free transformations below must not be fused
+                            const double aij = A[j * NN + i], xj = bcast_lane(xv, j);
+                            const double p = aij * xj, pe = fma(aij, xj, -p);      // aij xj = p + pe exactly
+                            const double t = hi - p, bb = t - hi;                  // two-sum of hi and -p
+                            const double err = (hi - (t - bb)) + (-p - bb);
+                            hi = t;
+                            lo += err - pe;
+                        }
+                        double r = hi + lo;
+                        // L y = r, z = D^-1 y, L^T d = z with the factors in the registers
+#pragma unroll
+                        for (int k = 0; k < NN - 1; ++k)
+                        {
+                            const double yk = bcast_lane(r, k);
+                            if (lane > k) r -= a[k] * yk;
+                        }
+                        double dv = r * rdi;
+#pragma unroll
+                        for (int j = NN - 1; j >= 1; --j)
+                        {
+                            const double dj = bcast_lane(dv, j);
+                            if (lane < j) dv -= (a[j] * rdi) * dj;
+                        }
+                        xv += dv;
+                        const double dn = wmax(lane < NN ? fabs(dv) : 0.0), xn = wmax(lane < NN ? fabs(xv) : 0.0);
+                        ok = dn <= 1e-13 * xn; // (NaN compares false)
+                    }
+                }
+            }
             if (lane < NN) x[lane] = xv;
-            return pos && dmax <= max_ratio * dmin;
+            return ok;
+        }
+        template <int NN>
+        __device__ __forceinline__ bool spd_solve_regs(const double *A, const double *b, double *x, int lane, double max_ratio)
+        {
+            return spd_solve_regs_impl<NN, false>(A, b, x, lane, max_ratio, 0.0);
         }
 
         // x = A^-1 b by LDL^T with diagonal pivoting (host_math.cpp:solve_ldlt); M holds A on entry

@@ -28,6 +28,7 @@ namespace mbavo
         int max_it, max_nonmono, solver, trace_cap, max_n, max_N;
         double min_q, min_dec, chi;
         double fast_ratio; // solver 0: pivot ratio up to which the LDL^T result stands in for the Jacobi SVD's (0: never)
+        double refined_ratio = 0.0; // batched LM: ... up to which the LDL^T result refined in double-double does (lm_solvers.h)
     };
 
     namespace

@@ -60,10 +60,16 @@ def _host_lm(mbavo, ctx, dw, b, p, solver, trace_cap=64):
                                      for r in trace[:n]]
 
 
-@pytest.mark.parametrize("k,N,F,solver", [(4, 4, 1, 0), (4, 6, 2, 0), (2, 3, 2, 1), (4, 4, 1, 1), (2, 2, 1, 0), (4, 16, 2, 0),
-                                              (4, 8, 2, 0)])  # n = 24, 36 (three blocks per thread), 12: eigenvalue Jacobi; 96: one-wave sweeps; 48: its largest
-def test_lm_batch_matches_host_loop(mbavo, gpu_ctx, k, N, F, solver):
+@pytest.mark.parametrize("k,N,F,solver,fast", [(4, 4, 1, 0, "0"), (4, 6, 2, 0, "0"), (2, 3, 2, 1, None), (4, 4, 1, 1, None), (2, 2, 1, 0, "0"),
+                                                   (4, 16, 2, 0, None), (4, 8, 2, 0, None),
+                                                   (4, 4, 1, 0, None), (2, 2, 1, 0, None), (2, 3, 2, 0, None), (2, 3, 2, 1, "0"), (4, 4, 1, 1, "0")])
+def test_lm_batch_matches_host_loop(mbavo, gpu_ctx, monkeypatch, k, N, F, solver, fast):
+    """fast = "0" (MBAVO_FAST_SOLVE=0): solver type 0 through the Jacobi solvers only -- n = 24, 36 (three blocks per thread), 12:
+    eigenvalue Jacobi; solver type 1 through the pivoted LDL^T only.  Default: LDL^T in registers, refined in double-double above a
+    pivot ratio of 1e8, stands in for either (n = 12, 18, 24); n = 96: one-wave sweeps, 48: the eigenvalue Jacobi's largest."""
     import torch
+    if fast is not None:
+        monkeypatch.setenv("MBAVO_FAST_SOLVE", fast)
     capi = mbavo.capi
     B = 6
     probs = _scene(B, k, N, F, seed=11 + k + N)
@@ -110,8 +116,10 @@ def test_lm_batch_eigenvalue_jacobi_matches_one_wave_sweeps(mbavo, gpu_ctx, monk
     capi = mbavo.capi
     B, k, N, F = 8, 4, 4, 1
     out = {}
-    for eig in ("1", "0"):
-        monkeypatch.setenv("MBAVO_LM_EIG", eig)
+    for eig in ("1", "0", "fast"):
+        # "fast": the default -- LDL^T in registers where the pivot ratio allows; the other two: Jacobi solvers only
+        monkeypatch.setenv("MBAVO_LM_EIG", "1" if eig == "fast" else eig)
+        monkeypatch.setenv("MBAVO_FAST_SOLVE", "1" if eig == "fast" else "0")
         probs = _scene(B, k, N, F, seed=23)
         dw = workloads.DeviceWorkload(probs)
         o = capi.LmBatchOpts()
@@ -125,10 +133,41 @@ def test_lm_batch_eigenvalue_jacobi_matches_one_wave_sweeps(mbavo, gpu_ctx, monk
         torch.cuda.synchronize()
         out[eig] = [[(t.iter, t.kind, t.num_outliers, t.eval_cost, t.candidate_cost) for t in trace[b * cap:b * cap + res[b].num_trace]]
                     for b in range(B)]
-    for a, b in zip(out["1"], out["0"]):
-        assert [t[:3] for t in a] == [t[:3] for t in b]
-        for ta, tb in zip(a, b):
-            assert abs(ta[3] - tb[3]) <= 1e-6 * max(1.0, abs(tb[3])) and abs(ta[4] - tb[4]) <= 1e-6 * max(1.0, abs(tb[4]))
+    for other in ("0", "fast"):
+        for a, b in zip(out["1"], out[other]):
+            assert [t[:3] for t in a] == [t[:3] for t in b]
+            for ta, tb in zip(a, b):
+                assert abs(ta[3] - tb[3]) <= 1e-6 * max(1.0, abs(tb[3])) and abs(ta[4] - tb[4]) <= 1e-6 * max(1.0, abs(tb[4]))
+
+
+@pytest.mark.parametrize("k,N,F,sync_every", [(4, 6, 2, 0), (2, 3, 1, 0), (4, 4, 1, 3)])
+def test_lm_batch_deferred_finalize_same_bits(mbavo, gpu_ctx, monkeypatch, k, N, F, sync_every):
+    """Lists of >= 64 (problem, frame) slots: the LM kernels sum the tile partials themselves (no finalize launch; engine.h:
+    set_defer_finalize) in the finalize kernel's order -- every trace record and every final knot is bit-identical to the run with
+    the finalize kernels (MBAVO_LM_DEFER=0); the done word in pinned host memory (sync_every 0) against the stream-drain scheme."""
+    import torch
+    capi = mbavo.capi
+    B = 70
+    out = {}
+    for defer in ("1", "0"):
+        monkeypatch.setenv("MBAVO_LM_DEFER", defer)
+        probs = _scene(B, k, N, F, seed=31)
+        dw = workloads.DeviceWorkload(probs)
+        o = capi.LmBatchOpts()
+        o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, 12, OPTS["max_nonmono"]
+        o.solver_type, o.sync_every = 0, sync_every
+        o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
+        cap = 32
+        res = (capi.LmBatchResult * B)()
+        trace = (capi.TraceRec * (B * cap))()
+        assert gpu_ctx.lib.mbavo_lm_batch(gpu_ctx.handle, B, dw.array, C.byref(o), res, trace, cap) == 0
+        torch.cuda.synchronize()
+        recs = [[(t.iter, t.kind, t.num_outliers, t.radius, t.eval_cost, t.candidate_cost, t.model_change, t.quality)
+                 for t in trace[b * cap:b * cap + res[b].num_trace]] for b in range(B)]
+        knots = [tuple(x.cpu().numpy().tobytes() for x in dw.keep_knots(b)) for b in range(B)]
+        out[defer] = (recs, knots, [(r.iterations, r.accepted, r.rejected, r.invalid, r.final_cost) for r in res])
+    assert out["1"] == out["0"]
+    assert sum(r[1] for r in out["1"][2]) > B // 2 and sum(r[2] + r[3] for r in out["1"][2]) > 0  # steps were taken and refused
 
 
 def test_lm_batch_packed_keyframes_same_records(mbavo, gpu_ctx):
