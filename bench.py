@@ -646,6 +646,7 @@ def main():
     # N > 1: BASELINE configs[3] (512 pairs over the ranks) in both shardings, bounded -- the driver's scaling run only
     # launches the default workload, so the batch's scaling points ride in its line
     if use_dist and not args.no_configs and args.workload == "c2_dense":
+        cfg_failed = False
         for mode, fmt in (("pairs", 0), ("keypoints", 0), ("pairs", 2)):  # (2: packed keyframes, mbavo_problem.grad_fp16 = 2)
             key = "c4_batch512_" + mode + ("_packed" if fmt == 2 else "")
             try:
@@ -669,7 +670,20 @@ def main():
             except Exception as e:
                 if rank == 0:
                     cfgs[key] = {"error": repr(e)}
+                cfg_failed = True
                 break  # the ranks may have diverged: no further collective configs
+        # whole alignments sharded: the device-side LM on every rank's own pairs, one all-gather of the records at the end
+        if max_over_ranks(float(cfg_failed)) == 0.0:  # (decided together: a rank that skipped would leave the others in a collective)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import lm_bench
+                line = lm_bench.sharded_line(M, ctx, dev, rank, world, (dist.barrier if use_dist and world > 1 else (lambda: None)),
+                                             max_over_ranks, sum_over_ranks)
+                if rank == 0:
+                    cfgs["lm_batch512_pairs"] = line
+            except Exception as e:
+                if rank == 0:
+                    cfgs["lm_batch512_pairs"] = {"error": repr(e)}
         if rank == 0:
             out["configs"] = cfgs
 

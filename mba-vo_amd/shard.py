@@ -15,7 +15,10 @@ equations (the reference's reduction point is merge_hessian_gradie
   * ONE joint problem, frames sharded (`mbavo_shard_frames`): rank r owns a contiguous frame range; every rank scatters
     its frames' blocks into the 6N x 6N system on the device (`mbavo_merge_device`) and the partial systems
     [cost | g | H] are summed: one all-reduce of 1 + 6N + 36N^2 doubles per problem.
-All end in ONE `mbavo_allreduce_blocks[_to]` on the context's own RCCL communicator (`mbavo_comm_init`), enqueued on the stream
+  * B INDEPENDENT pairs, whole ALIGNMENTS sharded (`ShardedLmBatch`): pair b on rank b % world, the device-side LM loop
+    (`mbavo_lm_batch`) runs on every rank over its own pairs with no collective inside, and ONE all-gather of fixed-size
+    records (final knots + result scalars, `lm_record_layout`) at the end leaves every pair's aligned spline on every rank.
+The evaluations end in ONE `mbavo_allreduce_blocks[_to]` on the context's own RCCL communicator (`mbavo_comm_init`), enqueued on the stream
 of the evaluation.  torch.distributed is used for the rendezvous only (broadcast of the 128-byte communicator id).
 The pure index helpers below are also what the CPU (gloo) tests exercise.
 """
@@ -251,6 +254,86 @@ class ShardedEvaluation:
         """'pairs' mode: the reduced packed frame blocks [F_b, E] of pair b (a view of `reduced`)."""
         r0 = self.row_of_pair[b]
         return self.reduced.view(self.nbf_whole, self.E)[r0:r0 + self.whole[b].F]
+
+
+LM_RECORD_SCALARS = 8  # initial cost, final cost, radius, iterations, accepted, rejected, invalid, outliers
+
+
+def lm_record_layout(num_pairs, world, max_N):
+    """Layout of the all-gathered records of a pair-sharded batched LM: (rows_per_rank, record_len, row_of_pair).
+    Rank r's pairs (b = r, r + world, ...) fill rows [r * rows_per_rank, ...) in ascending pair order -- equal slices, as
+    ncclAllGather wants them; a record is [knots_t 3 max_N | knots_R 4 max_N | LM_RECORD_SCALARS] doubles."""
+    rows = -(-num_pairs // world)
+    return rows, 7 * max_N + LM_RECORD_SCALARS, [(b % world) * rows + b // world for b in range(num_pairs)]
+
+
+class ShardedLmBatch:
+    """B independent keyframe-pair alignments over the ranks, pair b on rank b % world ("independent
+    keyframe-pair alignments shard naturally"): every rank runs the device-side LM loop (mbavo_lm_batch; what
+    BlurAwareDirectTracker::optimizePyramidLevel does per pair, blur_aware_direct_tracker.cpp:590-924) over ITS pairs --
+    there is no collective inside the loop, the pairs share nothing -- with the control knots living in this object's record
+    buffer, and ONE in-place all-gather (mbavo_allgather_blocks) of the records at the end.
+
+        whole      : capi.Problem array of all B pairs; only this rank's entries have to be populated
+        init_knots : per pair (knots_t [N, 3], knots_R [N, 4]) numpy arrays (None for pairs of other ranks)
+        run()      : reset the knots, mbavo_lm_batch on this rank's pairs, records of every rank gathered; returns the rc
+        record(b)  : dict of pair b's result after run() (any rank)
+    """
+
+    def __init__(self, ctx, whole, k, rank, world, device, opts, init_knots):
+        import torch
+        self.ctx, self.k, self.rank, self.world, self.opts = ctx, k, rank, world, opts
+        self.B = len(whole)
+        self.mine = pairs_of_rank(self.B, rank, world)
+        self.N = [int(whole[b].N) if b in set(self.mine) else 0 for b in range(self.B)]
+        self.max_N = 16  # the reference's max_num_ctrl_knots: the same record length on every rank without an exchange
+        self.rows, self.rec, self.row_of_pair = lm_record_layout(self.B, world, self.max_N)
+        self.records = torch.zeros(world * self.rows * self.rec, dtype=torch.float64, device=device)
+        self.live = (capi.Problem * max(len(self.mine), 1))()
+        init = np.zeros((self.rows, self.rec))
+        base = self.records.data_ptr()
+        for j, b in enumerate(self.mine):
+            C.memmove(C.byref(self.live[j]), C.byref(whole[b]), C.sizeof(capi.Problem))
+            row = self.row_of_pair[b]
+            assert row == rank * self.rows + j
+            kt, kR = init_knots[b]
+            n = self.N[b]
+            init[j, :3 * n] = np.asarray(kt, np.float64).ravel()
+            init[j, 3 * self.max_N:3 * self.max_N + 4 * n] = np.asarray(kR, np.float64).ravel()
+            self.live[j].d_knots_t = base + 8 * (row * self.rec)
+            self.live[j].d_knots_R = base + 8 * (row * self.rec + 3 * self.max_N)
+        self._init = torch.from_numpy(init.ravel()).pin_memory()
+        self._scal = torch.zeros(self.rows, LM_RECORD_SCALARS, dtype=torch.float64).pin_memory()
+        self.res = (capi.LmBatchResult * max(len(self.mine), 1))()
+        lo = rank * self.rows * self.rec
+        self._slice = self.records[lo:lo + self.rows * self.rec]
+        self._scal_dst = self._slice.view(self.rows, self.rec)[:, 7 * self.max_N:]
+
+    def run(self, gather=True):
+        lib, ctx = self.ctx.lib, self.ctx
+        self._slice.copy_(self._init, non_blocking=True)  # initial knots (the LM updates them in place), scalars zero
+        rc = 0
+        if self.mine:
+            rc = lib.mbavo_lm_batch(ctx.handle, len(self.mine), self.live, C.byref(self.opts), self.res, None, 0)  # (returns synchronised)
+            sc = self._scal.numpy()
+            for j in range(len(self.mine)):
+                r = self.res[j]
+                sc[j] = (r.initial_cost, r.final_cost, r.radius, r.iterations, r.accepted, r.rejected, r.invalid, r.num_outliers)
+            self._scal_dst.copy_(self._scal, non_blocking=True)
+        if gather and self.world > 1:
+            capi.check(lib.mbavo_allgather_blocks(ctx.handle, None, self.records.data_ptr(), self.rows * self.rec), "mbavo_allgather_blocks")
+        return rc
+
+    def record(self, b, N=None):
+        """Pair b's gathered record (synchronises): knots_t [N, 3], knots_R [N, 4] and the result scalars."""
+        import torch
+        torch.cuda.synchronize()
+        n = N if N is not None else (self.N[b] or 4)
+        row = self.records.view(-1, self.rec)[self.row_of_pair[b]].cpu().numpy()
+        s = row[7 * self.max_N:]
+        return {"knots_t": row[:3 * n].reshape(n, 3).copy(), "knots_R": row[3 * self.max_N:3 * self.max_N + 4 * n].reshape(n, 4).copy(),
+                "initial_cost": float(s[0]), "final_cost": float(s[1]), "radius": float(s[2]), "iterations": int(s[3]),
+                "accepted": int(s[4]), "rejected": int(s[5]), "invalid": int(s[6]), "num_outliers": int(s[7])}
 
 
 def allreduce_blocks(blocks, group=None):

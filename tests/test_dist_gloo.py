@@ -109,6 +109,17 @@ def _worker(rank, world, port, out_dir):
     acc = send.clone()  # (gloo's all-reduce is in place; the product's RCCL call is out of place, send stays untouched)
     shard.allreduce_blocks(acc)
     assert torch.equal(acc[row_base[rank]:row_base[rank + 1]], send[row_base[rank]:row_base[rank + 1]])  # x + 0 is exact
+    # ---- pair-sharded batched LM: the record all-gather (shard.lm_record_layout; the LM itself needs the GPU) -- every
+    # rank fills its pairs' records, equal slices are gathered, and pair b's record sits at row_of_pair[b] on every rank
+    rows, rec, lm_row = shard.lm_record_layout(7, world, 4)
+    mine = torch.zeros(rows, rec, dtype=torch.float64)
+    for j, b in enumerate(shard.pairs_of_rank(7, rank, world)):
+        assert lm_row[b] == rank * rows + j
+        mine[j] = torch.arange(rec, dtype=torch.float64) + 1000.0 * (b + 1)
+    gathered = torch.zeros(world * rows, rec, dtype=torch.float64)
+    dist.all_gather_into_tensor(gathered, mine)
+    for b in range(7):
+        assert torch.equal(gathered[lm_row[b]], torch.arange(rec, dtype=torch.float64) + 1000.0 * (b + 1))
     if rank == 0:
         np.save(os.path.join(out_dir, "joint.npy"), blocks.numpy())
         np.save(os.path.join(out_dir, "system.npy"), system.numpy())
@@ -200,3 +211,15 @@ def test_shard_partitions_cover_everything(mbavo):
     bad = mbavo.capi.Problem()
     assert lib.mbavo_shard_frames(C.byref(whole), 2, 2, C.byref(bad), None) == -1  # rank out of range
     assert lib.mbavo_system_len(4) == 601 and lib.mbavo_system_len(6) == 1333
+
+
+def test_lm_record_layout_is_an_equal_slice_partition(mbavo):
+    from mba_vo_amd import shard
+    for world in (1, 2, 3, 4, 8):
+        for B in (1, 7, 64, 512):
+            rows, rec, row_of = shard.lm_record_layout(B, world, 16)
+            assert rec == 7 * 16 + shard.LM_RECORD_SCALARS and rows * world >= B and (rows - 1) * world < B
+            assert len(set(row_of)) == B and max(row_of) < rows * world
+            for r in range(world):
+                mine = shard.pairs_of_rank(B, r, world)
+                assert [row_of[b] for b in mine] == list(range(r * rows, r * rows + len(mine)))  # contiguous from the slice's start

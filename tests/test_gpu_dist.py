@@ -119,6 +119,23 @@ def rank_body(rank, world, local_rank, port, out_path):
     o3 = B.evaluate(op3)["frame_blocks"][0]
     g3 = se3.blocks_of_pair(3)[0].cpu().numpy()
     res["pairs_vs_oracle"] = float(np.abs(g3 - o3).max() / np.abs(o3).max())
+    # ---- whole alignments sharded (shard.ShardedLmBatch): the batched LM on this rank's pairs of the same 7, ONE all-gather
+    # of the records; against the whole batch aligned by this rank alone (same counts, knots to 1e-9)
+    o = M.capi.LmBatchOpts()
+    o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps, o.solver_type, o.sync_every = 4, 6, 5, 0, 0
+    o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = 0.5, 0.0, 3.0
+    init = [(h["kt"], h["kR"]) for h in rb._host]
+    sl = shard.ShardedLmBatch(ctx, rb.array, 4, rank, world, dev, o, init)
+    assert sl.run() == 0
+    alone = shard.ShardedLmBatch(ctx, rb.array, 4, 0, 1, dev, o, init)
+    assert alone.run() == 0
+    worst, same = 0.0, True
+    for b in range(7):
+        a, r = sl.record(b, 4), alone.record(b, 4)
+        same = same and (a["iterations"], a["accepted"], a["rejected"], a["invalid"]) == (r["iterations"], r["accepted"], r["rejected"], r["invalid"])
+        worst = max(worst, float(np.abs(a["knots_t"] - r["knots_t"]).max()), float(np.abs(a["knots_R"] - r["knots_R"]).max()))
+    res["lm_sharded_same_counts"] = bool(same and sum(alone.record(b, 4)["accepted"] for b in range(7)) > 0)
+    res["lm_sharded_knots_vs_single_gpu"] = worst
     res["nonzero"] = bool(float(ref.abs().max()) > 0 and float(ref2.abs().max()) > 0 and float(ref3.abs().max()) > 0)
     # every rank holds the same reduced object
     chk = got2.clone()
@@ -146,6 +163,7 @@ def check(res, world):
     assert res["frame_blocks_merged_vs_frames_mode"] <= 1e-12
     assert res["frames_vs_oracle"] <= 1e-9 and res["pairs_vs_oracle"] <= 1e-9
     assert res["pairs_vs_single_gpu"] <= 1e-12 and res["pairs_own_slice_exact"] and res["pairs_foreign_slices_zero"]
+    assert res["lm_sharded_same_counts"] and res["lm_sharded_knots_vs_single_gpu"] <= 1e-9
 
 
 def _spawned(rank, world, port, out_path):

@@ -237,3 +237,46 @@ def test_lm_batch_argument_errors(mbavo, gpu_ctx):
     assert gpu_ctx.lib.mbavo_lm_batch(gpu_ctx.handle, 1, dw.array, C.byref(o), None, None, 0) == -1
     o.spline_deg_k, o.solver_type = 4, 7
     assert gpu_ctx.lib.mbavo_lm_batch(gpu_ctx.handle, 1, dw.array, C.byref(o), None, None, 0) == -1
+
+
+def test_sharded_lm_batch_ranks_add_up_on_one_gpu(mbavo, gpu_ctx):
+    """shard.ShardedLmBatch (pair b on rank b % world, the LM loop per rank, ONE all-gather of the records): the ranks of
+    world = 1, 2, 4 run one after the other on this GPU (no collective: every rank's slice is checked where it lands), every
+    pair's record against the whole batch's -- same accept / reject counts, knots to 1e-9 (a pair's result does not depend on
+    what else is in the batch; the tile layout of a smaller list may choose another kernel form: rounding, not bits)."""
+    import torch
+    from mba_vo_amd import shard
+    capi = mbavo.capi
+    B, k, N, F = 10, 4, 4, 1
+    probs = _scene(B, k, N, F, seed=41)
+    dw = workloads.DeviceWorkload(probs)
+    o = capi.LmBatchOpts()
+    o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, 12, OPTS["max_nonmono"]
+    o.solver_type, o.sync_every = 0, 0
+    o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
+    init = [(p.knots_t.reshape(N, 3), p.knots_R.reshape(N, 4)) for p in probs]
+    ref = None
+    for world in (1, 2, 4):
+        recs = {}
+        for rank in range(world):
+            sl = shard.ShardedLmBatch(gpu_ctx, dw.array, k, rank, world, "cuda:0", o, init)
+            assert sl.run(gather=False) == 0
+            assert sl.run(gather=False) == 0  # a second run starts from the initial knots again
+            for b in shard.pairs_of_rank(B, rank, world):
+                recs[b] = sl.record(b)
+            others = [b for b in range(B) if b % world != rank]
+            assert all(sl.record(b, N)["iterations"] == 0 and not sl.record(b, N)["knots_t"].any() for b in others[:2])
+        assert sorted(recs) == list(range(B))
+        if ref is None:
+            ref = recs
+            assert sum(r["accepted"] for r in ref.values()) >= B // 2 and all(r["final_cost"] <= r["initial_cost"] for r in ref.values())
+            assert any(r["final_cost"] < 0.9 * r["initial_cost"] for r in ref.values())
+            continue
+        for b in range(B):
+            a, r = recs[b], ref[b]
+            assert (a["iterations"], a["accepted"], a["rejected"], a["invalid"], a["num_outliers"]) == \
+                   (r["iterations"], r["accepted"], r["rejected"], r["invalid"], r["num_outliers"]), (world, b, a, r)
+            assert np.abs(a["knots_t"] - r["knots_t"]).max() < 1e-9 and np.abs(a["knots_R"] - r["knots_R"]).max() < 1e-9
+            assert abs(a["final_cost"] - r["final_cost"]) <= 1e-9 * r["final_cost"]
+    # the caller's own knot buffers were never touched: the records hold the aligned splines
+    assert np.array_equal(dw.keep_knots(0)[0].cpu().numpy(), probs[0].knots_t)

@@ -90,6 +90,42 @@ def bench_line(M, ctx, dev, B=64, iterations=10, host_pairs=8):
     return out
 
 
+def sharded_line(M, ctx, dev, rank, world, barrier, max_over_ranks, sum_over_ranks, B=512, iterations=10, reps=3, packed=True):
+    """bench.py N > 1 `configs.lm_batch512_pairs`: B pairs of the rendered sequence aligned by the device-side LM, pair b on
+    rank b % world (shard.ShardedLmBatch: no collective inside the loop, ONE all-gather of the records at the end).
+    Every rank renders only its own pairs.  value = LM iterations of all pairs / max-over-ranks wall time of a call."""
+    import torch
+    from mba_vo_amd import shard, workloads
+    capi = M.capi
+    mine = shard.pairs_of_rank(B, rank, world)
+    batch = workloads.RenderedPairBatch(ctx, B, S=8, k=4, device=dev, seed=1, pairs=mine, grad_fp16=2 if packed else 0)
+    o = capi.LmBatchOpts()
+    o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps, o.solver_type, o.sync_every = 4, iterations, 5, 0, 0
+    o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = 0.5, 0.0, 3.0
+    init = [None if h is None else (h["kt"], h["kR"]) for h in batch._host]
+    sl = shard.ShardedLmBatch(ctx, batch.array, 4, rank, world, dev, o, init)
+    best = None
+    for _ in range(reps + 1):  # (the first call sizes the engine's arenas)
+        barrier()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        rc = sl.run()
+        torch.cuda.synchronize()
+        dt = max_over_ranks(time.perf_counter() - t)
+        assert rc == 0, rc
+        best = dt if best is None or _ == 1 else min(best, dt)
+    iters = sum_over_ranks(float(sum(sl.res[j].iterations for j in range(len(mine)))))
+    acc = sum_over_ranks(float(sum(sl.res[j].accepted for j in range(len(mine)))))
+    # every rank holds every pair's record: the gathered iteration counts add up to the sum over the ranks
+    got = sum(sl.record(b, 4)["iterations"] for b in range(0, B, max(1, B // 16)))
+    want = sum_over_ranks(float(sum(sl.res[j].iterations for j, b in enumerate(mine) if b % max(1, B // 16) == 0)))
+    return {"workload": "%d pairs of the rendered blurred sequence (%s keyframes), device-side LM, %d iterations per pair, pair b on "
+                        "rank b %% N, one all-gather of the records" % (B, "packed" if packed else "float-gradient", iterations),
+            "n_gpus": world, "sharding": "pairs (whole alignments)", "scaling": "strong", "ms_total": round(1e3 * best, 4),
+            "lm_iterations": int(iters), "accepted": int(acc), "value": round(iters / best, 1), "unit": "pair LM iterations/s",
+            "us_per_pair_iteration": round(1e6 * best / max(iters, 1.0), 4), "gather_check": bool(got == int(want))}
+
+
 if __name__ == "__main__":
     import torch
     import mba_vo_amd as mbavo
