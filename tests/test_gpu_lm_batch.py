@@ -153,6 +153,7 @@ def test_lm_batch_deferred_finalize_same_bits(mbavo, gpu_ctx, monkeypatch, k, N,
         monkeypatch.setenv("MBAVO_LM_DEFER", defer)
         probs = _scene(B, k, N, F, seed=31)
         dw = workloads.DeviceWorkload(probs)
+        dw.array[3].K = 0  # a pair without keypoints: its slots have no tile (all-zero sums either way)
         o = capi.LmBatchOpts()
         o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, 12, OPTS["max_nonmono"]
         o.solver_type, o.sync_every = 0, sync_every
@@ -166,7 +167,7 @@ def test_lm_batch_deferred_finalize_same_bits(mbavo, gpu_ctx, monkeypatch, k, N,
                  for t in trace[b * cap:b * cap + res[b].num_trace]] for b in range(B)]
         knots = [tuple(x.cpu().numpy().tobytes() for x in dw.keep_knots(b)) for b in range(B)]
         out[defer] = (recs, knots, [(r.iterations, r.accepted, r.rejected, r.invalid, r.final_cost) for r in res])
-    assert out["1"] == out["0"]
+    assert repr(out["1"]) == repr(out["0"])  # (repr: the pair without keypoints carries NaN step qualities in both runs; 17 digits = the bits)
     assert sum(r[1] for r in out["1"][2]) > B // 2 and sum(r[2] + r[3] for r in out["1"][2]) > 0  # steps were taken and refused
 
 
