@@ -727,6 +727,10 @@ def main():
             cfgs["lm_batch64"] = lm_bench.bench_line(M, ctx, dev)
         except Exception as e:
             cfgs["lm_batch64"] = {"error": repr(e)}
+        try:  # configs[3]'s pairs through the same loop (device side only)
+            cfgs["lm_batch512"] = lm_bench.bench_line(M, ctx, dev, B=512, host_pairs=0)
+        except Exception as e:
+            cfgs["lm_batch512"] = {"error": repr(e)}
         out["configs"] = cfgs
 
     if rank == 0 and not args.no_cpu_baseline and world == 1 and fb_gpu is not None:  # rank 0 at N = 1 only

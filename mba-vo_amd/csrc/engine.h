@@ -118,7 +118,8 @@ namespace mbavo
         bool finalize_deferred() const { return deferred_last_; }
         const double *device_partials() const { return (const double *)d_partials_; }
         const int *device_bf_tile_begin() const { return (const int *)d_bf_tile_begin_; }
-        bool defer_finalize_ = false, deferred_last_ = false;
+        // (for the launch sequence, a free function template in engine.hip) leaves the finalize to the caller if asked to and possible
+        bool take_deferral(bool flat_finalize) { return deferred_last_ = flat_finalize && defer_finalize_; }
 
         // The WHOLE coarse-to-fine LM loop of one small problem on the device (k_lm_level, round 3): one resident kernel per
         // pyramid level, enqueued back to back; the workgroup that finishes an evaluation solves, decides and publishes the
@@ -191,6 +192,7 @@ namespace mbavo
         bool layout_uploaded_ = false;
         int sp_logs_ = 0; // > 0: the cached layout is tiled for the sample-parallel kernel with S = 2^sp_logs_
         bool flat_finalize_ = false; // many (problem, frame) slots of <= 4 tiles each: k_finalize_flat
+        bool defer_finalize_ = false, deferred_last_ = false; // set_defer_finalize / what the last evaluate() did
         bool empty_slots_ = false;   // some (problem, frame) slot has no tile (K == 0): no workgroup would finalize it in the single-launch form
 
         void *d_layout_ = nullptr; size_t cap_layout_ = 0; // one arena: descs | tiles | bf_tile_begin | bf_prob | entry_prob

@@ -2563,8 +2563,7 @@ namespace mbavo
 #undef MBAVO_GRAD_CASE
         }
         static_assert(Pack<KD>::E + 1 <= 384, "one thread per partial slot");
-        eng->deferred_last_ = flat_finalize && eng->defer_finalize_;
-        if (eng->deferred_last_) {} // the caller's kernels sum the tile partials (engine.h: set_defer_finalize)
+        if (eng->take_deferral(flat_finalize)) {} // the caller's kernels sum the tile partials (engine.h: set_defer_finalize)
         else if (flat_finalize)
             hipLaunchKernelGGL((k_finalize_flat<KD, WITH_J>), dim3(nbf), dim3(KD == 2 ? 128 : 384), 0, st, descs, bf_prob, bf_tile_begin,
                                partials, frame_blocks, valid);
