@@ -229,6 +229,11 @@ namespace mbavo
             __syncthreads(); // `order` is the Jacobi solvers' work area
             if (have && tid == 0) atomicAdd(num_done + 5, 1);
         }
+        else if (o.fast_ratio > 0.0 && n <= 64)
+        { // 5 .. 10 control knots: the same factorisation by the whole workgroup in LDS (V's place), the system read where it lives
+            have = spd_solve_coop<T>(V, H, g, x, tmp, order, n, tid, o.fast_ratio, o.refined_ratio);
+            if (have && tid == 0) atomicAdd(num_done + 5, 1);
+        }
         if (have) {}
         else if constexpr (T == kEigT)
         {

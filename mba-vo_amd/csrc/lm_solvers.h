@@ -749,6 +749,174 @@ namespace mbavo
             return spd_solve_regs_impl<NN, false>(A, b, x, lane, max_ratio, 0.0);
         }
 
+        // ---- the same stand-in for the systems the register form does not take (any even n <= 64: 5 .. 10 control knots),
+        // by a whole workgroup of T threads.  Factorisation: unpivoted LDL^T, right-looking, the trailing matrix held in
+        // REGISTERS in a TD x TD cyclic distribution (thread (ti, tj) owns the entries (ti + a TD, tj + b TD), lower triangle);
+        // in step k the owners of column k store it into column k of `F` (LDS, n x (n + 1): it is final, d_k on the diagonal and
+        // d_k L[i][k] below), ONE barrier, then every thread reads the pivot, its rows' and its columns' entries of that column
+        // (1 + 2 MAXD LDS reads) and updates its MAXD^2 registers -- no read-modify-write of LDS, no index division, the column
+        // of step k + 1 goes to another column of F while late threads still read column k.  The substitutions and the
+        // double-double refinement by wave 0 with lane i on row i (y_k handed over by v_readlane with a uniform lane index), the
+        // other waves waiting at the barrier.  `A`: the system as given (column-major n x n, LDS or global memory: read once for
+        // the registers and once per refinement step, lanes on consecutive rows), `rd`: n doubles of LDS (reciprocal pivots).
+        // Same acceptance rule and return value as spd_solve_regs_impl<.., true>; uniform over the workgroup.
+        // First form (every step a read-modify-write pass over the trailing block in LDS): 100 000 cycles at n = 48 / 256 threads.
+        __device__ __forceinline__ double bcast_lane_uniform(double v, int src) // src: the same in every lane (a loop counter)
+        {
+            const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
+            return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        }
+        template <int T>
+        __device__ __forceinline__ bool spd_solve_coop(double *F, const double *A, const double *b, double *x, double *rd, int *flag, int n,
+                                                       int tid, double max_ratio, double max_ratio_refined)
+        {
+            constexpr int TD = T >= 256 ? 16 : 8, MAXD = 64 / TD;
+            const int ld = n + 1, lane = tid & 63, ti = tid % TD, tj = (tid / TD) % TD;
+            const bool grid = tid < TD * TD;
+            double v[MAXD][MAXD];
+#pragma unroll
+            for (int bb = 0; bb < MAXD; ++bb)
+#pragma unroll
+                for (int a = 0; a < MAXD; ++a)
+                {
+                    const int i = ti + a * TD, j = tj + bb * TD;
+                    v[a][bb] = (grid && i < n && j <= i) ? A[j * n + i] : 0.0;
+                }
+            double dmax = 0.0, dmin = DBL_MAX;
+            bool pos = true;
+#pragma unroll
+            for (int kb = 0; kb < MAXD; ++kb) // the column block of step k, a compile-time index into the registers
+                for (int k = kb * TD; k < (kb + 1) * TD && k < n && pos; ++k)
+                {
+                    if (grid && tj == k - kb * TD)
+                    { // column k is final
+#pragma unroll
+                        for (int a = 0; a < MAXD; ++a)
+                        {
+                            const int i = ti + a * TD;
+                            if (i >= k && i < n) F[k * ld + i] = v[a][kb];
+                        }
+                    }
+                    __syncthreads();
+                    const double d = F[k * ld + k]; // (every thread: the state below is uniform)
+                    double ci[MAXD], cj[MAXD];
+#pragma unroll
+                    for (int a = 0; a < MAXD; ++a)
+                    {
+                        const int i = ti + a * TD, j = tj + a * TD;
+                        ci[a] = (i > k && i < n) ? F[k * ld + i] : 0.0;
+                        cj[a] = (j > k && j < n) ? F[k * ld + j] : 0.0;
+                    }
+                    pos = d > 0.0;
+                    dmax = fmax(dmax, d);
+                    dmin = fmin(dmin, d);
+                    const double r = 1.0 / d;
+                    if (tid == 0) rd[k] = r;
+#pragma unroll
+                    for (int bb = 0; bb < MAXD; ++bb)
+                    {
+                        const double lj = cj[bb] * r; // L[j][k] (zero outside the trailing block: nothing changes there)
+#pragma unroll
+                        for (int a = 0; a < MAXD; ++a) v[a][bb] -= ci[a] * lj;
+                    }
+                }
+            __syncthreads();
+            bool ok = false;
+            if (pos && tid < 64)
+            { // wave 0: F holds d_k on the diagonal and d_k L[i][k] below it
+                const int i = lane < n ? lane : n - 1; // lanes past the matrix shadow the last row (results unused)
+                const double rdi = rd[i], bi = b[i];
+                // (the factor entries of kU steps are fetched together, ahead of the dependent chain that uses them: one LDS / memory
+                // latency per kU steps instead of one per step -- 300 -> ~40 cycles per step)
+                constexpr int kU = 8;
+                auto solve = [&](double y) { // L D L^T w = y, row i of y in lane i; returns row i of w
+                    for (int k0 = 0; k0 < n - 1; k0 += kU)
+                    {
+                        double l[kU];
+#pragma unroll
+                        for (int u = 0; u < kU; ++u)
+                        {
+                            const int k = k0 + u < n - 1 ? k0 + u : n - 2;
+                            l[u] = F[k * ld + i] * rd[k];
+                        }
+#pragma unroll
+                        for (int u = 0; u < kU; ++u)
+                        {
+                            const int k = k0 + u;
+                            if (k < n - 1)
+                            {
+                                const double yk = bcast_lane_uniform(y, k);
+                                if (lane > k && lane < n) y -= l[u] * yk;
+                            }
+                        }
+                    }
+                    double w = y * rdi;
+                    for (int k0 = n - 1; k0 >= 1; k0 -= kU)
+                    {
+                        double l[kU];
+#pragma unroll
+                        for (int u = 0; u < kU; ++u)
+                        {
+                            const int k = k0 - u >= 1 ? k0 - u : 1;
+                            l[u] = F[i * ld + k] * rdi; // d_i L[k][i] sits in column i, row k
+                        }
+#pragma unroll
+                        for (int u = 0; u < kU; ++u)
+                        {
+                            const int k = k0 - u;
+                            if (k >= 1)
+                            {
+                                const double wk = bcast_lane_uniform(w, k);
+                                if (lane < k) w -= l[u] * wk;
+                            }
+                        }
+                    }
+                    return w;
+                };
+                double xv = solve(bi);
+                ok = dmax <= max_ratio * dmin;
+                if (!ok && dmax <= max_ratio_refined * dmin)
+                    for (int step = 0; step < kRefineSteps && !ok; ++step)
+                    {
+                        double hi = bi, lo = 0.0; // r_i = b_i - sum_j A_ij x_j as an unevaluated sum hi + lo
+                        for (int j0 = 0; j0 < n; j0 += kU)
+                        {
+                            double arow[kU];
+#pragma unroll
+                            for (int u = 0; u < kU; ++u) arow[u] = A[(j0 + u < n ? j0 + u : n - 1) * n + i];
+#pragma unroll
+                            for (int u = 0; u < kU; ++u)
+                            {
+#pragma clang fp contract(off) // the error-free transformations below must not be fused
+                                const int j = j0 + u;
+                                if (j < n)
+                                {
+                                    const double aij = arow[u], xj = bcast_lane_uniform(xv, j);
+                                    const double p = aij * xj, pe = fma(aij, xj, -p);
+                                    const double t = hi - p, bb = t - hi;
+                                    const double err = (hi - (t - bb)) + (-p - bb);
+                                    hi = t;
+                                    lo += err - pe;
+                                }
+                            }
+                        }
+                        const double dv = solve(hi + lo);
+                        xv += dv;
+                        const double dn = wmax(lane < n ? fabs(dv) : 0.0), xn = wmax(lane < n ? fabs(xv) : 0.0);
+                        ok = dn <= 1e-13 * xn; // (NaN compares false)
+                    }
+                if (lane < n) x[lane] = xv;
+                if (lane == 0) *flag = ok ? 1 : 0;
+            }
+            else if (tid == 0)
+                *flag = 0;
+            __syncthreads();
+            ok = *flag != 0;
+            __syncthreads(); // (`flag` may be part of the next solver's work area)
+            return ok;
+        }
+
         // x = A^-1 b by LDL^T with diagonal pivoting (host_math.cpp:solve_ldlt); M holds A on entry
         MBAVO_LDLT_FN void ldlt_solve(double *M, const double *b, double *x, double *y, int *order, int n, int lane)
         {

@@ -74,26 +74,47 @@ __global__ __launch_bounds__(64) void k_solve_refined(const double *A, const dou
     if (lane == 0) { *ok = good ? 1 : 0; *cycles = t1 - t0; }
 }
 
+// the workgroup form for the sizes the register form does not take (lm_solvers.h: spd_solve_coop), system in LDS or global memory
+template <int T>
+__global__ __launch_bounds__(T) void k_solve_coop(const double *A, const double *b, double *x, int *ok, int n, int a_in_lds, double max_ratio,
+                                                  double max_refined, long long *cycles)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x;
+    double *F = lds, *As = F + n * (n + 1), *bs = As + n * n, *xs = bs + n, *rd = xs + n;
+    int *flag = (int *)(rd + n);
+    for (int i = tid; i < n * n; i += T) As[i] = A[i];
+    for (int i = tid; i < n; i += T) bs[i] = b[i];
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    const bool good = mbavo::spd_solve_coop<T>(F, a_in_lds ? As : A, bs, xs, rd, flag, n, tid, max_ratio, max_refined);
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    for (int i = tid; i < n; i += T) x[i] = xs[i];
+    if (tid == 0) { *ok = good ? 1 : 0; *cycles = t1 - t0; }
+}
+
 // Systems with an exactly known solution: J integer with every column = one common column times 2^e + small integers (nearly
 // dependent columns: cond(J^T J) ~ 2^2e), x small integers, A = J^T J and b = A x exact in double (all integers below 2^53).
 // The plain LDL^T lands within ~cond eps of x, the refined one must land within 1e-12 |x|_inf -- or say that it did not converge.
-template <int NN>
+template <int NN, int COOP = 0> // COOP: 0 = register form (n = NN), 64 / 256 = workgroup form with that many threads (64: system in global memory)
 static int refined_case(int e, double max_ratio, const char *label)
 {
     const int n = NN, m = n + 8;
     std::vector<double> J((size_t)m * n), A((size_t)n * n), b(n), xt(n), xd(n), u(m);
-    for (int r = 0; r < m; ++r) u[r] = (double)(rand() % 15 - 7);
+    const int ur = n > 24 ? 7 : 15, xr = n > 24 ? 3 : 7; // smaller integers for the larger systems: every sum below stays under 2^53
+    for (int r = 0; r < m; ++r) u[r] = (double)(rand() % ur - ur / 2);
     for (int r = 0; r < m; ++r)
-        for (int c = 0; c < n; ++c) J[(size_t)r * n + c] = ldexp(u[r], e) + (double)(rand() % 15 - 7);
+        for (int c = 0; c < n; ++c) J[(size_t)r * n + c] = ldexp(u[r], e) + (double)(rand() % ur - ur / 2);
     for (int r = 0; r < n; ++r)
         for (int c = 0; c < n; ++c)
         {
-            double a = 0; // |J| < 2^(e + 3.1), 32 terms: below 2^(2 e + 11.2)
+            double a = 0; // n <= 24: |J| < 2^(e + 3.1), 32 terms: below 2^(2 e + 11.2); n <= 60: |J| < 2^(e + 2), 68 terms: below 2^(2 e + 10.1)
             for (int k = 0; k < m; ++k) a += J[(size_t)k * n + r] * J[(size_t)k * n + c];
             A[(size_t)c * n + r] = a;
         }
-    for (int c = 0; c < n; ++c) xt[c] = (double)(rand() % 7 - 3);
-    for (int r = 0; r < n; ++r) { double a = 0; for (int c = 0; c < n; ++c) a += A[(size_t)c * n + r] * xt[c]; b[r] = a; } // below 2^(2 e + 17.4): exact for e <= 17
+    for (int c = 0; c < n; ++c) xt[c] = (double)(rand() % xr - xr / 2);
+    for (int r = 0; r < n; ++r) { double a = 0; for (int c = 0; c < n; ++c) a += A[(size_t)c * n + r] * xt[c]; b[r] = a; } // below 2^(2 e + 17.4) / 2^(2 e + 16): exact for e <= 17
     double *dA, *db, *dx; int *dok, ok = 0; long long *dcyc, cyc = 0;
     hipMalloc(&dA, A.size() * 8); hipMalloc(&db, n * 8); hipMalloc(&dx, n * 8); hipMalloc(&dok, 4); hipMalloc(&dcyc, 8);
     hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
@@ -102,7 +123,15 @@ static int refined_case(int e, double max_ratio, const char *label)
     for (int refined = 0; refined < 2; ++refined)
     {
         // plain: every ratio admitted, no refinement; refined: nothing admitted unrefined
-        hipLaunchKernelGGL(k_solve_refined<NN>, dim3(1), dim3(64), 0, 0, dA, db, dx, dok, refined ? max_ratio : 1e300, refined ? 1e13 : 0.0, dcyc);
+        if constexpr (COOP == 0)
+            hipLaunchKernelGGL(k_solve_refined<NN>, dim3(1), dim3(64), 0, 0, dA, db, dx, dok, refined ? max_ratio : 1e300, refined ? 1e13 : 0.0, dcyc);
+        else
+        {
+            const size_t lds = ((size_t)n * (n + 1) + (size_t)n * n + 3 * n) * 8 + 16;
+            hipFuncSetAttribute((const void *)k_solve_coop<COOP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(k_solve_coop<COOP>, dim3(1), dim3(COOP), lds, 0, dA, db, dx, dok, n, COOP == 256 ? 1 : 0, refined ? max_ratio : 1e300,
+                               refined ? 1e13 : 0.0, dcyc);
+        }
         hipError_t e = hipDeviceSynchronize();
         hipMemcpy(xd.data(), dx, n * 8, hipMemcpyDeviceToHost);
         hipMemcpy(&ok, dok, 4, hipMemcpyDeviceToHost);
@@ -111,7 +140,9 @@ static int refined_case(int e, double max_ratio, const char *label)
         for (int i = 0; i < n; ++i) { err = fmax(err, fabs(xd[i] - xt[i])); nrm = fmax(nrm, fabs(xt[i])); }
         // a refined result that claims convergence must be within 1e-12; one that does not claim it sends the caller to Jacobi
         const bool pass = e == hipSuccess && (refined ? (!ok || err <= 1e-12 * nrm) : true);
-        printf("n=%3d %s %s  max|x_dev - x_exact| / |x| = %.3e  accepted %d  %lld cycles %s\n", n, refined ? "LDLT refined" : "LDLT plain  ", label,
+        printf("n=%3d %s %s  max|x_dev - x_exact| / |x| = %.3e  accepted %d  %lld cycles %s\n", n,
+               COOP == 0 ? (refined ? "LDLT refined" : "LDLT plain  ") : COOP == 64 ? (refined ? "LDLT refined, 1 wave  " : "LDLT plain, 1 wave    ")
+                                                                                     : (refined ? "LDLT refined, 4 waves " : "LDLT plain, 4 waves   "), label,
                err / nrm, ok, cyc, pass ? "ok" : "FAIL");
         bad += !pass;
     }
@@ -130,6 +161,10 @@ int main()
         bad += refined_case<12>(e, 0.0, label);
         bad += refined_case<18>(e, 0.0, label);
         bad += refined_case<24>(e, 0.0, label);
+        bad += refined_case<30, 256>(e, 0.0, label);
+        bad += refined_case<36, 64>(e, 0.0, label);
+        bad += refined_case<48, 256>(e, 0.0, label);
+        bad += refined_case<60, 64>(e, 0.0, label);
     }
     for (int N = 2; N <= 16; N += (N < 8 ? 1 : 4)) // up to the reference's max_num_ctrl_knots = 16 (n = 96)
         for (int solver = 0; solver < 2; ++solver)

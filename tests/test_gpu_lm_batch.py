@@ -62,7 +62,8 @@ def _host_lm(mbavo, ctx, dw, b, p, solver, trace_cap=64):
 
 @pytest.mark.parametrize("k,N,F,solver,fast", [(4, 4, 1, 0, "0"), (4, 6, 2, 0, "0"), (2, 3, 2, 1, None), (4, 4, 1, 1, None), (2, 2, 1, 0, "0"),
                                                    (4, 16, 2, 0, None), (4, 8, 2, 0, None),
-                                                   (4, 4, 1, 0, None), (2, 2, 1, 0, None), (2, 3, 2, 0, None), (2, 3, 2, 1, "0"), (4, 4, 1, 1, "0")])
+                                                   (4, 4, 1, 0, None), (2, 2, 1, 0, None), (2, 3, 2, 0, None), (2, 3, 2, 1, "0"), (4, 4, 1, 1, "0"),
+                                                   (4, 6, 3, 0, None), (2, 5, 4, 0, None), (4, 6, 3, 1, None)])  # n = 36, 30 with data on every knot: the workgroup LDL^T
 def test_lm_batch_matches_host_loop(mbavo, gpu_ctx, monkeypatch, k, N, F, solver, fast):
     """fast = "0" (MBAVO_FAST_SOLVE=0): solver type 0 through the Jacobi solvers only -- n = 24, 36 (three blocks per thread), 12:
     eigenvalue Jacobi; solver type 1 through the pivoted LDL^T only.  Default: LDL^T in registers, refined in double-double above a

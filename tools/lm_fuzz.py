@@ -24,7 +24,9 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 CONFIGS = (("default", {}), ("plain stand-in", {"MBAVO_LM_REFINE": "0"}), ("Jacobi only", {"MBAVO_FAST_SOLVE": "0"}))
-SHAPES = ((4, 4, 1), (2, 3, 2), (2, 2, 1), (4, 6, 2))  # (k, N, F): n = 24, 18, 12, 36 (the last: eigenvalue Jacobi in every configuration)
+# (k, N, F): n = 24, 18, 12 (LDL^T in registers), 36 with a knot without data (singular: Jacobi in every configuration), 36 and 30 with
+# data on every knot (the workgroup LDL^T)
+SHAPES = ((4, 4, 1), (2, 3, 2), (2, 2, 1), (4, 6, 2), (4, 6, 3), (2, 5, 4))
 
 
 def device(dw, k, B):
