@@ -653,7 +653,10 @@ namespace mbavo
         // FMA, two-sum): while cond(A) eps < 1 the iteration contracts by ~cond(A) eps per step onto the correctly rounded
         // solution of the system as given -- the centre of the ball of radius ~cond(A) eps |x| in which the reference's Jacobi
         // SVD (solve_normal_equation.h:10-35; every singular value above Eigen's threshold ~n eps sigma_max: full rank) lands.
-        // Accepted only when the last correction is below 1e-13 |x|_inf; anything else -- a non-positive pivot, a ratio above
+        // Accepted when the error LEFT after a correction d_m is below 1e-13 |x|_inf: the iteration contracts by a fixed factor,
+        // which the first step shows -- the first correction IS the error of the unrefined solution, so rho ~ |d_1| / |x| -- and
+        // the error after step m is ~rho |d_m|; the test is |d_m| min(1, 10 rho) <= 1e-13 |x| (one step suffices up to
+        // |d_1| <= 1e-7 |x|, i.e. cond ~1e9: the cubic spline's systems).  Anything else -- a non-positive pivot, a ratio above
         // max_ratio_refined, no convergence in kRefineSteps -- returns false and the caller takes the Jacobi solver.
         constexpr int kRefineSteps = 4;
         template <int NN, bool REFINE>
@@ -704,6 +707,7 @@ namespace mbavo
                 if (!ok && pos && dmax <= max_ratio_refined * dmin)
                 {
                     const double bi = b[i];
+                    double rho = 1.0;
                     for (int step = 0; step < kRefineSteps && !ok; ++step)
                     {
                         // r_i = b_i - sum_j A_ij x_j as an unevaluated sum hi + lo
@@ -736,7 +740,8 @@ namespace mbavo
                         }
                         xv += dv;
                         const double dn = wmax(lane < NN ? fabs(dv) : 0.0), xn = wmax(lane < NN ? fabs(xv) : 0.0);
-                        ok = dn <= 1e-13 * xn; // (NaN compares false)
+                        if (step == 0) rho = fmin(1.0, 10.0 * dn / xn);
+                        ok = dn * rho <= 1e-13 * xn; // (NaN compares false)
                     }
                 }
             }
@@ -876,6 +881,7 @@ namespace mbavo
                 };
                 double xv = solve(bi);
                 ok = dmax <= max_ratio * dmin;
+                double rho = 1.0;
                 if (!ok && dmax <= max_ratio_refined * dmin)
                     for (int step = 0; step < kRefineSteps && !ok; ++step)
                     {
@@ -904,7 +910,8 @@ namespace mbavo
                         const double dv = solve(hi + lo);
                         xv += dv;
                         const double dn = wmax(lane < n ? fabs(dv) : 0.0), xn = wmax(lane < n ? fabs(xv) : 0.0);
-                        ok = dn <= 1e-13 * xn; // (NaN compares false)
+                        if (step == 0) rho = fmin(1.0, 10.0 * dn / xn);
+                        ok = dn * rho <= 1e-13 * xn; // (NaN compares false)
                     }
                 if (lane < n) x[lane] = xv;
                 if (lane == 0) *flag = ok ? 1 : 0;
