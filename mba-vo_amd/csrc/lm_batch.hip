@@ -59,14 +59,17 @@ namespace mbavo
     }
 
     // The host's view of the loop without a copy or an event in the stream: the last workgroup of a k_lm_solve launch stores
-    // (slot + 1) << 32 | problems done into a pinned host word.  num_done[6] is the launch's ticket counter (zero between launches).
-    __device__ __forceinline__ void slot_publish(int *num_done, unsigned long long *host_word, int slot, int B)
+    // (slot + 1) << 32 | problems done into a pinned host word.
+    // Ticket and done count are ONE 64-bit word (num_done[6..7]; low half: workgroups that have passed, over all launches of the
+    // call; high half: problems done), bumped by one atomic -- the workgroup whose ticket completes (slot + 1) B sees every other
+    // workgroup's contribution in the value the atomic returns: no fence, no second counter read.
+    __device__ __forceinline__ void slot_publish(int *num_done, unsigned long long *host_word, int slot, int B, bool done_now)
     {
         if (!host_word) return;
-        __threadfence();
-        if (atomicAdd(num_done + 6, 1) != B - 1) return;
-        num_done[6] = 0;
-        const unsigned nd = (unsigned)atomicAdd(num_done, 0);
+        unsigned long long *ticket = reinterpret_cast<unsigned long long *>(num_done + 6);
+        const unsigned long long old = atomicAdd(ticket, 1ull + (done_now ? 1ull << 32 : 0ull));
+        if ((unsigned)(old & 0xffffffffull) + 1u != (unsigned)(slot + 1) * (unsigned)B) return;
+        const unsigned nd = (unsigned)(old >> 32) + (done_now ? 1u : 0u);
         __hip_atomic_store(host_word, ((unsigned long long)(slot + 1) << 32) | nd, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 
@@ -90,7 +93,7 @@ namespace mbavo
         LmState s = states[b];
         if (s.done)
         {
-            if (tid == 0) slot_publish(num_done, host_word, slot, B);
+            if (tid == 0) slot_publish(num_done, host_word, slot, B, false);
             return;
         }
 #if defined(MBAVO_EIG_STAMPS) // development aid: where the kernel's time goes (block 0 prints at its end)
@@ -113,6 +116,19 @@ namespace mbavo
 
         if (s.fresh)
         { // the H/g pass at the current point has completed: its cost is the evaluation-point cost
+            // Frame 0's packed entries (1 .. E - 1: g, then the upper triangle of H) for this thread are FETCHED FIRST, together with the
+            // costs, and scattered after the bookkeeping: one memory latency for all of it instead of a dependent chain cost ->
+            // bookkeeping -> g -> H (the kernel is a chain of such round trips: 11 700 of its 37 000 cycles were this merge).
+            constexpr int kEntries = E - 1, kPer = (kEntries + T - 1) / T;
+            const double inv = fs.deferred ? (d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals) : 0.0;
+            const int bf0 = d.bf_base, st0 = start_idx[bf0];
+            double val[kPer];
+#pragma unroll
+            for (int q = 0; q < kPer; ++q)
+            {
+                const int p = 1 + tid + q * T;
+                val[q] = p <= kEntries ? (fs.deferred ? slot_sum(fs, bf0, p) * inv : fs.fb[(size_t)bf0 * E + p]) : 0.0;
+            }
             double cost = 0.0;
             for (int f = 0; f < F; ++f) cost += slot_cost<E>(fs, d.bf_base + f);
             s.eval_cost = cost;
@@ -134,23 +150,34 @@ namespace mbavo
             for (int i = tid; i < n * n; i += T) H[i] = 0.0;
             for (int i = tid; i < n; i += T) g[i] = 0.0;
             __syncthreads();
-            const double inv = fs.deferred ? (d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals) : 0.0;
-            for (int f = 0; f < F; ++f)
+            auto knot_row = [&](int j, int st) { return j < 3 * KD ? 3 * st + j : 3 * (N + st) + (j - 3 * KD); };
+#pragma unroll
+            for (int q = 0; q < kPer; ++q)
+            { // frame 0, from the registers (distinct entries per thread: no two threads add into the same word)
+                const int p = 1 + tid + q * T;
+                if (p <= M6)
+                    g[knot_row(p - 1, st0)] += val[q];
+                else if (p <= kEntries)
+                {
+                    int r, c;
+                    tri_decode(p - ND, M6, r, c);
+                    const int R = knot_row(r, st0), C = knot_row(c, st0);
+                    H[C * n + R] += val[q];
+                    if (R != C) H[R * n + C] += val[q];
+                }
+            }
+            __syncthreads();
+            for (int f = 1; f < F; ++f)
             {
                 const int bf = d.bf_base + f;
                 const double *blk = fs.fb + (size_t)bf * E;
                 const int st = start_idx[bf];
-                for (int j = tid; j < M6; j += T)
-                {
-                    const int gi = j < 3 * KD ? 3 * st + j : 3 * (N + st) + (j - 3 * KD);
-                    g[gi] += fs.deferred ? slot_sum(fs, bf, 1 + j) * inv : blk[1 + j];
-                }
+                for (int j = tid; j < M6; j += T) g[knot_row(j, st)] += fs.deferred ? slot_sum(fs, bf, 1 + j) * inv : blk[1 + j];
                 for (int e = tid; e < M6 * (M6 + 1) / 2; e += T)
                 {
                     int r, c;
                     tri_decode(e, M6, r, c);
-                    const int R = r < 3 * KD ? 3 * st + r : 3 * (N + st) + (r - 3 * KD);
-                    const int C = c < 3 * KD ? 3 * st + c : 3 * (N + st) + (c - 3 * KD);
+                    const int R = knot_row(r, st), C = knot_row(c, st);
                     const double v = fs.deferred ? slot_sum(fs, bf, ND + e) * inv : blk[ND + e];
                     H[C * n + R] += v;
                     if (R != C) H[R * n + C] += v;
@@ -179,8 +206,8 @@ namespace mbavo
             {
                 active[b] = 0;
                 states[b] = s;
-                atomicAdd(num_done, 1);
-                slot_publish(num_done, host_word, slot, B);
+                atomicAdd(num_done, 1); // (what the stream-drain scheme and the final check read)
+                slot_publish(num_done, host_word, slot, B, true);
             }
             // leave the accepted point in the caller's knot buffers
             double *Wt = const_cast<double *>(d.knots_t), *WR = const_cast<double *>(d.knots_R);
@@ -281,7 +308,7 @@ namespace mbavo
             lm_rejected(s);
             trace_push(s, tr, o.trace_cap, tid, 0, 3, 0.0, s.model, 0.0);
             ++s.n_invalid;
-            if (tid == 0) { active[b] = 0; states[b] = s; slot_publish(num_done, host_word, slot, B); }
+            if (tid == 0) { active[b] = 0; states[b] = s; slot_publish(num_done, host_word, slot, B, false); }
             return;
         }
         // computeCandidatePointAndEvaluateCost (:833-883): candidate = current (+) step, into the evaluated buffers
@@ -292,7 +319,7 @@ namespace mbavo
             const Quat q = qmul(load_quat(CR + 4 * i), so3_exp(x + 3 * N + 3 * i)); // Spline.h:317-330, not re-normalised
             WR[4 * i] = q.x; WR[4 * i + 1] = q.y; WR[4 * i + 2] = q.z; WR[4 * i + 3] = q.w;
         }
-        if (tid == 0) { active[b] = 1; states[b] = s; slot_publish(num_done, host_word, slot, B); }
+        if (tid == 0) { active[b] = 1; states[b] = s; slot_publish(num_done, host_word, slot, B, false); }
 #if defined(MBAVO_EIG_STAMPS)
         if (tid == 0 && b == 0)
             printf("k_lm_solve<%d,%d> block 0: merge %lld | damp + store %lld | solve %lld | model + candidate %lld cycles\n", KD, T, ts1 - ts0,
