@@ -341,6 +341,14 @@ namespace mbavo
         LmState s = states[b];
         if (s.done || active[b] == 0) return; // finished, or an invalid step: nothing was evaluated
         mbavo_trace_rec *tr = trace ? trace + (size_t)b * o.trace_cap : nullptr;
+        // the patch costs of frame 0 (up to kPre per lane) are fetched WITH the costs, before the accept test needs either: the
+        // three statistics passes below then run from registers (same order of additions: bit-identical flags)
+        constexpr int kPre = 8;
+        const double *pc = patch_cost + d.patch_base;
+        const bool pre = d.K <= 64 * kPre;
+        double pcv[kPre];
+#pragma unroll
+        for (int q = 0; q < kPre; ++q) pcv[q] = (pre && lane + 64 * q < d.K) ? pc[lane + 64 * q] : 0.0;
         double cost = 0.0;
         for (int f = 0; f < d.F; ++f) cost += slot_cost<E>(fs, d.bf_base + f);
         s.cand_cost = cost;
@@ -348,31 +356,49 @@ namespace mbavo
         s.quality = tr_quality(s, s.cand_cost, s.model);
         if (s.quality > o.min_q && s.cand_cost < s.eval_cost)
         { // isStepSuccessful (:890-894) -> detectOutliersAndUploadToGpu (:639-699): patch costs of frame 0
-            const double *pc = patch_cost + d.patch_base;
             unsigned char *flags = const_cast<unsigned char *>(d.outlier);
-            double sum = 0.0, cnt = 0.0;
-            for (int i = lane; i < d.K; i += 64)
+            double sum = 0.0, cnt = 0.0, var = 0.0, nbad = 0.0;
+            if (pre)
             {
-                const double c = pc[i];
-                if (c < 1e-8) continue;
-                sum += c;
-                cnt += 1.0;
+#pragma unroll
+                for (int q = 0; q < kPre; ++q)
+                    if (lane + 64 * q < d.K && !(pcv[q] < 1e-8)) { sum += pcv[q]; cnt += 1.0; }
             }
+            else
+                for (int i = lane; i < d.K; i += 64)
+                {
+                    const double c = pc[i];
+                    if (c < 1e-8) continue;
+                    sum += c;
+                    cnt += 1.0;
+                }
             sum = wsum(sum);
             cnt = wsum(cnt);
             const double mu = sum / cnt;
-            double var = 0.0;
-            for (int i = lane; i < d.K; i += 64)
+            if (pre)
             {
-                const double c = pc[i];
-                if (c < 1e-8) continue;
-                var += (c - mu) * (c - mu);
+#pragma unroll
+                for (int q = 0; q < kPre; ++q)
+                    if (lane + 64 * q < d.K && !(pcv[q] < 1e-8)) var += (pcv[q] - mu) * (pcv[q] - mu);
             }
+            else
+                for (int i = lane; i < d.K; i += 64)
+                {
+                    const double c = pc[i];
+                    if (c < 1e-8) continue;
+                    var += (c - mu) * (c - mu);
+                }
             var = wsum(var) / cnt;
             const double bound = o.chi * (double)sqrtf((float)var);
-            double nbad = 0.0;
-            for (int i = lane; i < d.K; i += 64)
-                if (fabs(pc[i] - mu) > bound) { flags[i] = 1; nbad += 1.0; }
+            if (pre)
+            {
+#pragma unroll
+                for (int q = 0; q < kPre; ++q)
+                    if (lane + 64 * q < d.K && fabs(pcv[q] - mu) > bound) { flags[lane + 64 * q] = 1; nbad += 1.0; }
+            }
+            else
+                for (int i = lane; i < d.K; i += 64)
+                    if (fabs(pc[i] - mu) > bound) { flags[i] = 1; nbad += 1.0; }
             s.num_bad = (int)wsum(nbad);
             const long long num_residuals = (long long)(d.K - s.num_bad) * d.F * d.P;
             // accept: the candidate becomes the current point, the next pass re-evaluates H/g there
