@@ -128,7 +128,12 @@ int mbavo_merge_hessian_gradient_cost(int F, int spline_deg_k, const double *d_f
 /* the scatter alone, on host blocks (merge_hessian_gradient_cost.cpp:39-86) */
 int mbavo_merge_host(int F, int spline_deg_k, const double *h_frame_blocks, const int *h_start_idx, int N,
                      double *h_total_cost, double *h_H, double *h_g);
-/* solve_normal_equation (ba_tracker/solve_normal_equation.h:10-35): x = -A^+ b; 0 = Jacobi SVD, 1 = LDLT */
+/* solve_normal_equation (ba_tracker/solve_normal_equation.h:10-35): x = -A^+ b; 0 = Jacobi SVD, 1 = LDLT.
+ * Deviation from the reference, on by default: for solver_type 0 a positive definite system whose LDL^T pivot ratio is at
+ * most 1e8 is solved by LDL^T instead of the Jacobi SVD (the same x to rounding x cond(A); the batched LM additionally
+ * refines in double-double up to a ratio of 1e13).  MBAVO_FAST_SOLVE=0 in the environment (read once per
+ * mbavo_solve_normal_equation / mbavo_optimize_trajectory / mbavo_lm_batch call) reproduces solve_normal_equation.h case 0
+ * -- JacobiSVD::solve, minimum-norm least squares -- for every system; rank-deficient systems always take it. */
 int mbavo_solve_normal_equation(const double *h_A_colmajor, const double *h_b, int n, int solver_type, double *h_x);
 
 /* ---- host control flow that decides how often the path runs */

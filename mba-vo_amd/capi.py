@@ -253,6 +253,7 @@ class Context:
         self.lib = load()
         self.handle = vp()
         check(self.lib.mbavo_create(C.byref(self.handle), int(device_id)), "mbavo_create")
+        self.device_id, self.stream = int(device_id), stream  # (None / 0: the null stream)
         if stream is not None:
             check(self.lib.mbavo_set_stream(self.handle, vp(stream)), "mbavo_set_stream")
 

@@ -121,24 +121,6 @@ namespace mbavo
         // (for the launch sequence, a free function template in engine.hip) leaves the finalize to the caller if asked to and possible
         bool take_deferral(bool flat_finalize) { return deferred_last_ = flat_finalize && defer_finalize_; }
 
-        // The WHOLE coarse-to-fine LM loop of one small problem on the device (k_lm_level, round 3): one resident kernel per
-        // pyramid level, enqueued back to back; the workgroup that finishes an evaluation solves, decides and publishes the
-        // next evaluation's inputs in device memory; knots and trace count are carried from level to level on the device;
-        // the host waits once, for the last level's completion word.  `probs`: the levels coarse to fine (d_knots_t / d_knots_R /
-        // d_outlier / num_bad are ignored: the engine owns them), `pyr_level[i]`: the label of level i in the trace records.
-        // Returns 0 (done: knots, final cost and trace written), 1 = not applicable (nothing was enqueued: the caller runs the
-        // host-driven loop), otherwise an error.  Applicable: every level takes the single-launch sample-parallel kernel
-        // (S a power of two in 4 .. 32, fp32 gradients, at least one keypoint, no more tiles than CUs), N <= 4 control knots,
-        // F <= 16 frames, trace_cap <= 4096.
-        struct LmDeviceOpts
-        {
-            int max_it, max_nonmono, solver;
-            double min_q, min_dec, chi, fast_ratio;
-        };
-        int lm_device(int num_levels, const mbavo_problem *probs, const int *pyr_level, int kdeg, const LmDeviceOpts &o,
-                      double *h_knots_t, double *h_knots_R, int N, const int *h_start_idx, int F, double *h_final_cost,
-                      mbavo_trace_rec *h_trace, int trace_cap, int *h_ntrace);
-
         // range status since the previous fetch (call after a stream sync): non-zero if a blur
         // sample's knot segment had to be clamped into [0, N-k]
         int fetch_status();
@@ -233,11 +215,11 @@ namespace mbavo
         int persist_gen_of_[kPushSlots] = {};          // generation of the kernel enqueued on each slot
         int status_seen_ = 0;
         void *h_fb_ = nullptr; size_t cap_hfb_ = 0;
-        static constexpr int kPinnedSlots = 8; // 0-4 host-driven LM loop (tracker.cpp), 5-6 resident LM loop (lm_device)
+        static constexpr int kPinnedSlots = 8; // 0-4 host-driven LM loop (tracker.cpp), 7 lm_batch
         void *pinned_[kPinnedSlots] = {};
         size_t pinned_cap_[kPinnedSlots] = {};
 
-        static constexpr int kSlots = 16; // 0-6 LM loop (tracker.cpp), 8-10 keyframe detection (keyframe_ops.hip), 7 / 11 merge_device, 12-14 lm_device, 15 lm_batch
+        static constexpr int kSlots = 16; // 0-6 LM loop (tracker.cpp), 8-10 keyframe detection (keyframe_ops.hip), 7 / 11 merge_device, 15 lm_batch
         void *slots_[kSlots] = {};
         size_t slot_cap_[kSlots] = {};
 

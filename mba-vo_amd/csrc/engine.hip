@@ -16,7 +16,7 @@
 //     On gfx950 the f64 MFMA issues at the FP64 VALU rate and SHARES that pipe
 //     (tools/micro/mfma_valu_overlap.hip), so it is not a free second engine: what it buys
 //     over per-lane VALU accumulators is registers and instruction count (no cross-wave
-//     barrier, ~95 fewer VGPRs).  -DMBAVO_OUTER_16X16 keeps the earlier padded 16x16x4 tiles.
+//     barrier, ~95 fewer VGPRs).  (The padded 16x16x4 tiles of round 1: history, profiles/r02_kfused_experiments.txt.)
 //   * accumulators live across the whole tile loop and are reduced once per
 //     workgroup in a fixed order -- no atomics.
 #include "engine.h"
@@ -24,16 +24,6 @@
 #include "pixel_math.h"
 #include "se3_math.h"
 #include "timing.h"
-#include "lm_state.h"
-// the one-wave solvers run on wave 0 of the resident LM kernel's leader workgroup: a wave-level fence between their steps
-#define MBAVO_SOLVER_SYNC()                                          \
-    do                                                               \
-    {                                                                \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       \
-        __builtin_amdgcn_wave_barrier();                             \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       \
-    } while (0)
-#include "lm_solvers.h"
 
 #include <algorithm>
 #include <chrono>
@@ -90,9 +80,6 @@ namespace mbavo
     template <int KD>
     __device__ __forceinline__ void store_rotated_column(const Quat &q, const double av[3], int c, PoseEntry<KD> &pe)
     {
-#if defined(MBAVO_A_BODY) // A/B switch: the body-frame table of before (sample_retire must be built with the same switch)
-        for (int a = 0; a < 3; ++a) pe.A[a * 3 * KD + c] = av[a];
-#else
         const double qv[4] = {q.x, q.y, q.z, q.w};
         double R[9];
         rotation_entries(qv, R);
@@ -103,7 +90,6 @@ namespace mbavo
             r += R[3 * b + 2] * av[2];
             pe.A[b * 3 * KD + c] = r;
         }
-#endif
     }
 
     template <int KD, int KNOT>
@@ -270,7 +256,6 @@ namespace mbavo
     // ------------------------------------------------------------------ fused kernel
     typedef double f64x4 __attribute__((ext_vector_type(4)));
 
-#if !defined(MBAVO_OUTER_16X16)
     // Per-wave outer product rows^T * rows on v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 blocks per instruction,
     // ~17 cycles).  The row of ND = 6k + 1 entries is cut into G groups of four (25 -> 7 groups, 13 -> 4; the padding
     // needs no zeros: entry (i, j) of a block depends only on A's row i and B's column j, so whatever a padded lane
@@ -279,7 +264,7 @@ namespace mbavo
     // B = W[(4h + delta) % G], so its block d is group (4h + d) % G times group (4h + d + delta) % G.  delta = 0 .. G/2
     // and h = 0 .. ceil(G/4) - 1 cover every unordered pair of groups (a few block slots repeat a pair and are
     // ignored): k = 4: 8 instructions (~140 cycles) per four pixels against 3 x 66 for the padded 16x16x4 tiles
-    // (MBAVO_OUTER_16X16, the previous scheme), for 7 LDS reads per step instead of 2; 16 accumulator VGPRs instead
+    // (round 1's scheme), for 7 LDS reads per step instead of 2; 16 accumulator VGPRs instead
     // of 24.  The MFMA shares the FP64 pipe with the VALU, so instructions saved here are kernel time saved.
     // (Layout probed in tools/micro/mfma4_probe.hip and mfma4_outer_probe.hip; the cbsz / abid broadcast controls
     // are ignored by this instruction, which rules out a 7-instruction scheme with A broadcast from block 0.)
@@ -332,11 +317,7 @@ namespace mbavo
     struct OuterAcc
     {
         static constexpr int G = (ND + 3) / 4, ND_DELTA = G / 2 + 1, NH = (G + 3) / 4;
-#if defined(MBAVO_NO_TRAIL7) // A/B switch: the rotation scheme for every G (eight instructions for G = 7)
-        static constexpr bool TRAIL7 = false;
-#else
         static constexpr bool TRAIL7 = G == 7;
-#endif
         static constexpr int NI = TRAIL7 ? 7 : ND_DELTA * NH;
         static constexpr int STRIDE = ND;
         static constexpr int ROWS = 64;
@@ -367,7 +348,6 @@ namespace mbavo
 #pragma unroll
                 for (int m = 0; m < G; ++m) base[m] = slab + kq * ND + 4 * ((m + d) % G) + e;
             }
-#if !defined(MBAVO_MFMA_NOT_PIPELINED) // (A/B switch; 1080p S=16 193.2 -> 191.6 us, 512 pairs 95.4 -> 94.6, configs[1] unchanged)
             if constexpr (TRAIL7)
             {
                 if (nsteps == ROWS / 4)
@@ -399,7 +379,6 @@ namespace mbavo
                     return;
                 }
             }
-#endif
 #pragma unroll 4
             for (int step = 0; step < nsteps; ++step)
             {
@@ -454,59 +433,6 @@ namespace mbavo
             return s;
         }
     };
-#else
-    // The previous scheme, kept for A/B runs: v_mfma_f64_16x16x4_f64 (25 entries padded to 2 x 16 -> three 16x16
-    // tiles, 24 accumulator VGPRs; the padded tiles do 2.4x the useful flops on the FP64 pipe the VALU shares).
-    template <int ND>
-    struct OuterAcc
-    {
-        static constexpr int HALVES = ND > 16 ? 2 : 1;
-        static constexpr int STRIDE = ND;
-        static constexpr int ROWS = 64;
-        static constexpr int SLAB = ROWS * ND > 768 ? ROWS * ND : 768;
-        f64x4 t00, t01, t11;
-        __device__ __forceinline__ void init(int) { t00 = f64x4{0, 0, 0, 0}; t01 = t00; t11 = t00; }
-        __device__ __forceinline__ void accumulate(const double *slab, int lane, int nsteps = ROWS / 4)
-        {
-            const int col = lane & 15, kq = lane >> 4;
-            const bool has1 = HALVES == 2 && (16 + col) < ND;
-#pragma unroll 4
-            for (int step = 0; step < nsteps; ++step)
-            {
-                const double *r = slab + (4 * step + kq) * ND;
-                const double a0 = col < ND ? r[col] : 0.0;
-                t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, t00, 0, 0, 0);
-                if (HALVES == 2)
-                {
-                    const double a1 = has1 ? r[16 + col] : 0.0;
-                    t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a1, t01, 0, 0, 0);
-                    t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, t11, 0, 0, 0);
-                }
-            }
-        }
-        __device__ __forceinline__ void store(double *dst, int lane) const
-        {
-            const int col = lane & 15, kq = lane >> 4;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg)
-            {
-                const int row = kq + 4 * reg;
-                dst[0 * 256 + row * 16 + col] = t00[reg];
-                if (HALVES == 2) { dst[1 * 256 + row * 16 + col] = t01[reg]; dst[2 * 256 + row * 16 + col] = t11[reg]; }
-            }
-        }
-        // sum of element (i, j), i <= j, over the waves' parked tiles
-        static __device__ __forceinline__ double gather(const double *rows, int i, int j, int nwaves)
-        {
-            const int t = (i >= 16 ? 2 : (j >= 16 ? 1 : 0));
-            const int off = t * 256 + (i & 15) * 16 + (j & 15);
-            double s = 0.0;
-            for (int wv = 0; wv < nwaves; ++wv) s += rows[wv * SLAB + off];
-            return s;
-        }
-    };
-
-#endif
 
     // Device-scope, cache-bypassing accesses (global_load / global_store ... sc1): a store is written through to memory, a load
     // is served from there -- what one workgroup hands to a workgroup on another CU / XCD without a cache-wide fence on either side
@@ -758,17 +684,12 @@ namespace mbavo
 #ifndef MBAVO_SP_REM_MOD
 #define MBAVO_SP_REM_MOD 256 // (kThreads: the remainder beyond the last FULL round only, the scheme before)
 #endif
-#if defined(MBAVO_MIN_WAVES_EU) // experiments with several smaller workgroups per CU: keep the 3-waves-per-SIMD register budget
-#define MBAVO_FUSED_OCC __attribute__((amdgpu_waves_per_eu(MBAVO_MIN_WAVES_EU)))
-#else
-#define MBAVO_FUSED_OCC
-#endif
     // POSE: no pose kernel ahead of this one -- every workgroup computes ITS frame's S table entries itself (the two stages of
     // k_pose_table, segments in the not-yet-used row slabs) into its own S entries of `table_w`, which the host passes as
     // `table` too: the sample loop needs the entries behind wave-uniform SCALAR loads from read-only memory (through LDS it
     // was 1.5x slower), so they go out through the L2 and come back through the scalar cache.
     template <int KD, bool WITH_J, int HALF_GRAD, bool POSE = false> // HALF_GRAD: 0 float pairs, 1 IEEE half pairs, 2 packed keyframe words
-    __global__ __launch_bounds__((waves_of<KD, WITH_J>() * 64)) MBAVO_FUSED_OCC void k_fused(const ProblemDesc *__restrict__ descs,
+    __global__ __launch_bounds__((waves_of<KD, WITH_J>() * 64)) void k_fused(const ProblemDesc *__restrict__ descs,
                                                         const TileDesc *__restrict__ tiles,
                                                         const PoseEntry<KD> *__restrict__ table,
                                                         double *__restrict__ rho_out,
@@ -813,17 +734,6 @@ namespace mbavo
         // The frame's S table entries are read with wave-uniform addresses -> scalar loads.  (Staging the table
         // in LDS and reading it as a broadcast was measured 1.5x SLOWER on the fused kernel: one ds_read per FMA
         // operand instead of an SGPR operand.)
-#if defined(MBAVO_EXP_LDS_TABLE) // experiment: table staged in LDS and read as a broadcast
-        PoseEntry<KD> *ltab = (PoseEntry<KD> *)(red + 2 * kWavesPerGroup);
-        {
-            const MBAVO_GLOBAL double *src = (const MBAVO_GLOBAL double *)(table + d.pose_base + frame * S);
-            double *dst = (double *)ltab;
-            const int n = S * (int)(sizeof(PoseEntry<KD>) / sizeof(double));
-            for (int i = threadIdx.x; i < n; i += kThreads) dst[i] = src[i];
-        }
-        __syncthreads();
-        const PoseEntry<KD> *__restrict__ ftab = ltab;
-#else
         long long tab_off = d.pose_base + frame * S;
         if constexpr (POSE)
         {
@@ -861,7 +771,6 @@ namespace mbavo
             for (int l = wave; l < nlines; l += kWavesPerGroup) warm += tb[l * 8];
             if (warm == 1.2345678e301) red[0] = warm; // never true: keeps the loads alive
         }
-#endif
         const PoseEntry<KD> &mid = ftab[S / 2]; // patch centres use sample S/2 (compute_local_patches_xy.cu:26)
         const unsigned char *__restrict__ I_cur = (const unsigned char *)uniform_u64((unsigned long long)d.cur_imgs[frame]);
         const long long pix0 = d.pixel_base + ((long long)frame * K + tile.kp_begin) * P;
@@ -900,11 +809,7 @@ namespace mbavo
         if (sp_ok)
         {
             // S >= 8: two samples per lane (S / 2 lanes per pixel), see sp_round_rt
-#if defined(MBAVO_SP_MS1)
-            const int ms = 1;
-#else
             const int ms = sp_logs >= 3 ? 2 : 1;
-#endif
             const int lane_logs = sp_logs - (ms == 2 ? 1 : 0);
             // The lane-per-pixel rounds take a multiple of 256 pixels (the same number of 64-pixel chunks on each of the four
             // SIMDs; the last of these rounds may be a partial one), the pixels beyond go sample-parallel.
@@ -937,10 +842,6 @@ namespace mbavo
                         switch (sp_logs)
                         {
                         case 2: MBAVO_SP_ROUND(2, 1); break;
-#if defined(MBAVO_SP_MS1)
-                        case 3: MBAVO_SP_ROUND(3, 1); break;
-                        case 4: MBAVO_SP_ROUND(4, 1); break;
-#endif
                         default: MBAVO_SP_ROUND(-1, 1); break;
                         }
 #undef MBAVO_SP_ROUND
@@ -973,18 +874,12 @@ namespace mbavo
                 const double kx = d.kp_xy[(size_t)kp * d.kp_stride], ky = d.kp_xy[(size_t)kp * d.kp_stride + 1];
                 const double kz = d.kp_z[kp];
                 double pcx, pcy;
-#if defined(MBAVO_EXP_NO_CENTRE) // timing experiment switch
-                pcx = kx + mid.t[0]; pcy = ky + mid.t[1];
-#elif defined(MBAVO_CENTRE_EXACT) // A/B switch: the reference's operation order for every pixel
-                patch_centre_rt(mid.rt, mid.q, kx, ky, kz, cam, pcx, pcy);
-#else
                 // The pixel is (int)(centre + pattern offset): the cheap centre is good wherever that sum is not within
                 // 1e-5 of an integer; if ANY lane of the wave is (zero motion: all of them), the wave takes the reference's
                 // operation order -- a uniform branch, never taken on moving cameras (2e-5 of the pixels per axis).
                 patch_centre_fast(mid.rt, mid.R, kx, ky, kz, cam, inv_fx, inv_fy, pcx, pcy);
                 const bool unsure = !(patch_centre_sure(pcx + d.pattern[2 * pp]) && patch_centre_sure(pcy + d.pattern[2 * pp + 1]));
                 if (__builtin_amdgcn_ballot_w64(unsure) != 0) patch_centre_rt(mid.rt, mid.q, kx, ky, kz, cam, pcx, pcy);
-#endif
                 // Wave priority by remaining work (see below the round loop's head): the sample loop of a wave that is
                 // behind goes first, the row parking + MFMA phase one step lower.
                 const int rem_rounds = (main_end - base + kThreads - 1) / kThreads; // 1 in the last round
@@ -1038,9 +933,6 @@ namespace mbavo
             }
         }
 
-#if defined(MBAVO_EXP_NO_TAIL) // timing experiment: no end-of-tile work
-        if (npx >= 0) return;
-#endif
         MBAVO_WSTAMP(1, __builtin_amdgcn_s_memrealtime());
         MBAVO_FSTAMP(3); // (wave 0's own rounds are done; the barrier below waits for the slowest wave)
         // per-patch cost = slot 0 of the reference's patch block (:232-238), and the
@@ -1119,9 +1011,6 @@ namespace mbavo
         unsigned long long *host_flag;           // pinned host word, or null: set to `seq` when every slot is done
         unsigned long long seq;
         int nbf;
-        int lm;                                  // resident LM kernel (k_lm_level): the slots finished in this evaluation are counted,
-                                                 // every slot's frame block is released device-wide, and ticket_finalize tells its
-                                                 // caller whether THIS workgroup finished the evaluation's last slot
         unsigned long long t_seen;               // (timing experiment MBAVO_PERSIST_STAMPS)
     };
 
@@ -1201,20 +1090,16 @@ namespace mbavo
         // takes the ticket; the last workgroup acquires.  A device-scope fence by all 768 threads costs 9 us here (measured).
         // Round 3 tried the hand-over WITHOUT the two cache-wide fences (partials stored and loaded with sc1 accesses, vmcnt(0),
         // ticket): 27 parity tests failed and trackFrame was no longer reproducible run to run -- and it was not faster
-        // (0.384 vs 0.376 ms per frame; profiles/r03_kfused_experiments.txt 4.).  -DMBAVO_NO_TICKET_FENCES rebuilds that form.
+        // (0.384 vs 0.376 ms per frame; profiles/r03_kfused_experiments.txt 4.).
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0)
         {
-#if !defined(MBAVO_NO_TICKET_FENCES)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
             const int n = oa.bf_tile_begin[bf + 1] - oa.bf_tile_begin[bf];
             const int last = atomicAdd(&oa.tickets[bf], 1) == n - 1 ? 1 : 0;
-#if !defined(MBAVO_NO_TICKET_FENCES)
             if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the other workgroups' partials (other XCDs' L2s) are read from memory
-#endif
             s_last = last;
         }
         __syncthreads();
@@ -1258,7 +1143,7 @@ namespace mbavo
         // the frame block (pinned host memory) must land before the completion word does: every wave's stores are performed
         // at workgroup scope before the barrier, ONE thread then fences at system scope (a system-scope fence by all 768
         // threads was 3 of the 4.8 us this epilogue took inside the persistent kernel)
-        if (to_host || oa.lm)
+        if (to_host)
         {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave's frame-block stores are acknowledged
@@ -1266,48 +1151,16 @@ namespace mbavo
         __syncthreads();
         if (threadIdx.x == 0)
         {
-            if (oa.lm)
-            { // the slot's frame block (device memory) is released device-wide before the slot counts as finished; the workgroup
-              // that finishes the LAST slot acquires the others' and goes on as the evaluation's leader (lm_leader)
-                __hip_atomic_store(&oa.tickets[bf], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int fin = 1; // one slot (one frame): its last workgroup IS the leader and reads its own block back through the L2
-                if (oa.nbf > 1)
-                {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    fin = atomicAdd(oa.slots_done, 1) == oa.nbf - 1 ? 1 : 0;
-                    if (fin)
-                    {
-                        __hip_atomic_store(oa.slots_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    }
-                }
-                s_last = 1 + fin;
-            }
-            else
-            {
             __hip_atomic_store(&oa.tickets[bf], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next evaluation
             if (to_host) __threadfence_system(); // THIS slot's frame block is on its way to the host before the slot counts as done
             // (one slot -- one frame, the tracker's case -- needs no count: a device-memory round trip less before the word)
             if (to_host && (oa.nbf == 1 || atomicAdd(oa.slots_done, 1) == oa.nbf - 1))
             {
                 if (oa.nbf > 1) __hip_atomic_store(oa.slots_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if defined(MBAVO_PERSIST_STAMPS) // timing experiment: when this workgroup saw the command / finished (100 MHz ticks)
-                oa.host_flag[1] = __builtin_amdgcn_s_memrealtime();
-                oa.host_flag[2] = oa.t_seen;
-                for (int i = 0; i < 4; ++i) oa.host_flag[3 + i] = stamp_area()[i];
-                __threadfence_system();
-#endif
                 __hip_atomic_store(oa.host_flag, oa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (ordered by the fence above)
             }
-            }
         }
-        if (oa.lm)
-        {
-            __syncthreads();
-            return s_last == 2;
-        }
-        return false;
+        return true;
     }
 
     // ------------------------------------------------------------------ fused kernel, sample-parallel variant
@@ -1383,11 +1236,9 @@ namespace mbavo
         const PoseEntry<KD> *__restrict__ ftab = table + d.pose_base + frame * S; // S == SS (checked by the host)
         if constexpr (ONE)
         {
-#if !defined(MBAVO_EXP_ONE_NOPOSE) // timing experiment: entries left uninitialised
             SplineSeg *segs = (SplineSeg *)(WITH_J ? rows : stage + SS * (int)(sizeof(PoseEntry<KD>) / sizeof(double)));
             frame_pose_entries<KD, WITH_J>(d, PERSIST ? knots_t_fresh : d.knots_t, PERSIST ? knots_R_fresh : d.knots_R, frame,
                                            (PoseEntry<KD> *)stage, segs, wave, lane, oa.status, tile.kp_begin == 0);
-#endif
             __syncthreads();
             MBAVO_STAMP(0);
         }
@@ -1565,11 +1416,7 @@ namespace mbavo
         if (WITH_J) acc.store(slab, lane);
         __syncthreads();
         double *out = partials + (size_t)tile_id * PS;
-#if defined(MBAVO_NO_TICKET_FENCES)
-        auto put = [&](int e, double v) { if constexpr (ONE) st_fresh(out + e, v); else out[e] = v; };
-#else
         auto put = [&](int e, double v) { out[e] = v; };
-#endif
         if (threadIdx.x == 0)
         {
             double c = 0.0, v = 0.0;
@@ -1592,9 +1439,7 @@ namespace mbavo
             // or the kernel's epilogue area when there are none
             double *scratch = WITH_J ? rows : stage + SS * (int)(sizeof(PoseEntry<KD>) / sizeof(double));
             MBAVO_STAMP(1);
-#if !defined(MBAVO_EXP_ONE_NOTICKET) // timing experiment: no finalize at all
             return ticket_finalize<KD, WITH_J, kThreads>(d, d.bf_base + frame, partials, oa, scratch, inv);
-#endif
         }
         return false;
     }
@@ -1654,7 +1499,7 @@ namespace mbavo
         {
             if (threadIdx.x == 0)
             {
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned long long q;
                 int m = 0, pr = 0;
                 for (;;)
@@ -1668,6 +1513,7 @@ namespace mbavo
                         if ((int)((w >> 8) & 0xfff) != (gen & 0xfff)) m = 0;
                         if (m == 0 || pr == my_prob) break;
                         last_seq = q; // another problem's evaluation: not for this workgroup
+                        t0 = __builtin_amdgcn_s_memrealtime(); // ... but the host is alive: the give-up timer starts over
                     }
                     if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { m = 0; break; } // ~2 s: give up
                     __builtin_amdgcn_s_sleep(MBAVO_PERSIST_SLEEP);
@@ -1703,386 +1549,6 @@ namespace mbavo
         }
     }
 
-
-    // ------------------------------------------------------------------ resident LM loop of one pyramid level (round 3)
-    // optimizePyramidLevel (ba_tracker/blur_aware_direct_tracker.cpp:590-637) for ONE small problem entirely on the device:
-    // the level's workgroups stay resident as in k_sp_persist, but the commands come from the workgroup that FINISHES an
-    // evaluation (the one that draws the last ticket of the last slot -- the "leader" of that evaluation): its wave 0 does
-    // what the host did between two evaluations -- merge (merge_hessian_gradient_cost.cpp:39-86), damping, solve
-    // (solve_normal_equation.h:10-35), model change, candidate knots (Spline.h:307-330), step quality and accept / reject
-    // (:890-924), outlier statistics (:639-699), LM radius and step-evaluator updates -- and publishes the next evaluation's
-    // knots, residual scale, outlier flags and mode in DEVICE memory, which the other workgroups poll.  The host launches the
-    // levels' kernels back to back (the knots and the trace count are carried from level to level in device memory) and
-    // waits ONCE per tracked frame for the last level's completion word; no PCIe round trip per evaluation (4.4 us of a
-    // 14.4 us evaluation) and no host wake-ups.
-    // Hand-over rules (MI355X: per-XCD L2s, a CU's L1 is never refreshed by other CUs' stores): tile partials, frame blocks
-    // and patch costs go leader-wards as plain stores + agent-scope release / ticket / agent-scope acquire (ticket_finalize);
-    // everything a leader publishes or leaves for the next leader (knots, scale, flag words, LmState, H, g) is written AND
-    // read with 8- / 4-byte agent-scope atomics (write-through stores, cache-bypassing loads), ordered by vmcnt(0) before
-    // the mode and the sequence word -- no cache-wide fence on the command path.
-    struct LmLevelArgs
-    {
-        unsigned long long *seq;   // phase counter, bumped by every leader AFTER everything else of its command is out
-        int *mode;                 // next phase: 0 = exit, 1 = cost-only pass at eval_knots, 2 = H/g pass
-        double *inv;               // 1 / ((K - bad) F P)                 (ProblemDesc::inv_ptr points here)
-        double *eval_knots;        // [7 N] knots of the next evaluation   (t (3N) | R (4N))
-        unsigned *flag_words;      // outlier flags, 4 keypoints per word  (ProblemDesc::outlier points here)
-        unsigned long long *state; // LmState as 8-byte words: leader to leader
-        double *H, *g;             // damped system (n x n, column-major) and gradient: leader to leader
-        double *cur_knots;         // [7 N] accepted point; carried from level to level (the first evaluation's knots)
-        int *carry_ntrace;         // trace records written by the coarser levels
-        const int *start_idx;      // [F] knot segment of every frame
-        double *frame_blocks;      // [F E] finalize output (device)
-        const double *patch_cost;  // [F K] per-patch costs of the last evaluation (device)
-        mbavo_trace_rec *trace;    // pinned host memory, `o.trace_cap` records
-        double *host_out;          // pinned host memory, LAST level only (else null): [knots 7N | final cost | ntrace | status]
-        unsigned long long *host_flag; unsigned long long host_seq; // completion word of the last level
-        LmOpts o;
-        int level, N, F, K, P;
-        unsigned long long *stamps; // (timing experiment MBAVO_LM_STAMPS) [last publish | sum evaluation | sum leader | phases | first entry], 100 MHz ticks
-    };
-
-
-    // wave 0 of the leader workgroup, all 64 lanes.  mode_done: the evaluation that has just completed (2 = H/g, 1 = cost).
-    // (a real call, its arguments behind one pointer: inlined into the resident kernel it drove that kernel to 56-113 vector
-    // spills and ~300 scalar spills -- the tile body runs at the 256-register budget of two waves per SIMD already)
-#if defined(MBAVO_LM_LEADER_INLINE)
-#define MBAVO_LM_LEADER_FN __device__ __forceinline__
-#else
-#define MBAVO_LM_LEADER_FN __device__ __noinline__
-#endif
-    template <int KD>
-    MBAVO_LM_LEADER_FN void lm_leader(const LmLevelArgs *__restrict__ ap, int mode_done, unsigned long long seq_now, double *lds, int lane)
-    {
-        const LmLevelArgs &a = *ap;
-#if defined(MBAVO_LM_STAMPS)
-        const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
-        unsigned long long t_seg[5] = {t_in, t_in, t_in, t_in, t_in};
-#define MBAVO_LM_SEG(i) t_seg[i] = __builtin_amdgcn_s_memrealtime()
-#else
-#define MBAVO_LM_SEG(i) do { } while (0)
-#endif
-        constexpr int M6 = 6 * KD, ND = M6 + 1, E = ND * (ND + 1) / 2;
-        const int N = a.N, n = 6 * N, F = a.F, ld = n + 1;
-        // LDS (the tile's row slabs are free now): H | g | x | tmp | y | order | G (also the LDL^T work copy) | V
-        double *H = lds, *g = H + n * n, *x = g + n, *tmp = x + n, *y = tmp + n;
-        int *order = (int *)(y + n);
-        double *G = y + n + (n + 1) / 2 + 1, *V = G + n * ld;
-        const LmOpts &o = a.o;
-        LmState s;
-        {
-            unsigned long long *w = (unsigned long long *)&s;
-#pragma unroll
-            for (int i = 0; i < (int)(sizeof(LmState) / 8); ++i) w[i] = __hip_atomic_load(a.state + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (s.ntrace < 0) s.ntrace = *a.carry_ntrace; // first leader of the level: the coarser levels' count (kernel boundary)
-        const double *fb = a.frame_blocks; // (cache-bypassing loads: the blocks were stored by this or by other workgroups)
-        double cost = 0.0;
-        for (int f = 0; f < F; ++f) cost += ld_fresh(fb + (size_t)f * E);
-        int next_mode = -1;
-        bool solve = false;
-        MBAVO_LM_SEG(1); // state and cost loaded
-        if (mode_done == 2)
-        { // the H/g pass at the current point has completed: its cost is the evaluation-point cost
-            s.eval_cost = cost;
-            if (s.pending_accept)
-            { // handleSuccessfulStep (:896-903)
-                lm_accepted(s, s.quality);
-                tr_accepted(s, s.eval_cost, s.model, o.max_nonmono);
-                trace_push(s, a.trace, o.trace_cap, lane, a.level, 1, s.cand_cost, s.model, s.quality);
-                ++s.n_accept;
-            }
-            else
-            { // iteration 0 of the level (:590-606)
-                s.initial_cost = cost;
-                lm_reset(s);
-                tr_reset(s, cost);
-                trace_push(s, a.trace, o.trace_cap, lane, a.level, 0, 0.0, 0.0, 0.0);
-            }
-            // merge_hessian_gradient_cost.cpp:39-86, frames in order
-            for (int i = lane; i < n * n; i += 64) H[i] = 0.0;
-            for (int i = lane; i < n; i += 64) g[i] = 0.0;
-            MBAVO_SOLVER_SYNC();
-            for (int f = 0; f < F; ++f)
-            {
-                const double *blk = fb + (size_t)f * E;
-                const int st = a.start_idx[f];
-                for (int j = lane; j < M6; j += 64)
-                {
-                    const int gi = j < 3 * KD ? 3 * st + j : 3 * (N + st) + (j - 3 * KD);
-                    g[gi] += ld_fresh(blk + 1 + j);
-                }
-                for (int e = lane; e < M6 * (M6 + 1) / 2; e += 64)
-                {
-                    int r, c;
-                    tri_decode(e, M6, r, c);
-                    const int R = r < 3 * KD ? 3 * st + r : 3 * (N + st) + (r - 3 * KD);
-                    const int C = c < 3 * KD ? 3 * st + c : 3 * (N + st) + (c - 3 * KD);
-                    const double v = ld_fresh(blk + ND + e);
-                    H[C * n + R] += v;
-                    if (R != C) H[R * n + C] += v;
-                }
-                MBAVO_SOLVER_SYNC();
-            }
-            for (int i = lane; i < n; i += 64) st_fresh(a.g + i, g[i]);
-            s.fresh = 0;
-            s.pending_accept = 0;
-            solve = true;
-        }
-        else
-        { // the cost-only pass at the candidate: step quality, accept / reject (k_lm_decide)
-            s.cand_cost = cost;
-            s.abs_dec = s.eval_cost - s.cand_cost; // recorded before the accept test (:624)
-            s.quality = tr_quality(s, s.cand_cost, s.model);
-            if (s.quality > o.min_q && s.cand_cost < s.eval_cost)
-            { // isStepSuccessful (:890-894) -> detectOutliersAndUploadToGpu (:639-699): patch costs of frame 0
-                const double *pc = a.patch_cost;
-                const int K = a.K;
-                double sum = 0.0, cnt = 0.0;
-                for (int i = lane; i < K; i += 64)
-                {
-                    const double c = pc[i];
-                    if (c < 1e-8) continue;
-                    sum += c;
-                    cnt += 1.0;
-                }
-                sum = wsum(sum);
-                cnt = wsum(cnt);
-                const double mu = sum / cnt;
-                double var = 0.0;
-                for (int i = lane; i < K; i += 64)
-                {
-                    const double c = pc[i];
-                    if (c < 1e-8) continue;
-                    var += (c - mu) * (c - mu);
-                }
-                var = wsum(var) / cnt;
-                const double bound = o.chi * (double)sqrtf((float)var);
-                double nbad = 0.0;
-                for (int w0 = lane; w0 * 4 < K; w0 += 64)
-                { // four keypoints per flag word; flags are only ever set within a level (:686-693)
-                    unsigned word = __hip_atomic_load(a.flag_words + w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), add = 0;
-                    for (int j = 0; j < 4; ++j)
-                    {
-                        const int i = 4 * w0 + j;
-                        if (i < K && fabs(pc[i] - mu) > bound) { add |= 1u << (8 * j); nbad += 1.0; }
-                    }
-                    if (add) __hip_atomic_store(a.flag_words + w0, (word & 0xfefefefeu) | add | (word & 0x01010101u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                s.num_bad = (int)wsum(nbad);
-                const long long num_residuals = (long long)(K - s.num_bad) * F * a.P;
-                if (lane == 0) st_fresh(a.inv, num_residuals > 0 ? 1.0 / (double)num_residuals : 0.0);
-                // accept: the candidate (= the knots just evaluated) becomes the current point, the next pass re-evaluates H/g there
-                for (int i = lane; i < 7 * N; i += 64) st_fresh(a.cur_knots + i, ld_fresh(a.eval_knots + i));
-                s.fresh = 1;
-                s.pending_accept = 1;
-                next_mode = 2;
-            }
-            else
-            {
-                lm_rejected(s); // handleUnsuccessfulStep
-                trace_push(s, a.trace, o.trace_cap, lane, a.level, 2, s.cand_cost, s.model, s.quality);
-                ++s.n_reject;
-                for (int i = lane; i < n * n; i += 64) H[i] = ld_fresh(a.H + i);
-                for (int i = lane; i < n; i += 64) g[i] = ld_fresh(a.g + i);
-                MBAVO_SOLVER_SYNC();
-                solve = true;
-            }
-        }
-        bool damped = false;
-        MBAVO_LM_SEG(2); // merged / decided
-        while (solve)
-        {
-            // finalizeIterationAndCheckIfMinimizerCanContinue (:910-924)
-            ++s.iter;
-            if (s.iter > o.max_it || s.abs_dec < o.min_dec)
-            {
-                s.done = 1;
-                --s.iter;
-                next_mode = 0;
-                break;
-            }
-            // computeTrustRegionStep (:799-831): the damping is applied in place and accumulates over rejected steps
-            const double iradius = 1. / s.radius;
-            for (int i = lane; i < n; i += 64) H[i * n + i] = H[i * n + i] + H[i * n + i] * iradius;
-            damped = true;
-            MBAVO_SOLVER_SYNC();
-            bool have = false;
-            if (o.solver == 0 && o.fast_ratio > 0.0)
-            { // LDL^T in registers stands in for the Jacobi SVD when every pivot is positive and the pivot ratio small
-              // (host_math.cpp:solve_spd_fast is the host loop's twin)
-                if (n == 12) have = spd_solve_regs<12>(H, g, x, lane, o.fast_ratio);
-                else if (n == 18) have = spd_solve_regs<18>(H, g, x, lane, o.fast_ratio);
-                else if (n == 24) have = spd_solve_regs<24>(H, g, x, lane, o.fast_ratio);
-                MBAVO_SOLVER_SYNC();
-            }
-            else if (o.solver == 1)
-            { // pivoted LDL^T (solve_normal_equation.h:27-30)
-                for (int i = lane; i < n * n; i += 64) G[i] = H[i];
-                MBAVO_SOLVER_SYNC();
-                ldlt_solve(G, g, x, y, order, n, lane);
-                have = true;
-            }
-            if (!have)
-            {
-                for (int i = lane; i < n * n; i += 64) G[(i / n) * ld + i % n] = H[i];
-                MBAVO_SOLVER_SYNC();
-                svd_solve(G, V, g, x, tmp, n, ld, lane);
-            }
-            for (int i = lane; i < n; i += 64) x[i] = -x[i];
-            MBAVO_SOLVER_SYNC();
-            double gx = 0.0, xHx = 0.0;
-            for (int r = lane; r < n; r += 64)
-            {
-                gx += g[r] * x[r];
-                double acc = 0.0;
-                for (int c = 0; c < n; ++c) acc += H[c * n + r] * x[c];
-                xHx += x[r] * acc;
-            }
-            gx = wsum(gx);
-            xHx = wsum(xHx);
-            s.model = -(gx + 0.5 * xHx);
-            if (s.model < 0)
-            { // handleInvalidStep
-                lm_rejected(s);
-                trace_push(s, a.trace, o.trace_cap, lane, a.level, 3, 0.0, s.model, 0.0);
-                ++s.n_invalid;
-                continue;
-            }
-            // computeCandidatePointAndEvaluateCost (:833-883): candidate = current (+) step
-            for (int i = lane; i < 3 * N; i += 64) st_fresh(a.eval_knots + i, ld_fresh(a.cur_knots + i) + x[i]);
-            for (int i = lane; i < N; i += 64)
-            {
-                const double *cr = a.cur_knots + 3 * N + 4 * i;
-                const Quat c0{ld_fresh(cr), ld_fresh(cr + 1), ld_fresh(cr + 2), ld_fresh(cr + 3)};
-                const Quat q = qmul(c0, so3_exp(x + 3 * N + 3 * i)); // Spline.h:317-330, not re-normalised
-                double *wr = a.eval_knots + 3 * N + 4 * i;
-                st_fresh(wr, q.x); st_fresh(wr + 1, q.y); st_fresh(wr + 2, q.z); st_fresh(wr + 3, q.w);
-            }
-            next_mode = 1;
-            break;
-        }
-        MBAVO_LM_SEG(3); // solved
-        if (damped && next_mode == 1) // (the next leader re-damps and re-solves only after a rejected candidate)
-            for (int i = lane; i < n * n; i += 64) st_fresh(a.H + i, H[i]);
-        {
-            const unsigned long long *w = (const unsigned long long *)&s;
-            if (lane < (int)(sizeof(LmState) / 8)) __hip_atomic_store(a.state + lane, w[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (next_mode == 0)
-        { // the level is over: the accepted point stays in cur_knots for the next level; the last level reports to the host
-            if (lane == 0) __hip_atomic_store(a.carry_ntrace, s.ntrace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (a.host_out)
-            {
-                for (int i = lane; i < 7 * N; i += 64) a.host_out[i] = ld_fresh(a.cur_knots + i);
-                if (lane == 0)
-                {
-                    a.host_out[7 * N] = s.eval_cost;
-                    a.host_out[7 * N + 1] = (double)s.ntrace;
-                    a.host_out[7 * N + 2] = 1.0;
-                }
-            }
-        }
-#if defined(MBAVO_LM_STAMPS)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        MBAVO_LM_SEG(4); // state / H / outputs stored and acknowledged
-        if (lane == 0)
-        {
-            unsigned long long st[12];
-            for (int i = 0; i < 12; ++i) st[i] = __hip_atomic_load(a.stamps + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long t_out = __builtin_amdgcn_s_memrealtime();
-            if (st[0]) st[1] += t_in - st[0]; else st[4] = t_in;
-            st[2] += t_out - t_in;
-            st[3] += 1;
-            st[0] = t_out;
-            for (int i = 0; i < 4; ++i) st[5 + i] += t_seg[i + 1] - t_seg[i];
-            if (mode_done == 2) { st[9] += t_out - t_in; st[10] += 1; }
-            for (int i = 0; i < 12; ++i) __hip_atomic_store(a.stamps + i, st[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (next_mode == 0 && a.host_out)
-            {
-                a.host_out[7 * N + 3] = (double)st[1] * 0.01;
-                a.host_out[7 * N + 4] = (double)st[2] * 0.01;
-                a.host_out[7 * N + 5] = (double)st[3];
-                a.host_out[7 * N + 6] = (double)(t_out - st[4]) * 0.01;
-                for (int i = 0; i < 6; ++i) a.host_out[7 * N + 7 + i] = (double)st[5 + i] * (i == 5 ? 1.0 : 0.01);
-            }
-        }
-#endif
-        // everything of this command is out (write-through stores acknowledged, and -- belt and braces after the ticket experiment
-        // of profiles/r03_kfused_experiments.txt 4. -- an agent-scope release) before the mode, the mode before the sequence word
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0)
-        {
-            __hip_atomic_store(a.mode, next_mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(a.seq, seq_now + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (next_mode == 0 && a.host_flag)
-            {
-                __threadfence_system(); // host_out and the trace records (pinned host memory) ahead of the completion word
-                __hip_atomic_store(a.host_flag, a.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
-
-    template <int KD, int LOGS>
-    __global__ __launch_bounds__((kSpWaves * 64)) void k_lm_level(const ProblemDesc *__restrict__ descs, const TileDesc *__restrict__ tiles,
-                                                                double *__restrict__ rho_out, double *__restrict__ patch_cost,
-                                                                double *__restrict__ partials, OneArgs oa,
-                                                                const LmLevelArgs *__restrict__ ap)
-    {
-        extern __shared__ __attribute__((aligned(16))) double lds[];
-        __shared__ unsigned long long s_seq;
-        __shared__ int s_mode;
-        __shared__ double knots_lds[7 * 16];
-        unsigned long long last_seq = 0; // (the control block's sequence word starts at 0: the first evaluation needs no command)
-        int mode = 2;
-        const int N = ap->N;
-        for (bool first = true;; first = false)
-        {
-            if (!first)
-            {
-                if (threadIdx.x == 0)
-                {
-                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                    unsigned long long q;
-                    int m = 0;
-                    for (;;)
-                    {
-                        q = __hip_atomic_load(ap->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (q != last_seq)
-                        {
-                            m = __hip_atomic_load(ap->mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) { m = 0; break; } // ~1 s without a command: give up
-                        __builtin_amdgcn_s_sleep(MBAVO_PERSIST_SLEEP);
-                    }
-                    s_seq = q;
-                    s_mode = m;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // ONE poll, ONE acquire: the leader's command is visible
-                }
-                __syncthreads();
-                mode = s_mode;
-                last_seq = s_seq;
-                if (mode == 0) return;
-                asm volatile("" ::: "memory");
-            }
-            double *kn = knots_lds;
-            const double *src = first ? ap->cur_knots : ap->eval_knots;
-            for (int i = threadIdx.x; i < 7 * N; i += kSpWaves * 64) kn[i] = ld_fresh(src + i);
-            __syncthreads();
-            oa.seq = last_seq;
-            bool leader;
-            if (mode == 2)
-                leader = sp_tile_body<KD, true, false, LOGS, true, true>(lds, descs, tiles, nullptr, rho_out, patch_cost, nullptr, partials, oa, kn, kn + 3 * N);
-            else
-                leader = sp_tile_body<KD, false, false, LOGS, true, true>(lds, descs, tiles, nullptr, rho_out, patch_cost, nullptr, partials, oa, kn, kn + 3 * N);
-            if (leader && threadIdx.x < 64) lm_leader<KD>(ap, mode, last_seq, lds, (int)threadIdx.x);
-            __syncthreads(); // LDS (and s_seq / s_mode) are reused by the next phase
-        }
-    }
 
     // ------------------------------------------------------------------ finalize
     // Sum of the tile partials of one (problem, frame) in a fixed order: 16 tile-lanes each add
@@ -2509,9 +1975,6 @@ namespace mbavo
             constexpr int kWavesPerGroup = waves_of<KD, WITH_J>(), kThreads = kWavesPerGroup * 64;
             const size_t lds_plain = (WITH_J ? (size_t)kWavesPerGroup * OuterAcc<Pack<KD>::ND>::SLAB : 0) * sizeof(double) +
                                2 * kWavesPerGroup * sizeof(double)
-#if defined(MBAVO_EXP_LDS_TABLE)
-                               + (size_t)max_S * sizeof(PoseEntry<KD>)
-#endif
                 ;
             const size_t lds = lds_plain;
             (void)max_S;
@@ -2834,211 +2297,6 @@ namespace mbavo
 
     // ------------------------------------------------------------------ resident LM loop: host side
     // is `p` a problem the single-launch sample-parallel kernel takes (rebuild_layout's rule for a list of one)?
-    static bool sp_single_launch_applies(const mbavo_problem &p, int kdeg, int num_cus)
-    {
-        int lg = 0;
-        while ((1 << lg) < p.S) ++lg;
-        if ((1 << lg) != p.S || lg < 2 || lg > 5 || !sp_one_fits(kdeg, lg) || p.grad_fp16 || p.K < 1 || p.F < 1) return false;
-        const long long round_px = (long long)kSpWaves * (64 >> lg), pixels = (long long)p.F * p.K * p.P;
-        const int force = env_int("MBAVO_SP", -1);
-        return force != 0 && (force == 1 || pixels <= 2 * round_px * num_cus) && env_int("MBAVO_ONE", 1) != 0;
-    }
-
-    int Engine::lm_device(int num_levels, const mbavo_problem *probs, const int *pyr_level, int kdeg, const LmDeviceOpts &o,
-                          double *h_knots_t, double *h_knots_R, int N, const int *h_start_idx, int F, double *h_final_cost,
-                          mbavo_trace_rec *h_trace, int trace_cap, int *h_ntrace)
-    {
-        constexpr int kTraceCap = 4096;
-        if (num_levels < 1 || num_levels > 8 || !probs || (kdeg != 2 && kdeg != 4) || !h_knots_t || !h_knots_R || !h_start_idx) return MBAVO_E_ARG;
-        // MBAVO_DEVICE_LM: 0 (default) = the host-driven loop, 1 = this loop where the solve has its fast path (k = 2: cond(H) ~ 1e6
-        // on plane scenes; the cubic spline's systems sit at 1e9 and take the Jacobi sweeps, which one wave walks far slower than
-        // the host), 2 = always.  Measured on trackFrame (640x480, 4 levels, k = 2; profiles/r03_device_lm.txt): 0.546 ms per
-        // frame against 0.393 for the host-driven loop -- an evaluation costs 16.1 us between two leaders (the host sees 14.4 us
-        // INCLUDING its PCIe round trip: the cross-XCD hand-overs of a command cost what the bus does) and the leader 10.9 us
-        // (state in, merge, solve, state out: a chain of device-memory round trips) against 1.5 us of host work.  Kept as a
-        // tested option, not as the default.
-        const int want = env_int("MBAVO_DEVICE_LM", 0);
-        if (want == 0 || (want == 1 && (kdeg != 2 || o.fast_ratio <= 0.0) && o.solver == 0)) return 1;
-        if (N < kdeg || N > 4 || F < 1 || F > 16 || trace_cap > kTraceCap || persist_mask_) return 1;
-        for (int li = 0; li < num_levels; ++li)
-            if (!sp_single_launch_applies(probs[li], kdeg, num_cus_) || probs[li].N != N || probs[li].F != F) return 1;
-        int cur = -1;
-        if (hipGetDevice(&cur) != hipSuccess || cur != device_) HIP_TRY(hipSetDevice(device_));
-        PhaseScope ps_all(PhaseTimers::kLevel);
-
-        // device memory: [carry: cur_knots 7N | ntrace] [per level, initialised by ONE copy: seq | mode | inv | LmState | start_idx F |
-        // flag words] [per level, work: eval_knots 7N | g n | H n*n]; the patch costs in their own buffer
-        const int n = 6 * N, E = kdeg == 2 ? Pack<2>::E : Pack<4>::E;
-        auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
-        const size_t o_carry = 0, carry_bytes = al(sizeof(double) * 7 * N + 8 + 12 * 8); // knots | ntrace | (timing experiment) stamps
-        size_t o_init[8], o_flags[8], o_work[8], off = carry_bytes;
-        int maxK = 1;
-        for (int li = 0; li < num_levels; ++li)
-        {
-            o_init[li] = off;
-            const size_t head = 24 + sizeof(LmState) + al(sizeof(int) * F) + al(sizeof(LmLevelArgs)); // (LmState is 8-aligned, 24 + it too)
-            o_flags[li] = off + al(head);
-            off = o_flags[li] + al(((size_t)probs[li].K + 3) / 4 * 4);
-            maxK = probs[li].K > maxK ? probs[li].K : maxK;
-        }
-        const size_t init_bytes = off;
-        for (int li = 0; li < num_levels; ++li)
-        {
-            o_work[li] = off;
-            off += al(sizeof(double) * (7 * N + n + (size_t)n * n));
-        }
-        char *dev = (char *)named_scratch(12, off);
-        double *d_pc = (double *)named_scratch(13, sizeof(double) * (size_t)F * maxK);
-        double *d_fb = (double *)named_scratch(14, sizeof(double) * (size_t)F * E);
-        char *stage = (char *)pinned_scratch(5, init_bytes);
-        const size_t out_doubles = 7 * (size_t)N + 16;
-        char *hout = (char *)pinned_scratch(6, sizeof(double) * out_doubles + sizeof(mbavo_trace_rec) * (size_t)(trace_cap > 0 ? trace_cap : 1));
-        if (!dev || !d_pc || !d_fb || !stage || !hout) return (int)hipErrorOutOfMemory;
-        if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 64, hipHostMallocDefault) != hipSuccess) { h_flag_ = nullptr; return (int)hipErrorOutOfMemory; }
-        double *host_out = (double *)hout;
-        mbavo_trace_rec *host_trace = (mbavo_trace_rec *)(hout + sizeof(double) * out_doubles);
-        host_out[7 * N + 2] = 0.0;
-
-        memset(stage, 0, init_bytes);
-        memcpy(stage + o_carry, h_knots_t, sizeof(double) * 3 * N);
-        memcpy(stage + o_carry + sizeof(double) * 3 * N, h_knots_R, sizeof(double) * 4 * N);
-        const unsigned long long done_seq = ++flag_seq_;
-        const size_t o_args = 24 + sizeof(LmState) + al(sizeof(int) * F); // inside a level's initialised block
-        for (int li = 0; li < num_levels; ++li)
-        {
-            char *b = stage + o_init[li];
-            *(int *)(b + 8) = 2; // mode of the first evaluation (not polled: informational)
-            const long long nres = (long long)probs[li].K * F * probs[li].P; // spline_update_step.cpp:116-117, no outliers yet (:601)
-            *(double *)(b + 16) = nres > 0 ? 1.0 / (double)nres : 0.0;
-            LmState st;
-            memset(&st, 0, sizeof(st));
-            st.radius = 1e4; st.decrease_factor = 2.0; st.abs_dec = 1e10; st.fresh = 1;
-            st.ntrace = li == 0 ? 0 : -1; // finer levels: taken from the carry word when their kernel starts
-            memcpy(b + 24, &st, sizeof(st));
-            memcpy(b + 24 + sizeof(LmState), h_start_idx, sizeof(int) * F);
-            // the kernel's arguments live in the level's control block: the resident loop keeps ONE pointer in registers
-            char *ib = dev + o_init[li], *wb = dev + o_work[li];
-            LmLevelArgs &a = *(LmLevelArgs *)(b + o_args);
-            a.seq = (unsigned long long *)ib; a.mode = (int *)(ib + 8); a.inv = (double *)(ib + 16);
-            a.state = (unsigned long long *)(ib + 24);
-            a.start_idx = (const int *)(ib + 24 + sizeof(LmState));
-            a.flag_words = (unsigned *)(dev + o_flags[li]);
-            a.eval_knots = (double *)wb; a.g = (double *)wb + 7 * N; a.H = a.g + n;
-            a.cur_knots = (double *)(dev + o_carry); a.carry_ntrace = (int *)(dev + o_carry + sizeof(double) * 7 * N);
-            a.frame_blocks = d_fb; a.patch_cost = d_pc;
-            a.stamps = (unsigned long long *)(dev + o_carry + sizeof(double) * 7 * N + 8);
-            a.trace = h_trace ? host_trace : nullptr;
-            const bool last = li + 1 == num_levels;
-            a.host_out = last ? host_out : nullptr;
-            a.host_flag = last ? (unsigned long long *)h_flag_ : nullptr;
-            a.host_seq = done_seq;
-            a.o.max_it = o.max_it; a.o.max_nonmono = o.max_nonmono; a.o.solver = o.solver; a.o.trace_cap = h_trace ? trace_cap : 0;
-            a.o.max_n = n; a.o.max_N = N; a.o.min_q = o.min_q; a.o.min_dec = o.min_dec; a.o.chi = o.chi; a.o.fast_ratio = o.fast_ratio;
-            a.level = pyr_level ? pyr_level[li] : li; a.N = N; a.F = F; a.K = probs[li].K; a.P = probs[li].P;
-        }
-        for (int li = 0; li < num_levels; ++li)
-        { // every level's layout first (they park): a level that does not take the single-launch kernel after all (tiles per slot)
-          // must be known before anything is enqueued
-            char *ib = dev + o_init[li], *wb = dev + o_work[li];
-            mbavo_problem p = probs[li];
-            p.d_knots_t = (const double *)wb; p.d_knots_R = (const double *)wb + 3 * N;
-            p.d_outlier = (const unsigned char *)(dev + o_flags[li]); p.num_bad = 0; p.num_residuals = 0;
-            const int rc = rebuild_layout(1, &p, kdeg, nullptr, (const double *)(ib + 16));
-            if (rc) return rc;
-            if (sp_logs_ <= 0 || h_tiles_.empty() || (int)h_tiles_.size() > num_cus_ || empty_slots_) return 1;
-        }
-        HIP_TRY(hipMemcpyAsync(dev, stage, init_bytes, hipMemcpyHostToDevice, stream_));
-
-        for (int li = 0; li < num_levels; ++li)
-        {
-            char *ib = dev + o_init[li], *wb = dev + o_work[li];
-            mbavo_problem p = probs[li];
-            p.d_knots_t = (const double *)wb; p.d_knots_R = (const double *)wb + 3 * N;
-            p.d_outlier = (const unsigned char *)(dev + o_flags[li]); p.num_bad = 0; p.num_residuals = 0;
-            int rc = rebuild_layout(1, &p, kdeg, nullptr, (const double *)(ib + 16));
-            if (rc) return rc;
-            const int ntiles = (int)h_tiles_.size();
-            if (sp_logs_ <= 0 || ntiles < 1 || ntiles > num_cus_ || empty_slots_) return MBAVO_E_ARG; // (checked above: cannot happen)
-            OneArgs oa;
-            memset(&oa, 0, sizeof(oa));
-            oa.bf_tile_begin = (const int *)d_bf_tile_begin_;
-            oa.tickets = (int *)d_tickets_;
-            oa.slots_done = (int *)d_tickets_ + total_bf_;
-            oa.frame_blocks = d_fb; oa.valid_out = nullptr; oa.status = (int *)d_status_;
-            oa.nbf = total_bf_;
-            oa.lm = 1;
-            const LmLevelArgs *d_args = (const LmLevelArgs *)(ib + o_args);
-            hipStream_t st = stream_;
-#define MBAVO_LM_LAUNCH(KD, LG)                                                                                                    \
-    do                                                                                                                            \
-    {                                                                                                                             \
-        if constexpr (SpLds<KD, true, LG, true>::kFits)                                                                           \
-        {                                                                                                                         \
-            size_t lds_sp = SpLds<KD, true, LG, true>::kBytes > SpLds<KD, false, LG, true>::kBytes                                \
-                                ? SpLds<KD, true, LG, true>::kBytes : SpLds<KD, false, LG, true>::kBytes;                          \
-            const size_t need = sizeof(double) * ((size_t)n * n + 4 * (size_t)n + (n + 1) / 2 + 2 + 2 * (size_t)n * (n + 1));      \
-            if (need > lds_sp) lds_sp = need; /* the leader's solver work areas */                                                 \
-            HIP_TRY(ensure_lds((const void *)k_lm_level<KD, LG>, lds_sp));                                                        \
-            hipLaunchKernelGGL((k_lm_level<KD, LG>), dim3(ntiles), dim3(kSpWaves * 64), lds_sp, st, (const ProblemDesc *)d_descs_, \
-                               (const TileDesc *)d_tiles_, (double *)d_rho_, d_pc, (double *)d_partials_, oa, d_args);             \
-        }                                                                                                                         \
-    } while (0)
-#define MBAVO_LM_K(KD)                                     \
-    switch (sp_logs_)                                      \
-    {                                                      \
-    case 2: MBAVO_LM_LAUNCH(KD, 2); break;                  \
-    case 3: MBAVO_LM_LAUNCH(KD, 3); break;                  \
-    case 4: MBAVO_LM_LAUNCH(KD, 4); break;                  \
-    default: MBAVO_LM_LAUNCH(KD, 5); break;                 \
-    }
-            if (kdeg == 4) { MBAVO_LM_K(4) } else { MBAVO_LM_K(2) }
-#undef MBAVO_LM_K
-#undef MBAVO_LM_LAUNCH
-            HIP_TRY(hipGetLastError());
-            last_kernel_id_[0] = kdeg; last_kernel_id_[1] = 1; last_kernel_id_[2] = 0; last_kernel_id_[3] = sp_logs_; last_kernel_id_[4] = 1;
-        }
-        ps_all.stop();
-        {
-            PhaseScope ps_wait(PhaseTimers::kWait);
-            const auto t0 = std::chrono::steady_clock::now();
-            volatile unsigned long long *f = (volatile unsigned long long *)h_flag_;
-            bool ok = false;
-            for (long spins = 1;; ++spins)
-            {
-                if (*f == done_seq) { ok = true; break; }
-                host_spin_pause();
-                if ((spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(4)) break;
-            }
-            __atomic_thread_fence(__ATOMIC_ACQUIRE);
-            if (!ok || host_out[7 * N + 2] != 1.0)
-            {
-                fprintf(stderr, "mbavo: resident LM loop timed out\n");
-                (void)hipStreamSynchronize(stream_); // (the kernels give up by themselves after ~1 s without a command)
-                (void)hipMemsetAsync(d_tickets_, 0, cap_tickets_, stream_);
-                return (int)hipErrorLaunchTimeOut;
-            }
-        }
-#if defined(MBAVO_LM_STAMPS)
-        {
-            static double ev = 0, ld = 0, ph = 0, tot = 0, seg[6] = {0, 0, 0, 0, 0, 0}; static long calls = 0;
-            ev += host_out[7 * N + 3]; ld += host_out[7 * N + 4]; ph += host_out[7 * N + 5]; tot += host_out[7 * N + 6];
-            for (int i = 0; i < 6; ++i) seg[i] += host_out[7 * N + 7 + i];
-            if (++calls % 9 == 0)
-                fprintf(stderr, "lm_device: per call %.1f phases, evaluation (publish -> next leader's entry) %.2f us each, leader %.2f us each "
-                                "[load %.2f | merge/decide %.2f | solve %.2f | store %.2f], after an H/g pass %.2f us (%.1f per call); first leader's entry -> end %.1f us (mean of %ld calls)\n",
-                        ph / calls, ev / (ph - calls * num_levels > 0 ? ph - calls * num_levels : 1), ld / ph, seg[0] / ph, seg[1] / ph, seg[2] / ph,
-                        seg[3] / ph, seg[4] / (seg[5] > 0 ? seg[5] : 1), seg[5] / calls, tot / calls, calls);
-        }
-#endif
-        memcpy(h_knots_t, host_out, sizeof(double) * 3 * N);
-        memcpy(h_knots_R, host_out + 3 * N, sizeof(double) * 4 * N);
-        if (h_final_cost) *h_final_cost = host_out[7 * N];
-        const int ntrace = (int)host_out[7 * N + 1];
-        if (h_ntrace) *h_ntrace = ntrace;
-        if (h_trace && trace_cap > 0) memcpy(h_trace, host_trace, sizeof(mbavo_trace_rec) * (size_t)(ntrace < trace_cap ? ntrace : trace_cap));
-        return 0;
-    }
-
     const char *Engine::last_kernel()
     {
         const int *k = last_kernel_id_;

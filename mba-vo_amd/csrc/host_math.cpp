@@ -389,16 +389,14 @@ namespace mbavo
         return r > 1.0 ? r : (r == 1.0 ? 1e8 : 0.0);
     }
 
-    double fast_solve_ratio()
-    { // read once: the host loop asks at every LM iteration
-        static const double v = fast_solve_ratio_env();
-        return v;
-    }
-
-    int solve_normal_equation_host(const double *A, const double *b, int n, int solver_type, double *x)
+    int solve_normal_equation_host(const double *A, const double *b, int n, int solver_type, double *x, double fast_ratio)
     {
+        // fast_ratio < 0: ask the environment now.  The LM loops read it ONCE per call (optimize_trajectory, lm_batch) and pass
+        // it down, so that the host loop and the batched LM of one process always run the same solver (a value
+        // latched in a function static could differ from what mbavo_lm_batch read later)
+        if (fast_ratio < 0.0) fast_ratio = fast_solve_ratio_env();
         int rank;
-        if (solver_type == 0 && fast_solve_ratio() > 0.0 && solve_spd_fast(A, b, n, x, fast_solve_ratio())) rank = n;
+        if (solver_type == 0 && fast_ratio > 0.0 && solve_spd_fast(A, b, n, x, fast_ratio)) rank = n;
         else if (solver_type == 0) rank = solve_svd(A, b, n, x);
         else if (solver_type == 1) rank = solve_ldlt(A, b, n, x);
         else return -1;

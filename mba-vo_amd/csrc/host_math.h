@@ -18,10 +18,10 @@ namespace mbavo
                            double *total_cost, double *H_colmajor, double *g);
 
     // x = -pinv(A) b (type 0) or -A^{-1} b via LDL^T (type 1); returns rank, or -1 for an unknown type
-    int solve_normal_equation_host(const double *A_colmajor, const double *b, int n, int solver_type, double *x);
-    // pivot ratio up to which LDL^T stands in for the Jacobi SVD (solver type 0); 0 = never (MBAVO_FAST_SOLVE, default 1e8)
-    double fast_solve_ratio();
-    double fast_solve_ratio_env(); // the same, read from the environment at every call (per mbavo_lm_batch call)
+    // fast_ratio: pivot ratio up to which LDL^T stands in for the Jacobi SVD (solver type 0); 0 = never; < 0 = ask the
+    // environment now (MBAVO_FAST_SOLVE, default 1e8).  The LM loops read it once per call and pass it down.
+    int solve_normal_equation_host(const double *A_colmajor, const double *b, int n, int solver_type, double *x, double fast_ratio = -1.0);
+    double fast_solve_ratio_env(); // MBAVO_FAST_SOLVE read from the environment at every call
 } // namespace mbavo
 
 namespace SLAM

@@ -574,9 +574,7 @@ namespace mbavo
             if (lds > 48 * 1024)
             { // more than 8 control knots: the three n x n areas need the large-LDS attribute
                 if (k == 4) LM_HIP(hipFuncSetAttribute(eig ? (const void *)k_lm_solve<4, kEigT> : (const void *)k_lm_solve<4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-#if !defined(MBAVO_LM_K4_ONLY) // reproducer variant (tools/micro/lm_solve_calls.sh): one kernel only reaches the solvers
                 else LM_HIP(hipFuncSetAttribute(eig ? (const void *)k_lm_solve<2, kEigT> : (const void *)k_lm_solve<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-#endif
             }
             unsigned long long *d_word = const_cast<unsigned long long *>(h_word); // pinned host memory is device-visible at its own address
             for (int slot = 0; slot <= o.max_it + 1; ++slot)
@@ -586,12 +584,10 @@ namespace mbavo
                     hipLaunchKernelGGL((k_lm_solve<4, kEigT>), dim3(B), dim3(kEigT), lds, st, LM_SOLVE_ARGS);
                 else if (k == 4)
                     hipLaunchKernelGGL((k_lm_solve<4, 64>), dim3(B), dim3(64), lds, st, LM_SOLVE_ARGS);
-#if !defined(MBAVO_LM_K4_ONLY)
                 else if (eig)
                     hipLaunchKernelGGL((k_lm_solve<2, kEigT>), dim3(B), dim3(kEigT), lds, st, LM_SOLVE_ARGS);
                 else
                     hipLaunchKernelGGL((k_lm_solve<2, 64>), dim3(B), dim3(64), lds, st, LM_SOLVE_ARGS);
-#endif
 #undef LM_SOLVE_ARGS
                 if (sync_every <= 0)
                 {
@@ -679,6 +675,9 @@ namespace mbavo
                 }
         }
     done:
+        // an error exit may leave solve launches queued that still store into the pinned done word and the arena: drain them
+        // before the next call re-arms the word or regrows either buffer
+        if (rc != 0) (void)hipStreamSynchronize(st);
         eng.set_defer_finalize(false);
         return rc > 0 ? -1000 - rc : rc;
     }

@@ -21,34 +21,13 @@
 #define MBAVO_SVD_MULTILANE 1
 #endif
 
-// -DMBAVO_SOLVERS_NOINLINE builds the three solver entry points as real (called) device functions: the configuration
-// that faulted in round 1; kept as a build variant for the reproducer (tools/micro/lm_solve_calls.sh).
-#if defined(MBAVO_SOLVERS_LDS_PTR) // experiment: the matrices as LDS-typed pointers instead of generic ones
-#define MBAVO_LDS __attribute__((address_space(3)))
-#else
-#define MBAVO_LDS
-#endif
-#if defined(MBAVO_SOLVERS_NOINLINE)
-#define MBAVO_SOLVER_FN __device__ __noinline__
-#else
+// The solver entry points are force-inlined: as real (called) device functions they faulted inside k_lm_solve in round 1 --
+// a miscompile of the CALLER by this toolchain (profiles/r02_lm_solve_fault.txt; the reproducer build variants were removed
+// in round 4, they are in the history up to commit cfcf142).
 #define MBAVO_SOLVER_FN __device__ __forceinline__
-#endif
-// finer switches of the reproducer: one function at a time as a real call
-#if defined(MBAVO_NOINLINE_SWEEPS)
-#define MBAVO_SWEEPS_FN __device__ __noinline__
-#else
 #define MBAVO_SWEEPS_FN MBAVO_SOLVER_FN
-#endif
-#if defined(MBAVO_NOINLINE_SVD)
-#define MBAVO_SVD_FN __device__ __noinline__
-#else
 #define MBAVO_SVD_FN MBAVO_SOLVER_FN
-#endif
-#if defined(MBAVO_NOINLINE_LDLT)
-#define MBAVO_LDLT_FN __device__ __noinline__
-#else
 #define MBAVO_LDLT_FN MBAVO_SOLVER_FN
-#endif
 
 // The solvers are written for ONE wave; between their steps the wave's LDS writes must be visible to its other lanes.
 // In a one-wave workgroup (lm_batch.hip, the solver check) that is a workgroup barrier; a wave working alone inside a larger
@@ -523,7 +502,6 @@ namespace mbavo
             double *A0 = bufs, *A1 = bufs + sz, *V0 = bufs + 2 * sz;
             if (tid < 3) flags[tid] = 0;
             MBAVO_EIG_STAMP(0);
-#if !defined(MBAVO_EIG_NO_PRECONDITION)
             // sorted position of every index: falling diagonal, ties in index order -- n^2 comparisons over all threads, counted
             // in LDS (one thread per index walking the diagonal took 3 000 cycles)
             int *rank = ord + n;
@@ -575,9 +553,6 @@ namespace mbavo
                 }
             }
             else
-#else
-            const bool spd = false;
-#endif
             { // the plain path: sweeps on A itself, V = I
                 for (int e = tid; e < nn; e += T)
                 {
@@ -740,7 +715,10 @@ namespace mbavo
                         }
                         xv += dv;
                         const double dn = wmax(lane < NN ? fabs(dv) : 0.0), xn = wmax(lane < NN ? fabs(xv) : 0.0);
-                        if (step == 0) rho = fmin(1.0, 10.0 * dn / xn);
+                        // contraction per step: what the first correction shows, but never below the pivot ratio x eps -- |d1| / |x| can sit far
+                        // under cond(A) eps when b lies in well-conditioned directions, and one step would then be accepted with the
+                        // true contraction ~1e-3: from a ratio of ~1e10 on, a second correction is always taken
+                        if (step == 0) rho = fmin(1.0, fmax(10.0 * dn / xn, (dmax / dmin) * DBL_EPSILON));
                         ok = dn * rho <= 1e-13 * xn; // (NaN compares false)
                     }
                 }
@@ -910,7 +888,10 @@ namespace mbavo
                         const double dv = solve(hi + lo);
                         xv += dv;
                         const double dn = wmax(lane < n ? fabs(dv) : 0.0), xn = wmax(lane < n ? fabs(xv) : 0.0);
-                        if (step == 0) rho = fmin(1.0, 10.0 * dn / xn);
+                        // contraction per step: what the first correction shows, but never below the pivot ratio x eps -- |d1| / |x| can sit far
+                        // under cond(A) eps when b lies in well-conditioned directions, and one step would then be accepted with the
+                        // true contraction ~1e-3: from a ratio of ~1e10 on, a second correction is always taken
+                        if (step == 0) rho = fmin(1.0, fmax(10.0 * dn / xn, (dmax / dmin) * DBL_EPSILON));
                         ok = dn * rho <= 1e-13 * xn; // (NaN compares false)
                     }
                 if (lane < n) x[lane] = xv;

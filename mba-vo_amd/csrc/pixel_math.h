@@ -66,26 +66,8 @@ namespace mbavo
     // load-and-wait steps --, the Jacobian chain's c and A follow, and the two fields only the patch centre reads (from ONE
     // entry per frame) come last.  (Removing the table loads altogether, an ablation, takes 4 % off the dense kernel at S = 8
     // and 12 % at S = 16: most of that is the 40 doubles of c and A per sample, which no layout removes.)
-#if defined(MBAVO_POSE_ENTRY_OLD_LAYOUT) // A/B switch
     template <int KDEG>
     struct PoseEntry
-    {
-        double t[3];
-        double rt[3];
-        double q[4];
-        double R[9];
-        double c[KDEG];
-        double A[9 * KDEG];
-    };
-#else
-#if defined(MBAVO_POSE_ENTRY_ALIGN64) // A/B switch: 512-byte entries (the sample-parallel kernels' per-lane reads of their
-                                      // sample's entry in LDS then hit one bank: +14 % on the semi-dense evaluation)
-#define MBAVO_POSE_ENTRY_ALIGN alignas(64)
-#else
-#define MBAVO_POSE_ENTRY_ALIGN
-#endif
-    template <int KDEG>
-    struct MBAVO_POSE_ENTRY_ALIGN PoseEntry
     {
         double R[9];          // rotation matrix of q, row-major, reference term order
         double t[3];          // t_c2r
@@ -95,7 +77,6 @@ namespace mbavo
         double rt[3];         // conj(q) applied to t: the pixel-independent half of patch_centre (read from sample S/2)
         double q[4];          // R_c2r xyzw
     };
-#endif
 
     // The reference chains dI/dq (1x4) through J_R = dq/dw (4x3k).  I does not depend on |q| (the warped point
     // is (D - t_z) * rho / rho_z with rho = R_h(q) ray, homogeneous in q), so dI/dq is tangent to the unit sphere
@@ -166,7 +147,7 @@ namespace mbavo
     // coordinates) already differs from the reference's rounding by the fused multiply-adds of the rotation before it.
     MBAVO_HD double reciprocal_1ulp(double x)
     {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_SAMPLE_RCP_EXACT)
+#if defined(__HIP_DEVICE_COMPILE__)
         double r = __builtin_amdgcn_rcp(x);
         r = __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
         return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
@@ -287,14 +268,7 @@ namespace mbavo
         // Branch-free: an out-of-bounds (or NaN) coordinate only clears t.ok; its window is clamped into the image
         // so the loads stay legal and the garbage it produces is discarded by the caller.  Keeping the sample loop
         // free of divergent control flow lets the compiler overlap the issue of sample s+1 with the retire of s.
-#if defined(MBAVO_TAP_BOUNDS_NEGATED) // A/B switch: the test as the reference negates it, plus the NaN test it then needs
-        t.ok = !(x < 0 || x > W - 1 || y < 0 || y > H - 1) && x == x && y == y;
-#else
         t.ok = x >= 0 && x <= W - 1 && y >= 0 && y <= H - 1; // (ordered compares: false for NaN, four instructions instead of five)
-#endif
-#if defined(MBAVO_TAP_EARLY_RETURN)
-        if (!t.ok) return;
-#endif
 #if defined(__HIP_DEVICE_COMPILE__)
         // the conversion saturates and maps NaN to 0 (v_cvt_i32_f64), so the window is clamped on the integer side
         // (one v_med3_i32 per axis) instead of zeroing the coordinates of a dropped sample first
@@ -373,7 +347,7 @@ namespace mbavo
             const float x10 = (float)((int)(t.pk[2] << 15) >> 23), x11 = (float)((int)(t.pk[3] << 15) >> 23);
             const float y00 = (float)((int)t.pk[0] >> 23), y01 = (float)((int)t.pk[1] >> 23);
             const float y10 = (float)((int)t.pk[2] >> 23), y11 = (float)((int)t.pk[3] >> 23);
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_NO_PK_BLEND)
+#if defined(__HIP_DEVICE_COMPILE__)
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             const f32x2 g11 = {x11, y11}, g10 = {x10, y10}, g01 = {x01, y01}, g00 = {x00, y00};
             f32x2 ab = t.w11 * g11;
@@ -406,7 +380,7 @@ namespace mbavo
         val = (double)v;
         if (WITH_GRAD)
         {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_NO_PK_BLEND)
+#if defined(__HIP_DEVICE_COMPILE__)
             // the two gradient blends are the same four steps on (dx, dy) pairs that sit in adjacent registers as loaded:
             // packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32, the weight broadcast by op_sel) round each half exactly
             // like the scalar ones -- 7 instructions instead of 14
@@ -646,24 +620,6 @@ namespace mbavo
                                const unsigned char *__restrict__ I, const float *__restrict__ G, SampleInFlight &f)
     {
         const double *R = pe.R;
-#if defined(MBAVO_UV_NO_CONTRACT)
-        // Experiment (profiles/r02_ablations.txt): the whole warp up to the tap coordinates without FMA contraction, as the
-        // oracle rounds it.  It does NOT make the coordinates bit-identical -- the pose entries (R, t) come out of a
-        // log / exp / sin / cos chain evaluated by different math libraries on the two sides -- and costs instructions.
-        double u, v;
-        {
-#pragma clang fp contract(off)
-            f.rx = R[0] * ray[0] + R[1] * ray[1] + R[2] * ray[2];
-            f.ry = R[3] * ray[0] + R[4] * ray[1] + R[5] * ray[2];
-            const double rz = R[6] * ray[0] + R[7] * ray[1] + R[8] * ray[2];
-            f.C1 = reciprocal(rz);
-            f.sc = (D - pe.t[2]) * f.C1;
-            const double Px = f.sc * f.rx + pe.t[0];
-            const double Py = f.sc * f.ry + pe.t[1];
-            u = cam.fx * (Px * iz) + cam.cx;
-            v = cam.fy * (Py * iz) + cam.cy;
-        }
-#else
         f.rx = R[0] * ray[0] + R[1] * ray[1] + R[2] * ray[2];
         f.ry = R[3] * ray[0] + R[4] * ray[1] + R[5] * ray[2];
         const double rz = R[6] * ray[0] + R[7] * ray[1] + R[8] * ray[2];
@@ -676,15 +632,9 @@ namespace mbavo
             Px = f.sc * f.rx + pe.t[0];
             Py = f.sc * f.ry + pe.t[1];
         }
-#if defined(MBAVO_UV_TWO_STEP) // A/B switch: u = fx * (Px * iz) + cx, two instructions per coordinate
-        const double u = cam.fx * (Px * iz) + cam.cx;
-        const double v = cam.fy * (Py * iz) + cam.cy;
-#else
         // iz * f is per pixel (the retire half needs it anyway): one fused instruction per coordinate
         const double u = (iz * cam.fx) * Px + cam.cx;
         const double v = (iz * cam.fy) * Py + cam.cy;
-#endif
-#endif
         tap_fetch<WITH_J, HALF_GRAD>(I, G, cam.H, cam.W, u, v, f.taps);
     }
 
@@ -705,15 +655,6 @@ namespace mbavo
             const double dIx = gx * (iz * cam.fx); // iz * f is per pixel: hoisted out of the sample loop by the compiler
             const double dIy = gy * (iz * cam.fy);
             const double jt[3] = {dIx, dIy, -f.C1 * (dIx * rx + dIy * ry)};
-#if defined(MBAVO_A_BODY) // A/B switch: the table holds A in body axes (the pose kernels must be built with the same switch)
-            // phi = dI/d(body rotation) = sc * ray x (R^T * dI/dt): the same derivative the reference forms as
-            // twelve dP/dq terms (:179-206), restricted to the tangent space
-            const double w0 = R[0] * jt[0] + R[3] * jt[1] + R[6] * jt[2];
-            const double w1 = R[1] * jt[0] + R[4] * jt[1] + R[7] * jt[2];
-            const double w2 = R[2] * jt[0] + R[5] * jt[1] + R[8] * jt[2];
-            const double phi[3] = {f.sc * (ray[1] * w2 - ray[2] * w1), f.sc * (ray[2] * w0 - ray[0] * w2),
-                                   f.sc * (ray[0] * w1 - ray[1] * w0)};
-#else
             // phi = dI/d(rotation about the KEYFRAME's axes) = sc * (R ray) x dI/dt.  The derivative w.r.t. the body
             // rotation is sc * ray x (R^T dI/dt) = R^T phi (a rotation carries a cross product along); its product with
             // A = d(body rotation)/d(knots) is phi^T (R A), and R A is what the table holds: the nine-term transposed
@@ -723,16 +664,12 @@ namespace mbavo
             (void)R;
             const double dz = D - pe.t[2], sj = f.sc * jt[2];
             const double phi[3] = {ry * sj - dz * jt[1], dz * jt[0] - rx * sj, f.sc * (rx * jt[1] - ry * jt[0])};
-#endif
 #pragma unroll
             for (int j = 0; j < KDEG; ++j)
             {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) Jrow[3 * j + c] = FIRST ? pe.c[j] * jt[c] : Jrow[3 * j + c] + pe.c[j] * jt[c];
             }
-#if defined(MBAVO_EXP_NO_CHAIN) // timing experiment only
-            Jrow[3 * KDEG] = (FIRST ? 0.0 : Jrow[3 * KDEG]) + phi[0] + phi[1] + phi[2];
-#else
 #pragma unroll
             for (int cidx = 0; cidx < 3 * KDEG; ++cidx)
             { // three FMAs into the accumulator (one instruction less per entry than forming the sample's term first)
@@ -741,7 +678,6 @@ namespace mbavo
                 a += phi[2] * pe.A[6 * KDEG + cidx];
                 Jrow[3 * KDEG + cidx] = a;
             }
-#endif
         }
     }
 
@@ -774,11 +710,7 @@ namespace mbavo
         // back-edge: the compiler's s_waitcnt insertion cannot count loop-carried loads and falls back to vmcnt(0),
         // which would serialise every sample (measured on the ping-pong-across-iterations variant).
         SampleInFlight fa, fb;
-#if defined(MBAVO_EXP_ONE_ENTRY) // timing experiment: every sample uses table[0] (loads hoisted out of the loop)
-#define MBAVO_TAB(i) table[0]
-#else
 #define MBAVO_TAB(i) table[i]
-#endif
         int s;
         if (S >= 2)
         { // the first pair sets the accumulators

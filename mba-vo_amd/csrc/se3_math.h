@@ -44,7 +44,7 @@ namespace mbavo
     }
 
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_POSE_LIBM)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define MBAVO_POSE_FASTMATH 1
     // Device forms of the four library calls on the pose chain (round 3).  A sample's pose entries are ONE dependent chain per
     // lane -- 2.9 us of stage A on configs[1], every evaluation waits for it -- and the runtime's sqrt / division / atan / sin /
@@ -52,7 +52,7 @@ namespace mbavo
     // instructions.  The arguments here are a rotation's half-angle and the tangent of one: finite, moderate.  Each form
     // below is within one or two units in the last place of the correctly rounded value (the runtime's own bound for sin /
     // cos / atan); polynomial coefficients and reduction constants are those of fdlibm's k_sin.c / k_cos.c / s_atan.c /
-    // e_rem_pio2.c.  -DMBAVO_POSE_LIBM builds the chain on the runtime's functions again (A/B switch).
+    // e_rem_pio2.c.
     namespace fastm
     {
         __device__ __forceinline__ double rcp(double x) // 1 / x: v_rcp_f64 (2^-23) + two Newton steps; x finite, normal, non-zero
@@ -174,7 +174,7 @@ namespace mbavo
             }
             else
             {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_POSE_IEEE_DIV)
+#if defined(__HIP_DEVICE_COMPILE__)
                 // device: ONE reciprocal of n and products where the reference divides by n four times (an IEEE fp64
                 // division is ~13 dependent instructions, and a pose lane walks this chain alone on its SIMD); the results
                 // differ from the quotients in the last place at most
@@ -231,14 +231,14 @@ namespace mbavo
         }
         else
         {
-#if defined(MBAVO_POSE_FASTMATH) && !defined(MBAVO_POSE_IEEE_DIV)
+#if defined(MBAVO_POSE_FASTMATH)
             double th, rth, hs, hc;
             fastm::sqrt_rsqrt(th2, th, rth);
             fastm::sincos(0.5 * th, hs, hc);
 #else
             const double th = sqrt(th2);
 #endif
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_POSE_IEEE_DIV)
+#if defined(__HIP_DEVICE_COMPILE__)
 #if !defined(MBAVO_POSE_FASTMATH)
             // (sincos() for the pair measured 2 us SLOWER per evaluation: its results come back through private memory)
             const double hs = sin(0.5 * th), hc = cos(0.5 * th);
@@ -589,8 +589,8 @@ namespace mbavo
     // chain of the fastm forms came back as 6 vector spills in k_fused<4, .., POSE> (+0.5 us per dense evaluation); as a call the
     // kernel keeps its 166 registers and the semi-dense single-launch kernel drops from 172 to 150 with no scalar spill
     // (configs[1] dense step 37.44 -> 36.68 us, semi-dense evaluation 18.26 -> 17.58, trackFrame 0.407 -> 0.394 ms per frame;
-    // A/B in one call, profiles/r03_kfused_experiments.txt).  -DMBAVO_SEG_INLINE restores the inlined form.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MBAVO_SEG_INLINE)
+    // A/B in one call, profiles/r03_kfused_experiments.txt).
+#if defined(__HIP_DEVICE_COMPILE__)
 #define MBAVO_SEG_FN __device__ __noinline__
 #else
 #define MBAVO_SEG_FN MBAVO_HD

@@ -66,46 +66,6 @@ namespace mbavo
         return n;
     }
 
-    // The whole loop on the device (Engine::lm_device): 0 = done, 1 = not applicable (run the host-driven loop), else an error.
-    static int optimize_on_device(Engine &eng, const mbavo_track_opts &o, const mbavo_level *levels, int F, const double *h_cap,
-                                  const double *h_exp, const double *d_cap, const double *d_exp, double t0, double dt,
-                                  double *knots_t, double *knots_R, int N, const int *start_idx, double *final_cost,
-                                  mbavo_trace_rec *trace, int trace_cap, int *ntrace)
-    {
-        const int k = o.spline_deg_k;
-        mbavo_problem lp[8];
-        int label[8];
-        for (int li = 0; li < o.num_levels; ++li)
-        {
-            const int lv = o.num_levels - li - 1; // coarse to fine (:571-575)
-            const mbavo_level &L = levels[lv];
-            const int scale = 1 << lv;
-            mbavo_problem &p = lp[li];
-            memset(&p, 0, sizeof(p));
-            p.S = L.S; p.F = F; p.K = L.K; p.P = L.P; p.N = N; p.H = L.H; p.W = L.W;
-            p.d_ref_img = L.d_ref_img; p.d_ref_dIxy = L.d_ref_dIxy; p.d_cur_imgs = L.d_cur_imgs;
-            p.d_kp_xy = L.d_kp_xy; p.kp_stride = 2; p.d_kp_z = L.d_kp_z; p.d_pattern = L.d_pattern;
-            for (int a = 0; a < 4; ++a) p.intrinsics[a] = o.intrinsics[a] / scale; // :766-770
-            p.d_cap_time = d_cap; p.d_exp_time = d_exp; p.t0 = t0; p.dt = dt;
-            p.h_start_idx = start_idx; p.huber_a = o.huber_k;
-            label[li] = lv;
-            for (int f = 0; f < F; ++f) // every blur sample on knots that exist (see prepare() below)
-                for (int smp = 0; smp < L.S; ++smp)
-                {
-                    const double ts = h_cap[f] - h_exp[f] * 0.5 + smp * h_exp[f] / (L.S - 1 + 1e-8);
-                    int idx;
-                    double u;
-                    spline_segment(ts, t0, dt, idx, u);
-                    if (idx < 0 || idx + k > N) return MBAVO_E_RANGE;
-                }
-        }
-        Engine::LmDeviceOpts d;
-        d.max_it = o.max_num_iterations; d.max_nonmono = o.max_consecutive_nonmonotonic_steps; d.solver = o.solver_type;
-        d.min_q = o.min_step_quality; d.min_dec = o.min_abs_cost_decrease; d.chi = o.max_chi_square_error;
-        d.fast_ratio = fast_solve_ratio();
-        return eng.lm_device(o.num_levels, lp, label, k, d, knots_t, knots_R, N, start_idx, F, final_cost, trace, trace_cap, ntrace);
-    }
-
     int optimize_trajectory(Engine &eng, const mbavo_track_opts &o, const mbavo_level *levels, int F,
                             const double *h_cap, const double *h_exp, double t0, double dt, double *knots_t,
                             double *knots_R, int N, int *start_idx_out, double *final_cost, mbavo_trace_rec *trace,
@@ -116,6 +76,7 @@ namespace mbavo
         const int n = 6 * N, ndim = 6 * k + 1, E = ndim * (ndim + 1) / 2;
         int rc_ = 0, ntrace = 0;
         hipStream_t st = eng.stream();
+        const double fast_ratio = fast_solve_ratio_env(); // MBAVO_FAST_SOLVE, once per call (mbavo_lm_batch does the same)
 
         SLAM::Core::SplineSE3 spline(t0, dt);
         spline.setSplineDegK(k);
@@ -177,26 +138,6 @@ namespace mbavo
             TRK_HIP(hipMemcpyAsync(d_cap, stage, sizeof(double) * 2 * F, hipMemcpyHostToDevice, st));
         }
 
-        { // the resident LM loop where it applies (small levels, k = 2 by default): no host round trip per evaluation
-            double kt_dev[3 * 16], kR_dev[4 * 16];
-            int nt = 0;
-            if (N <= 16)
-            {
-                memcpy(kt_dev, spline.get_knot_data_t(), sizeof(double) * 3 * N);
-                memcpy(kR_dev, spline.get_knot_data_R(), sizeof(double) * 4 * N);
-                const int dr = optimize_on_device(eng, o, levels, F, h_cap, h_exp, d_cap, d_exp, t0, dt, kt_dev, kR_dev, N, start_idx.data(),
-                                                  &eval_cost, trace, trace_cap, &nt);
-                if (dr == 0)
-                {
-                    memcpy(knots_t, kt_dev, sizeof(double) * 3 * N);
-                    memcpy(knots_R, kR_dev, sizeof(double) * 4 * N);
-                    if (final_cost) *final_cost = eval_cost;
-                    ntrace = nt;
-                    goto done;
-                }
-                if (dr != 1) { rc_ = dr; goto done; }
-            }
-        }
         {
         // One run per pyramid level, coarse to fine (:571-575).  Small levels (everything the reference's semi-dense detector
         // produces) are ONE persistent launch each -- the evaluations are commands to its resident workgroups
@@ -411,7 +352,7 @@ namespace mbavo
                 PhaseScope ps_solve(PhaseTimers::kSolve);
                 const double iradius = 1. / lm.get_radius();
                 for (int i = 0; i < n; ++i) H[(size_t)i * n + i] += H[(size_t)i * n + i] * iradius;
-                if (solve_normal_equation_host(H.data(), g.data(), n, o.solver_type, step.data()) < 0) { rc_ = MBAVO_E_ARG; goto done; }
+                if (solve_normal_equation_host(H.data(), g.data(), n, o.solver_type, step.data(), fast_ratio) < 0) { rc_ = MBAVO_E_ARG; goto done; }
                 double gx = 0.0, xHx = 0.0;
                 for (int i = 0; i < n; ++i) gx += g[i] * step[i];
                 for (int r = 0; r < n; ++r)

@@ -256,7 +256,7 @@ class ShardedEvaluation:
         return self.reduced.view(self.nbf_whole, self.E)[r0:r0 + self.whole[b].F]
 
 
-LM_RECORD_SCALARS = 8  # initial cost, final cost, radius, iterations, accepted, rejected, invalid, outliers
+LM_RECORD_SCALARS = 9  # initial cost, final cost, radius, iterations, accepted, rejected, invalid, outliers, control knots N
 
 
 def lm_record_layout(num_pairs, world, max_N):
@@ -285,7 +285,8 @@ class ShardedLmBatch:
         self.ctx, self.k, self.rank, self.world, self.opts = ctx, k, rank, world, opts
         self.B = len(whole)
         self.mine = pairs_of_rank(self.B, rank, world)
-        self.N = [int(whole[b].N) if b in set(self.mine) else 0 for b in range(self.B)]
+        own = set(self.mine)
+        self.N = [int(whole[b].N) if b in own else 0 for b in range(self.B)]  # (other ranks' N arrives with their records)
         self.max_N = 16  # the reference's max_num_ctrl_knots: the same record length on every rank without an exchange
         self.rows, self.rec, self.row_of_pair = lm_record_layout(self.B, world, self.max_N)
         self.records = torch.zeros(world * self.rows * self.rec, dtype=torch.float64, device=device)
@@ -311,26 +312,37 @@ class ShardedLmBatch:
 
     def run(self, gather=True):
         lib, ctx = self.ctx.lib, self.ctx
-        self._slice.copy_(self._init, non_blocking=True)  # initial knots (the LM updates them in place), scalars zero
+        with self._on_ctx_stream():  # (the LM loop and the all-gather run on the context's stream: so do the copies)
+            self._slice.copy_(self._init, non_blocking=True)  # initial knots (the LM updates them in place), scalars zero
         rc = 0
         if self.mine:
             rc = lib.mbavo_lm_batch(ctx.handle, len(self.mine), self.live, C.byref(self.opts), self.res, None, 0)  # (returns synchronised)
             sc = self._scal.numpy()
             for j in range(len(self.mine)):
                 r = self.res[j]
-                sc[j] = (r.initial_cost, r.final_cost, r.radius, r.iterations, r.accepted, r.rejected, r.invalid, r.num_outliers)
-            self._scal_dst.copy_(self._scal, non_blocking=True)
+                sc[j] = (r.initial_cost, r.final_cost, r.radius, r.iterations, r.accepted, r.rejected, r.invalid, r.num_outliers,
+                         self.N[self.mine[j]])
+            with self._on_ctx_stream():
+                self._scal_dst.copy_(self._scal, non_blocking=True)
         if gather and self.world > 1:
             capi.check(lib.mbavo_allgather_blocks(ctx.handle, None, self.records.data_ptr(), self.rows * self.rec), "mbavo_allgather_blocks")
         return rc
 
+    def _on_ctx_stream(self):
+        """torch stream context of the stream the library works on (mbavo_set_stream); the null stream if none was set."""
+        import torch
+        if not self.ctx.stream:
+            return torch.cuda.stream(torch.cuda.default_stream())
+        return torch.cuda.stream(torch.cuda.ExternalStream(self.ctx.stream))
+
     def record(self, b, N=None):
-        """Pair b's gathered record (synchronises): knots_t [N, 3], knots_R [N, 4] and the result scalars."""
+        """Pair b's gathered record (synchronises): knots_t [N, 3], knots_R [N, 4] and the result scalars.  The number of
+        control knots travels in the record (the pairs of other ranks are not populated in `whole`)."""
         import torch
         torch.cuda.synchronize()
-        n = N if N is not None else (self.N[b] or 4)
         row = self.records.view(-1, self.rec)[self.row_of_pair[b]].cpu().numpy()
         s = row[7 * self.max_N:]
+        n = N if N is not None else int(s[8])
         return {"knots_t": row[:3 * n].reshape(n, 3).copy(), "knots_R": row[3 * self.max_N:3 * self.max_N + 4 * n].reshape(n, 4).copy(),
                 "initial_cost": float(s[0]), "final_cost": float(s[1]), "radius": float(s[2]), "iterations": int(s[3]),
                 "accepted": int(s[4]), "rejected": int(s[5]), "invalid": int(s[6]), "num_outliers": int(s[7])}

@@ -75,38 +75,33 @@ def test_tracker_evaluation_paths_agree(orc, mbavo, gpu_ctx, kw, monkeypatch):
         assert np.abs(ref["kt"] - r["kt"]).max() < 1e-4 and np.abs(ref["kR"] - r["kR"]).max() < 1e-4, name
 
 
-@pytest.mark.parametrize("name,kw,mode", [
-    ("k2_semidense", dict(H=120, W=160, levels=3, S=8, k=2, seed=2), "1"),
-    ("k2_fullsize", dict(H=480, W=640, levels=4, S=8, k=2, seed=6), "1"),
-    ("k2_three_frames", dict(H=120, W=160, levels=2, S=4, k=2, F=3, seed=1), "1"),
-    ("k4_semidense_jacobi_on_device", dict(H=120, W=160, levels=3, S=8, k=4, seed=1), "2"),
-    ("k4_ldlt", dict(H=120, W=160, levels=3, S=8, k=4, seed=4), "2"),
+@pytest.mark.parametrize("name,kw", [
+    ("k2_semidense", dict(H=120, W=160, levels=3, S=8, k=2, seed=2)),
+    ("k2_three_frames", dict(H=120, W=160, levels=2, S=4, k=2, F=3, seed=1)),
+    ("k4_semidense_jacobi", dict(H=120, W=160, levels=3, S=8, k=4, seed=1)),
+    ("k4_ldlt", dict(H=120, W=160, levels=3, S=8, k=4, seed=4)),
 ])
-def test_resident_lm_loop_matches_oracle(orc, mbavo, gpu_ctx, monkeypatch, name, kw, mode):
-    """MBAVO_DEVICE_LM: the whole coarse-to-fine LM loop inside resident kernels (k_lm_level: the workgroup that finishes an
-    evaluation merges, solves, decides, updates outliers and radius and publishes the next evaluation in device memory; the
-    host waits once per call) against the oracle's loop: identical knot start indices, accept / reject / invalid sequence and
-    outlier counts, costs 1e-6, poses at capture time 1e-5 -- the bars of the host-driven loop above.  k = 2 takes the
-    register-resident LDL^T where the pivot ratio allows (cond(H) ~ 1e6 here), k = 4 (mode 2) the one-wave Jacobi SVD or, with
-    solver type 1, the pivoted LDL^T.  Also against the host-driven loop of the same library: same traces."""
+@pytest.mark.parametrize("fast_solve", ["1", "0"])
+def test_lm_loop_shapes_and_solvers_match_oracle(orc, mbavo, gpu_ctx, monkeypatch, name, kw, fast_solve):
+    """The host-driven loop on the shapes the (removed, round 4) resident LM loop was held to -- three frames on one spline,
+    k = 4 with the Jacobi SVD, solver type 1 -- against the oracle's loop, with the LDL^T stand-in of solver type 0 on
+    (default) and off (MBAVO_FAST_SOLVE=0: solve_normal_equation.h case 0 for every system): identical knot start indices,
+    accept / reject / invalid sequence and outlier counts, costs 1e-6, poses at capture time 1e-5."""
     sc = tracking.make_tracking_scene(orc, **kw)
     opts = dict(tracking.OPTS)
     if "ldlt" in name:
         opts["solver_type"] = 1
     ro = tracking.run_oracle_tracker(orc, sc, opts)
-    monkeypatch.setenv("MBAVO_DEVICE_LM", "0")
-    rh = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, opts)
-    monkeypatch.setenv("MBAVO_DEVICE_LM", mode)
+    monkeypatch.setenv("MBAVO_FAST_SOLVE", fast_solve)
     rg = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, opts)
     assert gpu_ctx.lib.mbavo_last_kernel(gpu_ctx.handle).decode().startswith("k_fused_sp<")
-    for ref in (ro, rh):
-        assert np.array_equal(ref["start"], rg["start"]) and len(ref["trace"]) == len(rg["trace"])
-        for a, b in zip(ref["trace"], rg["trace"]):
-            assert a[:4] == b[:4], (a, b)
-            assert a[4] == pytest.approx(b[4], rel=1e-4)
-            assert a[5] == pytest.approx(b[5], rel=1e-6, abs=1e-12) and a[6] == pytest.approx(b[6], rel=1e-6, abs=1e-12)
-        assert np.abs(ref["kt"] - rg["kt"]).max() < 1e-4 and np.abs(ref["kR"] - rg["kR"]).max() < 1e-4
-        assert ref["cost"] == pytest.approx(rg["cost"], rel=1e-6)
+    assert np.array_equal(ro["start"], rg["start"]) and len(ro["trace"]) == len(rg["trace"])
+    for a, b in zip(ro["trace"], rg["trace"]):
+        assert a[:4] == b[:4], (a, b)
+        assert a[4] == pytest.approx(b[4], rel=1e-4)
+        assert a[5] == pytest.approx(b[5], rel=1e-6, abs=1e-12) and a[6] == pytest.approx(b[6], rel=1e-6, abs=1e-12)
+    assert np.abs(ro["kt"] - rg["kt"]).max() < 1e-4 and np.abs(ro["kR"] - rg["kR"]).max() < 1e-4
+    assert ro["cost"] == pytest.approx(rg["cost"], rel=1e-6)
     for c in sc["cap"]:
         po, qo = tracking.pose_at(orc, sc["k"], sc["t0"], sc["dt"], ro["kt"], ro["kR"], c)
         pg, qg = tracking.pose_at(orc, sc["k"], sc["t0"], sc["dt"], rg["kt"], rg["kR"], c)
