@@ -59,6 +59,15 @@ def parse():
     ap.add_argument("--workload", default="c2_dense", choices=WORKLOADS)
     ap.add_argument("--shard", default=None, choices=["pairs", "keypoints", "frames", "frame_blocks"],
                     help="N > 1 sharding (default: the workload's own -- frames for a single pair, pairs for a batch of pairs)")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "gloo"],
+                    help="N > 1 only.  rccl: one GPU per rank, the product's collectives on the context's RCCL communicator.  gloo: the "
+                         "ranks SHARE the visible GPU(s) (rank r on GPU r %% device_count) and a gloo collective on a pinned host copy "
+                         "stands in for RCCL (shard.HostStagedCollective) -- executes every line of the N > 1 path on a one-GPU box "
+                         "except ncclAllReduce / ncclAllGather themselves; its timings are not scaling figures")
+    ap.add_argument("--collective", default="allgather", choices=["allgather", "allreduce"],
+                    help="pair sharding: ONE in-place all-gather of equal slices (default) or, as BASELINE.json words it, ONE "
+                         "all-reduce of a send buffer that is zero outside the rank's slice (twice the bytes on the wire)")
+    ap.add_argument("--batch-pairs", type=int, default=512, help="pairs of the N > 1 batch configs (tests shrink it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the bounded runs of the other BASELINE configs")
     ap.add_argument("--grad-fp16", action="store_true",
@@ -74,7 +83,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_workload(name, frames=1, seed=1, ctx=None, dev="cuda:0", grad_fp16=False):
+def build_workload(name, frames=1, seed=1, ctx=None, dev="cuda:0", grad_fp16=False, pairs=None):
     """(list of Prob or a device-resident RenderedPairBatch, description, sharding mode at N > 1)"""
     from mba_vo_amd import workloads as wl
     if name == "c2_dense":
@@ -89,7 +98,7 @@ def build_workload(name, frames=1, seed=1, ctx=None, dev="cuda:0", grad_fp16=Fal
         return wl.pyramid_pair(480, 640, 1, S=1, k=4, N=4, mode="dense", seed=seed, frames=frames), \
             "640x480 pair, 1 level, S=1 (sharp degenerate case), dense (configs[0])", "frames"
     if name in ("c3_batch64", "c4_batch512"):
-        B = 64 if name == "c3_batch64" else 512
+        B = pairs if pairs else (64 if name == "c3_batch64" else 512)
         return wl.RenderedPairBatch(ctx, B, S=8, k=4, device=dev, seed=seed, grad_fp16=grad_fp16), \
             "batch of %d independent 640x480 pairs = %d consecutive frames of ONE GPU-rendered synthetic blurred sequence " \
             "(textured plane, camera on a ground-truth spline; generate_synthetic_data.cpp:127-214): every pair has its OWN " \
@@ -242,13 +251,27 @@ def cpu_baseline(probs, budget_s):
     return out, np.concatenate(blocks, 0)
 
 
+def _counts_of(se, probs):
+    """(valid pixels, S, problem) of every LOCAL problem of a sharded evaluation after one clean pass."""
+    import torch
+    se.evaluate_local(True)
+    torch.cuda.synchronize()
+    valid = se.valid.cpu().numpy()
+    row, out = 0, []
+    for p in probs:
+        out.append((float(valid[row:row + p.F].sum()), p.S, p))
+        row += p.F
+    return out
+
+
 class Runner:
     """One workload resident on this rank's GPU: step(), unit counts, roofline figures."""
 
-    def __init__(self, M, ctx, name, dev, rank, world, sharded, grad_fp16=False, shard_mode=None, sequential=False):
+    def __init__(self, M, ctx, name, dev, rank, world, sharded, grad_fp16=False, shard_mode=None, sequential=False, coll=None,
+                 pair_collective="allgather", pairs=None):
         from mba_vo_amd import shard, workloads as wl
         self.M, self.ctx, self.name, self.world, self.rank = M, ctx, name, world, rank
-        built, self.desc, self.mode = build_workload(name, frames=world if sharded else 1, ctx=ctx, dev=dev, grad_fp16=grad_fp16)
+        built, self.desc, self.mode = build_workload(name, frames=world if sharded else 1, ctx=ctx, dev=dev, grad_fp16=grad_fp16, pairs=pairs)
         if shard_mode is not None:
             self.mode = shard_mode
         elif self.mode == "frames":
@@ -264,7 +287,8 @@ class Runner:
                     p.grad_fp16 = int(grad_fp16)
                 self.desc += ", packed keyframe pyramid (one word per pixel: intensity + both differences)" if int(grad_fp16) == 2 else ", fp16 gradient pyramid"
             self.dw = wl.DeviceWorkload(self.probs, device=dev)
-        self.se = shard.ShardedEvaluation(ctx, self.dw.array, self.dw.k, rank, world, self.mode, dev) if sharded else None
+        self.se = shard.ShardedEvaluation(ctx, self.dw.array, self.dw.k, rank, world, self.mode, dev, collective=coll,
+                                          pair_collective=pair_collective) if sharded else None
         self.wl = wl
         # the four pyramid levels one after the other, as blur_aware_direct_tracker.cpp:571-575 runs them (an LM loop cannot
         # evaluate a finer level before the coarser one has converged): one mbavo_eval_batch call per problem
@@ -424,12 +448,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    shared_gpu = args.comm == "gloo"  # the ranks share the visible GPU(s); gloo stands in for RCCL (see --comm)
+    if shared_gpu:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("MBAVO_BENCH_FORCE_DIST") == "1"  # the env switch runs the N > 1 code on one GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import mba_vo_amd as M
     from mba_vo_amd import shard
@@ -438,9 +468,13 @@ def main():
     dev = "cuda:%d" % local_rank
     stream = torch.cuda.current_stream()
     ctx = M.capi.Context(local_rank, stream=stream.cuda_stream)
-    rccl_ranks = 0
-    if use_dist:
+    rccl_ranks, coll = 0, None
+    if use_dist and shared_gpu:
+        coll = shard.HostStagedCollective(ctx, rank, world)
+    elif use_dist:
         rccl_ranks = shard.comm_init(ctx, rank, world, shard.torch_bcast(dev))
+        coll = shard.RcclCollective(ctx)
+    hdev = "cpu" if shared_gpu else dev  # where the helper collectives below keep their scalars (gloo: host tensors)
 
     def sync():
         # torch.cuda.synchronize() is the contract's bracket; the stream is polled first because the runtime's blocking wait
@@ -456,14 +490,14 @@ def main():
     def max_over_ranks(x):
         if not use_dist:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=hdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def sum_over_ranks(x):
         if not use_dist:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=hdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return float(t.item())
 
@@ -471,7 +505,7 @@ def main():
         """the value of every rank, in rank order (a list on every rank)"""
         if not use_dist:
             return [float(x)]
-        mine = torch.tensor([x], dtype=torch.float64, device=dev)
+        mine = torch.tensor([x], dtype=torch.float64, device=hdev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
         return [float(t.item()) for t in every]
@@ -487,7 +521,13 @@ def main():
         obj = {"frames": "merged [cost | g | H] systems", "frame_blocks": "packed frame blocks (every rank's frames in its slice, rank-major)", "keypoints": "packed frame blocks (partial sums over the ranks' keypoint bands)",
                "pairs": "packed frame blocks (disjoint slices, rank-major)"}[run.mode]
         return {"object": obj, "doubles": int(run.se.count), "max_rel_diff_vs_single_gpu": diff,
-                "ok": bool(diff <= 1e-12), "bit_exact": bool(torch.equal(got, ref)), "sharding": run.mode}
+                "ok": bool(diff <= 1e-12), "bit_exact": bool(torch.equal(got, ref)), "sharding": run.mode,
+                "collective": collective_name(run)}
+
+    def collective_name(r):
+        call = ("mbavo_allgather_blocks" if r.se.pair_collective == "allgather" else "mbavo_allreduce_blocks_to") if r.mode == "pairs" \
+            else ("mbavo_allreduce_blocks_to" if r.mode == "frame_blocks" else "mbavo_allreduce_blocks")
+        return call + (" [RCCL]" if not shared_gpu else " -> STAND-IN: gloo on a pinned host copy (ranks share one GPU)")
 
     def comm_profile(run, n=40):
         """Per-rank duration of the all-reduce alone (events around the collective, every rank's own evaluation before it:
@@ -510,7 +550,8 @@ def main():
         red = statistics.median(b.elapsed_time(c) for a, b, c in ev)
         return loc, red
 
-    run = Runner(M, ctx, args.workload, dev, rank, world, use_dist, 2 if args.packed_keyframes else int(args.grad_fp16), shard_mode=args.shard)
+    run = Runner(M, ctx, args.workload, dev, rank, world, use_dist, 2 if args.packed_keyframes else int(args.grad_fp16), shard_mode=args.shard,
+                 coll=coll, pair_collective=args.collective, pairs=args.batch_pairs if args.batch_pairs != 512 else None)
 
     for _ in range(args.warmup):
         run.step()
@@ -581,10 +622,8 @@ def main():
             "repeats": len(regions), "ms_per_step_min_max": [round(min(per_step), 5), round(max(per_step), 5)],
             "config": {"workload": run.desc, "name": args.workload, "problems_per_rank": len(run.probs) if run.se is None else run.se.n_live,
                        "pixel_samples_per_step_per_rank": ps_rank, "pixel_samples_launched_per_rank": ps_launched,
-                       "parallelism": ("workload sharded by %s over %d rank(s): evaluation -> %sONE mbavo_allreduce_blocks%s "
-                                       "(RCCL, context's own communicator) of %d doubles per step"
-                                       % (run.mode, world, "device merge -> " if run.mode == "frames" else "",
-                                          "_to" if run.mode in ("pairs", "frame_blocks") else "", run.se.count))
+                       "parallelism": ("workload sharded by %s over %d rank(s): evaluation -> %sONE %s of %d doubles per step"
+                                       % (run.mode, world, "device merge -> " if run.mode == "frames" else "", collective_name(run), run.se.count))
                        if run.se is not None else "1 GPU"},
             "roofline": {"bound": "fp64", "achieved": round(ach_tf, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach_tf / FP64_PEAK_TFLOPS, 5),
@@ -628,12 +667,13 @@ def main():
                               "evaluation; never `value`)" % int(run.dw.frame_blocks.numel())
         if use_dist:
             out["rccl_ranks"] = rccl_ranks
+            out["comm"] = "rccl" if not shared_gpu else "gloo stand-in, %d ranks on %d GPU(s): NOT a scaling measurement" % (world, torch.cuda.device_count())
             out["reduction_check"] = reduction
             out["per_rank"] = {"kernel_ms": [round(v, 6) for v in k_ms_ranks],
                                "local_evaluation_ms": [round(v, 6) for v in comm_ms[0]],
-                               "allreduce_ms": [round(v, 6) for v in comm_ms[1]],
+                               "collective_ms": [round(v, 6) for v in comm_ms[1]],
                                "note": "kernel_ms: the dominant kernel's dispatch timestamps inside the timed region; "
-                                       "local_evaluation_ms / allreduce_ms: event pairs around the rank's evaluation (+ merge) "
+                                       "local_evaluation_ms / collective_ms: event pairs around the rank's evaluation (+ merge) "
                                        "and around the collective in a separate pass of 40 steps -- the collective's figure "
                                        "includes waiting for the slowest rank"}
     fb_gpu = None
@@ -643,28 +683,36 @@ def main():
         fb_gpu = run.dw.frame_blocks.cpu().numpy().reshape(run.dw.nbf, run.dw.E)
 
     cfgs = {}
-    # N > 1: BASELINE configs[3] (512 pairs over the ranks) in both shardings, bounded -- the driver's scaling run only
-    # launches the default workload, so the batch's scaling points ride in its line
+    # N > 1: BASELINE configs[3] (512 pairs over the ranks: STRONG scaling, every GPU holds 512 / N pairs) in both shardings and
+    # both pair collectives, then the WEAK-scaling points north_star's "independent keyframe-pair alignments shard naturally
+    # across the 8 GPUs" asks for (512 pairs PER rank), bounded -- the driver's scaling run only launches the default workload,
+    # so the batch's scaling points ride in its line
     if use_dist and not args.no_configs and args.workload == "c2_dense":
+        NP = args.batch_pairs
         cfg_failed = False
-        for mode, fmt in (("pairs", 0), ("keypoints", 0), ("pairs", 2)):  # (2: packed keyframes, mbavo_problem.grad_fp16 = 2)
-            key = "c4_batch512_" + mode + ("_packed" if fmt == 2 else "")
+
+        def batch_entry(r, n, dt, kms, kname, scaling, chk):
+            loc, red = comm_profile(r)
+            c = r.local_counts()
+            ps = sum_over_ranks(sum(px * S for px, S, _ in c))
+            kr, lr, rr = per_rank(kms), per_rank(loc), per_rank(red)
+            return {"workload": r.desc, "sharding": r.mode, "collective": collective_name(r), "n_gpus": world,
+                    "value": round(ps * n / dt / 1e6, 3), "unit": "Mpixel-samples/s", "scaling": scaling, "steps": n,
+                    "ms_per_step": round(dt / n * 1e3, 5), "kernel": kname, "pairs_per_rank": r.se.n_live,
+                    "per_rank": {"kernel_ms": [round(v, 6) for v in kr], "local_evaluation_ms": [round(v, 6) for v in lr],
+                                 "collective_ms": [round(v, 6) for v in rr]},
+                    "reduction_check": chk, "collective_doubles": int(r.se.count)}
+
+        for mode, fmt, pc in (("pairs", 0, "allgather"), ("pairs", 0, "allreduce"), ("keypoints", 0, None), ("pairs", 2, "allgather")):
+            key = "c4_batch512_" + mode + ("_allreduce" if pc == "allreduce" else "") + ("_packed" if fmt == 2 else "")  # (2: packed keyframes)
             try:
-                r = Runner(M, ctx, "c4_batch512", dev, rank, world, True, fmt, shard_mode=mode)
+                r = Runner(M, ctx, "c4_batch512", dev, rank, world, True, fmt, shard_mode=mode, coll=coll, pair_collective=pc or "allgather",
+                           pairs=NP if NP != 512 else None)
                 n, dt, kms, kname = bounded_run(M, ctx, r, min_steps=60, sync=sync)
                 dt = max_over_ranks(dt)
-                chk = reduction_check(r)
-                loc, red = comm_profile(r)
-                c = r.local_counts()
-                ps = sum_over_ranks(sum(px * S for px, S, _ in c))
-                kr, lr, rr = per_rank(kms), per_rank(loc), per_rank(red)
+                e = batch_entry(r, n, dt, kms, kname, "strong", reduction_check(r))
                 if rank == 0:
-                    cfgs[key] = {"workload": r.desc, "sharding": mode, "n_gpus": world, "value": round(ps * n / dt / 1e6, 3),
-                                 "unit": "Mpixel-samples/s", "scaling": "strong", "steps": n, "ms_per_step": round(dt / n * 1e3, 5),
-                                 "kernel": kname, "per_rank": {"kernel_ms": [round(v, 6) for v in kr],
-                                                               "local_evaluation_ms": [round(v, 6) for v in lr],
-                                                               "allreduce_ms": [round(v, 6) for v in rr]},
-                                 "reduction_check": chk, "allreduce_doubles": int(r.se.count)}
+                    cfgs[key] = e
                 del r
                 torch.cuda.empty_cache()
             except Exception as e:
@@ -672,18 +720,65 @@ def main():
                     cfgs[key] = {"error": repr(e)}
                 cfg_failed = True
                 break  # the ranks may have diverged: no further collective configs
-        # whole alignments sharded: the device-side LM on every rank's own pairs, one all-gather of the records at the end
-        if max_over_ranks(float(cfg_failed)) == 0.0:  # (decided together: a rank that skipped would leave the others in a collective)
+        # weak scaling of the evaluation: NP pairs PER rank (rank r renders and owns pairs b % N == r of an N * NP-pair sequence),
+        # ONE in-place all-gather of the N * NP packed blocks.  No rank holds the whole workload, so the check is by samples:
+        # rank 0 renders one pair of every other rank, evaluates it alone and compares the gathered block (1e-12: another tile
+        # partition).
+        if max_over_ranks(float(cfg_failed)) == 0.0:
+            try:
+                from mba_vo_amd import shard as sh, workloads as wl
+                BT = NP * world
+                mine = sh.pairs_of_rank(BT, rank, world)
+                batch = wl.RenderedPairBatch(ctx, BT, S=8, k=4, device=dev, seed=1, pairs=mine, grad_fp16=2)
+                r = Runner.__new__(Runner)
+                r.M, r.ctx, r.name, r.world, r.rank, r.mode, r.sequential, r.wl = M, ctx, "c4_batch512", world, rank, "pairs", False, wl
+                r.dw, r.probs = batch, [batch.probs[b] for b in mine]
+                r.desc = "%d pairs PER RANK of one rendered blurred sequence of %d (packed keyframes), pair b on rank b %% N" % (NP, BT)
+                r.se = sh.ShardedEvaluation(ctx, batch.array, 4, rank, world, "pairs", dev, collective=coll, frames_per_pair=[1] * BT)
+                n, dt, kms, kname = bounded_run(M, ctx, r, min_steps=60, sync=sync)
+                dt = max_over_ranks(dt)
+                r.se.step(True)
+                torch.cuda.synchronize()
+                chk = {"by": "samples: rank 0 re-renders one pair of every rank, evaluates it alone", "collective": collective_name(r)}
+                if rank == 0:
+                    samples = [rr_ + world * ((NP // 2) if NP > 1 else 0) for rr_ in range(world)]
+                    sb = wl.RenderedPairBatch(ctx, BT, S=8, k=4, device=dev, seed=1, pairs=samples, grad_fp16=2)
+                    one = (M.capi.Problem * len(samples))(*[sb.array[b] for b in samples])
+                    fb1 = torch.zeros(len(samples) * sb.E, dtype=torch.float64, device=dev)
+                    M.capi.check(ctx.lib.mbavo_eval_batch(ctx.handle, len(samples), one, 4, 1, fb1.data_ptr(), None, None), "mbavo_eval_batch")
+                    torch.cuda.synchronize()
+                    worst = 0.0
+                    for i, b in enumerate(samples):
+                        a, g = fb1.view(-1, sb.E)[i], r.se.blocks_of_pair(b)[0]
+                        worst = max(worst, float((a - g).abs().max() / a.abs().max()))
+                    chk.update(max_rel_diff_vs_single_gpu=worst, ok=bool(worst <= 1e-12), sampled_pairs=samples)
+                    del sb
+                r.local_counts = lambda se=r.se, pr=r.probs: _counts_of(se, pr)
+                e = batch_entry(r, n, dt, kms, kname, "weak", chk)
+                if rank == 0:
+                    cfgs["c4_batch512_pairs_weak_packed"] = e
+                del r, batch
+                torch.cuda.empty_cache()
+            except Exception as e:
+                if rank == 0:
+                    cfgs["c4_batch512_pairs_weak_packed"] = {"error": repr(e)}
+                cfg_failed = True
+        # whole alignments sharded: the device-side LM on every rank's own pairs, one all-gather of the records at the end;
+        # strong (NP pairs in all) and weak (NP pairs per rank)
+        for key, weak in (("lm_batch512_pairs", False), ("lm_batch_pairs_weak", True)):
+            if max_over_ranks(float(cfg_failed)) != 0.0:  # (decided together: a rank that skipped would leave the others in a collective)
+                break
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import lm_bench
                 line = lm_bench.sharded_line(M, ctx, dev, rank, world, (dist.barrier if use_dist and world > 1 else (lambda: None)),
-                                             max_over_ranks, sum_over_ranks)
+                                             max_over_ranks, sum_over_ranks, B=NP * (world if weak else 1), coll=coll, weak=weak)
                 if rank == 0:
-                    cfgs["lm_batch512_pairs"] = line
+                    cfgs[key] = line
             except Exception as e:
                 if rank == 0:
-                    cfgs["lm_batch512_pairs"] = {"error": repr(e)}
+                    cfgs[key] = {"error": repr(e)}
+                cfg_failed = True
         if rank == 0:
             out["configs"] = cfgs
 

@@ -134,6 +134,8 @@ namespace mbavo
         void *c = comm ? comm : comm_;
         if (!c || !d || count_per_rank < 0) return MBAVO_E_ARG;
         if (count_per_rank == 0) return 0;
+        int nranks = 0;
+        if (r.CommCount(c, &nranks) == 0 && nranks == 1) return 0; // one rank, in place: its slice IS the buffer (no collective kernel)
         int rank = 0;
         { // in place: this rank's slice sits at its rank offset of the receive buffer
             static int (*UserRank)(const void *, int *) = nullptr;

@@ -6,9 +6,12 @@ equations (the reference's reduction point is merge_hessian_gradie
     packed frame blocks are partial sums scaled by the WHOLE problem's residual count (`num_residuals`), so the blocks
     of all ranks add up to the whole problem's blocks: one all-reduce of the B*F*E packed doubles.
   * B INDEPENDENT pairs, pairs sharded (`pairs_of_rank`): pair b on rank b % world, whole; every rank
-    evaluates its pairs into ITS contiguous slice of a B*F*E send buffer whose other slices are zero and stay zero
-    (`pair_layout`), and ONE out-of-place all-reduce (`mbavo_allreduce_blocks_to`) leaves every pair's blocks on every
-    rank -- disjoint slices, so the sum is exact and bit-identical to a single-GPU evaluation.
+    evaluates its pairs into ITS slice of the result buffer (`pair_layout`: equal slices, rank-major) and ONE in-place
+    all-gather (`mbavo_allgather_blocks`, the default since round 4) leaves every pair's blocks on every rank -- the
+    pairs share nothing, so nothing has to be ADDED: (N-1)/N of the buffer crosses the links once.  `pair_collective=
+    "allreduce"` keeps the wording of BASELINE.json's north_star ("a final RCCL all-reduce of the normal equations"): the
+    slices sit in a zero send buffer and ONE out-of-place all-reduce (`mbavo_allreduce_blocks_to`) sums x + 0 + ... + 0 --
+    exact and bit-identical, at twice the bytes on the wire.
   * ONE joint problem, frames sharded, packed blocks summed ('frame_blocks', bench.py's default for a single pair): as
     'frames' below, but every rank's frame blocks go into its slice of a zero send buffer and the all-reduce carries the
     packed blocks; the scatter into the 6N x 6N system is the consumer's (no merge kernel in the step).
@@ -34,12 +37,15 @@ def pairs_of_rank(num_pairs, rank, world):
     return list(range(rank, num_pairs, world))
 
 
-def pair_layout(frames_per_pair, world):
+def pair_layout(frames_per_pair, world, equal_slices=False):
     """Rank-major layout of the packed frame blocks of B independent pairs sharded pair -> rank b % world.
-    Returns (row_base, row_of_pair): rank r's pairs occupy rows [row_base[r], row_base[r + 1]) of the reduced buffer, in
-    ascending pair order; pair b's first frame block is row row_of_pair[b].  Every rank writes a CONTIGUOUS slice, so its
-    evaluation writes straight into the send buffer of the all-reduce (no scatter kernel)."""
+    Returns (row_base, row_of_pair): rank r's pairs occupy rows [row_base[r], ...) of the result buffer, in ascending pair
+    order; pair b's first frame block is row row_of_pair[b].  Every rank writes a CONTIGUOUS slice, so its evaluation
+    writes straight into the buffer of the collective (no scatter kernel).  equal_slices (what ncclAllGather wants): every
+    rank's slice has the rows of the fullest rank, the unused tail rows of the others stay zero."""
     B = len(frames_per_pair)
+    per_rank = [sum(int(frames_per_pair[b]) for b in pairs_of_rank(B, r, world)) for r in range(world)]
+    width = max(per_rank) if per_rank else 0
     row_base = [0]
     row_of_pair = [0] * B
     for r in range(world):
@@ -47,7 +53,7 @@ def pair_layout(frames_per_pair, world):
         for b in pairs_of_rank(B, r, world):
             row_of_pair[b] = row
             row += int(frames_per_pair[b])
-        row_base.append(row)
+        row_base.append(row_base[-1] + width if equal_slices else row)
     return row_base, row_of_pair
 
 
@@ -103,6 +109,76 @@ def torch_bcast(device):
     return bcast
 
 
+def ctx_stream(ctx):
+    """torch stream context of the stream the library works on (mbavo_set_stream); the null stream if none was set."""
+    import torch
+    if not ctx.stream:
+        return torch.cuda.stream(torch.cuda.default_stream())
+    return torch.cuda.stream(torch.cuda.ExternalStream(ctx.stream))
+
+
+class RcclCollective:
+    """The product's collectives: mbavo_allreduce_blocks[_to] / mbavo_allgather_blocks on the context's own RCCL
+    communicator (mbavo_comm_init), enqueued on the stream of the evaluation.  Tensors are device tensors of doubles."""
+    name = "rccl"
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def allreduce(self, send, recv, count):
+        lib, h = self.ctx.lib, self.ctx.handle
+        if send.data_ptr() == recv.data_ptr():
+            capi.check(lib.mbavo_allreduce_blocks(h, None, recv.data_ptr(), count), "mbavo_allreduce_blocks")
+        else:
+            capi.check(lib.mbavo_allreduce_blocks_to(h, None, send.data_ptr(), recv.data_ptr(), count), "mbavo_allreduce_blocks_to")
+
+    def allgather(self, buf, count_per_rank):
+        capi.check(self.ctx.lib.mbavo_allgather_blocks(self.ctx.handle, None, buf.data_ptr(), count_per_rank), "mbavo_allgather_blocks")
+
+
+class HostStagedCollective:
+    """STAND-IN for RcclCollective where RCCL cannot form the communicator: several ranks on ONE GPU (RCCL refuses duplicate
+    devices) -- the two-process -m gpu test and `bench.py --comm gloo`, which execute every line of the N > 1 path on a
+    one-GPU box except ncclAllReduce / ncclAllGather themselves.  Same call sites, same device buffers, same layouts: the
+    buffer is copied to pinned host memory on the context's stream, the stream is drained, torch.distributed (gloo) runs
+    the collective on the host copy, and the result is copied back on the same stream.  Test / measurement plumbing, not
+    a product path: nothing selects it unless asked to."""
+    name = "gloo(host-staged stand-in for RCCL)"
+
+    def __init__(self, ctx, rank, world, group=None):
+        self.ctx, self.rank, self.world, self.group, self._stage = ctx, rank, world, group, {}
+
+    def _host(self, n):
+        import torch
+        t = self._stage.get(n)
+        if t is None:
+            t = self._stage[n] = torch.zeros(abs(n), dtype=torch.float64).pin_memory()
+        return t
+
+    def allreduce(self, send, recv, count):
+        import torch
+        import torch.distributed as dist
+        h = self._host(count)
+        with ctx_stream(self.ctx):
+            h.copy_(send[:count], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            if self.world > 1:
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            recv[:count].copy_(h, non_blocking=True)
+
+    def allgather(self, buf, count_per_rank):
+        import torch
+        import torch.distributed as dist
+        n = count_per_rank
+        mine, every = self._host(n), self._host(-(n * self.world))  # (two staging buffers even when their sizes coincide)
+        with ctx_stream(self.ctx):
+            mine.copy_(buf[self.rank * n:(self.rank + 1) * n], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            if self.world > 1:
+                dist.all_gather_into_tensor(every, mine, group=self.group)
+                buf[:n * self.world].copy_(every, non_blocking=True)
+
+
 class ShardedEvaluation:
     """This rank's share of one GN-iteration evaluation of a workload (a list of joint problems resident on this GPU as
     `whole`, a capi.Problem array) and the reduction of the normal equations over the ranks.
@@ -114,15 +190,22 @@ class ShardedEvaluation:
         reference() : the same object computed by THIS rank alone from the whole workload (for the N = 1 equality check)
     """
 
-    def __init__(self, ctx, whole, k, rank, world, mode, device):
+    def __init__(self, ctx, whole, k, rank, world, mode, device, collective=None, pair_collective="allgather",
+                 frames_per_pair=None):
+        """collective: RcclCollective(ctx) unless given (HostStagedCollective: several ranks on one GPU).
+        pair_collective ('pairs' mode): 'allgather' (default) or 'allreduce' (module docstring).
+        frames_per_pair ('pairs' mode): F of every pair when `whole` only holds this rank's pairs (weak scaling: every rank
+        renders its own pairs only; reference() is then not available)."""
         import torch
-        assert mode in ("keypoints", "frames", "frame_blocks", "pairs")
+        assert mode in ("keypoints", "frames", "frame_blocks", "pairs") and pair_collective in ("allgather", "allreduce")
         self.ctx, self.whole, self.k, self.rank, self.world, self.mode = ctx, whole, k, rank, world, mode
+        self.coll = collective if collective is not None else RcclCollective(ctx)
+        self.pair_collective = pair_collective if mode == "pairs" else None
         self.B = len(whole)
         lib = ctx.lib
         self.E = lib.mbavo_packed_len(k)
         if mode == "pairs":
-            self._init_pairs(device)
+            self._init_pairs(device, frames_per_pair)
             return
         if mode == "frame_blocks":
             self._init_frame_blocks(device)
@@ -175,11 +258,15 @@ class ShardedEvaluation:
         self._perm = torch.from_numpy(np.array(perm, np.int64)).to(device)
         self.row_of_frame = {int(p): i for i, p in enumerate(perm)}  # problem-major frame slot -> row of `reduced`
 
-    def _init_pairs(self, device):
+    def _init_pairs(self, device, frames_per_pair=None):
         import torch
         lib, whole, rank, world = self.ctx.lib, self.whole, self.rank, self.world
         mine = pairs_of_rank(self.B, rank, world)
-        self.row_base, self.row_of_pair = pair_layout([whole[b].F for b in range(self.B)], world)
+        self.partial_whole = frames_per_pair is not None  # only this rank's pairs are populated in `whole`
+        frames = [int(f) for f in frames_per_pair] if self.partial_whole else [int(whole[b].F) for b in range(self.B)]
+        gather = self.pair_collective == "allgather"
+        self.frames = frames
+        self.row_base, self.row_of_pair = pair_layout(frames, world, equal_slices=gather)
         self.shards = (capi.Problem * self.B)()   # this rank's pairs whole, the others empty (F == 0)
         for b in range(self.B):
             C.memmove(C.byref(self.shards[b]), C.byref(whole[b]), C.sizeof(capi.Problem))
@@ -188,27 +275,35 @@ class ShardedEvaluation:
         self.first = np.zeros(self.B, np.int32)
         self.live = (capi.Problem * max(len(mine), 1))(*[whole[b] for b in mine])
         self.n_live = len(mine)
-        self.nbf = sum(whole[b].F for b in mine)
-        self.nbf_whole = sum(whole[b].F for b in range(self.B))
-        assert self.row_base[rank + 1] - self.row_base[rank] == self.nbf and self.row_base[-1] == self.nbf_whole
+        self.nbf = sum(frames[b] for b in mine)
+        self.nbf_whole = sum(frames)
+        self.rows = self.row_base[-1]             # rows of the result buffer (>= nbf_whole with equal slices)
+        assert self.row_base[rank + 1] - self.row_base[rank] >= self.nbf and self.rows >= self.nbf_whole
         self.sys_len = 0
         z = lambda n: torch.zeros(max(n, 1), dtype=torch.float64, device=device)
-        self.send = z(self.nbf_whole * self.E)     # zero outside this rank's slice, for good: nothing else writes there
-        self.frame_blocks = self.send[self.row_base[rank] * self.E:(self.row_base[rank] + max(self.nbf, 0)) * self.E] \
-            if self.nbf else z(1)
+        lo = self.row_base[rank] * self.E
+        if gather:
+            # in place: every rank evaluates straight into its slice of the result buffer; the all-gather fills the others
+            self.slice_rows = self.row_base[1] - self.row_base[0]
+            self.reduced = z(self.rows * self.E)
+            self.send = self.reduced
+            self.count = self.rows * self.E       # doubles every rank holds afterwards ((N-1)/N of them cross the links)
+        else:
+            self.send = z(self.rows * self.E)     # zero outside this rank's slice, for good: nothing else writes there
+            self.reduced = z(self.rows * self.E) if world > 1 else self.send  # one rank: the send buffer
+            self.count = self.rows * self.E
+        self.frame_blocks = self.send[lo:lo + max(self.nbf, 0) * self.E] if self.nbf else z(1)
         self.valid = z(self.nbf)
         self.systems = None
-        self.reduced = z(self.nbf_whole * self.E) if world > 1 else self.send  # rank-major rows (pair_layout); one rank: the send buffer
-        self.count = self.nbf_whole * self.E
-        self._ref_fb, self._ref_sys = z(self.nbf_whole * self.E), None
-        # rows of the whole workload in problem order -> rank-major rows
-        rows, first_row = [], 0
-        perm = np.zeros(self.nbf_whole, np.int64)
+        self._ref_fb, self._ref_sys = (None if self.partial_whole else z(self.nbf_whole * self.E)), None
+        # rows of the whole workload in problem order -> rows of the result buffer
+        first_row = 0
+        dst = np.zeros(self.nbf_whole, np.int64)
         for b in range(self.B):
-            for f in range(whole[b].F):
-                perm[self.row_of_pair[b] + f] = first_row + f
-            first_row += whole[b].F
-        self._perm = torch.from_numpy(perm).to(device)
+            for f in range(frames[b]):
+                dst[first_row + f] = self.row_of_pair[b] + f
+            first_row += frames[b]
+        self._dst_rows = torch.from_numpy(dst).to(device)
 
     def evaluate_local(self, with_hessian=True):
         lib, ctx = self.ctx.lib, self.ctx
@@ -228,32 +323,37 @@ class ShardedEvaluation:
             self._reduce()
 
     def _reduce(self):
-        reduce = True
-        if reduce and self.mode in ("pairs", "frame_blocks"):
-            capi.check(self.ctx.lib.mbavo_allreduce_blocks_to(self.ctx.handle, None, self.send.data_ptr(),
-                                                              self.reduced.data_ptr(), self.count), "mbavo_allreduce_blocks_to")
-        elif reduce:
-            capi.check(self.ctx.lib.mbavo_allreduce_blocks(self.ctx.handle, None, self.reduced.data_ptr(), self.count),
-                       "mbavo_allreduce_blocks")
+        if self.mode == "pairs" and self.pair_collective == "allgather":
+            self.coll.allgather(self.reduced, self.slice_rows * self.E)
+        elif self.mode in ("pairs", "frame_blocks"):
+            self.coll.allreduce(self.send, self.reduced, self.count)
+        else:
+            self.coll.allreduce(self.reduced, self.reduced, self.count)
 
     def reference(self):
         """The reduced object of the WHOLE workload evaluated by this rank alone (synchronous; returns a clone)."""
         import torch
         lib, ctx = self.ctx.lib, self.ctx
+        if self._ref_fb is None:
+            raise RuntimeError("reference() needs the whole workload on this rank (frames_per_pair was given: weak scaling)")
         capi.check(lib.mbavo_eval_batch(ctx.handle, self.B, self.whole, self.k, 1, self._ref_fb.data_ptr(), None, None),
                    "mbavo_eval_batch")
         if self.mode == "frames":
             capi.check(lib.mbavo_merge_device(ctx.handle, self.B, self.whole, self.k, self._ref_fb.data_ptr(),
                                               self._ref_sys.data_ptr()), "mbavo_merge_device")
         torch.cuda.synchronize()
-        if self.mode in ("pairs", "frame_blocks"):  # the same rows in the rank-major order of the reduced buffer
+        if self.mode == "pairs":  # the same rows where the result buffer holds them (padding rows of equal slices stay zero)
+            out = torch.zeros(self.rows, self.E, dtype=torch.float64, device=self._ref_fb.device)
+            out[self._dst_rows] = self._ref_fb.view(self.nbf_whole, self.E)
+            return out.reshape(-1)
+        if self.mode == "frame_blocks":  # the same rows in the rank-major order of the reduced buffer
             return self._ref_fb.view(self.nbf_whole, self.E)[self._perm].reshape(-1).clone()
         return (self._ref_sys if self.mode == "frames" else self._ref_fb).clone()
 
     def blocks_of_pair(self, b):
         """'pairs' mode: the reduced packed frame blocks [F_b, E] of pair b (a view of `reduced`)."""
         r0 = self.row_of_pair[b]
-        return self.reduced.view(self.nbf_whole, self.E)[r0:r0 + self.whole[b].F]
+        return self.reduced.view(self.rows, self.E)[r0:r0 + self.frames[b]]
 
 
 LM_RECORD_SCALARS = 9  # initial cost, final cost, radius, iterations, accepted, rejected, invalid, outliers, control knots N
@@ -280,9 +380,10 @@ class ShardedLmBatch:
         record(b)  : dict of pair b's result after run() (any rank)
     """
 
-    def __init__(self, ctx, whole, k, rank, world, device, opts, init_knots):
+    def __init__(self, ctx, whole, k, rank, world, device, opts, init_knots, collective=None):
         import torch
         self.ctx, self.k, self.rank, self.world, self.opts = ctx, k, rank, world, opts
+        self.coll = collective if collective is not None else RcclCollective(ctx)
         self.B = len(whole)
         self.mine = pairs_of_rank(self.B, rank, world)
         own = set(self.mine)
@@ -312,7 +413,7 @@ class ShardedLmBatch:
 
     def run(self, gather=True):
         lib, ctx = self.ctx.lib, self.ctx
-        with self._on_ctx_stream():  # (the LM loop and the all-gather run on the context's stream: so do the copies)
+        with ctx_stream(self.ctx):  # (the LM loop and the all-gather run on the context's stream: so do the copies)
             self._slice.copy_(self._init, non_blocking=True)  # initial knots (the LM updates them in place), scalars zero
         rc = 0
         if self.mine:
@@ -322,18 +423,11 @@ class ShardedLmBatch:
                 r = self.res[j]
                 sc[j] = (r.initial_cost, r.final_cost, r.radius, r.iterations, r.accepted, r.rejected, r.invalid, r.num_outliers,
                          self.N[self.mine[j]])
-            with self._on_ctx_stream():
+            with ctx_stream(self.ctx):
                 self._scal_dst.copy_(self._scal, non_blocking=True)
         if gather and self.world > 1:
-            capi.check(lib.mbavo_allgather_blocks(ctx.handle, None, self.records.data_ptr(), self.rows * self.rec), "mbavo_allgather_blocks")
+            self.coll.allgather(self.records, self.rows * self.rec)
         return rc
-
-    def _on_ctx_stream(self):
-        """torch stream context of the stream the library works on (mbavo_set_stream); the null stream if none was set."""
-        import torch
-        if not self.ctx.stream:
-            return torch.cuda.stream(torch.cuda.default_stream())
-        return torch.cuda.stream(torch.cuda.ExternalStream(self.ctx.stream))
 
     def record(self, b, N=None):
         """Pair b's gathered record (synchronises): knots_t [N, 3], knots_R [N, 4] and the result scalars.  The number of

@@ -173,6 +173,9 @@ class RenderedPairBatch:
         own = range(B) if pairs is None else pairs  # (a rank may build only its own pairs; the others stay zero-filled)
         own = set(own)
         cap_kp = (H // cell + 1) * (W // cell + 1)
+        # pair b's knot perturbation is the b-th draw whoever renders it (a rank that builds only its own pairs, or a checker
+        # that re-renders single pairs, sees the pairs the whole batch holds)
+        perts = [rng.normal(0, perturb, (4, 3)) for _ in range(B)]
         for b in range(B):
             if b not in own:
                 self.probs.append(_PairInfo(S, k, 4, 1, 0, 8, H, W, grad_fp16))
@@ -224,7 +227,7 @@ class RenderedPairBatch:
             kR = np.stack([_qmul(qk_inv, self.kR_w[idx + i]) for i in range(4)])
             kR /= np.linalg.norm(kR, axis=1, keepdims=True)
             kt_gt = kt.copy()
-            kt = kt + rng.normal(0, perturb, kt.shape)
+            kt = kt + perts[b]
             t0 = t0w + idx * dtk
             capt, expt = torch.tensor([tc], dtype=torch.float64, device=device), torch.tensor([exp], dtype=torch.float64, device=device)
             dkt, dkR = torch.from_numpy(kt.ravel().copy()).to(device), torch.from_numpy(kR.ravel().copy()).to(device)

@@ -109,6 +109,17 @@ def _worker(rank, world, port, out_dir):
     acc = send.clone()  # (gloo's all-reduce is in place; the product's RCCL call is out of place, send stays untouched)
     shard.allreduce_blocks(acc)
     assert torch.equal(acc[row_base[rank]:row_base[rank + 1]], send[row_base[rank]:row_base[rank + 1]])  # x + 0 is exact
+    # (3b) the same pairs through the DEFAULT collective of pair mode (round 4): equal slices (pair_layout(..., equal_slices=True):
+    # the fullest rank's rows everywhere, unused tail rows zero), ONE in-place all-gather -- no sum, half the bytes on the wire
+    eq_base, eq_row = shard.pair_layout(frames, world, equal_slices=True)
+    width = eq_base[1] - eq_base[0]
+    mine_eq = torch.zeros(width, sc.E, dtype=torch.float64)
+    for b in shard.pairs_of_rank(7, rank, world):
+        mine_eq[eq_row[b] - eq_base[rank]:eq_row[b] - eq_base[rank] + frames[b]] = send[row_of_pair[b]:row_of_pair[b] + frames[b]]
+    gathered_eq = torch.zeros(world * width, sc.E, dtype=torch.float64)
+    dist.all_gather_into_tensor(gathered_eq, mine_eq)
+    for b in range(7):
+        assert torch.equal(gathered_eq[eq_row[b]:eq_row[b] + frames[b]], acc[row_of_pair[b]:row_of_pair[b] + frames[b]])
     # ---- pair-sharded batched LM: the record all-gather (shard.lm_record_layout; the LM itself needs the GPU) -- every
     # rank fills its pairs' records, equal slices are gathered, and pair b's record sits at row_of_pair[b] on every rank
     rows, rec, lm_row = shard.lm_record_layout(7, world, 4)
@@ -173,6 +184,12 @@ def test_pair_layout_is_a_rank_major_partition(mbavo):
             for r in range(world):  # ascending pair order inside a slice
                 mine = shard.pairs_of_rank(B, r, world)
                 assert [row_of_pair[b] for b in mine] == sorted(row_of_pair[b] for b in mine)
+            # equal slices (the all-gather's layout): the same order inside a slice, every slice as wide as the fullest rank's
+            eq_base, eq_row = shard.pair_layout(frames, world, equal_slices=True)
+            width = max(sum(frames[b] for b in shard.pairs_of_rank(B, r, world)) for r in range(world))
+            assert eq_base == [r * width for r in range(world + 1)]
+            for b in range(B):
+                assert eq_row[b] - eq_base[b % world] == row_of_pair[b] - row_base[b % world]
 
 
 def test_shard_partitions_cover_everything(mbavo):

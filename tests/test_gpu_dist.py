@@ -5,7 +5,10 @@ evaluation of the whole problem (1e-12: only the summation order differs), (b) t
 (c) the oracle (1e-9).  The reference's reduction point: merge_hessian_gradient_cost.cpp:39-86.
 
 world = 1 runs on the one-GPU box (every code path, a 1-rank communicator); world = 2 needs two GPUs and is skipped
-otherwise.  The same body runs under torchrun:
+otherwise -- and runs as TWO PROCESSES SHARING THE ONE GPU (round 4): every line of ranks > 0 executes -- shards, slices,
+layouts, device merge, the batched LM per rank -- with shard.HostStagedCollective (gloo on a pinned host copy) standing
+in for the RCCL collectives, which cannot form a communicator over duplicate devices; only ncclAllReduce / ncclAllGather
+themselves stay unexercised at N > 1.  The same body runs under torchrun:
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 tests/test_gpu_dist.py
 """
 import json
@@ -19,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def rank_body(rank, world, local_rank, port, out_path):
+def rank_body(rank, world, local_rank, port, out_path, comm="rccl"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -28,7 +31,10 @@ def rank_body(rank, world, local_rank, port, out_path):
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    if comm == "rccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:  # several ranks on one GPU: gloo is the process group AND stands in for the product's collectives
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     import mba_vo_amd as M
     from mba_vo_amd import shard, workloads as wl
     from oracle import binding as B
@@ -36,8 +42,12 @@ def rank_body(rank, world, local_rank, port, out_path):
     ctx = M.capi.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     assert ctx.lib.mbavo_comm_ranks(ctx.handle) == 0
     assert ctx.lib.mbavo_allreduce_blocks(ctx.handle, None, 8, 1) == -1  # no communicator yet: MBAVO_E_ARG
-    assert shard.comm_init(ctx, rank, world, shard.torch_bcast(dev)) == world
-    res = {"world": world, "rccl_ranks": ctx.lib.mbavo_comm_ranks(ctx.handle)}
+    if comm == "rccl":
+        assert shard.comm_init(ctx, rank, world, shard.torch_bcast(dev)) == world
+        coll = shard.RcclCollective(ctx)
+    else:
+        coll = shard.HostStagedCollective(ctx, rank, world)
+    res = {"world": world, "rccl_ranks": ctx.lib.mbavo_comm_ranks(ctx.handle) if comm == "rccl" else world, "collective": coll.name}
 
     def rel(a, b):
         return float((a - b).abs().max() / b.abs().max())
@@ -46,7 +56,7 @@ def rank_body(rank, world, local_rank, port, out_path):
     F = max(world, 2) + 1
     probs = wl.pyramid_pair(120, 160, 2, S=8, k=4, N=4, mode="dense", seed=7, frames=F)
     dw = wl.DeviceWorkload(probs, device=dev)
-    se = shard.ShardedEvaluation(ctx, dw.array, 4, rank, world, "frames", dev)
+    se = shard.ShardedEvaluation(ctx, dw.array, 4, rank, world, "frames", dev, collective=coll)
     for _ in range(3):  # repeated steps reuse the cached merge descriptors
         se.step(True)
     torch.cuda.synchronize()
@@ -79,7 +89,7 @@ def rank_body(rank, world, local_rank, port, out_path):
 
     # ---- frame_blocks mode (bench.py's default for a single pair): the same frame shards, but the packed blocks themselves are
     # summed from every rank's slice of a zero send buffer -- no merge kernel; rows in rank-major order
-    se_fb = shard.ShardedEvaluation(ctx, dw.array, 4, rank, world, "frame_blocks", dev)
+    se_fb = shard.ShardedEvaluation(ctx, dw.array, 4, rank, world, "frame_blocks", dev, collective=coll)
     for _ in range(2):
         se_fb.step(True)
     torch.cuda.synchronize()
@@ -98,7 +108,7 @@ def rank_body(rank, world, local_rank, port, out_path):
     # ---- keypoints mode: 5 semi-dense pairs, every pair's keypoints sharded, packed blocks summed
     pb = wl.pair_batch(5, H=240, W=320, S=8, k=4, N=4, mode="semidense", seed=3)
     dw2 = wl.DeviceWorkload(pb, device=dev)
-    se2 = shard.ShardedEvaluation(ctx, dw2.array, 4, rank, world, "keypoints", dev)
+    se2 = shard.ShardedEvaluation(ctx, dw2.array, 4, rank, world, "keypoints", dev, collective=coll)
     se2.step(True)
     torch.cuda.synchronize()
     got2, ref2 = se2.reduced.clone(), se2.reference()
@@ -106,12 +116,20 @@ def rank_body(rank, world, local_rank, port, out_path):
     # ---- pairs mode: 7 rendered pairs, pair b on rank b % world, slices of one zero send buffer, ONE
     # out-of-place all-reduce; three steps in a row (the send buffer's foreign slices must still be zero afterwards)
     rb = wl.RenderedPairBatch(ctx, 7, H=240, W=320, S=8, k=4, device=dev, seed=5)
-    se3 = shard.ShardedEvaluation(ctx, rb.array, 4, rank, world, "pairs", dev)
+    # (the default collective of pair mode: ONE in-place all-gather of equal slices -- 7 pairs do not divide by 2)
+    se3g = shard.ShardedEvaluation(ctx, rb.array, 4, rank, world, "pairs", dev, collective=coll)
+    for _ in range(3):
+        se3g.step(True)
+    torch.cuda.synchronize()
+    res["pairs_allgather_vs_single_gpu"] = rel(se3g.reduced.clone(), se3g.reference())
+    res["pairs_allgather_rows"] = int(se3g.rows)
+    se3 = shard.ShardedEvaluation(ctx, rb.array, 4, rank, world, "pairs", dev, collective=coll, pair_collective="allreduce")
     for _ in range(3):
         se3.step(True)
     torch.cuda.synchronize()
     got3, ref3 = se3.reduced.clone(), se3.reference()
     res["pairs_vs_single_gpu"] = rel(got3, ref3)
+    res["pairs_gather_equals_reduce"] = bool(all(torch.equal(se3g.blocks_of_pair(b), se3.blocks_of_pair(b)) for b in range(7)))
     lo, hi = se3.row_base[rank] * se3.E, se3.row_base[rank + 1] * se3.E
     res["pairs_own_slice_exact"] = bool(torch.equal(got3[lo:hi], se3.send[lo:hi]))
     res["pairs_foreign_slices_zero"] = bool(float(se3.send[:lo].abs().sum() + se3.send[hi:].abs().sum()) == 0.0)
@@ -125,7 +143,7 @@ def rank_body(rank, world, local_rank, port, out_path):
     o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps, o.solver_type, o.sync_every = 4, 6, 5, 0, 0
     o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = 0.5, 0.0, 3.0
     init = [(h["kt"], h["kR"]) for h in rb._host]
-    sl = shard.ShardedLmBatch(ctx, rb.array, 4, rank, world, dev, o, init)
+    sl = shard.ShardedLmBatch(ctx, rb.array, 4, rank, world, dev, o, init, collective=coll)
     assert sl.run() == 0
     alone = shard.ShardedLmBatch(ctx, rb.array, 4, 0, 1, dev, o, init)
     assert alone.run() == 0
@@ -138,9 +156,13 @@ def rank_body(rank, world, local_rank, port, out_path):
     res["lm_sharded_knots_vs_single_gpu"] = worst
     res["nonzero"] = bool(float(ref.abs().max()) > 0 and float(ref2.abs().max()) > 0 and float(ref3.abs().max()) > 0)
     # every rank holds the same reduced object
-    chk = got2.clone()
+    chk = got2.clone() if comm == "rccl" else got2.cpu()
     dist.all_reduce(chk, op=dist.ReduceOp.MAX)
-    res["ranks_agree"] = bool(torch.equal(chk, got2))
+    res["ranks_agree"] = bool(torch.equal(chk, got2 if comm == "rccl" else got2.cpu()))
+    gt = se3g.reduced.clone() if comm == "rccl" else se3g.reduced.cpu()
+    gmax = gt.clone()
+    dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
+    res["ranks_agree"] = res["ranks_agree"] and bool(torch.equal(gmax, gt))
     dist.barrier()
     assert ctx.lib.mbavo_comm_destroy(ctx.handle) == 0 and ctx.lib.mbavo_comm_ranks(ctx.handle) == 0
     ctx.close()
@@ -163,19 +185,23 @@ def check(res, world):
     assert res["frame_blocks_merged_vs_frames_mode"] <= 1e-12
     assert res["frames_vs_oracle"] <= 1e-9 and res["pairs_vs_oracle"] <= 1e-9
     assert res["pairs_vs_single_gpu"] <= 1e-12 and res["pairs_own_slice_exact"] and res["pairs_foreign_slices_zero"]
+    assert res["pairs_allgather_vs_single_gpu"] <= 1e-12 and res["pairs_gather_equals_reduce"]
+    assert res["pairs_allgather_rows"] == world * -(-7 // world)
     assert res["lm_sharded_same_counts"] and res["lm_sharded_knots_vs_single_gpu"] <= 1e-9
 
 
-def _spawned(rank, world, port, out_path):
-    rank_body(rank, world, rank, port, out_path)
+def _spawned(rank, world, port, out_path, comm="rccl"):
+    rank_body(rank, world, rank if comm == "rccl" else 0, port, out_path, comm)
 
 
-def _run(world, tmp_path):
+def _run(world, tmp_path, comm="rccl"):
     import torch.multiprocessing as mp
     out = str(tmp_path / "res.json")
     port = 29600 + (os.getpid() % 2000)
-    mp.spawn(_spawned, args=(world, port, out), nprocs=world, join=True)
-    check(json.load(open(out)), world)
+    mp.spawn(_spawned, args=(world, port, out, comm), nprocs=world, join=True)
+    res = json.load(open(out))
+    check(res, world)
+    return res
 
 
 def test_sharded_evaluation_one_rank(mbavo, tmp_path):
@@ -183,6 +209,18 @@ def test_sharded_evaluation_one_rank(mbavo, tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     _run(1, tmp_path)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_evaluation_ranks_sharing_one_gpu(mbavo, tmp_path, world):
+    """Two (three) processes, each with its own HIP context on GPU 0: the whole sharded path of ranks > 0 on the HIP engine
+    (frames / frame_blocks / keypoints / pairs by all-gather and by all-reduce, ShardedLmBatch), gloo on a host copy in
+    the place of the RCCL collective (module docstring).  Same assertions as with RCCL."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    res = _run(world, tmp_path, comm="gloo")
+    assert res["collective"].startswith("gloo")
 
 
 def test_sharded_evaluation_two_ranks(mbavo, tmp_path):

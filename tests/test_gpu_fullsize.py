@@ -227,14 +227,14 @@ def test_c4_batch512_rendered_pairs_full_size(orc, mbavo, gpu_ctx):
                                     p.intr, p.cap, p.exp, p.t0, p.dt, p.knots_t, p.knots_R, p.start_idx, p.huber)
         ro = orc.evaluate(op)
         assert np.abs(ro["frame_blocks"][0] - fb[b]).max() <= 1e-9 * np.abs(fb[b]).max()
-    for world in (2, 4, 8):
+    for world, coll in ((2, "allgather"), (4, "allreduce"), (8, "allgather")):
         total = None
         for r in range(world):
-            se = shard.ShardedEvaluation(gpu_ctx, batch.array, 4, r, world, "pairs", "cuda:0")
+            se = shard.ShardedEvaluation(gpu_ctx, batch.array, 4, r, world, "pairs", "cuda:0", pair_collective=coll)
             se.step(True, reduce=False)
             torch.cuda.synchronize()
             total = se.send.clone() if total is None else total + se.send
-        got = total.cpu().numpy().reshape(512, batch.E)
+        got = total.cpu().numpy().reshape(512, batch.E)  # (512 divides by every world size here: no padding rows)
         order = np.array(se.row_of_pair)
         assert np.abs(got[order] - fb).max() <= 1e-12 * np.abs(fb).max()
 

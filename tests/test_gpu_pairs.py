@@ -51,33 +51,37 @@ def test_rendered_pairs_match_oracle_and_are_consistent(orc, mbavo, gpu_ctx):
     assert c_gt < 0.5 * c_off, (c_gt, c_off)
 
 
+@pytest.mark.parametrize("collective", ["allgather", "allreduce"])
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_pair_shards_of_every_rank_on_one_gpu(orc, mbavo, gpu_ctx, world):
+def test_pair_shards_of_every_rank_on_one_gpu(orc, mbavo, gpu_ctx, world, collective):
     """bench.py --workload c4_batch512 --gpus N (pair sharding): rank r evaluates pairs b % N == r into ITS slice of the
-    zero send buffer.  The N ranks run one after the other on this GPU; the sum of their send buffers (what the
-    all-reduce computes: x + 0 + ... + 0, exact) must hold every pair's block -- bit-identical to the rank's own
-    evaluation, within 1e-12 of the whole batch evaluated at once (another tile partition, so another summation
-    grouping), and 1e-9 from the oracle for sampled pairs."""
+    result buffer (all-gather, the default: equal slices, B = 21 does not divide by N, so the fuller ranks' slices set the
+    width) or of the zero send buffer (all-reduce).  The N ranks run one after the other on this GPU; the sum of their
+    buffers (what either collective leaves on every rank: the slices are disjoint, x + 0 + ... + 0 is exact) must hold
+    every pair's block -- bit-identical to the rank's own evaluation, within 1e-12 of the whole batch evaluated at once
+    (another tile partition, so another summation grouping), and 1e-9 from the oracle for sampled pairs."""
     import torch
     B = 21
     batch = wl.RenderedPairBatch(gpu_ctx, B, H=240, W=320, S=8, k=4, seed=6)
     total, ref, mine = None, None, {}
     for r in range(world):
-        se = shard.ShardedEvaluation(gpu_ctx, batch.array, 4, r, world, "pairs", "cuda:0")
-        assert se.n_live == len(shard.pairs_of_rank(B, r, world)) and se.count == B * batch.E
+        se = shard.ShardedEvaluation(gpu_ctx, batch.array, 4, r, world, "pairs", "cuda:0", pair_collective=collective)
+        R = se.rows
+        assert se.n_live == len(shard.pairs_of_rank(B, r, world)) and se.count == R * batch.E
+        assert R == (B if collective == "allreduce" else world * -(-B // world))
         se.step(True, reduce=False)
         torch.cuda.synchronize()
         part = se.send.clone()
-        rows = part.view(B, batch.E)
+        rows = part.view(R, batch.E)
         lo, hi = se.row_base[r], se.row_base[r + 1]
-        assert float(rows[:lo].abs().max() if lo else 0.0) == 0.0 and float(rows[hi:].abs().max() if hi < B else 0.0) == 0.0
+        assert float(rows[:lo].abs().max() if lo else 0.0) == 0.0 and float(rows[hi:].abs().max() if hi < R else 0.0) == 0.0
         for b in shard.pairs_of_rank(B, r, world):
             mine[b] = rows[se.row_of_pair[b]].clone()
         total = part if total is None else total + part
         if r == world - 1:
             ref = se.reference()
             layout = se
-    got = total.view(B, batch.E)
+    got = total.view(layout.rows, batch.E)
     for b in range(B):
         assert torch.equal(got[layout.row_of_pair[b]], mine[b])                      # the sum is exact
     assert float((total - ref).abs().max() / ref.abs().max()) <= 1e-12                # vs the whole batch at once

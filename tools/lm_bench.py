@@ -90,7 +90,8 @@ def bench_line(M, ctx, dev, B=64, iterations=10, host_pairs=8):
     return out
 
 
-def sharded_line(M, ctx, dev, rank, world, barrier, max_over_ranks, sum_over_ranks, B=512, iterations=10, reps=3, packed=True):
+def sharded_line(M, ctx, dev, rank, world, barrier, max_over_ranks, sum_over_ranks, B=512, iterations=10, reps=3, packed=True, coll=None,
+                 weak=False):
     """bench.py N > 1 `configs.lm_batch512_pairs`: B pairs of the rendered sequence aligned by the device-side LM, pair b on
     rank b % world (shard.ShardedLmBatch: no collective inside the loop, ONE all-gather of the records at the end).
     Every rank renders only its own pairs.  value = LM iterations of all pairs / max-over-ranks wall time of a call."""
@@ -103,7 +104,7 @@ def sharded_line(M, ctx, dev, rank, world, barrier, max_over_ranks, sum_over_ran
     o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps, o.solver_type, o.sync_every = 4, iterations, 5, 0, 0
     o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = 0.5, 0.0, 3.0
     init = [None if h is None else (h["kt"], h["kR"]) for h in batch._host]
-    sl = shard.ShardedLmBatch(ctx, batch.array, 4, rank, world, dev, o, init)
+    sl = shard.ShardedLmBatch(ctx, batch.array, 4, rank, world, dev, o, init, collective=coll)
     best = None
     for _ in range(reps + 1):  # (the first call sizes the engine's arenas)
         barrier()
@@ -121,7 +122,8 @@ def sharded_line(M, ctx, dev, rank, world, barrier, max_over_ranks, sum_over_ran
     want = sum_over_ranks(float(sum(sl.res[j].iterations for j, b in enumerate(mine) if b % max(1, B // 16) == 0)))
     return {"workload": "%d pairs of the rendered blurred sequence (%s keyframes), device-side LM, %d iterations per pair, pair b on "
                         "rank b %% N, one all-gather of the records" % (B, "packed" if packed else "float-gradient", iterations),
-            "n_gpus": world, "sharding": "pairs (whole alignments)", "scaling": "strong", "ms_total": round(1e3 * best, 4),
+            "n_gpus": world, "sharding": "pairs (whole alignments)", "scaling": "weak" if weak else "strong", "pairs_per_rank": len(mine),
+            "collective": "one all-gather of %d-double records: %s" % (sl.rec, getattr(sl.coll, "name", "rccl")), "ms_total": round(1e3 * best, 4),
             "lm_iterations": int(iters), "accepted": int(acc), "value": round(iters / best, 1), "unit": "pair LM iterations/s",
             "us_per_pair_iteration": round(1e6 * best / max(iters, 1.0), 4), "gather_check": bool(got == int(want))}
 
