@@ -282,3 +282,93 @@ def test_sharded_lm_batch_ranks_add_up_on_one_gpu(mbavo, gpu_ctx):
             assert abs(a["final_cost"] - r["final_cost"]) <= 1e-9 * r["final_cost"]
     # the caller's own knot buffers were never touched: the records hold the aligned splines
     assert np.array_equal(dw.keep_knots(0)[0].cpu().numpy(), probs[0].knots_t)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# f4 against the ORACLE on configs[2]'s own data: pairs of the rendered 640x480 sequence, every
+# solver form of the batched LM meeting the oracle's loop directly, at the bar the host-driven loop is held to
+# (tests/test_gpu_tracker.py): identical accept / reject / invalid sequence and outlier counts, pose at capture time 1e-5,
+# |delta ATE| 1e-5.  Reference: blur_aware_direct_tracker.cpp:590-924, solve_normal_equation.h:20-26.
+_RENDERED = {}
+_ORACLE_RUNS = {}
+
+
+def _rendered(gpu_ctx, k):
+    if k not in _RENDERED:
+        _RENDERED[k] = workloads.RenderedPairBatch(gpu_ctx, 8, H=480, W=640, S=8, k=k, seed=1)  # the first 8 pairs of configs[2]
+    return _RENDERED[k]
+
+
+def _oracle_alignment(orc, batch, b, k, N, solver):
+    """The oracle's optimizePyramidLevel on pair b of the rendered batch with its first N control knots."""
+    import tracking
+    key = (k, N, solver, b)
+    if key not in _ORACLE_RUNS:
+        p = batch.host_problem(b)
+        sc = dict(levels=[dict(H=p.H, W=p.W, ref=p.ref, grad=p.grad, cur=p.cur, kp_xy=p.kp_xy, kp_z=p.kp_z, pattern=p.pattern, S=p.S)],
+                  k=k, N=N, F=1, cap=p.cap, exp=p.exp, t0=p.t0, dt=p.dt, intr=p.intr,
+                  kt0=np.ascontiguousarray(p.knots_t.reshape(-1, 3)[:N]), kR0=np.ascontiguousarray(p.knots_R.reshape(-1, 4)[:N]))
+        _ORACLE_RUNS[key] = (sc, tracking.run_oracle_tracker(orc, sc, dict(max_num_iterations=OPTS["max_it"], max_nonmono=OPTS["max_nonmono"],
+                                                                         solver_type=solver, huber_k=p.huber, min_step_quality=OPTS["min_q"],
+                                                                         min_abs_cost_decrease=OPTS["min_dec"], max_chi_square_error=OPTS["chi"])))
+    return _ORACLE_RUNS[key]
+
+
+@pytest.mark.parametrize("k,N,solver,env", [
+    (4, 4, 0, {}),                                                     # refined LDL^T stand-in in registers (default)
+    (4, 4, 0, {"MBAVO_LM_REFINE": "0"}),                               # plain LDL^T up to a pivot ratio of 1e8, the Jacobi solver above
+    (4, 4, 0, {"MBAVO_FAST_SOLVE": "0"}),                              # workgroup-parallel eigenvalue Jacobi for every system
+    (4, 4, 0, {"MBAVO_FAST_SOLVE": "0", "MBAVO_LM_EIG": "0"}),         # one-wave one-sided Jacobi SVD: solve_normal_equation.h case 0
+    (4, 4, 1, {}),                                                     # solver type 1 through the refined stand-in
+    (4, 4, 1, {"MBAVO_FAST_SOLVE": "0"}),                              # pivoted LDL^T: solve_normal_equation.h case 1
+    (2, 2, 0, {}), (2, 2, 0, {"MBAVO_FAST_SOLVE": "0"}), (2, 2, 1, {}),  # the reference's default degree, both solver types
+    (2, 4, 0, {}),                                                     # RANK-DEFICIENT: knots 2 and 3 have no data -> pseudo-inverse
+    (2, 4, 0, {"MBAVO_LM_EIG": "0"}),
+])
+def test_lm_batch_rendered_pairs_against_oracle(orc, mbavo, gpu_ctx, monkeypatch, k, N, solver, env):
+    import torch
+    import tracking
+    for name in ("MBAVO_FAST_SOLVE", "MBAVO_LM_EIG", "MBAVO_LM_REFINE"):
+        monkeypatch.delenv(name, raising=False)
+    for name, v in env.items():
+        monkeypatch.setenv(name, v)
+    capi = mbavo.capi
+    batch = _rendered(gpu_ctx, k)
+    B = batch.B
+    batch.reset_knots()
+    arr = (capi.Problem * B)()
+    for b in range(B):
+        C.memmove(C.byref(arr[b]), C.byref(batch.array[b]), C.sizeof(capi.Problem))
+        arr[b].N = N  # the first N of the pair's four knots (the exposure lies in segment 0)
+    o = capi.LmBatchOpts()
+    o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, OPTS["max_it"], OPTS["max_nonmono"]
+    o.solver_type, o.sync_every = solver, 0
+    o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
+    cap = 64
+    res = (capi.LmBatchResult * B)()
+    trace = (capi.TraceRec * (B * cap))()
+    assert gpu_ctx.lib.mbavo_lm_batch(gpu_ctx.handle, B, arr, C.byref(o), res, trace, cap) == 0
+    torch.cuda.synchronize()
+    e_gpu, e_orc, accepted = [], [], 0
+    for b in range(B):
+        sc, want = _oracle_alignment(orc, batch, b, k, N, solver)
+        got = [(t.iter, t.kind, t.num_outliers) for t in trace[b * cap:b * cap + res[b].num_trace]]
+        assert got == [(t[1], t[2], t[3]) for t in want["trace"]], (b, got, want["trace"])
+        accepted += res[b].accepted
+        assert abs(res[b].final_cost - want["cost"]) <= 1e-6 * max(1.0, want["cost"])
+        h = batch._host[b]
+        kt = h["dkt"].cpu().numpy().reshape(-1, 3)[:N]
+        kR = h["dkR"].cpu().numpy().reshape(-1, 4)[:N]
+        if k == 2 and N == 4:  # minimum-norm step: the knots without data stay where they were, on both sides, bit for bit
+            assert np.array_equal(kt[2:], sc["kt0"][2:]) and np.array_equal(kR[2:], sc["kR0"][2:])
+            assert np.array_equal(want["kt"][2:], sc["kt0"][2:]) and np.array_equal(want["kR"][2:], sc["kR0"][2:])
+        tc = float(sc["cap"][0])
+        pg, qg = tracking.pose_at(orc, k, sc["t0"], sc["dt"], kt, kR, tc)
+        po, qo = tracking.pose_at(orc, k, sc["t0"], sc["dt"], want["kt"], want["kR"], tc)
+        assert np.abs(pg - po).max() <= 1e-5 and np.abs(qg - qo).max() <= 1e-5, (b, pg - po, qg - qo)
+        p_gt, _ = tracking.pose_at(orc, 4, sc["t0"], sc["dt"], h["kt_gt"], h["kR"], tc)  # the rendered (cubic) ground truth
+        e_gpu.append(np.sum((pg - p_gt) ** 2))
+        e_orc.append(np.sum((po - p_gt) ** 2))
+    assert accepted >= B  # the loops really moved the knots
+    ate_g, ate_o = float(np.sqrt(np.mean(e_gpu))), float(np.sqrt(np.mean(e_orc)))
+    assert abs(ate_g - ate_o) <= 1e-5, (ate_g, ate_o)
