@@ -71,7 +71,10 @@ namespace mbavo
                      double *d_frame_blocks, double *d_patch_cost, double *d_valid,
                      double *d_patch_blocks_strided /* B == 1 only, stride E, may be null */,
                      const int *d_active_mask = nullptr /* [B] */, const double *d_inv = nullptr /* [B] */,
-                     bool signal_host = false /* arm the pinned completion word (see wait_evaluation) */);
+                     bool signal_host = false /* arm the pinned completion word (see wait_evaluation) */,
+                     bool same_list = false /* the caller vouches: the very problem list (every field, every pointer) of the previous
+                                               evaluate() of this engine -- the layout is not rebuilt or compared (the batched LM's
+                                               passes: building and comparing 512 descriptors cost ~25 us of host time per pass) */);
         // blocks until the evaluation just enqueued has completed (completion word, or the stream)
         int wait_evaluation();
 
@@ -124,6 +127,10 @@ namespace mbavo
         // range status since the previous fetch (call after a stream sync): non-zero if a blur
         // sample's knot segment had to be clamped into [0, N-k]
         int fetch_status();
+        // the same without a blocking copy of its own: enqueue the counter's copy into pinned host memory on the engine's stream
+        // (fetch_status_enqueue), synchronise the stream with whatever else is pending, then take the delta (fetch_status_take)
+        int fetch_status_enqueue(int *h_pinned);
+        int fetch_status_take(const int *h_pinned);
 
         int total_bf() const { return total_bf_; }
         // name of the dominant kernel the last evaluate() dispatched, e.g. "k_fused<4,true,false>" (bench labels)

@@ -2039,7 +2039,7 @@ namespace mbavo
 
     int Engine::evaluate(int B, const mbavo_problem *probs, int kdeg, bool with_hessian, double *d_frame_blocks,
                          double *d_patch_cost, double *d_valid, double *d_patch_blocks_strided, const int *d_active,
-                         const double *d_inv, bool signal_host)
+                         const double *d_inv, bool signal_host, bool same_list)
     {
         if (B < 1 || !probs || !d_frame_blocks || (kdeg != 2 && kdeg != 4)) return MBAVO_E_ARG;
         if (d_patch_blocks_strided && B != 1) return MBAVO_E_ARG;
@@ -2051,7 +2051,7 @@ namespace mbavo
             // the enqueue time of an evaluation); hipGetDevice is a thread-local read
             int cur = -1;
             if (hipGetDevice(&cur) != hipSuccess || cur != device_) HIP_TRY(hipSetDevice(device_));
-            rc = rebuild_layout(B, probs, kdeg, d_active, d_inv);
+            rc = same_list && layout_uploaded_ && (int)h_descs_.size() == B && cached_kdeg_ == kdeg ? 0 : rebuild_layout(B, probs, kdeg, d_active, d_inv);
         }
         if (rc) return rc;
         const ProblemDesc *descs = (const ProblemDesc *)d_descs_;
@@ -2360,6 +2360,20 @@ namespace mbavo
         if (ms_sum) *ms_sum = sum;
         if (launches) *launches = n;
         return 0;
+    }
+
+    int Engine::fetch_status_enqueue(int *h_pinned)
+    {
+        *h_pinned = status_seen_;
+        if (!d_status_) return 0;
+        return (int)hipMemcpyAsync(h_pinned, d_status_, sizeof(int), hipMemcpyDeviceToHost, stream_);
+    }
+
+    int Engine::fetch_status_take(const int *h_pinned)
+    {
+        const int delta = *h_pinned - status_seen_;
+        status_seen_ = *h_pinned;
+        return delta;
     }
 
     int Engine::fetch_status()

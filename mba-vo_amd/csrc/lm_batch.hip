@@ -72,6 +72,25 @@ namespace mbavo
         const unsigned nd = (unsigned)(old >> 32) + (done_now ? 1u : 0u);
         __hip_atomic_store(host_word, ((unsigned long long)(slot + 1) << 32) | nd, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    // The same for the decide launch of a slot, with the LOOK-AHEAD count (round 4): how many problems the NEXT solve launch will
+    // find finished (already done, or its loop check `iter + 1 > max_it || abs_dec < min_dec` will end them).  When that is all B,
+    // the host -- which has the next solve queued and reads this word before it enqueues that slot's three passes -- enqueues
+    // none: no idle launches behind the last solve (4 x ~4.6 us per call before).  Ticket word: num_done[8..9], the low half
+    // counts workgroups over all decide launches of the call, the high half is reset by the completing workgroup.
+    __device__ __forceinline__ void decide_publish(int *num_done, unsigned long long *host_word2, int slot, int B, bool will_finish)
+    {
+        if (!host_word2) return;
+        unsigned long long *ticket = reinterpret_cast<unsigned long long *>(num_done + 8);
+        const unsigned long long old = atomicAdd(ticket, 1ull + (will_finish ? 1ull << 32 : 0ull));
+        if ((unsigned)(old & 0xffffffffull) + 1u != (unsigned)(slot + 1) * (unsigned)B) return;
+        const unsigned nf = (unsigned)(old >> 32) + (will_finish ? 1u : 0u);
+        atomicAdd(ticket, 0ull - ((unsigned long long)nf << 32)); // the count starts over for the next slot's decide launch
+        __hip_atomic_store(host_word2, ((unsigned long long)(slot + 1) << 32) | nf, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __device__ __forceinline__ bool lm_will_finish(const LmState &s, const LmOpts &o)
+    {
+        return s.done != 0 || s.iter + 1 > o.max_it || s.abs_dec < o.min_dec; // k_lm_solve's loop check, one launch ahead
+    }
 
     // One workgroup of T threads per problem: finish the previous accepted step, loop control, damping, solve, model change,
     // candidate.  T = 64 (one wave: the one-sided Jacobi SVD / pivoted LDL^T of lm_solvers.h, any n up to 96) or T = kEigT
@@ -90,11 +109,18 @@ namespace mbavo
         const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
         const ProblemDesc &d = descs[b];
         const int N = d.N, n = 6 * N, F = d.F;
-        LmState s = states[b];
+        LmState s = states[b]; // (slot 0: the initial state, uploaded by the host with the head of the arena)
         if (s.done)
         {
             if (tid == 0) slot_publish(num_done, host_word, slot, B, false);
             return;
+        }
+        if (slot == 0)
+        { // the current point starts at the caller's knots (there is no init launch: one kernel less in every call)
+            double *Ct0 = cur_t + (size_t)b * 3 * o.max_N, *CR0 = cur_R + (size_t)b * 4 * o.max_N;
+            for (int i = tid; i < 3 * N; i += T) Ct0[i] = d.knots_t[i];
+            for (int i = tid; i < 4 * N; i += T) CR0[i] = d.knots_R[i];
+            __syncthreads();
         }
 #if defined(MBAVO_EIG_STAMPS) // development aid: where the kernel's time goes (block 0 prints at its end)
         const long long ts0 = __builtin_amdgcn_s_memtime();
@@ -333,13 +359,18 @@ namespace mbavo
                                                       FinSrc fs, const double *__restrict__ patch_cost,
                                                       double *__restrict__ inv,
                                                       double *__restrict__ cur_t, double *__restrict__ cur_R,
-                                                      int *__restrict__ active, mbavo_trace_rec *__restrict__ trace)
+                                                      int *__restrict__ active, mbavo_trace_rec *__restrict__ trace,
+                                                      int *__restrict__ num_done, unsigned long long *host_word2, int slot, int B)
     {
         constexpr int ND = 6 * KD + 1, E = ND * (ND + 1) / 2;
         const int b = blockIdx.x, lane = threadIdx.x;
         const ProblemDesc &d = descs[b];
         LmState s = states[b];
-        if (s.done || active[b] == 0) return; // finished, or an invalid step: nothing was evaluated
+        if (s.done || active[b] == 0)
+        { // finished, or an invalid step: nothing was evaluated
+            if (lane == 0) decide_publish(num_done, host_word2, slot, B, lm_will_finish(s, o));
+            return;
+        }
         mbavo_trace_rec *tr = trace ? trace + (size_t)b * o.trace_cap : nullptr;
         // the patch costs of frame 0 (up to kPre per lane) are fetched WITH the costs, before the accept test needs either: the
         // three statistics passes below then run from registers (same order of additions: bit-identical flags)
@@ -412,31 +443,14 @@ namespace mbavo
                 inv[b] = num_residuals > 0 ? 1.0 / (double)num_residuals : 0.0;
                 active[b] = 2;
                 states[b] = s;
+                decide_publish(num_done, host_word2, slot, B, lm_will_finish(s, o));
             }
             return;
         }
         lm_rejected(s); // handleUnsuccessfulStep
         trace_push(s, tr, o.trace_cap, lane, 0, 2, s.cand_cost, s.model, s.quality);
         ++s.n_reject;
-        if (lane == 0) { active[b] = 0; states[b] = s; }
-    }
-
-    __global__ void k_lm_init(const ProblemDesc *__restrict__ descs, int B, LmState *__restrict__ states, LmOpts o,
-                              double *__restrict__ cur_t, double *__restrict__ cur_R)
-    {
-        const int b = blockIdx.x, lane = threadIdx.x;
-        if (b >= B) return;
-        const ProblemDesc &d = descs[b];
-        double *Ct = cur_t + (size_t)b * 3 * o.max_N, *CR = cur_R + (size_t)b * 4 * o.max_N;
-        for (int i = lane; i < 3 * d.N; i += 64) Ct[i] = d.knots_t[i];
-        for (int i = lane; i < 4 * d.N; i += 64) CR[i] = d.knots_R[i];
-        if (lane == 0)
-        {
-            LmState s;
-            memset(&s, 0, sizeof(s));
-            s.radius = 1e4; s.decrease_factor = 2.0; s.abs_dec = 1e10; s.fresh = 1;
-            states[b] = s;
-        }
+        if (lane == 0) { active[b] = 0; states[b] = s; decide_publish(num_done, host_word2, slot, B, lm_will_finish(s, o)); }
     }
 
 #define LM_HIP(expr)                                                                        \
@@ -499,9 +513,10 @@ namespace mbavo
         auto take = [&](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
         // head: what the host initialises, contiguous so that ONE copy from pinned memory uploads it (three pageable copies and
         // a fill of the whole arena cost ~35 us of a 64-pair call: four blit kernels with a ~6 us gap behind each)
-        const size_t o_inv = take(sizeof(double) * B), o_act = take(sizeof(int) * B), o_done = take(sizeof(int) * 8),
-                     o_start = take(sizeof(int) * nbf), o_flags = take((size_t)total_K), head_bytes = off;
-        const size_t o_state = take(sizeof(LmState) * B), o_H = take(sizeof(double) * (size_t)B * max_n * max_n),
+        const size_t o_inv = take(sizeof(double) * B), o_act = take(sizeof(int) * B), o_done = take(sizeof(int) * 16),
+                     o_start = take(sizeof(int) * nbf), o_flags = take((size_t)total_K), o_state = take(sizeof(LmState) * B),
+                     head_bytes = off; // (the initial LM states ride in the head: no init launch)
+        const size_t o_H = take(sizeof(double) * (size_t)B * max_n * max_n),
                      o_g = take(sizeof(double) * (size_t)B * max_n), o_ct = take(sizeof(double) * (size_t)B * 3 * max_N),
                      o_cR = take(sizeof(double) * (size_t)B * 4 * max_N), o_fb = take(sizeof(double) * (size_t)nbf * E),
                      o_pc = take(sizeof(double) * (size_t)(total_patches + 1)),
@@ -541,6 +556,8 @@ namespace mbavo
                 const long long num_residuals = (long long)work[b].K * work[b].F * work[b].P;
                 h_inv[b] = num_residuals > 0 ? 1.0 / (double)num_residuals : 0.0;
                 h_act[b] = 2;
+                LmState &s0 = ((LmState *)(head + o_state))[b]; // (zero from the memset above)
+                s0.radius = 1e4; s0.decrease_factor = 2.0; s0.abs_dec = 1e10; s0.fresh = 1;
             }
             stamp(1);
             LM_HIP(hipMemcpyAsync(base, head, head_bytes, hipMemcpyHostToDevice, st));
@@ -554,11 +571,14 @@ namespace mbavo
             // solve i has been published -- nothing but kernels is in the stream (the D2H copy + event of the previous scheme cost a
             // 4.4 us blit kernel and a 5.8 us gap behind it per slot: tools/lm_timeline.py).
             const int sync_every = opt.sync_every;
-            volatile unsigned long long *h_word = nullptr;
+            volatile unsigned long long *h_word = nullptr, *h_word2 = nullptr;
+            int *h_status = (int *)(h_stage + 32); // pinned: the engine's range-status counter lands here with the final copies
             if (sync_every <= 0)
             {
-                h_word = (volatile unsigned long long *)h_stage;
-                *h_word = 0; // (no kernel that writes it is in flight: every call ends with a stream synchronisation)
+                h_word = (volatile unsigned long long *)h_stage;  // solve launches: (slot + 1, problems done)
+                h_word2 = h_word + 1;                             // decide launches: (slot + 1, problems the next solve will end)
+                *h_word = 0; // (no kernel that writes them is in flight: every call ends with a stream synchronisation)
+                *h_word2 = 0;
             }
             // MBAVO_LM_DEFER=0: the engine's finalize kernels write frame blocks and the LM kernels read those
             eng.set_defer_finalize(!(getenv("MBAVO_LM_DEFER") && getenv("MBAVO_LM_DEFER")[0] == '0'));
@@ -569,7 +589,6 @@ namespace mbavo
             fs.fb = fb; fs.partials = eng.device_partials(); fs.tile_begin = eng.device_bf_tile_begin();
             fs.stride = E + 2; // engine.hip: Pack<k>::PSTRIDE
             fs.deferred = eng.finalize_deferred() ? 1 : 0;
-            hipLaunchKernelGGL(k_lm_init, dim3(B), dim3(64), 0, st, descs, B, states, o, ct, cR);
             stamp(3);
             if (lds > 48 * 1024)
             { // more than 8 control knots: the three n x n areas need the large-LDS attribute
@@ -577,8 +596,27 @@ namespace mbavo
                 else LM_HIP(hipFuncSetAttribute(eig ? (const void *)k_lm_solve<2, kEigT> : (const void *)k_lm_solve<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             }
             unsigned long long *d_word = const_cast<unsigned long long *>(h_word); // pinned host memory is device-visible at its own address
+            unsigned long long *d_word2 = const_cast<unsigned long long *>(h_word2);
+            // bounded spin on a pinned word until its slot number reaches `want`; the value, or 0 after a time-out
+            auto spin_for = [&](volatile unsigned long long *word, unsigned long long want) -> unsigned long long {
+                unsigned long long w = *word;
+                if ((w >> 32) >= want) return w;
+                const auto t_spin = std::chrono::steady_clock::now();
+                for (unsigned long spins = 1; ((w = *word) >> 32) < want; ++spins)
+                {
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                    if ((spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t_spin > std::chrono::seconds(10)) return 0;
+                }
+                return w;
+            };
+#define LM_DECIDE_ARGS descs, states, o, fs, pc, inv, ct, cR, act, d_trace, num_done, d_word2, slot, B
+            std::vector<double> slot_us; // MBAVO_LM_STAMPS=1: per slot [solve launch | look-ahead wait | passes enqueued | solve word wait]
+            auto now_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp[0]).count(); };
             for (int slot = 0; slot <= o.max_it + 1; ++slot)
             {
+                const double ts0 = stamps ? now_us() : 0.0;
 #define LM_SOLVE_ARGS descs, states, o, fs, d_start, Hst, gst, ct, cR, act, d_trace, num_done, d_word, slot, B
                 if (k == 4 && eig)
                     hipLaunchKernelGGL((k_lm_solve<4, kEigT>), dim3(B), dim3(kEigT), lds, st, LM_SOLVE_ARGS);
@@ -592,38 +630,43 @@ namespace mbavo
                 if (sync_every <= 0)
                 {
                     // the three passes of this slot go in behind the solve BEFORE the host looks at the solve's word: the device
-                    // has ~45 us of work queued while the host waits, and a finished batch costs at most these three idle launches
+                    // has ~45 us of work queued while the host waits.  Look-ahead: the PREVIOUS slot's decide launch has told
+                    // how many problems this solve will end (decide_publish; that launch retired at least a whole H/g pass ago
+                    // by the time the device gets here, so the wait below is for the host's own benefit, not the device's);
+                    // if that is every one, nothing is enqueued behind the solve.
                     const bool last = slot == o.max_it + 1;
-                    if (!last)
+                    bool ending = last;
+                    const double ts1 = stamps ? now_us() : 0.0;
+                    if (!last && slot > 0)
                     {
-                        if ((rc = eng.evaluate(B, work.data(), k, false, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
-                        if (k == 4)
-                            hipLaunchKernelGGL((k_lm_decide<4>), dim3(B), dim3(64), 0, st, descs, states, o, fs, pc, inv, ct, cR, act, d_trace);
-                        else
-                            hipLaunchKernelGGL((k_lm_decide<2>), dim3(B), dim3(64), 0, st, descs, states, o, fs, pc, inv, ct, cR, act, d_trace);
-                        if ((rc = eng.evaluate(B, work.data(), k, true, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
+                        const unsigned long long w2 = spin_for(h_word2, (unsigned long long)slot);
+                        if (w2 == 0) { LM_HIP(hipStreamSynchronize(st)); LM_HIP(hipGetLastError()); rc = MBAVO_E_RANGE; goto done; }
+                        ending = (int)(unsigned)(w2 & 0xffffffffull) >= B;
                     }
-                    const unsigned long long want = (unsigned long long)slot + 1;
-                    unsigned long long w = *h_word;
-                    if ((w >> 32) < want)
-                    {
-                        const auto t_spin = std::chrono::steady_clock::now();
-                        for (unsigned long spins = 1; ((w = *h_word) >> 32) < want; ++spins)
-                        {
-#if defined(__x86_64__)
-                            __builtin_ia32_pause();
-#endif
-                            if ((spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t_spin > std::chrono::seconds(10))
-                            { // a launch failed or the device is wedged: let the runtime say which
-                                LM_HIP(hipStreamSynchronize(st));
-                                LM_HIP(hipGetLastError());
-                                rc = MBAVO_E_RANGE;
-                                goto done;
-                            }
-                        }
+                    auto enqueue_passes = [&]() -> int {
+                        int r = eng.evaluate(B, work.data(), k, false, fb, pc, nullptr, nullptr, act, inv, false, true);
+                        if (r != 0) return r;
+                        if (k == 4)
+                            hipLaunchKernelGGL((k_lm_decide<4>), dim3(B), dim3(64), 0, st, LM_DECIDE_ARGS);
+                        else
+                            hipLaunchKernelGGL((k_lm_decide<2>), dim3(B), dim3(64), 0, st, LM_DECIDE_ARGS);
+                        return eng.evaluate(B, work.data(), k, true, fb, pc, nullptr, nullptr, act, inv, false, true);
+                    };
+                    const double ts2 = stamps ? now_us() : 0.0;
+                    if (!ending && (rc = enqueue_passes()) != 0) goto done;
+                    const double ts3 = stamps ? now_us() : 0.0;
+                    const unsigned long long w = spin_for(h_word, (unsigned long long)slot + 1);
+                    if (stamps) { slot_us.push_back(ts1 - ts0); slot_us.push_back(ts2 - ts1); slot_us.push_back(ts3 - ts2); slot_us.push_back(now_us() - ts3); }
+                    if (w == 0)
+                    { // a launch failed or the device is wedged: let the runtime say which
+                        LM_HIP(hipStreamSynchronize(st));
+                        LM_HIP(hipGetLastError());
+                        rc = MBAVO_E_RANGE;
+                        goto done;
                     }
                     h_done = (int)(unsigned)(w & 0xffffffffull);
                     if (h_done >= B || last) break;
+                    if (ending && (rc = enqueue_passes()) != 0) goto done; // (the look-ahead over-counted: cannot happen, but never hang on it)
                     continue;
                 }
                 else if (slot % sync_every == sync_every - 1 || slot == o.max_it + 1)
@@ -634,24 +677,28 @@ namespace mbavo
                 }
                 if ((rc = eng.evaluate(B, work.data(), k, false, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
                 if (k == 4)
-                    hipLaunchKernelGGL((k_lm_decide<4>), dim3(B), dim3(64), 0, st, descs, states, o, fs, pc, inv, ct, cR, act, d_trace);
+                    hipLaunchKernelGGL((k_lm_decide<4>), dim3(B), dim3(64), 0, st, LM_DECIDE_ARGS);
                 else
-                    hipLaunchKernelGGL((k_lm_decide<2>), dim3(B), dim3(64), 0, st, descs, states, o, fs, pc, inv, ct, cR, act, d_trace);
+                    hipLaunchKernelGGL((k_lm_decide<2>), dim3(B), dim3(64), 0, st, LM_DECIDE_ARGS);
                 if ((rc = eng.evaluate(B, work.data(), k, true, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
             }
             stamp(4);
             LM_HIP(hipGetLastError());
             LM_HIP(hipMemcpyAsync(const_cast<LmState *>(h_states), states, sizeof(LmState) * B, hipMemcpyDeviceToHost, st)); // pinned: no staging
             if (trace) LM_HIP(hipMemcpyAsync(trace, d_trace, sizeof(mbavo_trace_rec) * (size_t)B * trace_cap, hipMemcpyDeviceToHost, st));
+            if ((rc = eng.fetch_status_enqueue(h_status)) != 0) goto done; // (no blocking copy of its own after the drain: ~10 us)
             LM_HIP(hipStreamSynchronize(st));
             stamp(5);
             if (stamps)
             {
                 auto us = [&](int a, int b) { return std::chrono::duration<double, std::micro>(tp[b] - tp[a]).count(); };
-                fprintf(stderr, "mbavo lm_batch: host set-up %.1f us | head upload call %.1f | first evaluation + init enqueued %.1f | LM slots %.1f | results + drain %.1f\n",
+                fprintf(stderr, "mbavo lm_batch: host set-up %.1f us | head upload call %.1f | first evaluation enqueued %.1f | LM slots %.1f | results + drain %.1f\n",
                         us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5));
+                for (size_t i = 0; i + 3 < slot_us.size(); i += 4)
+                    fprintf(stderr, "mbavo lm_batch:   slot %zu: solve launch %.1f us | look-ahead wait %.1f | passes enqueued %.1f | solve word wait %.1f\n", i / 4,
+                            slot_us[i], slot_us[i + 1], slot_us[i + 2], slot_us[i + 3]);
             }
-            if (eng.fetch_status() != 0) { rc = MBAVO_E_RANGE; goto done; } // a capture time outside the spline somewhere in the call
+            if (eng.fetch_status_take(h_status) != 0) { rc = MBAVO_E_RANGE; goto done; } // a capture time outside the spline somewhere in the call
             if (h_done < B)
             {
                 LM_HIP(hipMemcpy(&h_done, num_done, sizeof(int), hipMemcpyDeviceToHost));
