@@ -204,7 +204,8 @@ def cpu_baseline(probs, budget_s):
         kind = "reference"
         how = ("per-sample code = the reference's compute_pixel_intensity<double>, C2/C4 spline functors and "
                "Core::MatrixMatrixMultiply compiled from its sources (oracle/_ref, g++ -O2 -ffp-contract=off); kernel launch "
-               "geometry, Huber and block reductions = oracle restatement; keypoint chunks of 4096 spread over the threads")
+               "geometry, Huber and block reductions = oracle restatement; chunks of 64 keypoints spread over OpenMP threads INSIDE the "
+               "compiled code (oracle/ref_shim.cpp: ref_evaluate_omp), per-thread frame blocks added in thread order")
     else:
         plist, keeps = [], []
         for p in probs:
@@ -239,10 +240,10 @@ def cpu_baseline(probs, budget_s):
         out["all_threads"] = dict(value=round(vT, 3), unit="Mpixel-samples/s", cores=T,
                                   sample="%d evaluation(s) on %d threads, %.1f s" % (rT, T, tT),
                                   speedup_over_1_thread=round(vT / v1, 2), cpus_in_affinity_mask=usable,
-                                  note="a stated baseline, not a tuned one: the chunks run on a Python thread pool (the C "
-                                       "code releases the GIL) and the sandboxed host gives this process a fraction of its "
-                                       "logical CPUs' real time, so the speed-up over 1 thread is what the sandbox allows, "
-                                       "not what the code could reach on the bare host")
+                                  note="a stated baseline, not a tuned one: an OpenMP loop over keypoint chunks inside the compiled "
+                                       "reference code (round 4; a Python thread pool around it before).  The sandboxed host gives "
+                                       "this process a fraction of its logical CPUs' real time, so the speed-up over 1 thread is "
+                                       "bounded by the sandbox's CPU quota, not by the code")
         if vT > v1:  # the better of the two is the quoted baseline, its thread count stated
             out.update(value=round(vT, 3), cores=T)
             out["single_thread"] = dict(value=round(v1, 3), cores=1)

@@ -210,6 +210,11 @@ def ref():
             R.ref_compute_pixel_jacobian_residual.argtypes = [
                 c_u8p, c_fp, C.POINTER(c_u8p), C.c_int, C.c_int, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp, C.c_int,
                 c_ip, C.c_int, c_dp, C.c_int, C.c_int, c_dp, c_dp]
+        if hasattr(R, "ref_evaluate_omp"):
+            R.ref_evaluate_omp.restype = C.c_int
+            R.ref_evaluate_omp.argtypes = [c_u8p, c_fp, C.POINTER(c_u8p), C.c_int, C.c_int, c_dp, c_dp, C.c_int, C.c_double, C.c_double,
+                                           c_dp, c_dp, c_dp, c_dp, C.c_int, c_ip, C.c_int, c_dp, C.c_int, C.c_int, C.c_double,
+                                           C.c_void_p, C.c_int, C.c_int, c_dp]
         R.ref_lm_new.restype = C.c_void_p
         R.ref_tr_new.restype = C.c_void_p
         R.ref_tr_new.argtypes = [C.c_int]
@@ -332,6 +337,19 @@ def evaluate_with_reference(prob_args, chunk=4096, threads=1):
     a = dict(prob_args)
     K, F, P, k = a["K"], a["F"], a["P"], a["k"]
     E = packed_len(k)
+    R = ref()
+    if R is not None and hasattr(R, "ref_evaluate_omp") and os.environ.get("MBAVO_REF_OMP", "1") != "0":
+        # the loop over keypoint chunks INSIDE the compiled code (OpenMP; round 4): a baseline of the code, not of a Python
+        # thread pool around it.  Chunks of 64 keypoints; a thread adds its chunks in ascending order, the threads' frame
+        # blocks are added in thread order.
+        fb = np.zeros((F, E))
+        cur_arr = (c_u8p * F)(*[u8p(c) for c in a["cur_imgs"]])
+        patch_fn = C.cast(lib().orc_compute_patch_cost_gradient_hessian, C.c_void_p)
+        used = R.ref_evaluate_omp(u8p(a["ref_img"]), fp(a["ref_dIxy"]), cur_arr, a["S"], F, dp(a["cap"]), dp(a["exp_t"]), k, a["t0"], a["dt"],
+                                  dp(a["knots_t"]), dp(a["knots_R"]), dp(a["kp_xy"]), dp(a["kp_z"]), K, ip(a["pattern"]), P, dp(a["intr"]),
+                                  a["H"], a["W"], a["huber_a"], patch_fn, int(threads), int(chunk) if chunk <= 256 else 64, dp(fb))
+        assert used >= 1
+        return fb
     total = np.zeros((F, E))
     spans = [(k0, min(K, k0 + chunk)) for k0 in range(0, max(K, 1), chunk) if min(K, k0 + chunk) > k0]
 

@@ -19,10 +19,17 @@
 //     ref_compute_local_patches_xy          kernel body of compute_local_patches_xy.cu:19-49 (Vector3d, Quaterniond)
 //     ref_compute_pixel_jacobian_residual   kernel body of compute_hessian_gradients_cost.cu:51-153
 //                                           (compute_pixel_intensity<double>, Core::MatrixMatrixMultiply)
+//     ref_evaluate_omp                      the three drivers above over a whole problem, keypoint chunks spread over OpenMP
+//                                           threads (bench.py's CPU baseline on all host threads: a loop inside the compiled
+//                                           code instead of a Python thread pool around it)
 // The CUDA kernels (.cu), merge (Eigen), Spline.h (Sophus) cannot be built here.
 #include <cmath>
 #include <cstring>
 #include <cstdio>
+#include <vector>
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
 
 #include "ba_tracker/compute_pixel_intensity.h"
 #include "ba_tracker/levenberg_marquardt_strategy.h"
@@ -286,5 +293,65 @@ void ref_compute_local_patches_xy(int S, int F, const double *poses, const doubl
             centres[((size_t)f * K + i) * 2] = P3dc(0) / P3dc(2) * intr[0] + intr[2];
             centres[((size_t)f * K + i) * 2 + 1] = P3dc(1) / P3dc(2) * intr[1] + intr[3];
         }
+}
+
+// One whole H/g evaluation on `threads` OpenMP threads: poses and patch centres once, then chunks of `chunk` keypoints of a
+// frame in parallel -- per chunk the reference's per-sample code (ref_compute_pixel_jacobian_residual above), the per-patch
+// Huber / packed outer product through `patch_fn` (the oracle's restatement of compute_hessian_gradients_cost.cu:165-239,
+// handed over as a function pointer: the two checker libraries do not link against each other) and the chunk's frame sum.
+// Every thread adds its chunks in ascending order into its own frame blocks; the threads' blocks are added in thread order
+// (static schedule: deterministic for a given thread count).  frame_blocks: F x E, scaled by 1 / (K F P).
+typedef void (*ref_patch_fn)(int F, int K, int P, int k, const double *res, const double *jac, double huber_a, double inv, double *pb);
+int ref_evaluate_omp(const unsigned char *I_ref, const float *dIxy_ref, const unsigned char *const *I_cur, int S, int F,
+                     const double *cap, const double *exp_t, int k, double t0, double dt, const double *knots_t,
+                     const double *knots_R, const double *kp_xy, const double *kp_z, int K, const int *pattern, int P,
+                     const double intr[4], int H, int W, double huber_a, ref_patch_fn patch_fn, int threads, int chunk,
+                     double *frame_blocks)
+{
+    const int nd = 6 * k + 1, E = nd * (nd + 1) / 2, n6k = 6 * k;
+    std::vector<double> poses((size_t)F * S * 7), Jt((size_t)F * S * 9 * k), JR((size_t)F * S * 12 * k), centres((size_t)F * K * 2 + 2);
+    ref_compute_virtual_camera_poses(S, F, cap, exp_t, k, t0, dt, knots_t, knots_R, poses.data(), Jt.data(), JR.data());
+    ref_compute_local_patches_xy(S, F, poses.data(), kp_xy, kp_z, K, intr, centres.data());
+    if (chunk < 1) chunk = 64;
+    const int nchunk = (K + chunk - 1) / chunk;
+    const long jobs = (long)F * nchunk;
+    if (threads < 1) threads = 1;
+    const double inv = (double)K * F * P > 0 ? 1.0 / ((double)K * F * P) : 0.0;
+    std::vector<double> acc((size_t)threads * F * E, 0.0);
+    int used = 1;
+#if defined(_OPENMP)
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+        int tid = 0, nth = 1;
+#if defined(_OPENMP)
+        tid = omp_get_thread_num();
+        nth = omp_get_num_threads();
+#pragma omp single
+        used = nth;
+#endif
+        std::vector<double> res((size_t)chunk * P), jac((size_t)chunk * P * n6k), pb((size_t)chunk * E);
+        double *mine = acc.data() + (size_t)tid * F * E;
+        const long lo = jobs * tid / nth, hi = jobs * (tid + 1) / nth; // contiguous share, ascending
+        for (long j = lo; j < hi; ++j)
+        {
+            const int f = (int)(j / nchunk), i0 = (int)(j % nchunk) * chunk, n = (K - i0) < chunk ? (K - i0) : chunk;
+            ref_compute_pixel_jacobian_residual(I_ref, dIxy_ref, I_cur + f, S, 1, poses.data() + (size_t)f * S * 7, k,
+                                                Jt.data() + (size_t)f * S * 9 * k, JR.data() + (size_t)f * S * 12 * k,
+                                                centres.data() + ((size_t)f * K + i0) * 2, kp_z + i0, n, pattern, P, intr, H, W,
+                                                res.data(), jac.data());
+            patch_fn(1, n, P, k, res.data(), jac.data(), huber_a, inv, pb.data());
+            double *dst = mine + (size_t)f * E;
+            for (int i = 0; i < n; ++i)
+                for (int e = 0; e < E; ++e) dst[e] += pb[(size_t)i * E + e];
+        }
+    }
+    for (size_t e = 0; e < (size_t)F * E; ++e)
+    {
+        double v = 0.0;
+        for (int t = 0; t < used; ++t) v += acc[(size_t)t * F * E + e];
+        frame_blocks[e] = v;
+    }
+    return used;
 }
 } // extern "C"

@@ -37,10 +37,14 @@ def test_evaluate_fast_equals_evaluate(orc, name):
 
 
 @pytest.mark.parametrize("name", ["k4_S8_P8_F2", "k2_S4_P8", "k4_S1_dense", "k4_S16_dense_6knots"])
-def test_evaluate_with_reference_live(orc, name):
+@pytest.mark.parametrize("omp", ["1", "0"])
+def test_evaluate_with_reference_live(orc, monkeypatch, name, omp):
     """Where oracle/_ref is present (this container; it travels to the GPU box as a built .so): the evaluation assembled
     from the REFERENCE's compiled per-sample code, in keypoint chunks on 1 and 2 threads, against the restatement.  No
-    outliers (the chunked driver has no flags).  1e-12: the chunks' frame sums are added in another grouping."""
+    outliers (the chunked driver has no flags).  1e-12: the chunks' frame sums are added in another grouping.
+    omp = 1 (round 4, the default): the chunk loop is an OpenMP loop inside oracle/ref_shim.cpp (ref_evaluate_omp); 0: the
+    Python thread pool over stages_with_reference."""
+    monkeypatch.setenv("MBAVO_REF_OMP", omp)
     if orc.ref() is None or not hasattr(orc.ref(), "ref_compute_pixel_jacobian_residual"):
         pytest.skip("oracle/_ref is not built here")
     sc = scenes.Scene(**CASES[name])
