@@ -109,7 +109,7 @@ SYMBOLS = [
 ]
 
 
-KERNEL_SOURCES = ("csrc/engine.hip", "csrc/pixel_math.h", "csrc/se3_math.h")
+KERNEL_SOURCES = ("csrc/engine.hip", "csrc/pixel_math.h", "csrc/se3_math.h", "csrc/pose_entries.h")
 
 
 def kernel_source_sha():

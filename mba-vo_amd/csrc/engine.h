@@ -117,6 +117,13 @@ namespace mbavo
         // <= 4 tiles each) launches NO finalize kernel and leaves d_frame_blocks untouched; finalize_deferred() says whether the
         // last evaluate() did so.  Partial of tile t: doubles [t * stride, (t + 1) * stride) = [valid | g, H sums 1 .. E-1 | cost |
         // spare] (unscaled: the residual scale is applied by whoever sums); slot bf owns tiles [begin[bf], begin[bf + 1]).
+        // The batched LM's solve kernel writes the pose entries of the candidate it produces into the engine's table itself
+        // (entry of (problem, frame f, sample s) at pose_base + f S + s, the k_pose_table layout): with set_external_poses(true)
+        // an evaluate() launches neither k_pose_table nor the fused kernel's pose prologue (the single-launch sample-parallel
+        // kernels keep computing their own in LDS).
+        void set_external_poses(bool on) { external_poses_ = on; }
+        void *device_pose_table() const { return d_poses_; }
+        int *device_status() const { return (int *)d_status_; }
         void set_defer_finalize(bool on) { defer_finalize_ = on; }
         bool finalize_deferred() const { return deferred_last_; }
         const double *device_partials() const { return (const double *)d_partials_; }
@@ -182,6 +189,7 @@ namespace mbavo
         int sp_logs_ = 0; // > 0: the cached layout is tiled for the sample-parallel kernel with S = 2^sp_logs_
         bool flat_finalize_ = false; // many (problem, frame) slots of <= 4 tiles each: k_finalize_flat
         bool defer_finalize_ = false, deferred_last_ = false; // set_defer_finalize / what the last evaluate() did
+        bool external_poses_ = false;                          // set_external_poses
         bool empty_slots_ = false;   // some (problem, frame) slot has no tile (K == 0): no workgroup would finalize it in the single-launch form
 
         void *d_layout_ = nullptr; size_t cap_layout_ = 0; // one arena: descs | tiles | bf_tile_begin | bf_prob | entry_prob

@@ -25,6 +25,27 @@
 #include "se3_math.h"
 #include "timing.h"
 
+#if defined(MBAVO_FUSED_STAMPS) // timing experiment (tools/fused_stamps.py): where a workgroup of k_fused spends its time
+namespace mbavo
+{
+    __device__ unsigned long long g_fused_stamps[2048 * 8];
+    __device__ unsigned long long g_wave_stamps[1024 * 16 * 4]; // [block][wave][loop start, loop end, HW_ID, rounds]
+}
+#define MBAVO_WSTAMP(i, v) do { if (lane == 0 && blockIdx.x < 1024) g_wave_stamps[(blockIdx.x * 16 + wave) * 4 + (i)] = (v); } while (0)
+#if defined(MBAVO_POSE_STAMPS) // (tools/pose_stamps.py) the pose prologue's steps instead of the kernel's phases: 1 descriptors read, 2 stage A done, 3 stage B done, 4 visible + scalar cache invalidated, 5 ready
+#define MBAVO_PSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_fused_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MBAVO_FSTAMP(i) do { if ((i) == 0 && threadIdx.x == 0 && blockIdx.x < 2048) g_fused_stamps[blockIdx.x * 8] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MBAVO_PSTAMP(i) do { } while (0)
+#define MBAVO_FSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_fused_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#endif
+#else
+#define MBAVO_PSTAMP(i) do { } while (0)
+#define MBAVO_FSTAMP(i) do { } while (0)
+#define MBAVO_WSTAMP(i, v) do { } while (0)
+#endif
+#include "pose_entries.h"
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -54,8 +75,11 @@ namespace mbavo
     // vectors) and 44 scalar spills into VGPR lanes, none of them inside the sample-pair loop; k = 2 (124 VGPRs) and
     // the cost-only kernels (63; 117 with the pose prologue) take the 16 waves a workgroup can have.  Figures: profiles/r02_kernel_resources.txt
     // (tools/kernel_resources.py, from the code-object metadata).
+#ifndef MBAVO_WAVES_K2
+#define MBAVO_WAVES_K2 16
+#endif
     template <int KD, bool WITH_J>
-    constexpr int waves_of() { return WITH_J && KD == 4 ? MBAVO_WAVES_PER_GROUP : 16; }
+    constexpr int waves_of() { return WITH_J ? (KD == 4 ? MBAVO_WAVES_PER_GROUP : MBAVO_WAVES_K2) : 16; }
 
     template <int KD>
     struct Pack
@@ -65,155 +89,7 @@ namespace mbavo
         static constexpr int PSTRIDE = E + 2; // partial: [nvalid | g,H sums (1..E-1) | cost | spare]
     };
 
-    // ------------------------------------------------------------------ pose table
-    // Latency-bound: one sample's pose and pose-to-knot Jacobians are a chain of fp64 log / atan / exp / sin / cos and
-    // quaternion products, ~2 600 dependent instructions if one lane does it all.  Two stages per workgroup
-    // (se3_math.h "two STAGES"): A -- one lane per (sample, segment) evaluates A_g = exp(c_g log(R_g^-1 R_g+1)) with both
-    // Jacobians, segment g on wave g; B -- one WAVE per knot (compile-time knot index, so each knot only touches the
-    // segments it differentiates), one LANE per (sample, column of that knot's 4x3 block), reading the segments from LDS.
-    // The pose itself is written by knot 0 / column 0.  kPoseSPB samples per workgroup: 21 x 3 columns fill a wave.
-    constexpr int kPoseSPB = 21;
-
-    // The table holds R * A (pixel_math.h PoseEntry): this lane's column of A = d(body rotation) / d(knot rotation), turned
-    // into the keyframe's axes by the sample's own rotation matrix -- once per (sample, column) here instead of a transposed
-    // product per pixel-sample in the fused kernels.
-    template <int KD>
-    __device__ __forceinline__ void store_rotated_column(const Quat &q, const double av[3], int c, PoseEntry<KD> &pe)
-    {
-        const double qv[4] = {q.x, q.y, q.z, q.w};
-        double R[9];
-        rotation_entries(qv, R);
-        for (int b = 0; b < 3; ++b)
-        {
-            double r = R[3 * b] * av[0];
-            r += R[3 * b + 1] * av[1];
-            r += R[3 * b + 2] * av[2];
-            pe.A[b * 3 * KD + c] = r;
-        }
-    }
-
-    template <int KD, int KNOT>
-    __device__ __forceinline__ Quat pose_table_entry(const double *kR, double u, int col, const SplineSeg *sg, PoseEntry<KD> &pe)
-    {
-        JacC<1> blk;
-        const Quat q = spline_rotation_knot_from_segs<KD, 1, KNOT>(kR, u, col, sg, blk);
-        // tangent form of this column: A[a][3*knot + col] = 2 * L3(q)^T[a] . blk      (pixel_math.h)
-        const double L3[4][3] = {{q.w, -q.z, q.y}, {q.z, q.w, -q.x}, {-q.y, q.x, q.w}, {-q.x, -q.y, -q.z}};
-        const Quat &v = blk.c[0];
-        double av[3];
-        for (int a = 0; a < 3; ++a)
-        {
-            double r = L3[0][a] * v.x;
-            r += L3[1][a] * v.y;
-            r += L3[2][a] * v.z;
-            r += L3[3][a] * v.w;
-            av[a] = 2.0 * r;
-        }
-        store_rotated_column<KD>(q, av, 3 * KNOT + col, pe);
-        return q;
-    }
-
-    // sample time, segment index (clamped into the knot range, reported through *oob) and normalised time of sample
-    // `smp` of frame f (compute_virtual_camera_poses.cu:33: S == 1 samples the START of the exposure)
-    template <int KD>
-    __device__ __forceinline__ void pose_sample_segment(const ProblemDesc &d, int f, int smp, int &idx, double &u, bool &oob)
-    {
-        const double t_cap = d.cap[f], t_mu = d.exp_t[f];
-        const double t = t_cap - t_mu * 0.5 + smp * t_mu / (d.S - 1 + 1e-8);
-        spline_segment(t, d.t0, d.dt, idx, u);
-        oob = idx < 0 || idx + KD > d.N;
-        if (oob) idx = idx < 0 ? 0 : d.N - KD; // the reference reads out of bounds here; clamp for memory safety and report
-    }
-
-    // stage B for one (sample, knot = wave, column) lane + the pose record by knot 0 / column 0
-    template <int KD, bool WITH_J>
-    __device__ __forceinline__ void pose_stage_b(const double *knots_t, const double *knots_R, int idx, double u, int wave, int col,
-                                                 const SplineSeg *sg, PoseEntry<KD> &pe)
-    {
-        double kR[4 * KD];
-        for (int i = 0; i < 4 * KD; ++i) kR[i] = knots_R[4 * idx + i];
-        Quat q;
-        if constexpr (WITH_J)
-        {
-            if constexpr (KD == 2)
-                q = wave == 0 ? pose_table_entry<KD, 0>(kR, u, col, sg, pe) : pose_table_entry<KD, 1>(kR, u, col, sg, pe);
-            else
-                switch (wave)
-                {
-                case 0: q = pose_table_entry<KD, 0>(kR, u, col, sg, pe); break;
-                case 1: q = pose_table_entry<KD, 1>(kR, u, col, sg, pe); break;
-                case 2: q = pose_table_entry<KD, KD == 4 ? 2 : 0>(kR, u, col, sg, pe); break;
-                default: q = pose_table_entry<KD, KD == 4 ? 3 : 1>(kR, u, col, sg, pe); break;
-                }
-        }
-        else
-        {
-            q = spline_rotation_from_segs<KD>(kR, sg);
-            for (int i = 0; i < 9 * KD; ++i) pe.A[i] = 0.0;
-        }
-        if (wave == 0 && col == 0)
-        {
-            double kt[3 * KD];
-            for (int i = 0; i < 3 * KD; ++i) kt[i] = knots_t[3 * idx + i];
-            double c[KD], p[3], qv[4] = {q.x, q.y, q.z, q.w}, R[9];
-            trans_coeffs<KD>(u, c);
-            spline_translation<KD>(kt, c, p);
-            rotation_entries(qv, R);
-            double rt[3];
-            rotated_translation(p, qv, rt);
-            for (int i = 0; i < 3; ++i) { pe.t[i] = p[i]; pe.rt[i] = rt[i]; }
-            for (int i = 0; i < 4; ++i) pe.q[i] = qv[i];
-            for (int i = 0; i < 9; ++i) pe.R[i] = R[i];
-            for (int i = 0; i < KD; ++i) pe.c[i] = c[i];
-        }
-    }
-
-    // the whole chain on one lane (spline_rotation_knot: logs, exps and products back to back); used where there is a single
-    // segment (k = 2) inside the fused kernel's prologue
-    template <int KD, bool WITH_J>
-    __device__ __forceinline__ void pose_unstaged(const double *knots_t, const double *knots_R, int idx, double u, int wave, int col,
-                                                  PoseEntry<KD> &pe)
-    {
-        double kR[4 * KD];
-        for (int i = 0; i < 4 * KD; ++i) kR[i] = knots_R[4 * idx + i];
-        Quat q;
-        if constexpr (WITH_J)
-        {
-            JacC<1> blk;
-            q = wave == 0 ? spline_rotation_knot<KD, 1, 0>(kR, u, col, blk) : spline_rotation_knot<KD, 1, KD - 1>(kR, u, col, blk);
-            static_assert(KD == 2, "one wave per knot beyond k = 2 goes through the staged form");
-            const double L3[4][3] = {{q.w, -q.z, q.y}, {q.z, q.w, -q.x}, {-q.y, q.x, q.w}, {-q.x, -q.y, -q.z}};
-            const Quat &v = blk.c[0];
-            double av[3];
-            for (int a = 0; a < 3; ++a)
-            {
-                double r = L3[0][a] * v.x;
-                r += L3[1][a] * v.y;
-                r += L3[2][a] * v.z;
-                r += L3[3][a] * v.w;
-                av[a] = 2.0 * r;
-            }
-            store_rotated_column<KD>(q, av, 3 * wave + col, pe);
-        }
-        else
-            q = spline_rotation<KD, false>(kR, u, nullptr);
-        if (wave == 0 && col == 0)
-        {
-            double kt[3 * KD];
-            for (int i = 0; i < 3 * KD; ++i) kt[i] = knots_t[3 * idx + i];
-            double c[KD], p[3], qv[4] = {q.x, q.y, q.z, q.w}, R[9];
-            trans_coeffs<KD>(u, c);
-            spline_translation<KD>(kt, c, p);
-            rotation_entries(qv, R);
-            double rt[3];
-            rotated_translation(p, qv, rt);
-            for (int i = 0; i < 3; ++i) { pe.t[i] = p[i]; pe.rt[i] = rt[i]; }
-            for (int i = 0; i < 4; ++i) pe.q[i] = qv[i];
-            for (int i = 0; i < 9; ++i) pe.R[i] = R[i];
-            for (int i = 0; i < KD; ++i) pe.c[i] = c[i];
-        }
-    }
-
+    // ------------------------------------------------------------------ pose table (device code: pose_entries.h)
     // grid = ceil(entries / kPoseSPB), block = KD waves
     template <int KD, bool WITH_J>
     __global__ __launch_bounds__(64 * KD) void k_pose_table(const ProblemDesc *__restrict__ descs, const int *__restrict__ entry_prob,
@@ -655,22 +531,6 @@ namespace mbavo
         }
     }
 
-#if defined(MBAVO_FUSED_STAMPS) // timing experiment (tools/fused_stamps.py): where a workgroup of k_fused spends its time
-    __device__ unsigned long long g_fused_stamps[2048 * 8];
-    __device__ unsigned long long g_wave_stamps[1024 * 16 * 4]; // [block][wave][loop start, loop end, HW_ID, rounds]
-#define MBAVO_WSTAMP(i, v) do { if (lane == 0 && blockIdx.x < 1024) g_wave_stamps[(blockIdx.x * 16 + wave) * 4 + (i)] = (v); } while (0)
-#if defined(MBAVO_POSE_STAMPS) // (tools/pose_stamps.py) the pose prologue's steps instead of the kernel's phases: 1 descriptors read, 2 stage A done, 3 stage B done, 4 visible + scalar cache invalidated, 5 ready
-#define MBAVO_PSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_fused_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define MBAVO_FSTAMP(i) do { if ((i) == 0 && threadIdx.x == 0 && blockIdx.x < 2048) g_fused_stamps[blockIdx.x * 8] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define MBAVO_PSTAMP(i) do { } while (0)
-#define MBAVO_FSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_fused_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#endif
-#else
-#define MBAVO_PSTAMP(i) do { } while (0)
-#define MBAVO_FSTAMP(i) do { } while (0)
-#define MBAVO_WSTAMP(i, v) do { } while (0)
-#endif
     __device__ __forceinline__ void set_prio(int p) // s_setprio takes an immediate; p is wave-uniform
     {
         switch (p)
@@ -741,8 +601,8 @@ namespace mbavo
             // (cost-only kernels have no row slabs: the segments get their own LDS behind the wave sums, see the launch)
             SplineSeg *segs = (SplineSeg *)(WITH_J ? rows : red + 2 * kWavesPerGroup);
             MBAVO_PSTAMP(1);
-            frame_pose_entries<KD, WITH_J>(d, d.knots_t, d.knots_R, frame, table_w + tab_off, segs, wave, lane, status,
-                                           tile.kp_begin == 0);
+            frame_pose_entries<KD, WITH_J, true>(d, d.knots_t, d.knots_R, frame, table_w + tab_off, segs, wave, lane, status,
+                                                 tile.kp_begin == 0);
             MBAVO_PSTAMP(3);
             // the entries are in this XCD's L2 (vector stores write through) once every wave's stores are performed; the
             // scalar cache has never seen these lines in this launch.  The offset is made opaque AFTER the barrier: the
@@ -1013,62 +873,6 @@ namespace mbavo
         int nbf;
         unsigned long long t_seen;               // (timing experiment MBAVO_PERSIST_STAMPS)
     };
-
-    // S pose entries of (problem d, frame) -> dst[0 .. S-1] (LDS), in the two stages of k_pose_table: segment g of sample
-    // `lane` on wave g into `segs` (LDS scratch: S x (KD - 1) SplineSeg), a workgroup barrier, then knot = wave and
-    // lane = (sample, column).  EVERY wave of the workgroup calls this (it contains barriers); the caller synchronises
-    // the workgroup once more afterwards.
-    template <int KD, bool WITH_J>
-    __device__ __forceinline__ void frame_pose_entries(const ProblemDesc &d, const double *knots_t, const double *knots_R, int frame,
-                                                       PoseEntry<KD> *dst, SplineSeg *segs, int wave, int lane, int *status, bool report)
-    {
-        constexpr int NCOL = WITH_J ? 3 : 1, NKW = WITH_J ? KD : 1, NSEG = KD - 1;
-        const int S = d.S;
-        if constexpr (KD == 2)
-        { // one segment only: nothing to spread out, every (sample, column) lane evaluates it itself -- no barrier, no LDS
-          // round trip (the staged form measured +1.1 us per evaluation here)
-            (void)segs;
-            for (int s0 = 0; s0 < S; s0 += kPoseSPB)
-            {
-                const int sl = lane / NCOL, col = lane - sl * NCOL, smp = s0 + sl;
-                if (wave < NKW && sl < kPoseSPB && smp < S)
-                {
-                    int idx;
-                    double u;
-                    bool oob;
-                    pose_sample_segment<KD>(d, frame, smp, idx, u, oob);
-                    if (oob && report && wave == 0 && col == 0) atomicAdd(status, 1);
-                    pose_unstaged<KD, WITH_J>(knots_t, knots_R, idx, u, wave, col, dst[smp]);
-                }
-            }
-            return;
-        }
-        for (int s0 = 0; s0 < S; s0 += kPoseSPB)
-        {
-            if (wave < NSEG && lane < kPoseSPB && s0 + lane < S)
-            {
-                int idx;
-                double u;
-                bool oob;
-                pose_sample_segment<KD>(d, frame, s0 + lane, idx, u, oob);
-                spline_segment_eval<WITH_J>(knots_R + 4 * (idx + wave), knots_R + 4 * (idx + wave + 1), seg_weight<KD>(u, wave),
-                                            segs[lane * NSEG + wave]);
-            }
-            __syncthreads();
-            MBAVO_PSTAMP(2);
-            const int sl = lane / NCOL, col = lane - sl * NCOL, smp = s0 + sl;
-            if (wave < NKW && sl < kPoseSPB && smp < S)
-            {
-                int idx;
-                double u;
-                bool oob;
-                pose_sample_segment<KD>(d, frame, smp, idx, u, oob);
-                if (oob && report && wave == 0 && col == 0) atomicAdd(status, 1);
-                pose_stage_b<KD, WITH_J>(knots_t, knots_R, idx, u, wave, col, segs + sl * NSEG, dst[smp]);
-            }
-            if (s0 + kPoseSPB < S) __syncthreads(); // the next pass overwrites the segments
-        }
-    }
 
     // After the workgroup wrote partials[tile_id]: take a ticket of the tile's (problem, frame) slot; the workgroup
     // that draws the last one sums the slot's partials -- LANES tile-lanes per entry, lane l adds tiles l, l + LANES,
@@ -1936,13 +1740,12 @@ namespace mbavo
     static int launch_all(Engine *eng, hipStream_t st, int max_S, int grad_mode, int sp_logs, bool one, bool flat_finalize, const ProblemDesc *descs, const int *entry_prob, int entries, const TileDesc *tiles, int ntiles,
                           const int *bf_prob, const int *bf_tile_begin, int nbf, void *poses, double *rho,
                           double *patch_cost, double *patch_blocks_strided, double *partials, int *status,
-                          double *frame_blocks, double *valid, const OneArgs &oa, bool fused_pose_ok)
+                          double *frame_blocks, double *valid, const OneArgs &oa, bool fused_pose_ok, bool external_poses)
     {
         PoseEntry<KD> *table = (PoseEntry<KD> *)poses;
-        // one workgroup per CU at most, lane-per-pixel kernel with Jacobians: the pose entries are the fused kernel's prologue
-        // (k = 4 only: the k = 2 kernels run 16 waves on a 128-VGPR budget the one-lane k = 2 pose chain does not fit -- 36 vector
-        // spills; the instantiations exist but are not dispatched)
-        const bool fused_pose = fused_pose_ok && KD == 4 && sp_logs == 0 && !one && ntiles > 0;
+        // one workgroup per CU at most, lane-per-pixel kernel: the pose entries are the fused kernel's prologue (k = 2 too since
+        // round 4: through the two stages, see frame_pose_entries)
+        const bool fused_pose = fused_pose_ok && sp_logs == 0 && !one && ntiles > 0;
         if (one)
         { // single launch: pose entries in the prologue, finalize by the last workgroup of every slot
 #define MBAVO_SP_ONE(LG)                                                                                                       \
@@ -1967,7 +1770,7 @@ namespace mbavo
             HIP_TRY(hipGetLastError());
             return 0;
         }
-        if (!fused_pose)
+        if (!fused_pose && !external_poses)
             hipLaunchKernelGGL((k_pose_table<KD, WITH_J>), dim3((entries + kPoseSPB - 1) / kPoseSPB), dim3(64 * KD), 0, st, descs, entry_prob,
                                entries, table, status);
         if (ntiles > 0)
@@ -2011,14 +1814,11 @@ namespace mbavo
             }
             else if (fused_pose)
             {
-                if constexpr (KD == 4) // (k = 2 never takes the prologue, see above: its instantiations are not compiled)
-                {
-                    // cost-only: the pose prologue's segments need LDS of their own (there are no slabs to borrow)
-                    const size_t lds = lds_plain + (WITH_J ? 0 : (size_t)kPoseSPB * (KD - 1) * sizeof(SplineSeg));
-                    MBAVO_GRAD_CASE(HIP_TRY(eng->ensure_lds((const void *)k_fused<KD, WITH_J, G, true>, lds));
-                                    MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, G, true>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho,
-                                                       patch_cost, patch_blocks_strided, partials, table, status, max_S));
-                }
+                // cost-only: the pose prologue's segments need LDS of their own (there are no slabs to borrow)
+                const size_t lds = lds_plain + (WITH_J ? 0 : (size_t)kPoseSPB * (KD - 1) * sizeof(SplineSeg));
+                MBAVO_GRAD_CASE(HIP_TRY(eng->ensure_lds((const void *)k_fused<KD, WITH_J, G, true>, lds));
+                                MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, G, true>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho,
+                                                   patch_cost, patch_blocks_strided, partials, table, status, max_S));
             }
             else
                 MBAVO_GRAD_CASE(MBAVO_LAUNCH_TIMED((k_fused<KD, WITH_J, G>), dim3(ntiles), dim3(kThreads), lds, descs, tiles, table, rho, patch_cost,
@@ -2097,17 +1897,17 @@ namespace mbavo
         // (rebuild_layout sizes it for that).  MBAVO_FUSED_POSE=0 keeps the pose kernel.
         // Measured (profiles/r02_kfused_experiments.txt 16.): S = 8: the prologue costs a workgroup 4.8 us against the pose
         // kernel's 5.7; S = 16: 7.4 us, slower than the kernel.
-        const bool fused_pose_ok = ntiles <= num_cus_ && max_S <= env_int("MBAVO_FUSED_POSE_MAX_S", 8) && max_S <= kPoseSPB &&
+        const bool fused_pose_ok = !external_poses_ && ntiles <= num_cus_ && max_S <= env_int("MBAVO_FUSED_POSE_MAX_S", 8) && max_S <= kPoseSPB &&
                                    env_int("MBAVO_FUSED_POSE", 1) != 0;
 #define MBAVO_LAUNCH(KD, WJ)                                                                                      \
     launch_all<KD, WJ>(this, stream_, max_S, half_grad, sp_logs_, one, flat_finalize_, descs, (const int *)d_entry_prob_, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
                        (const int *)d_bf_tile_begin_, total_bf_, d_poses_, (double *)d_rho_, d_patch_cost,        \
-                       d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid, oa, fused_pose_ok)
+                       d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid, oa, fused_pose_ok, external_poses_)
         if (kdeg == 4) rc = with_hessian ? MBAVO_LAUNCH(4, true) : MBAVO_LAUNCH(4, false);
         else rc = with_hessian ? MBAVO_LAUNCH(2, true) : MBAVO_LAUNCH(2, false);
 #undef MBAVO_LAUNCH
         last_kernel_id_[0] = kdeg; last_kernel_id_[1] = with_hessian; last_kernel_id_[2] = half_grad; last_kernel_id_[3] = sp_logs_;
-        last_kernel_id_[4] = one; last_kernel_id_[5] = fused_pose_ok && kdeg == 4 && sp_logs_ == 0 && !one && ntiles > 0;
+        last_kernel_id_[4] = one; last_kernel_id_[5] = fused_pose_ok && sp_logs_ == 0 && !one && ntiles > 0;
         return rc;
     }
 

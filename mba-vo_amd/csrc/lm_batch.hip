@@ -22,6 +22,7 @@
 #include "lm_solvers.h"
 #include "lm_state.h"
 #include "host_math.h"
+#include "pose_entries.h"
 
 #include <cfloat>
 #include <cmath>
@@ -102,7 +103,8 @@ namespace mbavo
                                                     double *__restrict__ Hst, double *__restrict__ gst,
                                                     double *__restrict__ cur_t, double *__restrict__ cur_R,
                                                     int *__restrict__ active, mbavo_trace_rec *__restrict__ trace,
-                                                    int *__restrict__ num_done, unsigned long long *host_word, int slot, int B)
+                                                    int *__restrict__ num_done, unsigned long long *host_word, int slot, int B,
+                                                    PoseEntry<KD> *pose_table, int *pose_status)
     {
         constexpr int M6 = 6 * KD, ND = M6 + 1, E = ND * (ND + 1) / 2;
         extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -339,13 +341,34 @@ namespace mbavo
         }
         // computeCandidatePointAndEvaluateCost (:833-883): candidate = current (+) step, into the evaluated buffers
         double *Wt = const_cast<double *>(d.knots_t), *WR = const_cast<double *>(d.knots_R);
-        for (int i = tid; i < 3 * N; i += T) Wt[i] = Ct[i] + x[i];
+        // (a copy in LDS, V's place -- the solvers are done with it: the pose entries below read the candidate from there)
+        double *Lt = V, *LR = V + 3 * N;
+        for (int i = tid; i < 3 * N; i += T) { const double v = Ct[i] + x[i]; Wt[i] = v; Lt[i] = v; }
         for (int i = tid; i < N; i += T)
         {
             const Quat q = qmul(load_quat(CR + 4 * i), so3_exp(x + 3 * N + 3 * i)); // Spline.h:317-330, not re-normalised
             WR[4 * i] = q.x; WR[4 * i + 1] = q.y; WR[4 * i + 2] = q.z; WR[4 * i + 3] = q.w;
+            LR[4 * i] = q.x; LR[4 * i + 1] = q.y; LR[4 * i + 2] = q.z; LR[4 * i + 3] = q.w;
         }
         if (tid == 0) { active[b] = 1; states[b] = s; slot_publish(num_done, host_word, slot, B, false); }
+        // The blur samples' pose entries of the candidate, WITH the knot Jacobians (round 4): the cost-only pass and -- if the
+        // step is accepted -- the H/g pass of this slot evaluate at exactly these knots, so the entries are computed ONCE here,
+        // by the workgroup that has the knots in its LDS, instead of by a pose launch / a pose prologue in each of the two passes
+        // (Engine::set_external_poses; the arithmetic of k_pose_table: frame_pose_entries, one wave per knot).
+        if constexpr (T >= 64 * KD)
+        {
+            if (pose_table != nullptr)
+            {
+                __syncthreads(); // the candidate is complete in LDS
+                const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+                SplineSeg *segs = (SplineSeg *)(V + 8 * N); // (8-byte aligned; S x (KD - 1) segments: sized by the host)
+                for (int f = 0; f < F; ++f)
+                {
+                    frame_pose_entries<KD, true>(d, Lt, LR, f, pose_table + d.pose_base + f * d.S, segs, wave, lane, pose_status, true);
+                    __syncthreads(); // the next frame overwrites the segments
+                }
+            }
+        }
 #if defined(MBAVO_EIG_STAMPS)
         if (tid == 0 && b == 0)
             printf("k_lm_solve<%d,%d> block 0: merge %lld | damp + store %lld | solve %lld | model + candidate %lld cycles\n", KD, T, ts1 - ts0,
@@ -504,8 +527,15 @@ namespace mbavo
         // MBAVO_LM_EIG=0 keeps the one-wave one-sided sweeps
         const char *eig_env = getenv("MBAVO_LM_EIG");
         const bool eig = opt.solver_type == 0 && max_n <= kEigMaxN && !(eig_env && eig_env[0] == '0');
-        const size_t lds = eig ? (eig_lds_doubles(max_n) + 3 * max_n + (size_t)max_n * max_n) * sizeof(double) + (size_t)(4 + 2 * max_n) * sizeof(int)
+        const size_t lds_solver = eig ? (eig_lds_doubles(max_n) + 3 * max_n + (size_t)max_n * max_n) * sizeof(double) + (size_t)(4 + 2 * max_n) * sizeof(int)
                                : ((size_t)2 * max_n * (max_n + 1) + 6 * max_n) * sizeof(double) + (size_t)max_n * sizeof(int);
+        // the solve kernel's pose entries (eigenvalue-Jacobi form only: it has the KD waves): candidate knots + the segments of
+        // a frame's samples in the solvers' area
+        int max_S = 1;
+        for (int b = 0; b < B; ++b) max_S = probs[b].S > max_S ? probs[b].S : max_S;
+        const bool ext_poses = eig && !(getenv("MBAVO_LM_POSES") && getenv("MBAVO_LM_POSES")[0] == '0');
+        const size_t lds_pose = ext_poses ? (size_t)8 * max_N * sizeof(double) + (size_t)(max_S < kPoseSPB ? max_S : kPoseSPB) * (k - 1) * sizeof(SplineSeg) : 0;
+        const size_t lds = lds_solver > lds_pose ? lds_solver : lds_pose;
         if (lds > 160 * 1024) return MBAVO_E_ARG;
 
         // one arena for all LM state
@@ -617,16 +647,18 @@ namespace mbavo
             for (int slot = 0; slot <= o.max_it + 1; ++slot)
             {
                 const double ts0 = stamps ? now_us() : 0.0;
-#define LM_SOLVE_ARGS descs, states, o, fs, d_start, Hst, gst, ct, cR, act, d_trace, num_done, d_word, slot, B
+#define LM_SOLVE_ARGS(KD) descs, states, o, fs, d_start, Hst, gst, ct, cR, act, d_trace, num_done, d_word, slot, B, \
+                          (PoseEntry<KD> *)(ext_poses ? eng.device_pose_table() : nullptr), eng.device_status()
                 if (k == 4 && eig)
-                    hipLaunchKernelGGL((k_lm_solve<4, kEigT>), dim3(B), dim3(kEigT), lds, st, LM_SOLVE_ARGS);
+                    hipLaunchKernelGGL((k_lm_solve<4, kEigT>), dim3(B), dim3(kEigT), lds, st, LM_SOLVE_ARGS(4));
                 else if (k == 4)
-                    hipLaunchKernelGGL((k_lm_solve<4, 64>), dim3(B), dim3(64), lds, st, LM_SOLVE_ARGS);
+                    hipLaunchKernelGGL((k_lm_solve<4, 64>), dim3(B), dim3(64), lds, st, LM_SOLVE_ARGS(4));
                 else if (eig)
-                    hipLaunchKernelGGL((k_lm_solve<2, kEigT>), dim3(B), dim3(kEigT), lds, st, LM_SOLVE_ARGS);
+                    hipLaunchKernelGGL((k_lm_solve<2, kEigT>), dim3(B), dim3(kEigT), lds, st, LM_SOLVE_ARGS(2));
                 else
-                    hipLaunchKernelGGL((k_lm_solve<2, 64>), dim3(B), dim3(64), lds, st, LM_SOLVE_ARGS);
+                    hipLaunchKernelGGL((k_lm_solve<2, 64>), dim3(B), dim3(64), lds, st, LM_SOLVE_ARGS(2));
 #undef LM_SOLVE_ARGS
+                eng.set_external_poses(ext_poses); // from here on the passes read the entries the solve launches leave in the table
                 if (sync_every <= 0)
                 {
                     // the three passes of this slot go in behind the solve BEFORE the host looks at the solve's word: the device
@@ -637,7 +669,10 @@ namespace mbavo
                     const bool last = slot == o.max_it + 1;
                     bool ending = last;
                     const double ts1 = stamps ? now_us() : 0.0;
-                    if (!last && slot > 0)
+                    // (batches of up to 128 problems only: a big batch's passes take the host 20-90 us to enqueue, which must overlap
+                    // the device's previous slot -- waiting for the decide word first cost the 512-pair call 54 us in bubbles for
+                    // 30 us of idle launches saved)
+                    if (!last && slot > 0 && B <= 128)
                     {
                         const unsigned long long w2 = spin_for(h_word2, (unsigned long long)slot);
                         if (w2 == 0) { LM_HIP(hipStreamSynchronize(st)); LM_HIP(hipGetLastError()); rc = MBAVO_E_RANGE; goto done; }
@@ -725,6 +760,7 @@ namespace mbavo
         // an error exit may leave solve launches queued that still store into the pinned done word and the arena: drain them
         // before the next call re-arms the word or regrows either buffer
         if (rc != 0) (void)hipStreamSynchronize(st);
+        eng.set_external_poses(false);
         eng.set_defer_finalize(false);
         return rc > 0 ? -1000 - rc : rc;
     }

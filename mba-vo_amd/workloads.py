@@ -132,7 +132,11 @@ class _PairInfo:
         # whole images (keyframe u8 + gradient 2 x f32 + current u8), all of them this pair's own
         # (keyframe formats 1 / 2: half pairs 1 + 4 bytes per pixel, 20 per tap; packed words 4 and 16)
         img, tap = {0: (9, 36), 1: (5, 20), 2: (4, 16)}[int(fmt)]
-        self.image_bytes = min(H * W * img + F * H * W, F * K * P * (S * tap + 1))
+        self.fmt = int(fmt)
+        self.image_bytes_upper = min(H * W * img + F * H * W, F * K * P * (S * tap + 1))  # the gather bound: no reuse at all
+        # until distinct_tap_bytes() has counted the pair's distinct tap locations the upper bound stands in
+        self.image_bytes = self.image_bytes_upper
+        self.distinct = None  # (distinct keyframe pixels tapped, distinct current pixels read, 128-byte lines touched)
 
     @property
     def pixel_samples(self):
@@ -254,6 +258,70 @@ class RenderedPairBatch:
         self.valid = torch.zeros(self.nbf, dtype=torch.float64, device=device)
         torch.cuda.synchronize()
 
+    def count_distinct_taps(self, ctx, pairs=None):
+        """the COMPULSORY bytes of a semi-dense pair are the bytes of its DISTINCT tap locations (36 B per
+        pixel-sample is the no-reuse upper bound).  Counts them on the host for the pairs' actual keypoints and knots: patch
+        centre at blur sample S/2 (compute_local_patches_xy.cu:19-49), the truncated pixel (A3), for every blur sample the warp
+        through its pose (compute_pixel_intensity.h:117-144) and the 2 x 2 tap window anchored at min(floor, size - 2) -- plain
+        numpy (the figure is a count of locations; a last-place difference in a coordinate moves no window).  Sets, per pair,
+        probs[b].distinct = (keyframe pixels, current pixels, 128-byte lines of the row-major images) and
+        probs[b].image_bytes = the distinct-tap bytes in the pair's keyframe format."""
+        L = ctx.lib
+        H, W, S = self.H, self.W, self.S
+        fx, fy, cx, cy = [float(v) for v in self.intr]
+        pat = synth.PATTERN8.reshape(-1, 2).astype(np.int64)
+        per_px = {0: (1, 8), 1: (1, 4), 2: (0, 4)}  # keyframe bytes per distinct pixel: (u8 image, gradient / packed image)
+        for b in (range(self.B) if pairs is None else pairs):
+            h = self._host[b]
+            if h is None:
+                continue
+            xy = h["xy"].cpu().numpy().reshape(-1, 2)
+            kz = h["kz"].cpu().numpy()
+            kt, kR = np.ascontiguousarray(h["kt"].ravel()), np.ascontiguousarray(h["kR"].ravel())
+            poses = []
+            for i in range(S):
+                t = h["cap"] - h["exp"] * 0.5 + i * h["exp"] / (S - 1 + 1e-8)
+                pp, qq = np.zeros(3), np.zeros(4)
+                capi.check(L.mbavo_spline_get_pose(self.k, h["t0"], 0.5, capi.dp(kt), capi.dp(kR), 4, float(t), capi.dp(pp), capi.dp(qq),
+                                                   None, None), "mbavo_spline_get_pose")
+                x, y, z, w = qq
+                R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                              [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                              [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+                poses.append((R, pp))
+            Rm, tm = poses[S // 2]
+            P3r = np.stack([kz * (xy[:, 0] - cx) / fx, kz * (xy[:, 1] - cy) / fy, kz], 1)
+            P3c = (P3r - tm) @ Rm                       # R^T (P - t)
+            cen = np.stack([P3c[:, 0] / P3c[:, 2] * fx + cx, P3c[:, 1] / P3c[:, 2] * fy + cy], 1)
+            px = (cen[:, None, 0] + pat[None, :, 0]).astype(np.int64)   # truncation toward zero, as (int)
+            py = (cen[:, None, 1] + pat[None, :, 1]).astype(np.int64)
+            inb = (px >= 0) & (px <= W - 1) & (py >= 0) & (py <= H - 1)
+            d = np.broadcast_to(kz[:, None], px.shape)[inb]
+            px, py = px[inb], py[inb]
+            cur_ids = np.unique(py * W + px)
+            rx, ry = (px - cx) / fx, (py - cy) / fy
+            zh = 1.0 / np.sqrt(1.0 + rx * rx + ry * ry)
+            ray = np.stack([rx * zh, ry * zh, zh], 1)
+            ids = []
+            for R, t in poses:
+                rr = ray @ R.T
+                lam = (d - t[2]) / rr[:, 2]
+                Pr = rr * lam[:, None] + t
+                u, v = Pr[:, 0] / Pr[:, 2] * fx + cx, Pr[:, 1] / Pr[:, 2] * fy + cy
+                ok = (u >= 0) & (u <= W - 1) & (v >= 0) & (v <= H - 1)
+                x0 = np.minimum(np.floor(u[ok]).astype(np.int64), W - 2)
+                y0 = np.minimum(np.floor(v[ok]).astype(np.int64), H - 2)
+                for dy in (0, 1):
+                    for dx in (0, 1):
+                        ids.append((y0 + dy) * W + (x0 + dx))
+            ref_ids = np.unique(np.concatenate(ids)) if ids else np.zeros(0, np.int64)
+            fmt = self.probs[b].fmt
+            b_img, b_grad = per_px[fmt]
+            lines = len(np.unique(cur_ids // 128)) + (len(np.unique(ref_ids // 128)) if b_img else 0) + len(np.unique(ref_ids * b_grad // 128))
+            self.probs[b].distinct = (int(len(ref_ids)), int(len(cur_ids)), int(lines))
+            self.probs[b].image_bytes = int(len(ref_ids) * (b_img + b_grad) + len(cur_ids))
+        return self
+
     def reset_knots(self):
         """Initial control knots back into the device buffers (mbavo_lm_batch updates them in place)."""
         import torch
@@ -360,7 +428,7 @@ def algorithmic_flops(probs, valid_pixels=None):
     return total
 
 
-def algorithmic_bytes(probs, shard=None):
+def algorithmic_bytes(probs, shard=None, upper=False):
     """compulsory HBM bytes: images once (ref u8 + gradient 2 x f32 + current u8 per frame),
     keypoints (xy, z), pose tables, packed output blocks.  shard = (mode, rank, world): the bytes of that rank's share
     of the workload -- 'frames': keyframe images and keypoints in full, its own frames' current images; 'keypoints': a
@@ -375,7 +443,9 @@ def algorithmic_bytes(probs, shard=None):
         f0, f1 = ((p.F * rank) // world, (p.F * (rank + 1)) // world) if mode == "frames" else (0, p.F)
         band = 1.0 / world if mode == "keypoints" else 1.0
         if hasattr(p, "image_bytes"):  # a device-resident pair with its own images (RenderedPairBatch)
-            total += p.image_bytes * band
+            # (its distinct tap locations once count_distinct_taps() has run -- SURVEY 8(d)'s compulsory figure; `upper`: the
+            # gather bound, no reuse at all)
+            total += (p.image_bytes_upper if upper else p.image_bytes) * band
         for a in ([] if hasattr(p, "image_bytes") else [p.ref, p.grad] + list(p.cur[f0:f1])):
             key = a.__array_interface__["data"][0]
             if key not in seen:

@@ -183,6 +183,8 @@ def lib():
     return _LIB
 
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # (see bench.py: metered sandboxes; read by libgomp at its first load)
+
 def ref():
     """The reference's own compilable sources (oracle/_ref), or None."""
     global _REF

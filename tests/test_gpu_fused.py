@@ -279,18 +279,26 @@ def test_non_finite_depth_is_dropped_in_both_kernels(orc, mbavo, sp, monkeypatch
         ctx.close()
 
 
-@pytest.mark.parametrize("name", ["k4_dense_S8", "k4_dense_S1", "k4_P8_lane_per_pixel", "k4_batch_mixed_S"])
+@pytest.mark.parametrize("name", ["k4_dense_S8", "k4_dense_S1", "k4_P8_lane_per_pixel", "k4_batch_mixed_S", "k2_dense_S8", "k2_P8_three_frames",
+                                  "k2_batch_mixed_S"])
 def test_pose_prologue_equals_pose_kernel(orc, mbavo, monkeypatch, name):
-    """k = 4, tiles <= CUs, S <= 8: the pose entries are the fused kernel's prologue (k_fused<.., POSE>, two launches);
+    """Tiles <= CUs, S <= 8: the pose entries are the fused kernel's prologue (k_fused<.., POSE>, two launches);
     MBAVO_FUSED_POSE=0 keeps k_pose_table (three launches).  Same arithmetic per entry -> the frame blocks, per-patch
-    costs and valid counts must be IDENTICAL, H/g and cost-only, and both must match the oracle (1e-9)."""
+    costs and valid counts must be IDENTICAL, H/g and cost-only, and both must match the oracle (1e-9).  k = 2 -- the
+    reference's default degree, blur_aware_direct_tracker.h:50 -- takes the prologue since round 4 (through the two stages:
+    the one-lane chain spilled at the k = 2 kernels' 128-register budget)."""
     import torch
     monkeypatch.setenv("MBAVO_SP", "0")  # the lane-per-pixel kernel whatever the size
     kws = {"k4_dense_S8": [dict(H=96, W=128, S=8, F=2, k=4, P=1, kp="dense", margin=0)],
            "k4_dense_S1": [dict(H=60, W=80, S=1, F=1, k=4, P=1, kp="dense", margin=0)],
            "k4_P8_lane_per_pixel": [dict(S=8, F=3, k=4, P=8, K=211, N=6)],
            "k4_batch_mixed_S": [dict(S=8, F=1, k=4, P=8, K=97, seed=3), dict(S=4, F=2, k=4, P=5, K=60, seed=4),
-                                dict(S=2, F=1, k=4, P=8, K=31, seed=5)]}[name]
+                                dict(S=2, F=1, k=4, P=8, K=31, seed=5)],
+           "k2_dense_S8": [dict(H=96, W=128, S=8, F=2, k=2, P=1, kp="dense", margin=0)],
+           "k2_P8_three_frames": [dict(S=8, F=3, k=2, P=8, K=211, N=4)],
+           "k2_batch_mixed_S": [dict(S=8, F=1, k=2, P=8, K=97, seed=3), dict(S=4, F=2, k=2, P=5, K=60, seed=4),
+                                dict(S=1, F=1, k=2, P=8, K=31, seed=5)]}[name]
+    kdeg = 2 if name.startswith("k2") else 4
     scs = [scenes.Scene(**kw) for kw in kws]
     got = {}
     for mode in ("0", "1"):
@@ -298,9 +306,9 @@ def test_pose_prologue_equals_pose_kernel(orc, mbavo, monkeypatch, name):
         ctx = mbavo.capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
         try:
             ds = [scenes.DeviceScene(sc) for sc in scs]
-            fb, pc, valid = scenes.gpu_eval_batch(ctx, ds, 4)
+            fb, pc, valid = scenes.gpu_eval_batch(ctx, ds, kdeg)
             kern = ctx.lib.mbavo_last_kernel(ctx.handle).decode()
-            fbc, pcc, _ = scenes.gpu_eval_batch(ctx, ds, 4, with_hessian=False)
+            fbc, pcc, _ = scenes.gpu_eval_batch(ctx, ds, kdeg, with_hessian=False)
             got[mode] = (fb.copy(), pc.copy(), valid.copy(), fbc.copy(), pcc.copy(), kern)
         finally:
             ctx.close()
