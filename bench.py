@@ -78,8 +78,6 @@ def parse():
                     help="gradient pyramid stored as IEEE half pairs (BASELINE configs[4]: lossless for 8-bit images)")
     ap.add_argument("--packed-keyframes", action="store_true",
                     help="keyframes as one word per pixel: intensity + both central differences (mbavo_problem.grad_fp16 = 2, lossless)")
-    ap.add_argument("--tiled-keyframes", action="store_true",
-                    help="the packed words in 8 x 4-pixel tiles, one 128-byte line each (mbavo_problem.grad_fp16 = 3, lossless)")
     ap.add_argument("--time-every", type=int, default=8,
                     help="HIP-event pair around the dominant kernel on every n-th timed step (events cost launch gaps)")
     ap.add_argument("--min-seconds", type=float, default=0.3, help="repeat the K-step region until this much was timed")
@@ -307,15 +305,13 @@ class Runner:
             self.dw, self.probs = built, built.probs
             built.count_distinct_taps(ctx)  # compulsory bytes = the DISTINCT tap locations (host count, actual knots)
             if grad_fp16:
-                self.desc += {2: ", packed keyframes (one word per pixel: intensity + both differences)",
-                              3: ", packed keyframes in 8 x 4-pixel tiles (one 128-byte line per tile)"}.get(int(grad_fp16), ", fp16 gradient images")
+                self.desc += ", packed keyframes (one word per pixel: intensity + both differences)" if int(grad_fp16) == 2 else ", fp16 gradient images"
         else:
             self.probs = built
             if grad_fp16:
                 for p in self.probs:
                     p.grad_fp16 = int(grad_fp16)
-                self.desc += {2: ", packed keyframe pyramid (one word per pixel: intensity + both differences)",
-                              3: ", tiled packed keyframe pyramid (8 x 4-pixel tiles)"}.get(int(grad_fp16), ", fp16 gradient pyramid")
+                self.desc += ", packed keyframe pyramid (one word per pixel: intensity + both differences)" if int(grad_fp16) == 2 else ", fp16 gradient pyramid"
             self.dw = wl.DeviceWorkload(self.probs, device=dev)
         self.se = shard.ShardedEvaluation(ctx, self.dw.array, self.dw.k, rank, world, self.mode, dev, collective=coll,
                                           pair_collective=pair_collective) if sharded else None
@@ -595,7 +591,7 @@ def main():
         red = statistics.median(b.elapsed_time(c) for a, b, c in ev)
         return loc, red
 
-    run = Runner(M, ctx, args.workload, dev, rank, world, use_dist, 3 if args.tiled_keyframes else 2 if args.packed_keyframes else int(args.grad_fp16), shard_mode=args.shard,
+    run = Runner(M, ctx, args.workload, dev, rank, world, use_dist, 2 if args.packed_keyframes else int(args.grad_fp16), shard_mode=args.shard,
                  coll=coll, pair_collective=args.collective, pairs=args.batch_pairs if args.batch_pairs != 512 else None)
 
     for _ in range(args.warmup):
@@ -840,9 +836,9 @@ def main():
             todo.insert(0, ("c2_dense", False, True))
         # named extras: the keyframe in the two lossless compact formats (mbavo_problem.grad_fp16 = 1: half pairs, 2: packed words)
         todo += [("c3_batch64_shared", False, False), ("c4_batch512", 1, False), ("c4_batch512", 2, False), ("c3_batch64", 2, False),
-                 ("c2_dense", 2, False), ("c4_batch512", 3, False), ("c3_batch64", 3, False)]  # (3: the packed words in 8 x 4-pixel tiles)
+                 ("c2_dense", 2, False)]
         for name, half, seq_levels in todo:
-            key = name + ("_tiled" if int(half) == 3 else "_packed" if int(half) == 2 else "_fp16grad" if half else "") + ("_sequential" if seq_levels else "")
+            key = name + ("_packed" if int(half) == 2 else "_fp16grad" if half else "") + ("_sequential" if seq_levels else "")
             try:
                 r = Runner(M, ctx, name, dev, 0, 1, False, half, sequential=seq_levels)
                 if seq_levels:

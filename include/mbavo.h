@@ -62,8 +62,6 @@ typedef struct mbavo_problem {
                                              exactly representable in fp16, so both formats see identical tap values (results agree to rounding).
                                              2: d_ref_dIxy is the packed keyframe of mbavo_pack_keyframe_u8 (4 B/pixel: intensity and both
                                              differences in one word; H/g passes read nothing else of the keyframe, cost-only passes d_ref_img).
-                                             3: the same words in 8 x 4-pixel tiles, one 128-byte line per tile (mbavo_pack_keyframe_u8_tiled):
-                                             for batches of sparse patches in many keyframes, where every touched line is fetched whole.
                                              All problems of one mbavo_eval_batch call must use the same format. */
     long long num_residuals;              /* 0: the blocks are scaled by 1/((K - num_bad)*F*P) of THIS problem
                                              (inv_num_residuals, spline_update_step.cpp:116-117).  > 0: by 1/num_residuals --
@@ -224,12 +222,6 @@ int mbavo_image_gradients_u8_half(const unsigned char *d_src, int H, int W, void
  * doubled central differences 2 dI/dx, 2 dI/dy of Gradient.h:16-75 as 9-bit two's complement (zero on the 1-pixel border).  Holds
  * exactly what the u8 image and its float gradient image hold (4 bytes per pixel instead of 9); d_ref_dIxy then points at it. */
 int mbavo_pack_keyframe_u8(const unsigned char *d_src, int H, int W, void *d_packed /* H*W uint32 */, void *hip_stream);
-/* the same words in TILES of 8 x 4 pixels (mbavo_problem.grad_fp16 = 3): a tile is 32 consecutive words = one 128-byte line, row-major
- * inside the tile, tiles row-major, the image padded to whole tiles -- word index of pixel (x, y) =
- * (y / 4) * 32 * ceil(W / 8) + (x / 8) * 32 + (y % 4) * 8 + x % 8; the buffer holds mbavo_tiled_keyframe_words(H, W) words (padding
- * words are never read).  The taps of compute_pixel_intensity.h:25-72 then touch ~0.6 of the lines they touch in the row-major image. */
-long long mbavo_tiled_keyframe_words(int H, int W);
-int mbavo_pack_keyframe_u8_tiled(const unsigned char *d_src, int H, int W, void *d_packed, void *hip_stream);
 
 /* gradient magnitude image (Gradient.h:56-71, the detector's score) */
 int mbavo_gradient_magnitude_u8(const unsigned char *d_src, int H, int W, float *d_mag, void *hip_stream);

@@ -99,7 +99,7 @@ SYMBOLS = [
     "mbavo_lm_new", "mbavo_lm_delete", "mbavo_lm_reset", "mbavo_lm_step_accepted", "mbavo_lm_step_rejected",
     "mbavo_lm_get_radius", "mbavo_tr_new", "mbavo_tr_delete", "mbavo_tr_reset", "mbavo_tr_step_quality",
     "mbavo_tr_step_accepted", "mbavo_spline_get_pose", "mbavo_spline_plus", "mbavo_segment_start_index",
-    "mbavo_optimize_trajectory", "mbavo_pyramid_down_u8", "mbavo_pyramid_levels_u8", "mbavo_image_gradients_u8", "mbavo_image_gradients_u8_half", "mbavo_pack_keyframe_u8", "mbavo_pack_keyframe_u8_tiled", "mbavo_tiled_keyframe_words", "mbavo_synthesize_blur", "mbavo_allreduce_blocks", "mbavo_allreduce_blocks_to", "mbavo_allgather_blocks",
+    "mbavo_optimize_trajectory", "mbavo_pyramid_down_u8", "mbavo_pyramid_levels_u8", "mbavo_image_gradients_u8", "mbavo_image_gradients_u8_half", "mbavo_pack_keyframe_u8", "mbavo_synthesize_blur", "mbavo_allreduce_blocks", "mbavo_allreduce_blocks_to", "mbavo_allgather_blocks",
     "mbavo_profile", "mbavo_profile_read", "mbavo_version", "mbavo_abi_version",
     "mbavo_gradient_magnitude_u8", "mbavo_detect_semidense", "mbavo_se3_exp", "mbavo_se3_log", "mbavo_transform_mul",
     "mbavo_transform_inverse", "mbavo_spline_transform_to", "mbavo_vo_create", "mbavo_vo_destroy", "mbavo_vo_set_spline",
@@ -193,9 +193,6 @@ def load():
     L.mbavo_image_gradients_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.mbavo_image_gradients_u8_half.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.mbavo_pack_keyframe_u8.argtypes = [vp, C.c_int, C.c_int, vp, vp]
-    L.mbavo_pack_keyframe_u8_tiled.argtypes = [vp, C.c_int, C.c_int, vp, vp]
-    L.mbavo_tiled_keyframe_words.argtypes = [C.c_int, C.c_int]
-    L.mbavo_tiled_keyframe_words.restype = C.c_longlong
     L.mbavo_pyramid_levels_u8.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_int]
     L.mbavo_synthesize_blur.argtypes = [vp, C.c_int, C.c_int, C.c_double, c_dp, C.c_int, C.c_double, C.c_double, c_dp,
                                         c_dp, C.c_int, C.c_double, C.c_double, C.c_int, vp, vp]

@@ -1546,7 +1546,7 @@ namespace mbavo
             const long long num_residuals = p.num_residuals > 0 ? p.num_residuals : (long long)(p.K - p.num_bad) * p.F * p.P;
             d.inv_num_residuals = num_residuals > 0 ? 1.0 / (double)num_residuals : 0.0; // empty problem: all-zero blocks
             d.S = p.S; d.F = p.F; d.K = p.K; d.P = p.P; d.N = p.N; d.H = p.H; d.W = p.W; d.kp_stride = p.kp_stride;
-            d.grad_fp16 = p.grad_fp16 == 2 || p.grad_fp16 == 3 ? p.grad_fp16 : (p.grad_fp16 ? 1 : 0);
+            d.grad_fp16 = p.grad_fp16 == 2 ? 2 : (p.grad_fp16 ? 1 : 0);
             d.active = d_active ? d_active + b : nullptr;
             d.inv_ptr = d_inv ? d_inv + b : nullptr;
             d.pose_base = entries; d.bf_base = bf; d.pixel_base = pixels; d.patch_base = patches;
@@ -1784,13 +1784,12 @@ namespace mbavo
             // the large-LDS attribute is per device and per kernel: remembered per engine (= per device)
             // gradient format of the instantiation: cost-only passes of the packed format tap the u8 image like format 0
             // (and are format 0's instantiation); MBAVO_GRAD_CASE runs its statement with G = the compile-time format
-            const int gm = (!WITH_J && grad_mode >= 2) ? 0 : grad_mode;
+            const int gm = (!WITH_J && grad_mode == 2) ? 0 : grad_mode;
 #define MBAVO_GRAD_CASE(...)                                                       \
     do                                                                             \
     {                                                                              \
         if (gm == 1) { constexpr int G = 1; __VA_ARGS__; }                         \
         else if (gm == 2) { constexpr int G = WITH_J ? 2 : 0; __VA_ARGS__; }       \
-        else if (gm == 3) { constexpr int G = WITH_J ? 3 : 0; __VA_ARGS__; }       \
         else { constexpr int G = 0; __VA_ARGS__; }                                 \
     } while (0)
             MBAVO_GRAD_CASE(HIP_TRY(eng->ensure_lds((const void *)k_fused<KD, WITH_J, G>, lds)));
@@ -2105,7 +2104,7 @@ namespace mbavo
         else if (k[3] > 0)
             snprintf(last_kernel_, sizeof(last_kernel_), "k_fused_sp<%d,%s,false,%d,%s>", k[0], k[1] ? "true" : "false", k[3], k[4] ? "true" : "false");
         else
-            snprintf(last_kernel_, sizeof(last_kernel_), "k_fused<%d,%s,%s,%s>", k[0], k[1] ? "true" : "false", k[2] == 3 && k[1] ? "tiled" : k[2] == 2 && k[1] ? "packed" : k[2] == 1 ? "true" : "false", k[5] ? "true" : "false");
+            snprintf(last_kernel_, sizeof(last_kernel_), "k_fused<%d,%s,%s,%s>", k[0], k[1] ? "true" : "false", k[2] == 2 && k[1] ? "packed" : k[2] == 1 ? "true" : "false", k[5] ? "true" : "false");
         return last_kernel_;
     }
 

@@ -52,7 +52,6 @@ namespace mbavo
         g[i] = __floats2half2_rn(dx, dy);
     }
     // intensity and both doubled differences in one word per pixel (pixel_math.h: pack_keyframe_word)
-    template <bool TILED> // TILED: 8 x 4-pixel tiles, one 128-byte line each (pixel_math.h: tiled_word_index; padding words are never read)
     __global__ void k_pack_keyframe(const unsigned char *__restrict__ src, int H, int W, unsigned *__restrict__ out)
     {
         const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
@@ -64,7 +63,7 @@ namespace mbavo
             kx = (int)src[i + 1] - (int)src[i - 1];
             ky = (int)src[i + W] - (int)src[i - W];
         }
-        out[TILED ? (size_t)tiled_word_index(x, y, W) : i] = pack_keyframe_word((int)src[i], kx, ky);
+        out[i] = pack_keyframe_word((int)src[i], kx, ky);
     }
     // Synthetic motion blur (generate_synthetic_data.cpp:127-214): every output pixel is warped into the sharp
     // image through each of the n sampled poses, every warp is truncated to 8 bits as warp_image() stores it, the n
@@ -150,16 +149,7 @@ extern "C" int mbavo_image_gradients_u8_half(const unsigned char *d_src, int H, 
 extern "C" int mbavo_pack_keyframe_u8(const unsigned char *d_src, int H, int W, void *d_packed, void *stream)
 {
     if (!d_src || !d_packed || H < 1 || W < 1) return MBAVO_E_ARG;
-    hipLaunchKernelGGL(mbavo::k_pack_keyframe<false>, dim3((W + 255) / 256, H), dim3(256), 0, (hipStream_t)stream, d_src, H, W, (unsigned *)d_packed);
-    return (int)hipGetLastError();
-}
-
-extern "C" long long mbavo_tiled_keyframe_words(int H, int W) { return H < 1 || W < 1 ? 0 : (long long)mbavo::tiled_keyframe_words(H, W); }
-
-extern "C" int mbavo_pack_keyframe_u8_tiled(const unsigned char *d_src, int H, int W, void *d_packed, void *stream)
-{
-    if (!d_src || !d_packed || H < 1 || W < 1) return MBAVO_E_ARG;
-    hipLaunchKernelGGL(mbavo::k_pack_keyframe<true>, dim3((W + 255) / 256, H), dim3(256), 0, (hipStream_t)stream, d_src, H, W, (unsigned *)d_packed);
+    hipLaunchKernelGGL(mbavo::k_pack_keyframe, dim3((W + 255) / 256, H), dim3(256), 0, (hipStream_t)stream, d_src, H, W, (unsigned *)d_packed);
     return (int)hipGetLastError();
 }
 

@@ -256,21 +256,11 @@ namespace mbavo
     // runs on the doubled differences and its result is halved, which commutes with every rounding of the blend.
     struct __attribute__((aligned(4))) Word2A4 { unsigned v[2]; };
     MBAVO_HD unsigned pack_keyframe_word(int I, int kx, int ky) { return (unsigned)I | ((unsigned)kx & 0x1ffu) << 8 | (unsigned)ky << 23; }
-    // TILED packed keyframe (mbavo_problem.grad_fp16 = 3, mbavo_pack_keyframe_u8_tiled; round 4): the same word per pixel, stored
-    // in tiles of 8 x 4 pixels = 32 words = ONE 128-byte line (row-major inside a tile, tiles row-major, the image padded to whole
-    // tiles).  A sparse gather fetches whole lines: a row-major line is a 32 x 1 strip of which a patch's ~8 x 8 footprint uses a
-    // quarter, a tile is all footprint.  Word index of pixel (x, y):
-    MBAVO_HD unsigned tiled_words_per_tile_row(int W) { return (((unsigned)W + 7u) >> 3) * 32u; }
-    MBAVO_HD unsigned tiled_word_index(int x, int y, int W)
-    {
-        return ((unsigned)y >> 2) * tiled_words_per_tile_row(W) + (((unsigned)x >> 3) << 5) + (((unsigned)y & 3u) << 3) + ((unsigned)x & 7u);
-    }
-    MBAVO_HD size_t tiled_keyframe_words(int H, int W) { return (size_t)(((unsigned)H + 3u) >> 2) * tiled_words_per_tile_row(W); }
 
     // HALF_GRAD: the gradient image holds IEEE half pairs (4 B/pixel) instead of float pairs.  A compile-time
     // switch: a run-time branch around the loads makes the compiler wait for ALL outstanding loads (vmcnt(0)) at
     // the first use, which serialises the sample pipeline.
-    template <bool WITH_GRAD, int HALF_GRAD = 0> // 0: float pairs, 1: IEEE half pairs, 2: packed keyframe words, 3: the same in 8 x 4 tiles
+    template <bool WITH_GRAD, int HALF_GRAD = 0> // 0: float pairs, 1: IEEE half pairs, 2: packed keyframe words
     MBAVO_HD void tap_fetch(const unsigned char *__restrict__ I, const float *__restrict__ G, int H, int W,
                             double x, double y, TapLoads &t)
     {
@@ -310,16 +300,6 @@ namespace mbavo
 #endif
         const unsigned idx1 = idx + (unsigned)W;
         const MBAVO_GLOBAL unsigned char *Ig = (const MBAVO_GLOBAL unsigned char *)I;
-        if (WITH_GRAD && HALF_GRAD == 3)
-        { // four words, one per tap: the window's second column / row may sit in the neighbouring tile (shifts, masks, two selects)
-            const MBAVO_GLOBAL unsigned *Gw = (const MBAVO_GLOBAL unsigned *)G;
-            const unsigned tpr = tiled_words_per_tile_row(W);
-            const unsigned a00 = ((unsigned)yi >> 2) * tpr + (((unsigned)xi >> 3) << 5) + (((unsigned)yi & 3u) << 3) + ((unsigned)xi & 7u);
-            const unsigned sx = ((unsigned)xi & 7u) == 7u ? 25u : 1u;          // next column: same row of the tile, or column 0 of the next tile
-            const unsigned sy = ((unsigned)yi & 3u) == 3u ? tpr - 24u : 8u;    // next row: same tile, or row 0 of the tile below
-            t.pk[0] = Gw[a00]; t.pk[1] = Gw[a00 + sx]; t.pk[2] = Gw[a00 + sy]; t.pk[3] = Gw[a00 + sy + sx];
-            return;
-        }
         if (WITH_GRAD && HALF_GRAD == 2)
         { // everything a tap needs is in the packed image (cost-only passes keep to the u8 image: 2 bytes a row)
             const MBAVO_GLOBAL unsigned char *Gb = (const MBAVO_GLOBAL unsigned char *)G;
@@ -353,8 +333,8 @@ namespace mbavo
     MBAVO_HD void tap_blend(const TapLoads &t, double &val, double &gx, double &gy)
     {
 #pragma clang fp contract(off)
-        if (WITH_GRAD && GRAD >= 2)
-        { // packed keyframe words (row-major or tiled): the same blend on the doubled differences, halved at the end (exact)
+        if (WITH_GRAD && GRAD == 2)
+        { // packed keyframe words: the same blend on the doubled differences, halved at the end (exact)
             const float i00 = (float)(t.pk[0] & 0xffu), i01 = (float)(t.pk[1] & 0xffu);
             const float i10 = (float)(t.pk[2] & 0xffu), i11 = (float)(t.pk[3] & 0xffu);
             float v = t.w11 * i11;

@@ -162,23 +162,6 @@ def packed_len(k):
     return nd * (nd + 1) // 2
 
 
-def tiled_keyframe_words(H, W):
-    """words of the tiled packed keyframe of an H x W image (8 x 4-pixel tiles, the image padded to whole tiles)"""
-    return ((H + 3) // 4) * ((W + 7) // 8) * 32
-
-
-def pack_keyframe_tiled(img):
-    """mbavo_pack_keyframe_u8_tiled (mbavo_problem.grad_fp16 = 3) on the host: the words of pack_keyframe in 8 x 4-pixel tiles
-    (32 consecutive words = one 128-byte line per tile; padding words zero)."""
-    w = pack_keyframe(img)
-    H, W = w.shape
-    out = np.zeros(tiled_keyframe_words(H, W), np.uint32)
-    y, x = np.mgrid[0:H, 0:W]
-    idx = (y // 4) * (((W + 7) // 8) * 32) + (x // 8) * 32 + (y % 4) * 8 + (x % 8)
-    out[idx.ravel()] = w.ravel()
-    return out
-
-
 def segment_start_index(t, t0, dt):
     """(int)((t - t0)/dt), truncation toward zero (SplineFunctor.h:13-19)."""
     return int((t - t0) / dt)

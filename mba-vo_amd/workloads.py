@@ -131,7 +131,7 @@ class _PairInfo:
         # gather figure 36 B per pixel-sample (2 x 2 u8 + 2 x 2 x 8 B gradient taps) + the current pixel -- and by the
         # whole images (keyframe u8 + gradient 2 x f32 + current u8), all of them this pair's own
         # (keyframe formats 1 / 2: half pairs 1 + 4 bytes per pixel, 20 per tap; packed words 4 and 16)
-        img, tap = {0: (9, 36), 1: (5, 20), 2: (4, 16), 3: (4, 16)}[int(fmt)]
+        img, tap = {0: (9, 36), 1: (5, 20), 2: (4, 16)}[int(fmt)]
         self.fmt = int(fmt)
         self.image_bytes_upper = min(H * W * img + F * H * W, F * K * P * (S * tap + 1))  # the gather bound: no reuse at all
         # until distinct_tap_bytes() has counted the pair's distinct tap locations the upper bound stands in
@@ -195,10 +195,7 @@ class RenderedPairBatch:
                 capi.check(L.mbavo_synthesize_blur(base.data_ptr(), H, W, float(D), capi.dp(intr), 4, t0w, dtk, capi.dp(ktw),
                                                    capi.dp(kRw), n_world, float(t), float(e), ns, dst.data_ptr(), None),
                            "mbavo_synthesize_blur")
-            if int(grad_fp16) == 3:  # the packed words in 8 x 4-pixel tiles (one 128-byte line each)
-                grad = torch.zeros(int(L.mbavo_tiled_keyframe_words(H, W)), dtype=torch.int32, device=device)
-                capi.check(L.mbavo_pack_keyframe_u8_tiled(ref.data_ptr(), H, W, grad.data_ptr(), None), "mbavo_pack_keyframe_u8_tiled")
-            elif int(grad_fp16) == 2:  # packed keyframe: intensity + both differences in one word per pixel
+            if int(grad_fp16) == 2:  # packed keyframe: intensity + both differences in one word per pixel
                 grad = torch.empty(H * W, dtype=torch.int32, device=device)
                 capi.check(L.mbavo_pack_keyframe_u8(ref.data_ptr(), H, W, grad.data_ptr(), None), "mbavo_pack_keyframe_u8")
             elif grad_fp16:  # IEEE half pairs (lossless for central differences of an 8-bit image)
@@ -273,7 +270,7 @@ class RenderedPairBatch:
         H, W, S = self.H, self.W, self.S
         fx, fy, cx, cy = [float(v) for v in self.intr]
         pat = synth.PATTERN8.reshape(-1, 2).astype(np.int64)
-        per_px = {0: (1, 8), 1: (1, 4), 2: (0, 4), 3: (0, 4)}  # keyframe bytes per distinct pixel: (u8 image, gradient / packed image)
+        per_px = {0: (1, 8), 1: (1, 4), 2: (0, 4)}  # keyframe bytes per distinct pixel: (u8 image, gradient / packed image)
         for b in (range(self.B) if pairs is None else pairs):
             h = self._host[b]
             if h is None:
@@ -320,11 +317,7 @@ class RenderedPairBatch:
             ref_ids = np.unique(np.concatenate(ids)) if ids else np.zeros(0, np.int64)
             fmt = self.probs[b].fmt
             b_img, b_grad = per_px[fmt]
-            if fmt == 3:  # a line is an 8 x 4-pixel tile
-                tiles = np.unique((ref_ids // W // 4) * ((W + 7) // 8) + (ref_ids % W) // 8)
-                lines = len(np.unique(cur_ids // 128)) + len(tiles)
-            else:
-                lines = len(np.unique(cur_ids // 128)) + (len(np.unique(ref_ids // 128)) if b_img else 0) + len(np.unique(ref_ids * b_grad // 128))
+            lines = len(np.unique(cur_ids // 128)) + (len(np.unique(ref_ids // 128)) if b_img else 0) + len(np.unique(ref_ids * b_grad // 128))
             self.probs[b].distinct = (int(len(ref_ids)), int(len(cur_ids)), int(lines))
             self.probs[b].image_bytes = int(len(ref_ids) * (b_img + b_grad) + len(cur_ids))
         return self
@@ -375,11 +368,7 @@ class DeviceWorkload:
         self.array = (capi.Problem * B)()
         for b, p in enumerate(probs):
             ref = up(p.ref)
-            if int(p.grad_fp16) == 3:
-                if not hasattr(p, "_packed_tiled"):
-                    p._packed_tiled = synth.pack_keyframe_tiled(p.ref)
-                grad = up(p._packed_tiled)
-            elif int(p.grad_fp16) == 2:
+            if int(p.grad_fp16) == 2:
                 grad = up(synth.pack_keyframe(p.ref))
             elif p.grad_fp16:
                 if not hasattr(p, "_grad_half"):

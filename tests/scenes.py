@@ -90,9 +90,7 @@ class DeviceScene:
         self.ref = t(sc.ref)
         # packed: the keyframe as one word per pixel (mbavo_problem.grad_fp16 = 2) instead of the float gradient image
         self.packed = packed
-        # (packed = 3: the same words in 8 x 4-pixel tiles, mbavo_problem.grad_fp16 = 3)
-        self.grad = t(synth.pack_keyframe_tiled(sc.ref).view(np.int32)) if packed == 3 else \
-            (t(synth.pack_keyframe(sc.ref).view(np.int32)) if packed else t(sc.grad))
+        self.grad = t(synth.pack_keyframe(sc.ref).view(np.int32)) if packed else t(sc.grad)
         self.cur = [t(c) for c in sc.cur]
         self.cur_ptrs = torch.tensor([c.data_ptr() for c in self.cur], dtype=torch.int64, device=dev)
         if vec2d:  # Core::Vector2d array: {int nDim; pad; double x; double y} = 3 doubles
@@ -138,7 +136,7 @@ class DeviceScene:
         p.d_knots_R = self.knots_R.data_ptr()
         p.h_start_idx = self.start_idx.ctypes.data_as(C.POINTER(C.c_int))
         p.huber_a = sc.huber
-        p.grad_fp16 = 3 if self.packed == 3 else (2 if self.packed else 0)
+        p.grad_fp16 = 2 if self.packed else 0
         return p
 
 

@@ -213,10 +213,3 @@ def test_packed_keyframe_holds_image_and_gradients_exactly(orc):
         a = a + wts[:, j] * (np.float32(0.5) * k4[:, j])
         b = b + wts[:, j] * k4[:, j]
     assert np.array_equal(a, np.float32(0.5) * b)
-    # the tiled form (grad_fp16 = 3): the same words at (y / 4) * 32 * ceil(W / 8) + (x / 8) * 32 + (y % 4) * 8 + x % 8, zero padding
-    t = synth.pack_keyframe_tiled(img)
-    H, W = img.shape
-    assert t.size == synth.tiled_keyframe_words(H, W) == ((H + 3) // 4) * ((W + 7) // 8) * 32
-    for (y, x) in ((0, 0), (3, 7), (4, 8), (36, 52), (17, 23), (35, 47)):
-        assert t[(y // 4) * 32 * ((W + 7) // 8) + (x // 8) * 32 + (y % 4) * 8 + x % 8] == w[y, x]
-    assert np.sort(t[t != 0]).tolist() == np.sort(w[w != 0].ravel()).tolist()

@@ -87,9 +87,6 @@ def bench_line(M, ctx, dev, B=64, iterations=10, host_pairs=8):
     # the same pairs with packed keyframes (mbavo_problem.grad_fp16 = 2: one word per pixel, identical tap values)
     packed = workloads.RenderedPairBatch(ctx, B, S=8, k=4, device=dev, seed=1, grad_fp16=2)
     out["device_svd_packed_keyframes"] = device_lm(M, ctx, packed, 0, iterations)
-    del packed
-    tiled = workloads.RenderedPairBatch(ctx, B, S=8, k=4, device=dev, seed=1, grad_fp16=3)  # the same words in 8 x 4-pixel tiles
-    out["device_svd_tiled_keyframes"] = device_lm(M, ctx, tiled, 0, iterations)
     return out
 
 

@@ -10,7 +10,7 @@ for B in 64 512; do
   python - <<P
 import json
 d=json.loads(open("gpurun_out/${TAG}_lm_batch$B.jsonl").read().strip().splitlines()[-1])
-for k in ("device_svd","device_ldlt","device_svd_packed_keyframes","device_svd_tiled_keyframes"):
+for k in ("device_svd","device_ldlt","device_svd_packed_keyframes"):
     v=d[k]; print("B=$B %-28s %7.2f us/round  total %.4f ms  rounds %d  acc %d rej %d  cost %.12g"%(k,v["us_per_round"],v["ms_total"],v["rounds"],v["accepted"],v["rejected"],v["final_cost_sum"]))
 P
 done
