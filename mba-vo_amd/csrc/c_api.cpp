@@ -11,8 +11,10 @@
 #include "vo_frontend.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 using namespace SLAM;
@@ -20,6 +22,11 @@ using namespace SLAM;
 struct mbavo_ctx
 {
     mbavo::Engine *engine;
+    // mbavo_lm_batch on big batches: a second engine on a stream of its own (created at first use), so that two halves of the
+    // batch run as independent chains the GPU interleaves
+    std::vector<mbavo::Engine *> extra_engines;
+    std::vector<hipStream_t> extra_streams;
+    hipEvent_t fork = nullptr;
 };
 struct mbavo_vo
 {
@@ -72,6 +79,9 @@ extern "C"
     {
         if (!ctx) return MBAVO_E_ARG;
         delete ctx->engine;
+        for (mbavo::Engine *e : ctx->extra_engines) delete e;
+        for (hipStream_t s : ctx->extra_streams) (void)hipStreamDestroy(s);
+        if (ctx->fork) (void)hipEventDestroy(ctx->fork);
         delete ctx;
         return 0;
     }
@@ -246,7 +256,49 @@ extern "C"
                        mbavo_lm_batch_result *results, mbavo_trace_rec *trace, int trace_cap)
     {
         if (!ctx || !probs || !o || trace_cap < 0) return MBAVO_E_ARG;
-        return mbavo::lm_batch(*ctx->engine, B, probs, *o, results, trace, trace_cap);
+        // Big batches as TWO independent groups (round 4): the pairs share nothing, so the halves run
+        // the whole loop side by side -- the second on its own engine, stream and host thread -- and the GPU fills one group's
+        // solve / decide launches (one latency-bound workgroup per problem, ~35 us of a 512-pair slot) and the ramps and tails of
+        // its passes with the other group's kernels.  Measured (rendered 640x480 pairs, us per LM round, one / two / four groups):
+        // 512 pairs 159-163 / 144-145 / 145-149 (packed keyframes 143 / 132 / 132-136), 256 pairs 109 / 115, 128 pairs 86 / 102,
+        // 64 pairs 74 / 96 -- below ~400 problems a group's passes no longer fill the machine and every phase is latency-bound
+        // either way, so smaller batches stay one group.  Two groups of a 512-pair batch keep the single group's tiling (one
+        // tile per pair): identical records.  MBAVO_LM_GROUPS=n overrides (1 .. 8).
+        const char *ge = getenv("MBAVO_LM_GROUPS");
+        int groups = ge && *ge ? atoi(ge) : (B >= 384 ? 2 : 1);
+        if (groups > 8) groups = 8;
+        if (groups > B) groups = B;
+        if (groups < 2) return mbavo::lm_batch(*ctx->engine, B, probs, *o, results, trace, trace_cap);
+        const int dev = ctx->engine->device();
+        if (hipSetDevice(dev) != hipSuccess) return MBAVO_E_NODEVICE;
+        if (!ctx->fork && hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming) != hipSuccess) return MBAVO_E_NODEVICE;
+        while ((int)ctx->extra_engines.size() < groups - 1)
+        {
+            hipStream_t s = nullptr;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return MBAVO_E_NODEVICE;
+            ctx->extra_streams.push_back(s);
+            ctx->extra_engines.push_back(new mbavo::Engine(dev));
+            ctx->extra_engines.back()->set_stream(s);
+        }
+        // whatever the caller enqueued on the context's stream (knot resets, uploads) comes before the other groups' work too
+        if (hipEventRecord(ctx->fork, ctx->engine->stream()) != hipSuccess) return MBAVO_E_NODEVICE;
+        std::vector<int> rcs(groups, 0);
+        std::vector<std::thread> workers;
+        auto first_of = [&](int g) { return (int)((long long)B * g / groups); }; // contiguous, near-equal shares
+        for (int g = 1; g < groups; ++g)
+        {
+            if (hipStreamWaitEvent(ctx->extra_streams[g - 1], ctx->fork, 0) != hipSuccess) { rcs[g] = MBAVO_E_NODEVICE; continue; }
+            workers.emplace_back([&, g]() {
+                const int b0 = first_of(g), n = first_of(g + 1) - b0;
+                rcs[g] = mbavo::lm_batch(*ctx->extra_engines[g - 1], n, probs + b0, *o, results ? results + b0 : nullptr,
+                                         trace ? trace + (size_t)b0 * trace_cap : nullptr, trace_cap);
+            });
+        }
+        rcs[0] = mbavo::lm_batch(*ctx->engine, first_of(1), probs, *o, results, trace, trace_cap);
+        for (std::thread &t : workers) t.join(); // (every call returns synchronised with its stream)
+        for (int g = 0; g < groups; ++g)
+            if (rcs[g] != 0) return rcs[g];
+        return 0;
     }
 
     // ---- trackFrame front end

@@ -64,13 +64,20 @@ namespace mbavo
     // Ticket and done count are ONE 64-bit word (num_done[6..7]; low half: workgroups that have passed, over all launches of the
     // call; high half: problems done), bumped by one atomic -- the workgroup whose ticket completes (slot + 1) B sees every other
     // workgroup's contribution in the value the atomic returns: no fence, no second counter read.
-    __device__ __forceinline__ void slot_publish(int *num_done, unsigned long long *host_word, int slot, int B, bool done_now)
+    // (round 4) The completing workgroup also leaves the engine's range-status counter in pinned memory (host_word[4], as an int)
+    // before the word: with every problem's final state stored to pinned memory by the workgroup that ended it (k_lm_solve), a
+    // finished call needs no copy back and no blocking stream synchronisation (~20 us of a 64-pair call).
+    __device__ __forceinline__ void slot_publish(int *num_done, unsigned long long *host_word, int slot, int B, bool done_now,
+                                                 const int *status_src = nullptr)
     {
         if (!host_word) return;
         unsigned long long *ticket = reinterpret_cast<unsigned long long *>(num_done + 6);
         const unsigned long long old = atomicAdd(ticket, 1ull + (done_now ? 1ull << 32 : 0ull));
         if ((unsigned)(old & 0xffffffffull) + 1u != (unsigned)(slot + 1) * (unsigned)B) return;
         const unsigned nd = (unsigned)(old >> 32) + (done_now ? 1u : 0u);
+        if (status_src != nullptr)
+            __hip_atomic_store(reinterpret_cast<int *>(host_word + 4), __hip_atomic_load(status_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(host_word, ((unsigned long long)(slot + 1) << 32) | nd, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // The same for the decide launch of a slot, with the LOOK-AHEAD count (round 4): how many problems the NEXT solve launch will
@@ -104,7 +111,7 @@ namespace mbavo
                                                     double *__restrict__ cur_t, double *__restrict__ cur_R,
                                                     int *__restrict__ active, mbavo_trace_rec *__restrict__ trace,
                                                     int *__restrict__ num_done, unsigned long long *host_word, int slot, int B,
-                                                    PoseEntry<KD> *pose_table, int *pose_status)
+                                                    PoseEntry<KD> *pose_table, int *pose_status, LmState *h_final)
     {
         constexpr int M6 = 6 * KD, ND = M6 + 1, E = ND * (ND + 1) / 2;
         extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -114,7 +121,7 @@ namespace mbavo
         LmState s = states[b]; // (slot 0: the initial state, uploaded by the host with the head of the arena)
         if (s.done)
         {
-            if (tid == 0) slot_publish(num_done, host_word, slot, B, false);
+            if (tid == 0) slot_publish(num_done, host_word, slot, B, false, pose_status);
             return;
         }
         if (slot == 0)
@@ -234,8 +241,13 @@ namespace mbavo
             {
                 active[b] = 0;
                 states[b] = s;
+                if (h_final != nullptr)
+                { // the final state straight into pinned host memory, on its way before this workgroup counts as passed
+                    h_final[b] = s;
+                    __threadfence_system();
+                }
                 atomicAdd(num_done, 1); // (what the stream-drain scheme and the final check read)
-                slot_publish(num_done, host_word, slot, B, true);
+                slot_publish(num_done, host_word, slot, B, true, pose_status);
             }
             // leave the accepted point in the caller's knot buffers
             double *Wt = const_cast<double *>(d.knots_t), *WR = const_cast<double *>(d.knots_R);
@@ -336,7 +348,7 @@ namespace mbavo
             lm_rejected(s);
             trace_push(s, tr, o.trace_cap, tid, 0, 3, 0.0, s.model, 0.0);
             ++s.n_invalid;
-            if (tid == 0) { active[b] = 0; states[b] = s; slot_publish(num_done, host_word, slot, B, false); }
+            if (tid == 0) { active[b] = 0; states[b] = s; slot_publish(num_done, host_word, slot, B, false, pose_status); }
             return;
         }
         // computeCandidatePointAndEvaluateCost (:833-883): candidate = current (+) step, into the evaluated buffers
@@ -350,7 +362,7 @@ namespace mbavo
             WR[4 * i] = q.x; WR[4 * i + 1] = q.y; WR[4 * i + 2] = q.z; WR[4 * i + 3] = q.w;
             LR[4 * i] = q.x; LR[4 * i + 1] = q.y; LR[4 * i + 2] = q.z; LR[4 * i + 3] = q.w;
         }
-        if (tid == 0) { active[b] = 1; states[b] = s; slot_publish(num_done, host_word, slot, B, false); }
+        if (tid == 0) { active[b] = 1; states[b] = s; slot_publish(num_done, host_word, slot, B, false, pose_status); }
         // The blur samples' pose entries of the candidate, WITH the knot Jacobians (round 4): the cost-only pass and -- if the
         // step is accepted -- the H/g pass of this slot evaluate at exactly these knots, so the entries are computed ONCE here,
         // by the workgroup that has the knots in its LDS, instead of by a pose launch / a pose prologue in each of the two passes
@@ -648,7 +660,8 @@ namespace mbavo
             {
                 const double ts0 = stamps ? now_us() : 0.0;
 #define LM_SOLVE_ARGS(KD) descs, states, o, fs, d_start, Hst, gst, ct, cR, act, d_trace, num_done, d_word, slot, B, \
-                          (PoseEntry<KD> *)(ext_poses ? eng.device_pose_table() : nullptr), eng.device_status()
+                          (PoseEntry<KD> *)(ext_poses ? eng.device_pose_table() : nullptr), eng.device_status(), \
+                          (LmState *)(sync_every <= 0 && !trace ? h_states : nullptr)
                 if (k == 4 && eig)
                     hipLaunchKernelGGL((k_lm_solve<4, kEigT>), dim3(B), dim3(kEigT), lds, st, LM_SOLVE_ARGS(4));
                 else if (k == 4)
@@ -719,10 +732,23 @@ namespace mbavo
             }
             stamp(4);
             LM_HIP(hipGetLastError());
-            LM_HIP(hipMemcpyAsync(const_cast<LmState *>(h_states), states, sizeof(LmState) * B, hipMemcpyDeviceToHost, st)); // pinned: no staging
-            if (trace) LM_HIP(hipMemcpyAsync(trace, d_trace, sizeof(mbavo_trace_rec) * (size_t)B * trace_cap, hipMemcpyDeviceToHost, st));
-            if ((rc = eng.fetch_status_enqueue(h_status)) != 0) goto done; // (no blocking copy of its own after the drain: ~10 us)
-            LM_HIP(hipStreamSynchronize(st));
+            if (sync_every <= 0 && !trace && h_done >= B)
+            { // every problem's final state and the status counter are in pinned memory already (k_lm_solve, slot_publish); what is
+              // still in flight is the tail of the last solve launch: poll the stream instead of a blocking wait (~20 us to wake up)
+                const auto t_q = std::chrono::steady_clock::now();
+                hipError_t q;
+                while ((q = hipStreamQuery(st)) == hipErrorNotReady)
+                    if (std::chrono::steady_clock::now() - t_q > std::chrono::seconds(10)) break;
+                if (q != hipSuccess) LM_HIP(hipStreamSynchronize(st));
+                *h_status = *reinterpret_cast<volatile int *>(const_cast<unsigned long long *>(h_word) + 4);
+            }
+            else
+            {
+                LM_HIP(hipMemcpyAsync(const_cast<LmState *>(h_states), states, sizeof(LmState) * B, hipMemcpyDeviceToHost, st)); // pinned: no staging
+                if (trace) LM_HIP(hipMemcpyAsync(trace, d_trace, sizeof(mbavo_trace_rec) * (size_t)B * trace_cap, hipMemcpyDeviceToHost, st));
+                if ((rc = eng.fetch_status_enqueue(h_status)) != 0) goto done; // (no blocking copy of its own after the drain: ~10 us)
+                LM_HIP(hipStreamSynchronize(st));
+            }
             stamp(5);
             if (stamps)
             {
