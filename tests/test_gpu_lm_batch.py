@@ -372,3 +372,71 @@ def test_lm_batch_rendered_pairs_against_oracle(orc, mbavo, gpu_ctx, monkeypatch
     assert accepted >= B  # the loops really moved the knots
     ate_g, ate_o = float(np.sqrt(np.mean(e_gpu))), float(np.sqrt(np.mean(e_orc)))
     assert abs(ate_g - ate_o) <= 1e-5, (ate_g, ate_o)
+
+
+def test_lm_batch_groups_same_records(mbavo, gpu_ctx, monkeypatch):
+    """mbavo_lm_batch on big batches runs as independent GROUPS (round 4: the second on its own engine, stream and host thread;
+    default from 384 problems).  Forced here on 11 pairs (MBAVO_LM_GROUPS = 2 and 3, uneven shares) against one group: the same
+    trace records per pair (kinds, iterations, outlier counts), costs 1e-9 relative (a group's list may be tiled differently),
+    knots 1e-9; traces land at the pair's own rows."""
+    import torch
+    capi = mbavo.capi
+    B, k, N, F = 11, 4, 4, 1
+    out = {}
+    for groups in ("1", "2", "3"):
+        monkeypatch.setenv("MBAVO_LM_GROUPS", groups)
+        probs = _scene(B, k, N, F, seed=53)
+        dw = workloads.DeviceWorkload(probs)
+        o = capi.LmBatchOpts()
+        o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, OPTS["max_it"], OPTS["max_nonmono"]
+        o.solver_type, o.sync_every = 0, 0
+        o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
+        cap = 48
+        res = (capi.LmBatchResult * B)()
+        trace = (capi.TraceRec * (B * cap))()
+        assert gpu_ctx.lib.mbavo_lm_batch(gpu_ctx.handle, B, dw.array, C.byref(o), res, trace, cap) == 0
+        torch.cuda.synchronize()
+        recs = [[(t.iter, t.kind, t.num_outliers, t.eval_cost, t.candidate_cost) for t in trace[b * cap:b * cap + res[b].num_trace]] for b in range(B)]
+        knots = [np.concatenate([x.cpu().numpy().ravel() for x in dw.keep_knots(b)]) for b in range(B)]
+        out[groups] = (recs, knots, [(r.iterations, r.accepted, r.rejected, r.invalid, r.num_outliers) for r in res], [r.final_cost for r in res])
+        # without a trace buffer the results come back through pinned memory (no copy, no blocking synchronisation): the same numbers
+        for kt, kR in [dw.keep_knots(b) for b in range(B)]:
+            pass
+    ref = out["1"]
+    assert sum(r[1] for r in ref[2]) >= B // 2
+    for g in ("2", "3"):
+        recs, knots, counts, costs = out[g]
+        assert counts == ref[2]
+        for a, b in zip(recs, ref[0]):
+            assert [t[:3] for t in a] == [t[:3] for t in b]
+            for ta, tb in zip(a, b):
+                assert abs(ta[3] - tb[3]) <= 1e-9 * max(1.0, abs(tb[3])) and abs(ta[4] - tb[4]) <= 1e-9 * max(1.0, abs(tb[4]))
+        for a, b in zip(knots, ref[1]):
+            assert np.abs(a - b).max() < 1e-9
+        assert np.allclose(costs, ref[3], rtol=1e-9, atol=0)
+
+
+def test_lm_batch_results_without_trace_come_from_pinned_memory(mbavo, gpu_ctx):
+    """trace == NULL and sync_every <= 0: every problem's final state is stored to pinned host memory by the workgroup that ends it and
+    the call polls the stream instead of copying back -- the results must equal those of the call WITH a trace buffer (which takes
+    the copy path)."""
+    import torch
+    capi = mbavo.capi
+    B, k, N, F = 9, 4, 4, 1
+    got = []
+    for with_trace in (True, False):
+        probs = _scene(B, k, N, F, seed=61)
+        dw = workloads.DeviceWorkload(probs)
+        o = capi.LmBatchOpts()
+        o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, OPTS["max_it"], OPTS["max_nonmono"]
+        o.solver_type, o.sync_every = 0, 0
+        o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
+        res = (capi.LmBatchResult * B)()
+        trace = (capi.TraceRec * (B * 32))() if with_trace else None
+        for rep in range(2):  # (a second call re-arms the pinned words)
+            for b, p in enumerate(probs):
+                dw.keep_knots(b)[0].copy_(torch.from_numpy(p.knots_t))
+                dw.keep_knots(b)[1].copy_(torch.from_numpy(p.knots_R))
+            assert gpu_ctx.lib.mbavo_lm_batch(gpu_ctx.handle, B, dw.array, C.byref(o), res, trace, 32 if with_trace else 0) == 0
+        got.append([(r.iterations, r.accepted, r.rejected, r.invalid, r.num_outliers, r.initial_cost, r.final_cost, r.radius) for r in res])
+    assert got[0] == got[1] and sum(r[1] for r in got[0]) > 0
