@@ -76,8 +76,9 @@ def bench_line(M, ctx, dev, B=64, iterations=10, host_pairs=8):
     from mba_vo_amd import workloads
     batch = workloads.RenderedPairBatch(ctx, B, S=8, k=4, device=dev, seed=1)
     out = {"workload": "%d pairs of the rendered blurred sequence (configs[2] data), device-side LM (mbavo_lm_batch), "
-                       "%d iterations per pair, no early exit; us_per_round = whole batch, one LM iteration slot "
-                       "(solve + cost-only pass + decide + H/g pass)" % (B, iterations),
+                       "%d iterations per pair, no early exit; us_per_round = wall time of a whole call / the largest iteration count, i.e. one "
+                       "LM iteration slot of the whole batch (solve + pose entries, cost-only pass, decide, H/g pass); batches of 384+ pairs "
+                       "run as two independent groups on their own streams" % (B, iterations),
            "B": B, "max_iterations": iterations, "K_mean": float(np.mean([p.K for p in batch.probs])), "P": 8, "S": 8}
     for solver, name in ((0, "svd"), (1, "ldlt")):
         out["device_" + name] = device_lm(M, ctx, batch, solver, iterations)
