@@ -13,11 +13,77 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <thread>
 #include <vector>
 
 using namespace SLAM;
+
+// One helper thread per extra group of mbavo_lm_batch, kept between calls: a job is handed over through a flag the helper
+// spins on for a short while after its last job (back-to-back calls: no wake-up latency) before it blocks on a condition variable
+// (creating a thread per call cost ~60 us of a 1.2 ms call).
+struct GroupWorker
+{
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    std::atomic<int> state{0}; // 0 idle, 1 job posted, 2 job done, 3 exit
+    GroupWorker()
+    {
+        th = std::thread([this]() {
+            for (;;)
+            {
+                int s = state.load(std::memory_order_acquire);
+                if (s != 1 && s != 3)
+                { // spin ~200 us, then sleep
+                    const auto t0 = std::chrono::steady_clock::now();
+                    while ((s = state.load(std::memory_order_acquire)) != 1 && s != 3)
+                    {
+                        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(200))
+                        {
+                            std::unique_lock<std::mutex> lk(m);
+                            cv.wait(lk, [&]() { const int v = state.load(std::memory_order_acquire); return v == 1 || v == 3; });
+                            s = state.load(std::memory_order_acquire);
+                            break;
+                        }
+                    }
+                }
+                if (s == 3) return;
+                job();
+                state.store(2, std::memory_order_release);
+            }
+        });
+    }
+    void post(std::function<void()> f)
+    {
+        job = std::move(f);
+        {
+            std::lock_guard<std::mutex> lk(m);
+            state.store(1, std::memory_order_release);
+        }
+        cv.notify_one();
+    }
+    void wait()
+    {
+        while (state.load(std::memory_order_acquire) != 2) std::this_thread::yield();
+        state.store(0, std::memory_order_release);
+    }
+    ~GroupWorker()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            state.store(3, std::memory_order_release);
+        }
+        cv.notify_one();
+        if (th.joinable()) th.join();
+    }
+};
 
 struct mbavo_ctx
 {
@@ -26,6 +92,7 @@ struct mbavo_ctx
     // batch run as independent chains the GPU interleaves
     std::vector<mbavo::Engine *> extra_engines;
     std::vector<hipStream_t> extra_streams;
+    std::vector<GroupWorker *> workers;
     hipEvent_t fork = nullptr;
 };
 struct mbavo_vo
@@ -79,6 +146,7 @@ extern "C"
     {
         if (!ctx) return MBAVO_E_ARG;
         delete ctx->engine;
+        for (GroupWorker *w : ctx->workers) delete w;
         for (mbavo::Engine *e : ctx->extra_engines) delete e;
         for (hipStream_t s : ctx->extra_streams) (void)hipStreamDestroy(s);
         if (ctx->fork) (void)hipEventDestroy(ctx->fork);
@@ -279,23 +347,25 @@ extern "C"
             ctx->extra_streams.push_back(s);
             ctx->extra_engines.push_back(new mbavo::Engine(dev));
             ctx->extra_engines.back()->set_stream(s);
+            ctx->workers.push_back(new GroupWorker());
         }
         // whatever the caller enqueued on the context's stream (knot resets, uploads) comes before the other groups' work too
         if (hipEventRecord(ctx->fork, ctx->engine->stream()) != hipSuccess) return MBAVO_E_NODEVICE;
         std::vector<int> rcs(groups, 0);
-        std::vector<std::thread> workers;
+        std::vector<int> posted;
         auto first_of = [&](int g) { return (int)((long long)B * g / groups); }; // contiguous, near-equal shares
         for (int g = 1; g < groups; ++g)
         {
             if (hipStreamWaitEvent(ctx->extra_streams[g - 1], ctx->fork, 0) != hipSuccess) { rcs[g] = MBAVO_E_NODEVICE; continue; }
-            workers.emplace_back([&, g]() {
+            ctx->workers[g - 1]->post([&, g]() {
                 const int b0 = first_of(g), n = first_of(g + 1) - b0;
                 rcs[g] = mbavo::lm_batch(*ctx->extra_engines[g - 1], n, probs + b0, *o, results ? results + b0 : nullptr,
                                          trace ? trace + (size_t)b0 * trace_cap : nullptr, trace_cap);
             });
+            posted.push_back(g - 1);
         }
         rcs[0] = mbavo::lm_batch(*ctx->engine, first_of(1), probs, *o, results, trace, trace_cap);
-        for (std::thread &t : workers) t.join(); // (every call returns synchronised with its stream)
+        for (int w : posted) ctx->workers[w]->wait(); // (every call returns synchronised with its stream)
         for (int g = 0; g < groups; ++g)
             if (rcs[g] != 0) return rcs[g];
         return 0;

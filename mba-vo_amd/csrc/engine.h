@@ -121,8 +121,16 @@ namespace mbavo
         // (entry of (problem, frame f, sample s) at pose_base + f S + s, the k_pose_table layout): with set_external_poses(true)
         // an evaluate() launches neither k_pose_table nor the fused kernel's pose prologue (the single-launch sample-parallel
         // kernels keep computing their own in LDS).
-        void set_external_poses(bool on) { external_poses_ = on; }
+        void set_external_poses(bool on, void *table = nullptr) { external_poses_ = on; external_table_ = on ? table : nullptr; }
         void *device_pose_table() const { return d_poses_; }
+        // A second tiling of the same problem list (batched LM, round 4): `tiles` > 0 makes the layout aim at that many tiles instead
+        // of one per CU (e.g. 4 per pair: a pass over a FEW active pairs then takes one round instead of a pair's three); prepare()
+        // builds and uploads the layout of a list without launching anything (so that the first pass through it finds it ready).
+        void set_tile_target(long long tiles) { tile_target_ = tiles; }
+        int prepare(int B, const mbavo_problem *probs, int kdeg, const int *d_active_mask, const double *d_inv);
+        // the engine's companion for that second tiling (created at first use on the same device and stream, owned by this engine)
+        Engine *companion();
+        Engine *companion_if_any() const { return companion_; }
         int *device_status() const { return (int *)d_status_; }
         void set_defer_finalize(bool on) { defer_finalize_ = on; }
         bool finalize_deferred() const { return deferred_last_; }
@@ -140,6 +148,9 @@ namespace mbavo
         int fetch_status_take(const int *h_pinned);
 
         int total_bf() const { return total_bf_; }
+        int num_tiles() const { return (int)h_tiles_.size(); }
+        int num_cus() const { return num_cus_; }
+        bool layout_flat() const { return flat_finalize_; } // the cached layout takes the one-block-per-slot finalize (deferrable)
         // name of the dominant kernel the last evaluate() dispatched, e.g. "k_fused<4,true,false>" (bench labels)
         const char *last_kernel();
 
@@ -190,6 +201,9 @@ namespace mbavo
         bool flat_finalize_ = false; // many (problem, frame) slots of <= 4 tiles each: k_finalize_flat
         bool defer_finalize_ = false, deferred_last_ = false; // set_defer_finalize / what the last evaluate() did
         bool external_poses_ = false;                          // set_external_poses
+        void *external_table_ = nullptr;                       // ... reading another engine's table
+        long long tile_target_ = 0;                            // set_tile_target
+        Engine *companion_ = nullptr;
         bool empty_slots_ = false;   // some (problem, frame) slot has no tile (K == 0): no workgroup would finalize it in the single-launch form
 
         void *d_layout_ = nullptr; size_t cap_layout_ = 0; // one arena: descs | tiles | bf_tile_begin | bf_prob | entry_prob

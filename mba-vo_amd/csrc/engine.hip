@@ -1439,8 +1439,24 @@ namespace mbavo
             num_cus_ = prop.multiProcessorCount;
     }
 
+    Engine *Engine::companion()
+    {
+        if (!companion_) companion_ = new Engine(device_);
+        companion_->set_stream(stream_);
+        return companion_;
+    }
+
+    int Engine::prepare(int B, const mbavo_problem *probs, int kdeg, const int *d_active, const double *d_inv)
+    {
+        if (B < 1 || !probs || (kdeg != 2 && kdeg != 4) || persist_mask_) return MBAVO_E_ARG;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != device_) HIP_TRY(hipSetDevice(device_));
+        return rebuild_layout(B, probs, kdeg, d_active, d_inv);
+    }
+
     Engine::~Engine()
     {
+        delete companion_;
         (void)persistent_end_all();
         (void)comm_destroy();
         void *bufs[] = {d_layout_, d_poses_, d_rho_, d_partials_,
@@ -1582,7 +1598,7 @@ namespace mbavo
         // the tile count must not exceed CUs x rounds or a nearly empty extra round doubles the time: take the
         // smallest tile size (in pixels) whose tile count fits, found by bisection.
         const int tiles_per_cu = env_int("MBAVO_TILES_PER_CU", 1);
-        const long long target_tiles = (long long)num_cus_ * (tiles_per_cu > 0 ? tiles_per_cu : 1);
+        const long long target_tiles = tile_target_ > 0 ? tile_target_ : (long long)num_cus_ * (tiles_per_cu > 0 ? tiles_per_cu : 1);
         auto count_tiles = [&](long long ppt) {
             long long n = 0;
             for (int b = 0; b < B; ++b)
@@ -1901,7 +1917,7 @@ namespace mbavo
                                    env_int("MBAVO_FUSED_POSE", 1) != 0;
 #define MBAVO_LAUNCH(KD, WJ)                                                                                      \
     launch_all<KD, WJ>(this, stream_, max_S, half_grad, sp_logs_, one, flat_finalize_, descs, (const int *)d_entry_prob_, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
-                       (const int *)d_bf_tile_begin_, total_bf_, d_poses_, (double *)d_rho_, d_patch_cost,        \
+                       (const int *)d_bf_tile_begin_, total_bf_, external_poses_ && external_table_ ? external_table_ : d_poses_, (double *)d_rho_, d_patch_cost,        \
                        d_patch_blocks_strided, (double *)d_partials_, (int *)d_status_, d_frame_blocks, d_valid, oa, fused_pose_ok, external_poses_)
         if (kdeg == 4) rc = with_hessian ? MBAVO_LAUNCH(4, true) : MBAVO_LAUNCH(4, false);
         else rc = with_hessian ? MBAVO_LAUNCH(2, true) : MBAVO_LAUNCH(2, false);

@@ -631,6 +631,31 @@ namespace mbavo
             fs.fb = fb; fs.partials = eng.device_partials(); fs.tile_begin = eng.device_bf_tile_begin();
             fs.stride = E + 2; // engine.hip: Pack<k>::PSTRIDE
             fs.deferred = eng.finalize_deferred() ? 1 : 0;
+            // RE-TILING for the late slots of a big batch (round 4).  A batch of more pairs than CUs is tiled one tile per pair -- three
+            // rounds of pixels per workgroup, the right grain while most pairs are active -- and a pass then lasts ~38 us as long as ONE
+            // pair is active.  A second layout of the same list with four tiles per pair lives in the engine's companion (built while
+            // the first evaluation runs); once few enough pairs are left that their fine tiles fit the CUs, both passes of a slot go
+            // through it: one round per workgroup.  The LM kernels are told per launch whose partials to sum (FinSrc).
+            // MBAVO_LM_RETILE=0: one layout.
+            Engine *fine = nullptr;
+            FinSrc fs_fine = fs;
+            if (sync_every <= 0 && fs.deferred && ext_poses && eng.num_tiles() < 4 * nbf && eng.num_tiles() * 2 >= eng.num_cus() &&
+                !(getenv("MBAVO_LM_RETILE") && getenv("MBAVO_LM_RETILE")[0] == '0'))
+            {
+                fine = eng.companion();
+                fine->set_tile_target(4ll * nbf);
+                if ((rc = fine->prepare(B, work.data(), k, act, inv)) != 0) goto done;
+                if (fine->layout_flat() && fine->num_tiles() > eng.num_tiles())
+                {
+                    fs_fine.partials = fine->device_partials();
+                    fs_fine.tile_begin = fine->device_bf_tile_begin();
+                    fs_fine.deferred = 1;
+                }
+                else
+                    fine = nullptr;
+            }
+            bool use_fine = false;         // the layout of the passes enqueued last
+            FinSrc fs_hg = fs, fs_cost = fs; // whose partials the next solve / decide launch sums
             stamp(3);
             if (lds > 48 * 1024)
             { // more than 8 control knots: the three n x n areas need the large-LDS attribute
@@ -638,7 +663,9 @@ namespace mbavo
                 else LM_HIP(hipFuncSetAttribute(eig ? (const void *)k_lm_solve<2, kEigT> : (const void *)k_lm_solve<2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             }
             unsigned long long *d_word = const_cast<unsigned long long *>(h_word); // pinned host memory is device-visible at its own address
-            unsigned long long *d_word2 = const_cast<unsigned long long *>(h_word2);
+            // (the look-ahead word is only read for batches of up to 128 problems, see below: bigger batches' decide launches skip
+            // their B atomics on one address)
+            unsigned long long *d_word2 = B <= 128 ? const_cast<unsigned long long *>(h_word2) : nullptr;
             // bounded spin on a pinned word until its slot number reaches `want`; the value, or 0 after a time-out
             auto spin_for = [&](volatile unsigned long long *word, unsigned long long want) -> unsigned long long {
                 unsigned long long w = *word;
@@ -653,13 +680,13 @@ namespace mbavo
                 }
                 return w;
             };
-#define LM_DECIDE_ARGS descs, states, o, fs, pc, inv, ct, cR, act, d_trace, num_done, d_word2, slot, B
+#define LM_DECIDE_ARGS descs, states, o, fs_cost, pc, inv, ct, cR, act, d_trace, num_done, d_word2, slot, B
             std::vector<double> slot_us; // MBAVO_LM_STAMPS=1: per slot [solve launch | look-ahead wait | passes enqueued | solve word wait]
             auto now_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp[0]).count(); };
             for (int slot = 0; slot <= o.max_it + 1; ++slot)
             {
                 const double ts0 = stamps ? now_us() : 0.0;
-#define LM_SOLVE_ARGS(KD) descs, states, o, fs, d_start, Hst, gst, ct, cR, act, d_trace, num_done, d_word, slot, B, \
+#define LM_SOLVE_ARGS(KD) descs, states, o, fs_hg, d_start, Hst, gst, ct, cR, act, d_trace, num_done, d_word, slot, B, \
                           (PoseEntry<KD> *)(ext_poses ? eng.device_pose_table() : nullptr), eng.device_status(), \
                           (LmState *)(sync_every <= 0 && !trace ? h_states : nullptr)
                 if (k == 4 && eig)
@@ -692,13 +719,24 @@ namespace mbavo
                         ending = (int)(unsigned)(w2 & 0xffffffffull) >= B;
                     }
                     auto enqueue_passes = [&]() -> int {
-                        int r = eng.evaluate(B, work.data(), k, false, fb, pc, nullptr, nullptr, act, inv, false, true);
+                        // (h_done: the count the previous slot's solve published)
+                        if (fine != nullptr && !use_fine && (long long)(B - h_done) * 4 <= eng.num_cus())
+                        {
+                            use_fine = true;
+                            fine->set_defer_finalize(true);
+                            fine->set_external_poses(true, eng.device_pose_table());
+                        }
+                        Engine &E = use_fine ? *fine : eng;
+                        fs_cost = use_fine ? fs_fine : fs;
+                        int r = E.evaluate(B, work.data(), k, false, fb, pc, nullptr, nullptr, act, inv, false, true);
                         if (r != 0) return r;
                         if (k == 4)
                             hipLaunchKernelGGL((k_lm_decide<4>), dim3(B), dim3(64), 0, st, LM_DECIDE_ARGS);
                         else
                             hipLaunchKernelGGL((k_lm_decide<2>), dim3(B), dim3(64), 0, st, LM_DECIDE_ARGS);
-                        return eng.evaluate(B, work.data(), k, true, fb, pc, nullptr, nullptr, act, inv, false, true);
+                        r = E.evaluate(B, work.data(), k, true, fb, pc, nullptr, nullptr, act, inv, false, true);
+                        fs_hg = fs_cost; // (the next solve launch sums this pass' partials)
+                        return r;
                     };
                     const double ts2 = stamps ? now_us() : 0.0;
                     if (!ending && (rc = enqueue_passes()) != 0) goto done;
@@ -788,6 +826,7 @@ namespace mbavo
         if (rc != 0) (void)hipStreamSynchronize(st);
         eng.set_external_poses(false);
         eng.set_defer_finalize(false);
+        if (Engine *c = eng.companion_if_any()) { c->set_external_poses(false); c->set_defer_finalize(false); }
         return rc > 0 ? -1000 - rc : rc;
     }
 } // namespace mbavo

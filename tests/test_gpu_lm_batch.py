@@ -145,11 +145,14 @@ def test_lm_batch_eigenvalue_jacobi_matches_one_wave_sweeps(mbavo, gpu_ctx, monk
 def test_lm_batch_deferred_finalize_same_bits(mbavo, gpu_ctx, monkeypatch, k, N, F, sync_every):
     """Lists of >= 64 (problem, frame) slots: the LM kernels sum the tile partials themselves (no finalize launch; engine.h:
     set_defer_finalize) in the finalize kernel's order -- every trace record and every final knot is bit-identical to the run with
-    the finalize kernels (MBAVO_LM_DEFER=0); the done word in pinned host memory (sync_every 0) against the stream-drain scheme."""
+    the finalize kernels (MBAVO_LM_DEFER=0); the done word in pinned host memory (sync_every 0) against the stream-drain scheme.
+    (MBAVO_LM_RETILE=0: the second, finer tiling of the late slots -- which only exists with deferred sums -- would change the grouping
+    of the sums; test_lm_batch_retiled_late_slots covers it.)"""
     import torch
     capi = mbavo.capi
     B = 70
     out = {}
+    monkeypatch.setenv("MBAVO_LM_RETILE", "0")
     for defer in ("1", "0"):
         monkeypatch.setenv("MBAVO_LM_DEFER", defer)
         probs = _scene(B, k, N, F, seed=31)
@@ -440,3 +443,48 @@ def test_lm_batch_results_without_trace_come_from_pinned_memory(mbavo, gpu_ctx):
             assert gpu_ctx.lib.mbavo_lm_batch(gpu_ctx.handle, B, dw.array, C.byref(o), res, trace, 32 if with_trace else 0) == 0
         got.append([(r.iterations, r.accepted, r.rejected, r.invalid, r.num_outliers, r.initial_cost, r.final_cost, r.radius) for r in res])
     assert got[0] == got[1] and sum(r[1] for r in got[0]) > 0
+
+
+def test_lm_batch_retiled_late_slots(orc, mbavo, gpu_ctx, monkeypatch):
+    """Round 4: a batch of more pairs than its coarse tiling has tiles per CU (one or two tiles per pair) switches both passes of a slot
+    to a second layout with four tiles per pair once few pairs are left (lm_batch.hip "RE-TILING"); the LM kernels are told per launch
+    whose partials to sum.  160 rendered 480x640 pairs (two coarse tiles per pair), early exit so that the pairs finish at different
+    slots: against MBAVO_LM_RETILE=0 the same iteration / accept / reject / invalid / outlier counts for every pair, final costs 1e-9,
+    knots 1e-9 (another grouping of the sums, rounding only); three pairs against the oracle's loop (pose at capture 1e-5)."""
+    import torch
+    import tracking
+    capi = mbavo.capi
+    B = 160
+    batch = workloads.RenderedPairBatch(gpu_ctx, B, H=480, W=640, S=8, k=4, seed=3)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MBAVO_LM_RETILE", mode)
+        batch.reset_knots()
+        o = capi.LmBatchOpts()
+        o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = 4, OPTS["max_it"], OPTS["max_nonmono"]
+        o.solver_type, o.sync_every = 0, 0
+        o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
+        res = (capi.LmBatchResult * B)()
+        assert gpu_ctx.lib.mbavo_lm_batch(gpu_ctx.handle, B, batch.array, C.byref(o), res, None, 0) == 0
+        torch.cuda.synchronize()
+        knots = [np.concatenate([h["dkt"].cpu().numpy(), h["dkR"].cpu().numpy()]) for h in batch._host]
+        out[mode] = ([(r.iterations, r.accepted, r.rejected, r.invalid, r.num_outliers) for r in res], [r.final_cost for r in res], knots)
+    its = [c[0] for c in out["1"][0]]
+    assert max(its) - min(its) >= 2 and sum(c[1] for c in out["1"][0]) >= B  # the pairs finish at different slots; steps were taken
+    assert out["1"][0] == out["0"][0]
+    assert np.allclose(out["1"][1], out["0"][1], rtol=1e-9, atol=0)
+    for a, b in zip(out["1"][2], out["0"][2]):
+        assert np.abs(a - b).max() < 1e-9
+    for b in (0, 77, 159):
+        p = batch.host_problem(b)
+        sc = dict(levels=[dict(H=p.H, W=p.W, ref=p.ref, grad=p.grad, cur=p.cur, kp_xy=p.kp_xy, kp_z=p.kp_z, pattern=p.pattern, S=p.S)],
+                  k=4, N=4, F=1, cap=p.cap, exp=p.exp, t0=p.t0, dt=p.dt, intr=p.intr,
+                  kt0=np.ascontiguousarray(batch._host[b]["kt"]), kR0=np.ascontiguousarray(batch._host[b]["kR"]))
+        want = tracking.run_oracle_tracker(orc, sc, dict(max_num_iterations=OPTS["max_it"], max_nonmono=OPTS["max_nonmono"], solver_type=0,
+                                                         huber_k=p.huber, min_step_quality=OPTS["min_q"], min_abs_cost_decrease=OPTS["min_dec"],
+                                                         max_chi_square_error=OPTS["chi"]))
+        kn = out["1"][2][b]
+        tc = float(sc["cap"][0])
+        pg, qg = tracking.pose_at(orc, 4, sc["t0"], sc["dt"], kn[:12].reshape(4, 3), kn[12:].reshape(4, 4), tc)
+        po, qo = tracking.pose_at(orc, 4, sc["t0"], sc["dt"], want["kt"], want["kR"], tc)
+        assert np.abs(pg - po).max() <= 1e-5 and np.abs(qg - qo).max() <= 1e-5
