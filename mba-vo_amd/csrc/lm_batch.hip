@@ -791,8 +791,8 @@ namespace mbavo
             if (stamps)
             {
                 auto us = [&](int a, int b) { return std::chrono::duration<double, std::micro>(tp[b] - tp[a]).count(); };
-                fprintf(stderr, "mbavo lm_batch: host set-up %.1f us | head upload call %.1f | first evaluation enqueued %.1f | LM slots %.1f | results + drain %.1f\n",
-                        us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5));
+                fprintf(stderr, "mbavo lm_batch: [stream %p, %d problems] host set-up %.1f us | head upload call %.1f | first evaluation enqueued %.1f | LM slots %.1f | results + drain %.1f\n",
+                        (void *)st, B, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5));
                 for (size_t i = 0; i + 3 < slot_us.size(); i += 4)
                     fprintf(stderr, "mbavo lm_batch:   slot %zu: solve launch %.1f us | look-ahead wait %.1f | passes enqueued %.1f | solve word wait %.1f\n", i / 4,
                             slot_us[i], slot_us[i + 1], slot_us[i + 2], slot_us[i + 3]);
