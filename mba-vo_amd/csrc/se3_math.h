@@ -683,9 +683,17 @@ namespace mbavo
         }
         else
         {
+#if defined(MBAVO_POSE_FASTMATH) // (device: the batched LM's candidate step sits on the chain of every iteration -- the runtime's sqrt, sin, cos and division are ~430 instructions of it)
+            double th, rth, hs, hc;
+            fastm::sqrt_rsqrt(th2, th, rth);
+            fastm::sincos(0.5 * th, hs, hc);
+            im = hs * rth;
+            re = hc;
+#else
             const double th = sqrt(th2);
             im = sin(0.5 * th) / th;
             re = cos(0.5 * th);
+#endif
         }
         return Quat{im * om[0], im * om[1], im * om[2], re};
     }
