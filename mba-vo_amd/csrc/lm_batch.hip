@@ -19,6 +19,16 @@
 #include "engine.h"
 #include "pixel_math.h"
 #include "se3_math.h"
+// The one-wave solvers of lm_solvers.h (one-sided Jacobi SVD, pivoted LDL^T) synchronise their steps with MBAVO_SOLVER_SYNC: a
+// wave-level fence here -- LDS executes a wave's operations in order, so that is all a wave working alone needs, in the one-wave
+// workgroups (k_lm_solve<KD, 64>) and as wave 0 of the wide ones (k_lm_solve<KD, kEigT> with solver type 1).
+#define MBAVO_SOLVER_SYNC()                                   \
+    do                                                        \
+    {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
 #include "lm_solvers.h"
 #include "lm_state.h"
 #include "host_math.h"
@@ -140,7 +150,7 @@ namespace mbavo
         // T = kEigT: the four n x eig_ld(n) areas of eig_solve first (16-byte aligned), then the vectors.
         // T = kEigT additionally keeps the system itself in LDS for the length of the kernel (merge, damping, model change:
         // ~25 dependent global round trips otherwise); global memory holds it between launches.
-        constexpr bool eig = T == kEigT; // the host launches this form only for solver 0 with every n <= kEigMaxN
+        constexpr bool eig = T == kEigT; // the host launches this form when every n <= kEigMaxN
         double *V = lds, *g = V + (eig ? eig_lds_doubles(n) : (size_t)n * (n + 1)), *x = g + n, *tmp = x + n;
         double *Hl = tmp + n;                                        // T = kEigT: n x n
         int *order = eig ? (int *)(Hl + n * n) : (int *)(tmp + n);   // T = kEigT: eig_solve's 4 + 2 n ints
@@ -304,6 +314,16 @@ namespace mbavo
         if (have) {}
         else if constexpr (T == kEigT)
         {
+          if (o.solver == 1)
+          { // the reference's LDLT option in the wide workgroup (round 4: so that its candidates get their pose entries here too):
+            // the pivoted LDL^T of lm_solvers.h by wave 0 on a copy, the other waves wait
+            for (int i = tid; i < n * n; i += T) V[i] = H[i];
+            __syncthreads();
+            if (tid < 64) ldlt_solve(V, g, x, tmp, order, n, lane);
+            __syncthreads();
+          }
+          else
+          {
             const int info = eig_solve(V, Hl, g, x, tmp, order, n, tid);
             if (tid == 0)
             { // solver statistics in the spare words behind num_done (MBAVO_LM_STATS=1 prints them)
@@ -312,6 +332,7 @@ namespace mbavo
                 atomicMax(num_done + 3, info & 255);
                 atomicAdd(num_done + 4, info >> 8);
             }
+          }
         }
         else if (o.solver == 1)
         {
@@ -535,10 +556,12 @@ namespace mbavo
             const double r = e && *e ? atof(e) : 1.0;
             o.refined_ratio = o.fast_ratio > 0.0 ? (r > 1.0 ? r : (r == 1.0 ? 1e13 : 0.0)) : 0.0;
         }
-        // solver 0 with every system within the workgroup-parallel eigenvalue Jacobi's reach (k_lm_solve<KD, kEigT>);
+        // every system within the wide workgroup's reach (k_lm_solve<KD, kEigT>: solver 0 falls back to the workgroup-parallel
+        // eigenvalue Jacobi there, solver 1 to the pivoted LDL^T on wave 0; both get their candidates' pose entries from it);
         // MBAVO_LM_EIG=0 keeps the one-wave one-sided sweeps
         const char *eig_env = getenv("MBAVO_LM_EIG");
-        const bool eig = opt.solver_type == 0 && max_n <= kEigMaxN && !(eig_env && eig_env[0] == '0');
+        // (solver type 1 takes the wide workgroup as well: its stand-in is the same, its fallback the pivoted LDL^T on wave 0)
+        const bool eig = max_n <= kEigMaxN && !(eig_env && eig_env[0] == '0');
         const size_t lds_solver = eig ? (eig_lds_doubles(max_n) + 3 * max_n + (size_t)max_n * max_n) * sizeof(double) + (size_t)(4 + 2 * max_n) * sizeof(int)
                                : ((size_t)2 * max_n * (max_n + 1) + 6 * max_n) * sizeof(double) + (size_t)max_n * sizeof(int);
         // the solve kernel's pose entries (eigenvalue-Jacobi form only: it has the KD waves): candidate knots + the segments of

@@ -323,7 +323,8 @@ def _oracle_alignment(orc, batch, b, k, N, solver):
     (4, 4, 0, {"MBAVO_FAST_SOLVE": "0"}),                              # workgroup-parallel eigenvalue Jacobi for every system
     (4, 4, 0, {"MBAVO_FAST_SOLVE": "0", "MBAVO_LM_EIG": "0"}),         # one-wave one-sided Jacobi SVD: solve_normal_equation.h case 0
     (4, 4, 1, {}),                                                     # solver type 1 through the refined stand-in
-    (4, 4, 1, {"MBAVO_FAST_SOLVE": "0"}),                              # pivoted LDL^T: solve_normal_equation.h case 1
+    (4, 4, 1, {"MBAVO_FAST_SOLVE": "0"}),                              # pivoted LDL^T: solve_normal_equation.h case 1 (wave 0 of the wide workgroup)
+    (4, 4, 1, {"MBAVO_FAST_SOLVE": "0", "MBAVO_LM_EIG": "0"}),         # the same in the one-wave workgroup
     (2, 2, 0, {}), (2, 2, 0, {"MBAVO_FAST_SOLVE": "0"}), (2, 2, 1, {}),  # the reference's default degree, both solver types
     (2, 4, 0, {}),                                                     # RANK-DEFICIENT: knots 2 and 3 have no data -> pseudo-inverse
     (2, 4, 0, {"MBAVO_LM_EIG": "0"}),
