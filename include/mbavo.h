@@ -273,6 +273,22 @@ int mbavo_vo_destroy(mbavo_vo *vo);
 /* getSplineTrajectory()->InsertControlKnot(...) before the first frame (the `get_num_knots() == 0` test at .cpp:99) */
 int mbavo_vo_set_spline(mbavo_vo *vo, double t0, double dt, int N, const double *h_knots_t, const double *h_knots_R);
 int mbavo_vo_get_spline(mbavo_vo *vo, double *h_t0, double *h_dt, int *h_N, double *h_knots_t /*3*16*/, double *h_knots_R /*4*16*/);
+/* LM records of the last mbavo_vo_track_frame's optimizeTrajectory (blur_aware_direct_tracker.cpp:590-924 logs them per
+ * iteration), as mbavo_optimize_trajectory writes them, at most 512; returns the number copied (>= 0) or an error (< 0) */
+int mbavo_vo_last_trace(mbavo_vo *vo, mbavo_trace_rec *trace, int trace_cap);
+/* Checkpoint / resume of a tracker (the reference keeps this state in BlurAwareDirectTracker's members,
+ * blur_aware_direct_tracker.h:69-125: mSplineTrajectory, mTKeyframe, mTprevB2W, mNeighFrameVelocity, mPrevTimestamp,
+ * mIsFirstFrame): everything trackFrame carries from one frame to the next besides the keyframe's own data; the keyframe
+ * (pyramid, gradients, keypoints) is re-made from its sharp frame and depth map by mbavo_vo_set_keyframe =
+ * tmpProcessKeyframe (blur_aware_direct_tracker.cpp:342-415).  Poses are 7 doubles t[3], q[4] xyzw, restored bit for bit. */
+typedef struct mbavo_vo_state {
+    double t0, dt; int N, is_first;
+    double knots_t[3 * 16], knots_R[4 * 16];
+    double T_keyframe[7], T_prev_b2w[7], velocity[6], prev_timestamp;
+} mbavo_vo_state;
+int mbavo_vo_get_state(mbavo_vo *vo, mbavo_vo_state *h_state);
+int mbavo_vo_set_state(mbavo_vo *vo, const mbavo_vo_state *h_state);
+int mbavo_vo_set_keyframe(mbavo_vo *vo, const unsigned char *h_sharp, const float *h_depth_z, double sharp_cap_time);
 int mbavo_vo_num_keypoints(mbavo_vo *vo, int level);
 int mbavo_vo_get_keypoints(mbavo_vo *vo, int level, double *h_xy /*K*2*/, double *h_z /*K*/);
 /* trackFrame (.cpp:88-203): images and the z-depth map of the sharp frame are HOST buffers (H x W), as the

@@ -46,6 +46,14 @@ class TrackOpts(C.Structure):
     ]
 
 
+class VoState(C.Structure):
+    """struct mbavo_vo_state"""
+    _fields_ = [("t0", C.c_double), ("dt", C.c_double), ("N", C.c_int), ("is_first", C.c_int),
+                ("knots_t", C.c_double * 48), ("knots_R", C.c_double * 64),
+                ("T_keyframe", C.c_double * 7), ("T_prev_b2w", C.c_double * 7), ("velocity", C.c_double * 6),
+                ("prev_timestamp", C.c_double)]
+
+
 class TraceRec(C.Structure):
     """struct mbavo_trace_rec"""
     _fields_ = [
@@ -103,7 +111,7 @@ SYMBOLS = [
     "mbavo_profile", "mbavo_profile_read", "mbavo_version", "mbavo_abi_version",
     "mbavo_gradient_magnitude_u8", "mbavo_detect_semidense", "mbavo_se3_exp", "mbavo_se3_log", "mbavo_transform_mul",
     "mbavo_transform_inverse", "mbavo_spline_transform_to", "mbavo_vo_create", "mbavo_vo_destroy", "mbavo_vo_set_spline",
-    "mbavo_vo_get_spline", "mbavo_vo_num_keypoints", "mbavo_vo_get_keypoints", "mbavo_vo_track_frame", "mbavo_lm_batch",
+    "mbavo_vo_get_spline", "mbavo_vo_last_trace", "mbavo_vo_get_state", "mbavo_vo_set_state", "mbavo_vo_set_keyframe", "mbavo_vo_num_keypoints", "mbavo_vo_get_keypoints", "mbavo_vo_track_frame", "mbavo_lm_batch",
     "mbavo_shard_keypoints", "mbavo_shard_frames", "mbavo_system_len", "mbavo_merge_device", "mbavo_comm_unique_id",
     "mbavo_comm_init", "mbavo_comm_ranks", "mbavo_comm_destroy", "mbavo_last_kernel", "mbavo_timing_report",
 ]
@@ -223,6 +231,10 @@ def load():
     L.mbavo_vo_set_spline.argtypes = [vp, C.c_double, C.c_double, C.c_int, c_dp, c_dp]
     L.mbavo_vo_get_spline.argtypes = [vp, c_dp, c_dp, c_ip, c_dp, c_dp]
     L.mbavo_vo_num_keypoints.argtypes = [vp, C.c_int]
+    L.mbavo_vo_last_trace.argtypes = [vp, C.POINTER(TraceRec), C.c_int]
+    L.mbavo_vo_get_state.argtypes = [vp, C.POINTER(VoState)]
+    L.mbavo_vo_set_state.argtypes = [vp, C.POINTER(VoState)]
+    L.mbavo_vo_set_keyframe.argtypes = [vp, vp, vp, C.c_double]
     L.mbavo_vo_get_keypoints.argtypes = [vp, C.c_int, c_dp, c_dp]
     L.mbavo_vo_track_frame.argtypes = [vp, vp, vp, C.c_double, vp, C.c_double, C.c_double, c_dp, C.POINTER(VoInfo)]
     L.mbavo_lm_batch.argtypes = [vp, C.c_int, C.POINTER(Problem), C.POINTER(LmBatchOpts), C.POINTER(LmBatchResult),

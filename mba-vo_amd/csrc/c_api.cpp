@@ -495,6 +495,38 @@ extern "C"
         return 0;
     }
 
+    int mbavo_vo_last_trace(mbavo_vo *vo, mbavo_trace_rec *trace, int trace_cap)
+    {
+        if (!vo || trace_cap < 0 || (trace_cap > 0 && !trace)) return MBAVO_E_ARG;
+        return vo->impl.lastTrace(trace, trace_cap);
+    }
+
+    static_assert(sizeof(mbavo_vo_state) == sizeof(VO::TrackerState), "mbavo_vo_state mirrors VO::TrackerState");
+
+    int mbavo_vo_get_state(mbavo_vo *vo, mbavo_vo_state *st)
+    {
+        if (!vo || !st) return MBAVO_E_ARG;
+        VO::TrackerState s;
+        vo->impl.getState(s);
+        memcpy(st, &s, sizeof(s));
+        return 0;
+    }
+
+    int mbavo_vo_set_state(mbavo_vo *vo, const mbavo_vo_state *st)
+    {
+        if (!vo || !st) return MBAVO_E_ARG;
+        VO::TrackerState s;
+        memcpy(&s, st, sizeof(s));
+        return vo->impl.setState(s);
+    }
+
+    int mbavo_vo_set_keyframe(mbavo_vo *vo, const unsigned char *sharp, const float *depth_z, double sharp_cap)
+    {
+        if (!vo || !sharp || !depth_z) return MBAVO_E_ARG;
+        VO::FrameView s{sharp, sharp_cap, 0.0};
+        return vo->impl.setKeyframe(s, depth_z);
+    }
+
     int mbavo_vo_num_keypoints(mbavo_vo *vo, int level)
     {
         if (!vo || level < 0 || level >= vo->impl.getOptions().num_pyramid_levels) return MBAVO_E_ARG;

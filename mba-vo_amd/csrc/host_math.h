@@ -77,6 +77,8 @@ namespace SLAM
             size_t get_num_knots() const { return mT.size() / 3; }
             double *get_knot_data_t() { return mT.data(); }
             double *get_knot_data_R() { return mR.data(); }
+            const double *get_knot_data_t() const { return mT.data(); }
+            const double *get_knot_data_R() const { return mR.data(); }
 
             void InsertControlKnot(const double q_xyzw[4], const double t[3]);
             void PopFrontControlKnot();

@@ -162,7 +162,7 @@ namespace SLAM
 
         BlurAwareDirectTracker::BlurAwareDirectTracker(mbavo::Engine &engine, const BlurAwareDirectTrackerOptions &options)
             : mEngine(engine), mOptions(options), mPrevTimestamp(0), mEvaluationPointCost(0), mIsFirstFrame(true),
-              mCurCap(0), mCurExp(0), mStatus(0), mDepth(nullptr), mKpArena(nullptr), mPicksDev(nullptr), mPicksHost(nullptr), mKpStage(nullptr)
+              mCurCap(0), mCurExp(0), mStatus(0), mTrace(new mbavo_trace_rec[kTraceCap]), mNumTrace(0), mDepth(nullptr), mKpArena(nullptr), mPicksDev(nullptr), mPicksHost(nullptr), mKpStage(nullptr)
         { // blur_aware_direct_tracker.cpp:14-34; the shared storages are the engine's
             for (int i = 0; i < 6; ++i) mNeighFrameVelocity[i] = mSplineVelocity[i] = 0;
             for (int l = 0; l < 8; ++l)
@@ -214,8 +214,47 @@ namespace SLAM
             return 0;
         }
 
+        int BlurAwareDirectTracker::lastTrace(mbavo_trace_rec *out, int cap) const
+        {
+            const int n = mNumTrace < cap ? mNumTrace : cap;
+            if (n > 0) memcpy(out, mTrace, sizeof(mbavo_trace_rec) * n);
+            return n;
+        }
+
+        void BlurAwareDirectTracker::getState(TrackerState &s) const
+        {
+            memset(&s, 0, sizeof(s));
+            s.t0 = mSpline.getStartTime(); s.dt = mSpline.getSamplingFreq();
+            s.N = (int)mSpline.get_num_knots(); s.is_first = mIsFirstFrame ? 1 : 0;
+            if (s.N > 16) s.N = 16;
+            if (s.N > 0)
+            {
+                memcpy(s.knots_t, mSpline.get_knot_data_t(), sizeof(double) * 3 * s.N);
+                memcpy(s.knots_R, mSpline.get_knot_data_R(), sizeof(double) * 4 * s.N);
+            }
+            memcpy(s.T_keyframe, mTKeyframe.getData(), sizeof(double) * 7);
+            memcpy(s.T_prev_b2w, mTprevB2W.getData(), sizeof(double) * 7);
+            for (int i = 0; i < 6; ++i) s.velocity[i] = mNeighFrameVelocity[i];
+            s.prev_timestamp = mPrevTimestamp;
+        }
+
+        int BlurAwareDirectTracker::setState(const TrackerState &s)
+        {
+            if (s.N < 0 || s.N > 16) return MBAVO_E_ARG;
+            mSpline.Clear();
+            mSpline.setStartTime(s.t0); mSpline.setSamplingFreq(s.dt); mSpline.setSplineDegK(mOptions.spline_deg_k);
+            for (int i = 0; i < s.N; ++i) mSpline.InsertControlKnot(s.knots_R + 4 * i, s.knots_t + 3 * i);
+            mTKeyframe = Core::Transformation::fromData(s.T_keyframe);
+            mTprevB2W = Core::Transformation::fromData(s.T_prev_b2w);
+            for (int i = 0; i < 6; ++i) mNeighFrameVelocity[i] = mSplineVelocity[i] = s.velocity[i];
+            mPrevTimestamp = s.prev_timestamp;
+            mIsFirstFrame = s.is_first != 0;
+            return 0;
+        }
+
         BlurAwareDirectTracker::~BlurAwareDirectTracker()
         {
+            delete[] mTrace;
             (void)hipFree(mDepth); (void)hipFree(mKpArena);
             (void)hipFree(mPicksDev); (void)hipHostFree(mPicksHost); (void)hipHostFree(mKpStage);
             for (int l = 0; l < 8; ++l)
@@ -351,7 +390,8 @@ namespace SLAM
             o.min_abs_cost_decrease = mOptions.min_abs_cost_decrease; o.max_chi_square_error = mOptions.max_chi_square_error;
             const int n = mbavo::optimize_trajectory(mEngine, o, lv, 1, &mCurCap, &mCurExp, mSpline.getStartTime(),
                                                      mSpline.getSamplingFreq(), mSpline.get_knot_data_t(), mSpline.get_knot_data_R(),
-                                                     (int)mSpline.get_num_knots(), start_idx, &mEvaluationPointCost, nullptr, 0);
+                                                     (int)mSpline.get_num_knots(), start_idx, &mEvaluationPointCost, mTrace, kTraceCap);
+            mNumTrace = n < 0 ? 0 : (n < kTraceCap ? n : kTraceCap);
             if (n < 0) return n;
             if (num_trace) *num_trace = n;
             return 0;

@@ -16,6 +16,8 @@
 #include "host_math.h"
 #include <vector>
 
+struct mbavo_trace_rec; // include/mbavo.h
+
 namespace mbavo
 {
     // keyframe_ops.hip: semi-dense keypoints of one pyramid level, device in / device out; count to the host
@@ -58,6 +60,12 @@ namespace SLAM
             const double *getTranslationData() const { return d; }
             static Transformation exp(const double tangent[6]);         // [upsilon, omega]
             static void log(const Transformation &T, double tangent[6]);
+            static Transformation fromData(const double t_then_q[7]) // the stored bits, not re-normalised (state restore)
+            {
+                Transformation T;
+                for (int i = 0; i < 7; ++i) T.d[i] = t_then_q[i];
+                return T;
+            }
 
         private:
             double d[7];
@@ -101,6 +109,14 @@ namespace SLAM
             double avg_flow, avg_kernel, final_cost;
         };
 
+        struct TrackerState
+        { // what trackFrame carries from frame to frame besides the keyframe's own data (checkpoint / resume of a tracker)
+            double t0, dt;
+            int N, is_first;
+            double knots_t[3 * 16], knots_R[4 * 16];
+            double T_keyframe[7], T_prev_b2w[7], velocity[6], prev_timestamp;
+        };
+
         class BlurAwareDirectTracker
         {
         public:
@@ -120,6 +136,12 @@ namespace SLAM
             const double *deviceKeypointsXY(int level) const { return mKpXY[level]; }
             const double *deviceKeypointsZ(int level) const { return mKpZ[level]; }
             int status() const { return mStatus; } // allocation status of the constructor
+            // LM records of the last trackFrame's optimizeTrajectory (the reference logs them; the long-horizon parity runs compare them)
+            int lastTrace(mbavo_trace_rec *out, int cap) const;
+            // checkpoint / resume: the inter-frame state, and the keyframe re-made from its sharp frame + depth map
+            void getState(TrackerState &s) const;
+            int setState(const TrackerState &s);
+            int setKeyframe(const FrameView &keyframe, const float *depth_z) { return mStatus ? mStatus : tmpProcessKeyframe(keyframe, depth_z); }
 
         private:
             int tmpProcessKeyframe(const FrameView &keyframe, const float *depth_z);
@@ -136,6 +158,9 @@ namespace SLAM
             bool mIsFirstFrame;
             double mCurCap, mCurExp;
             int mStatus;
+            mbavo_trace_rec *mTrace; // kTraceCap records
+            int mNumTrace;
+            static constexpr int kTraceCap = 512;
 
             // device-resident pyramids (keyframe: image + gradient; current frame: image) and keypoints
             unsigned char *mRef[8], *mCur[8];

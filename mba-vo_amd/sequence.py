@@ -35,13 +35,19 @@ def plane_depth_map(H, W, intr, q, t, D):
 
 
 def make_sequence(ctx, H=480, W=640, M=8, k_gt=4, trans_scale=0.15, rot_scale=0.02, D=7.5, exp=0.04, frame_dt=0.1,
-                  t_first=0.1, blur_samples=8, seed=3, device="cuda:0"):
+                  t_first=0.1, blur_samples=8, seed=3, device="cuda:0", trajectory="harness"):
+    """trajectory: "harness" = the 7-knot spline of the reference's module harness at the given scales (leaves the texture after
+    ~15 frames at 640 x 480); "loop" = synth.loop_spline, bounded, any M (the long-horizon parity runs)."""
     import torch
     L = ctx.lib
     I0 = synth.texture_image(H, W, seed=seed, octaves=(32, 16, 8, 4))
     intr = np.array([W / 2.0, W / 2.0, W / 2.0, H / 2.0])
-    N = 7
-    kt, kR = synth.harness_spline(trans_scale, rot_scale, N)
+    if trajectory == "loop":
+        N = int((t_first + frame_dt * M) / 0.5) + 6
+        kt, kR = synth.loop_spline(N)
+    else:
+        N = 7
+        kt, kR = synth.harness_spline(trans_scale, rot_scale, N)
     kt, kR = np.ascontiguousarray(kt.ravel()), np.ascontiguousarray(kR.ravel())
     t0, dtk = 0.0, 0.5
     times = t_first + frame_dt * np.arange(M + 1)

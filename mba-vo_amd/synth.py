@@ -34,6 +34,18 @@ def harness_spline(trans_scale=1.0, rot_scale=1.0, n_knots=7):
     return np.ascontiguousarray(kt), np.ascontiguousarray(kR)
 
 
+def loop_spline(n_knots, radius=0.9, knots_per_turn=9.0, z_amp=0.25, rot_amp=0.012):
+    """A bounded ground-truth trajectory for long sequences: the knots walk a circle of `radius` in the image plane (one turn
+    every `knots_per_turn` knots) with a slow depth and roll / pitch / yaw oscillation at incommensurate rates, so that any
+    number of frames stays in front of the same textured plane (the harness spline runs off it after ~15 frames at 640 x 480).
+    Returns (knots_t [n,3], knots_R [n,4] xyzw); about the harness spline's image-plane speed at its 0.15 / 0.02 scales."""
+    a = 2.0 * np.pi * np.arange(n_knots) / knots_per_turn
+    kt = np.stack([radius * (1.0 - np.cos(a)), radius * np.sin(a), z_amp * np.sin(0.37 * a)], 1)
+    kR = np.stack([rpy_quat(rot_amp * np.sin(0.61 * x), rot_amp * np.sin(0.43 * x + 1.0), 0.5 * rot_amp * np.sin(0.29 * x + 2.0))
+                   for x in a])
+    return np.ascontiguousarray(kt), np.ascontiguousarray(kR)
+
+
 def ramp_image(H=480, W=640):
     """create_uniform_image (test/...modules.cpp:69-81)."""
     return ((np.arange(W)[None, :] + np.arange(H)[:, None]) % 255).astype(np.uint8)

@@ -76,6 +76,13 @@ class OrcVoInfo(C.Structure):
                 ("avg_flow", C.c_double), ("avg_kernel", C.c_double), ("final_cost", C.c_double)]
 
 
+class OrcVoState(C.Structure):
+    _fields_ = [("t0", C.c_double), ("dt", C.c_double), ("N", C.c_int), ("is_first", C.c_int),
+                ("knots_t", C.c_double * 48), ("knots_R", C.c_double * 64),
+                ("T_keyframe", C.c_double * 7), ("T_prev_b2w", C.c_double * 7), ("velocity", C.c_double * 6),
+                ("prev_timestamp", C.c_double)]
+
+
 class OrcTrackOpts(C.Structure):
     _fields_ = [
         ("num_levels", C.c_int), ("k", C.c_int), ("max_num_iterations", C.c_int),
@@ -110,12 +117,8 @@ def build(quiet=True):
                    stdout=subprocess.DEVNULL if quiet else None)
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        path = os.path.join(_HERE, "libmbavo_oracle.so")
-        if not os.path.exists(path):
-            build()
+def _bind(path):
+    if True:
         L = C.CDLL(path)
         L.orc_tr_quality.restype = C.c_double
         L.orc_optimize_trajectory.restype = C.c_int
@@ -175,12 +178,51 @@ def lib():
         L.orc_vo_destroy.argtypes = [C.c_void_p]
         L.orc_vo_set_spline.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, c_dp, c_dp]
         L.orc_vo_num_keypoints.argtypes = [C.c_void_p, C.c_int]
+        L.orc_vo_last_trace.argtypes = [C.c_void_p, C.POINTER(OrcTraceRec), C.c_int]
+        L.orc_vo_get_state.argtypes = [C.c_void_p, C.POINTER(OrcVoState)]
+        L.orc_vo_set_state.argtypes = [C.c_void_p, C.POINTER(OrcVoState)]
+        L.orc_vo_set_keyframe.argtypes = [C.c_void_p, c_u8p, c_fp]
+        L.orc_margins_get.argtypes = [c_dp]
         L.orc_vo_keypoints.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp]
         L.orc_vo_spline.argtypes = [C.c_void_p, c_dp, c_dp, c_ip, c_dp, c_dp]
         L.orc_vo_track_frame.argtypes = [C.c_void_p, c_u8p, c_fp, C.c_double, c_u8p, C.c_double, C.c_double, c_dp,
                                          C.POINTER(OrcVoInfo)]
-        _LIB = L
+    return L
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libmbavo_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = _bind(path)
     return _LIB
+
+
+class _Variant:
+    """This module with lib() answering for another build of the same sources (everything else is shared)."""
+
+    def __init__(self, path):
+        self._path, self._lib = path, None
+
+    def lib(self):
+        if self._lib is None:
+            self._lib = _bind(self._path)
+        return self._lib
+
+    def __getattr__(self, name):
+        return globals()[name]
+
+
+def fma_variant():
+    """The restatement compiled WITH floating-point contraction (-ffp-contract=fast -mfma: what nvcc does to the reference's
+    .cu files by default, -fmad=true): NOT the pinned oracle -- the long-horizon runs use it to show how far two roundings of the
+    same algorithm drift apart (tools/long_horizon.py).  None where the host compiler / CPU has no FMA."""
+    path = os.path.join(_HERE, "libmbavo_oracle_fma.so")
+    if not os.path.exists(path):
+        subprocess.run(["make", "-C", _HERE, "fma"], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return _Variant(path) if os.path.exists(path) else None
 
 
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # (see bench.py: metered sandboxes; read by libgomp at its first load)

@@ -575,6 +575,14 @@ void orc_compute_local_patches_xy(int S, int F, const double *poses,
 /* (compute_hessian_gradients_cost.cu:23-156).  A9: a pixel is valid iff the */
 /* current pixel and ALL S warped samples are in bounds; else r = 0, J = 0.  */
 /* ------------------------------------------------------------------------ */
+/* Instrument of the long-horizon parity runs (tools/long_horizon.py): how close the evaluations since the last reset came to a
+ * DISCONTINUITY of the objective -- [0] the smallest distance of a truncated pixel coordinate (A3, :69-70) from the next integer,
+ * in pixels; [1] the smallest | |c - mu| - chi sigma | / (chi sigma) of the outlier test (blur_aware_direct_tracker.cpp:639-699).
+ * A difference of that size between two implementations' inputs flips the pixel / the flag.  Single-threaded use only. */
+static double g_margins[2] = { 1e300, 1e300 };
+void orc_margins_reset(void) { g_margins[0] = g_margins[1] = 1e300; }
+void orc_margins_get(double out[2]) { out[0] = g_margins[0]; out[1] = g_margins[1]; }
+
 static int pixel_row(const unsigned char *I_ref, const float *dIxy_ref,
                      const unsigned char *I_cur, int S, const double *poses_f, int k,
                      const double *Jt_f, const double *JR_f, double cxp, double cyp, double z,
@@ -584,6 +592,12 @@ static int pixel_row(const unsigned char *I_ref, const float *dIxy_ref,
     const int n6k = 6 * k;
     const int px = (int)(cxp + dx); /* A3 (:69-70) */
     const int py = (int)(cyp + dy);
+    {
+        const double fx_ = cxp + dx, fy_ = cyp + dy;
+        const double mx_ = fabs(fx_ - nearbyint(fx_)), my_ = fabs(fy_ - nearbyint(fy_));
+        if (mx_ < g_margins[0]) g_margins[0] = mx_;
+        if (my_ < g_margins[0]) g_margins[0] = my_;
+    }
     *residual = 0.0;
     if (Jrow) memset(Jrow, 0, sizeof(double) * n6k);
     if (px < 0 || px > W - 1 || py < 0 || py > H - 1) return 0;
@@ -1185,6 +1199,10 @@ static int detect_outliers(const double *patch_blocks, int K, int E, double chi,
     for (int i = 0; i < K; ++i) {
         const double c = patch_blocks[(size_t)i * E];
         if (fabs(c - mu) > chi * (double)sqrtf((float)var)) { flags[i] = 1; ++n_out; }
+        {
+            const double thr_ = chi * (double)sqrtf((float)var), m_ = fabs(fabs(c - mu) - thr_) / (thr_ > 0 ? thr_ : 1.0);
+            if (m_ < g_margins[1]) g_margins[1] = m_;
+        }
     }
     return n_out;
 }

@@ -217,6 +217,19 @@ typedef struct orc_vo orc_vo;
 orc_vo *orc_vo_create(const orc_vo_opts *o);
 void orc_vo_destroy(orc_vo *v);
 int orc_vo_set_spline(orc_vo *v, double t0, double dt, int N, const double *kt, const double *kR);
+int orc_vo_last_trace(const orc_vo *v, orc_trace_rec *out, int cap);
+/* the tracker's state between two frames (everything trackFrame carries over besides the keyframe's own data) and the
+ * keyframe itself: the teacher-forced long-horizon runs put the HIP tracker into the oracle's state before every frame */
+typedef struct orc_vo_state {
+    double t0, dt; int N, is_first;
+    double knots_t[3 * 16], knots_R[4 * 16];
+    double T_keyframe[7], T_prev_b2w[7], velocity[6], prev_timestamp;
+} orc_vo_state;
+void orc_vo_get_state(const orc_vo *v, orc_vo_state *s);
+void orc_vo_set_state(orc_vo *v, const orc_vo_state *s);
+void orc_vo_set_keyframe(orc_vo *v, const unsigned char *sharp, const float *depth_z);
+void orc_margins_reset(void);
+void orc_margins_get(double out[2]);
 int orc_vo_num_keypoints(const orc_vo *v, int level);
 void orc_vo_keypoints(const orc_vo *v, int level, double *xy, double *z);
 void orc_vo_spline(const orc_vo *v, double *t0, double *dt, int *N, double *kt, double *kR);

@@ -289,6 +289,7 @@ int orc_is_keyframe(const double intr[4], const double *kp_xy, const double *kp_
 /* trackFrame                                                                */
 /* ------------------------------------------------------------------------ */
 #define ORC_MAX_LV 8
+#define ORC_VO_TRACE_CAP 512
 struct orc_vo {
     orc_vo_opts o;
     int first;
@@ -301,6 +302,7 @@ struct orc_vo {
     double kt[3 * 16], kR[4 * 16]; int N; double t0, dtk; /* max_num_ctrl_knots = 16 */
     double T_keyframe[7], T_prev_b2w[7], vel[6], prev_stamp;
     double last_cost;
+    orc_trace_rec trace[ORC_VO_TRACE_CAP]; int ntrace; /* the last trackFrame's LM records (long-horizon parity runs) */
 };
 
 orc_vo *orc_vo_create(const orc_vo_opts *o)
@@ -360,6 +362,28 @@ int orc_vo_set_spline(orc_vo *v, double t0, double dt, int N, const double *kt, 
     return 0;
 }
 
+int orc_vo_last_trace(const orc_vo *v, orc_trace_rec *out, int cap)
+{ /* records of the last trackFrame's optimizeTrajectory, in order; returns how many were copied */
+    const int n = v->ntrace < cap ? v->ntrace : cap;
+    if (n > 0) memcpy(out, v->trace, sizeof(orc_trace_rec) * n);
+    return n;
+}
+void orc_vo_get_state(const orc_vo *v, orc_vo_state *s)
+{
+    memset(s, 0, sizeof(*s));
+    s->t0 = v->t0; s->dt = v->dtk; s->N = v->N; s->is_first = v->first;
+    memcpy(s->knots_t, v->kt, sizeof(v->kt)); memcpy(s->knots_R, v->kR, sizeof(v->kR));
+    memcpy(s->T_keyframe, v->T_keyframe, sizeof(v->T_keyframe)); memcpy(s->T_prev_b2w, v->T_prev_b2w, sizeof(v->T_prev_b2w));
+    memcpy(s->velocity, v->vel, sizeof(v->vel)); s->prev_timestamp = v->prev_stamp;
+}
+void orc_vo_set_state(orc_vo *v, const orc_vo_state *s)
+{
+    v->t0 = s->t0; v->dtk = s->dt; v->N = s->N; v->first = s->is_first;
+    memcpy(v->kt, s->knots_t, sizeof(v->kt)); memcpy(v->kR, s->knots_R, sizeof(v->kR));
+    memcpy(v->T_keyframe, s->T_keyframe, sizeof(v->T_keyframe)); memcpy(v->T_prev_b2w, s->T_prev_b2w, sizeof(v->T_prev_b2w));
+    memcpy(v->vel, s->velocity, sizeof(v->vel)); v->prev_stamp = s->prev_timestamp;
+}
+void orc_vo_set_keyframe(orc_vo *v, const unsigned char *sharp, const float *depth_z) { process_keyframe(v, sharp, depth_z); }
 int orc_vo_num_keypoints(const orc_vo *v, int level) { return v->K[level]; }
 void orc_vo_keypoints(const orc_vo *v, int level, double *xy, double *z)
 {
@@ -422,7 +446,8 @@ int orc_vo_track_frame(orc_vo *v, const unsigned char *sharp, const float *depth
     to.min_abs_cost_decrease = o->min_abs_cost_decrease; to.max_chi_square_error = o->max_chi_square_error;
     int start = 0;
     const int ntrace = orc_optimize_trajectory(&to, lv, 1, &blur_cap, &blur_exp, v->t0, v->dtk, v->kt, v->kR, v->N,
-                                               &start, &v->last_cost, NULL, 0);
+                                               &start, &v->last_cost, v->trace, ORC_VO_TRACE_CAP);
+    v->ntrace = ntrace < ORC_VO_TRACE_CAP ? (ntrace > 0 ? ntrace : 0) : ORC_VO_TRACE_CAP;
 
     double af = 0, ak = 0;
     const int is_kf = orc_is_keyframe(o->intr, v->kp_xy[0], v->kp_z[0], v->K[0], o->spline_deg_k, v->t0, v->dtk, v->kt, v->kR,

@@ -29,12 +29,16 @@ def plane_depth_map(H, W, intr, q, t, D):
 
 
 def make_sequence(orc, H=120, W=160, M=6, k_gt=4, trans_scale=0.15, rot_scale=0.02, D=7.5, exp=0.04, frame_dt=0.1,
-                  t_first=0.1, blur_samples=12, seed=3):
+                  t_first=0.1, blur_samples=12, seed=3, trajectory="harness"):
     L = orc.lib()
     I0 = synth.texture_image(H, W, seed=seed, octaves=(32, 16, 8, 4))
     intr = np.array([W / 2.0, W / 2.0, W / 2.0, H / 2.0])
-    N = 7
-    kt, kR = synth.harness_spline(trans_scale, rot_scale, N)
+    if trajectory == "loop":  # bounded, any M (mba-vo_amd/synth.py: loop_spline)
+        N = int((t_first + frame_dt * M) / 0.5) + 6
+        kt, kR = synth.loop_spline(N)
+    else:
+        N = 7
+        kt, kR = synth.harness_spline(trans_scale, rot_scale, N)
     kt, kR = np.ascontiguousarray(kt.ravel()), np.ascontiguousarray(kR.ravel())
     t0, dtk = 0.0, 0.5
     times = t_first + frame_dt * np.arange(M + 1)
@@ -100,22 +104,52 @@ def fill_gpu_opts(capi, seq, cfg):
     return o, pats
 
 
-def run_oracle_vo(orc, seq, cfg=DEFAULTS):
+TRACE_CAP = 512
+
+
+def _trace_rows(recs, n):
+    """LM records of one trackFrame as rows (level, iter, kind, num_outliers, radius, eval_cost, candidate_cost, model_change,
+    quality); kind: 0 initial evaluation, 1 accepted, 2 rejected, 3 invalid step."""
+    return [(r.level, r.iter, r.kind, r.num_outliers, r.radius, r.eval_cost, r.candidate_cost, r.model_change, r.quality)
+            for r in recs[:n]]
+
+
+def _identity_knots(n):
+    return np.zeros(3 * n), np.ascontiguousarray(np.tile(np.array([0.0, 0, 0, 1]), n))
+
+
+def run_oracle_vo(orc, seq, cfg=DEFAULTS, init_knots=0):
+    """init_knots > 0: that many identity control knots through getSplineTrajectory() before the first frame (k = 4 needs four:
+    trackFrame itself only ever inserts two, blur_aware_direct_tracker.cpp:99-106)."""
     L = orc.lib()
     o, keep = fill_oracle_opts(orc, seq, cfg)
     vo = L.orc_vo_create(C.byref(o))
     assert vo
+    if init_knots:
+        kt, kR = _identity_knots(init_knots)
+        assert L.orc_vo_set_spline(vo, 0.0, seq["frame_dt"], init_knots, orc.dp(kt), orc.dp(kR)) == 0
+    recs = (orc.OrcTraceRec * TRACE_CAP)()
     out = []
+    kf_index = 0  # the frame whose sharp image is the current keyframe
     try:
         for i, t in enumerate(seq["times"]):
             T = np.zeros(7)
             info = orc.OrcVoInfo()
+            st = orc.OrcVoState()
+            L.orc_vo_get_state(vo, C.byref(st))
+            L.orc_margins_reset()
             rc = L.orc_vo_track_frame(vo, orc.u8p(seq["sharp"][i]), orc.fp(seq["depth"][i]), float(t), orc.u8p(seq["blur"][i]),
                                       float(t), float(seq["exp"]), orc.dp(T), C.byref(info))
             assert rc == 0
+            mg = np.zeros(2)
+            L.orc_margins_get(orc.dp(mg))
             K = [L.orc_vo_num_keypoints(vo, l) for l in range(cfg["levels"])]
             out.append(dict(T=T, is_keyframe=info.is_keyframe, K=K, num_trace=info.num_trace, start_idx=info.start_idx,
-                            avg_flow=info.avg_flow, avg_kernel=info.avg_kernel, cost=info.final_cost))
+                            avg_flow=info.avg_flow, avg_kernel=info.avg_kernel, cost=info.final_cost,
+                            trace=_trace_rows(recs, L.orc_vo_last_trace(vo, recs, TRACE_CAP)) if i else [],
+                            state_before=st, kf_before=kf_index, margins=(float(mg[0]), float(mg[1]))))
+            if info.is_keyframe:
+                kf_index = i
         xy, z = np.zeros(2 * out[-1]["K"][0]), np.zeros(out[-1]["K"][0])
         L.orc_vo_keypoints(vo, 0, orc.dp(xy), orc.dp(z))
         out[-1]["kp0"] = (xy.reshape(-1, 2), z)
@@ -124,19 +158,37 @@ def run_oracle_vo(orc, seq, cfg=DEFAULTS):
     return out
 
 
-def run_gpu_vo(mbavo, ctx, seq, cfg=DEFAULTS, frame_seconds=None):
-    """frame_seconds: optional list, receives the wall time of every mbavo_vo_track_frame call (tools/vo_bench.py)."""
+def run_gpu_vo(mbavo, ctx, seq, cfg=DEFAULTS, frame_seconds=None, init_knots=0, teacher=None):
+    """frame_seconds: optional list, receives the wall time of every mbavo_vo_track_frame call (tools/vo_bench.py).
+    teacher: an oracle run (run_oracle_vo) -- TEACHER FORCING: before every frame the tracker is put into the state the ORACLE
+    had before that frame (mbavo_vo_set_state; the keyframe re-made with mbavo_vo_set_keyframe where the two disagree about
+    it), so every frame is a one-step comparison from identical inputs and differences cannot accumulate."""
     import time
     capi = mbavo.capi
     o, keep = fill_gpu_opts(capi, seq, cfg)
     vo = capi.vp()
     capi.check(ctx.lib.mbavo_vo_create(ctx.handle, C.byref(o), C.byref(vo)), "mbavo_vo_create")
+    if init_knots:
+        kt, kR = _identity_knots(init_knots)
+        capi.check(ctx.lib.mbavo_vo_set_spline(vo, 0.0, seq["frame_dt"], init_knots, capi.dp(kt), capi.dp(kR)), "mbavo_vo_set_spline")
+    recs = (capi.TraceRec * TRACE_CAP)()
     out = []
+    kf_index, resyncs = 0, 0
     try:
         for i, t in enumerate(seq["times"]):
             T = np.zeros(7)
             info = capi.VoInfo()
             sharp, depth, blur = seq["sharp"][i], seq["depth"][i], seq["blur"][i]
+            if teacher is not None and i > 0:
+                st = capi.VoState()
+                assert C.sizeof(st) == C.sizeof(teacher[i]["state_before"])
+                C.memmove(C.byref(st), C.byref(teacher[i]["state_before"]), C.sizeof(st))
+                capi.check(ctx.lib.mbavo_vo_set_state(vo, C.byref(st)), "mbavo_vo_set_state")
+                if teacher[i]["kf_before"] != kf_index:
+                    kf_index = teacher[i]["kf_before"]
+                    resyncs += 1
+                    capi.check(ctx.lib.mbavo_vo_set_keyframe(vo, seq["sharp"][kf_index].ctypes.data, seq["depth"][kf_index].ctypes.data,
+                                                             float(seq["times"][kf_index])), "mbavo_vo_set_keyframe")
             t_call = time.perf_counter()
             rc = ctx.lib.mbavo_vo_track_frame(vo, sharp.ctypes.data, depth.ctypes.data, float(t), blur.ctypes.data, float(t),
                                               float(seq["exp"]), capi.dp(T), C.byref(info))
@@ -145,7 +197,11 @@ def run_gpu_vo(mbavo, ctx, seq, cfg=DEFAULTS, frame_seconds=None):
             assert rc == 0, rc
             K = [ctx.lib.mbavo_vo_num_keypoints(vo, l) for l in range(cfg["levels"])]
             out.append(dict(T=T, is_keyframe=info.is_keyframe, K=K, num_trace=info.num_trace, start_idx=info.start_idx,
-                            avg_flow=info.avg_flow, avg_kernel=info.avg_kernel, cost=info.final_cost))
+                            avg_flow=info.avg_flow, avg_kernel=info.avg_kernel, cost=info.final_cost,
+                            trace=_trace_rows(recs, ctx.lib.mbavo_vo_last_trace(vo, recs, TRACE_CAP)) if i else [],
+                            keyframe_resyncs=resyncs))
+            if info.is_keyframe:
+                kf_index = i
         xy, z = np.zeros(2 * out[-1]["K"][0]), np.zeros(out[-1]["K"][0])
         capi.check(ctx.lib.mbavo_vo_get_keypoints(vo, 0, capi.dp(xy), capi.dp(z)), "mbavo_vo_get_keypoints")
         out[-1]["kp0"] = (xy.reshape(-1, 2), z)

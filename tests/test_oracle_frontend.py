@@ -154,3 +154,39 @@ def test_track_frame_sequence(orc):
         assert err < 0.1 * flow + 0.1, (err, flow)  # pixels; drift accumulates over keyframe changes
     again = frontend.run_oracle_vo(orc, seq)
     assert all(np.array_equal(a["T"], b["T"]) for a, b in zip(out, again))
+
+
+def test_tracker_state_round_trip_and_horizon_statistics(orc):
+    """The instruments of the long-horizon parity runs (tests/test_gpu_horizon.py) on CPU: replaying every frame from the recorded
+    inter-frame state (orc_vo_get_state / _set_state / _set_keyframe) reproduces the free-running oracle bit for bit; the comparison
+    reports no divergence for identical runs and the right frame for a perturbed one; the LM records come with every frame."""
+    import ctypes as C
+    import horizon
+    L = orc.lib()
+    seq = frontend.make_sequence(orc, H=120, W=160, M=8, trajectory="loop", blur_samples=8)
+    a = frontend.run_oracle_vo(orc, seq)
+    assert all(len(f["trace"]) == f["num_trace"] for f in a) and sum(f["num_trace"] for f in a) > 20
+    assert a[1]["margins"][0] == 0.0 and all(m["margins"][0] > 0 for m in a[2:])  # frame 1 starts at the identity: integer coordinates
+    o, keep = frontend.fill_oracle_opts(orc, seq, frontend.DEFAULTS)
+    vo = L.orc_vo_create(C.byref(o))
+    kf = 0
+    for i, t in enumerate(seq["times"]):
+        if i > 0:
+            L.orc_vo_set_state(vo, C.byref(a[i]["state_before"]))
+            if a[i]["kf_before"] != kf:
+                kf = a[i]["kf_before"]
+                L.orc_vo_set_keyframe(vo, orc.u8p(seq["sharp"][kf]), orc.fp(seq["depth"][kf]))
+        T, info = np.zeros(7), orc.OrcVoInfo()
+        assert L.orc_vo_track_frame(vo, orc.u8p(seq["sharp"][i]), orc.fp(seq["depth"][i]), float(t), orc.u8p(seq["blur"][i]), float(t),
+                                    float(seq["exp"]), orc.dp(T), C.byref(info)) == 0
+        if info.is_keyframe:
+            kf = i
+        assert np.array_equal(T, a[i]["T"]), i
+    L.orc_vo_destroy(vo)
+    gt = frontend.gt_relative(orc, seq)
+    st = horizon.compare(a, a, gt, window=4)
+    assert st["first_discrete_divergence"] is None and st["max_abs_pose_diff"] == 0.0 and st["abs_delta_ate"] == 0.0
+    b = [dict(f) for f in a]
+    b[5] = dict(b[5], T=b[5]["T"] + 1e-5, num_trace=b[5]["num_trace"] + 1)
+    st = horizon.compare(b, a, gt, window=4)
+    assert st["first_discrete_divergence"] == 5 and st["first_pose_divergence"]["1e-06"] == 5 and st["first_pose_divergence"]["0.0001"] is None
