@@ -72,6 +72,10 @@ def parse():
                     help="pair sharding: ONE in-place all-gather of equal slices (default) or, as BASELINE.json words it, ONE "
                          "all-reduce of a send buffer that is zero outside the rank's slice (twice the bytes on the wire)")
     ap.add_argument("--batch-pairs", type=int, default=512, help="pairs of the N > 1 batch configs (tests shrink it)")
+    ap.add_argument("--cost-only", action="store_true",
+                    help="the cost-only evaluation (evaluate_cost_hessian_gradient with nullptr, nullptr: half of every LM iteration, "
+                         "blur_aware_direct_tracker.cpp:863-880) as the timed step; flops_alg = 122 PS + 13 PX (SURVEY.md 8d)")
+    ap.add_argument("--spline-k", type=int, default=4, choices=[2, 4], help="spline degree (N = k control poses); 2 is the reference's default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the bounded runs of the other BASELINE configs")
     ap.add_argument("--grad-fp16", action="store_true",
@@ -87,23 +91,24 @@ def parse():
     return ap.parse_args()
 
 
-def build_workload(name, frames=1, seed=1, ctx=None, dev="cuda:0", grad_fp16=False, pairs=None):
+def build_workload(name, frames=1, seed=1, ctx=None, dev="cuda:0", grad_fp16=False, pairs=None, k=4):
     """(list of Prob or a device-resident RenderedPairBatch, description, sharding mode at N > 1)"""
     from mba_vo_amd import workloads as wl
+    kd = "" if k == 4 else "; LINEAR spline k = 2 on N = 2 control poses (the reference's default degree, blur_aware_direct_tracker.h:50)"
     if name == "c2_dense":
-        return wl.pyramid_pair(480, 640, 4, S=8, k=4, N=4, mode="dense", seed=seed, frames=frames), \
-            "640x480 pair, 4-level pyramid, S=8 blur samples, N=4 control poses (k=4), dense P=1 (configs[1]); synthetic " \
-            "band-limited noise keyframe, current image = shifted keyframe + noise", "frames"
+        return wl.pyramid_pair(480, 640, 4, S=8, k=k, N=k, mode="dense", seed=seed, frames=frames), \
+            "640x480 pair, 4-level pyramid, S=8 blur samples, N=%d control poses (k=%d), dense P=1 (configs[1]); synthetic " \
+            "band-limited noise keyframe, current image = shifted keyframe + noise" % (k, k), "frames"
     if name == "c2_semidense":
-        return wl.pyramid_pair(480, 640, 4, S=8, k=4, N=4, mode="semidense", seed=seed, frames=frames), \
-            "640x480 pair, 4-level pyramid, S=8, N=4, semi-dense 30px grid keypoints x 8-pixel pattern (configs[1], " \
-            "reference-shaped)", "frames"
+        return wl.pyramid_pair(480, 640, 4, S=8, k=k, N=k, mode="semidense", seed=seed, frames=frames), \
+            "640x480 pair, 4-level pyramid, S=8, N=%d, semi-dense 30px grid keypoints x 8-pixel pattern (configs[1], " \
+            "reference-shaped)" % k + kd, "frames"
     if name == "c1_dense":
-        return wl.pyramid_pair(480, 640, 1, S=1, k=4, N=4, mode="dense", seed=seed, frames=frames), \
-            "640x480 pair, 1 level, S=1 (sharp degenerate case), dense (configs[0])", "frames"
+        return wl.pyramid_pair(480, 640, 1, S=1, k=k, N=k, mode="dense", seed=seed, frames=frames), \
+            "640x480 pair, 1 level, S=1 (sharp degenerate case), dense (configs[0])" + kd, "frames"
     if name in ("c3_batch64", "c4_batch512"):
         B = pairs if pairs else (64 if name == "c3_batch64" else 512)
-        return wl.RenderedPairBatch(ctx, B, S=8, k=4, device=dev, seed=seed, grad_fp16=grad_fp16), \
+        return wl.RenderedPairBatch(ctx, B, S=8, k=k, device=dev, seed=seed, grad_fp16=grad_fp16), \
             "batch of %d independent 640x480 pairs = %d consecutive frames of ONE GPU-rendered synthetic blurred sequence " \
             "(textured plane, camera on a ground-truth spline; generate_synthetic_data.cpp:127-214): every pair has its OWN " \
             "keyframe (sharp rendering), gradient image, grid-selected keypoints x 8-pixel pattern with depths from its own " \
@@ -293,10 +298,16 @@ class Runner:
     """One workload resident on this rank's GPU: step(), unit counts, roofline figures."""
 
     def __init__(self, M, ctx, name, dev, rank, world, sharded, grad_fp16=False, shard_mode=None, sequential=False, coll=None,
-                 pair_collective="allgather", pairs=None):
+                 pair_collective="allgather", pairs=None, cost_only=False, k=4):
         from mba_vo_amd import shard, workloads as wl
         self.M, self.ctx, self.name, self.world, self.rank = M, ctx, name, world, rank
-        built, self.desc, self.mode = build_workload(name, frames=world if sharded else 1, ctx=ctx, dev=dev, grad_fp16=grad_fp16, pairs=pairs)
+        self.cost_only = bool(cost_only)
+        built, self.desc, self.mode = build_workload(name, frames=world if sharded else 1, ctx=ctx, dev=dev, grad_fp16=grad_fp16, pairs=pairs, k=k)
+        if cost_only:
+            self.desc += "; COST-ONLY evaluation (no Jacobians, no H / g: the candidate pass of an LM iteration)"
+        elif not sharded and not sequential:
+            self.desc += "; the step ENDS IN THE REFERENCE'S UNIT: merged [cost | g | H] per problem on the device (mbavo_eval_batch_merged: " \
+                         "merge_hessian_gradient_cost inside the finalize step), packed frame blocks beside it"
         if shard_mode is not None:
             self.mode = shard_mode
         elif self.mode == "frames":
@@ -330,7 +341,9 @@ class Runner:
                 self._seq.append((one, int(rows[b])))
 
     def step(self):
-        if self.se is not None:
+        if self.cost_only:
+            self.dw.step(self.ctx, False)
+        elif self.se is not None:
             self.se.step(True)
         elif self.sequential:
             lib, dw = self.ctx.lib, self.dw
@@ -370,7 +383,8 @@ class Runner:
         flops = 0.0
         for px, S, p in counts:
             E = synth.packed_len(p.k)
-            flops += px * S * (363 + 48 * p.k) + px * (2 * E + 12 * p.k + 13)
+            # H/g evaluation PS (363 + 48 k) + PX (2 E + 12 k + 13); cost-only 122 PS + 13 PX
+            flops += (px * S * 122 + px * 13) if self.cost_only else (px * S * (363 + 48 * p.k) + px * (2 * E + 12 * p.k + 13))
         sh = None if self.se is None else (self.mode.replace("frame_blocks", "frames"), self.rank, self.world)
         nbytes = self.wl.algorithmic_bytes(self.probs, sh)
         self.nbytes_upper = self.wl.algorithmic_bytes(self.probs, sh, upper=True)  # (== nbytes unless the pairs carry a distinct-tap count)
@@ -623,7 +637,10 @@ def main():
         return loc, red
 
     run = Runner(M, ctx, args.workload, dev, rank, world, use_dist, 2 if args.packed_keyframes else int(args.grad_fp16), shard_mode=args.shard,
-                 coll=coll, pair_collective=args.collective, pairs=args.batch_pairs if args.batch_pairs != 512 else None)
+                 coll=coll, pair_collective=args.collective, pairs=args.batch_pairs if args.batch_pairs != 512 else None,
+                 cost_only=args.cost_only, k=args.spline_k)
+    # key of the committed counter extracts: the workload plus the variant of the evaluation
+    wkey = args.workload + ("_k2" if args.spline_k == 2 else "") + ("_cost_only" if args.cost_only else "")
 
     for _ in range(args.warmup):
         run.step()
@@ -680,13 +697,13 @@ def main():
     out = None
     if rank == 0:
         flops, nbytes, ach_tf, ach_gbs = run.figures(counts, k_ms)
-        traffic, traffic_src = measured_hbm_traffic(args.workload, kernel)
-        exe, exe_src = executed_fp64_flops(args.workload, kernel)
-        sha_now, stale = stale_flags([("hbm_counters", args.workload), ("pmc_fp64", args.workload), ("pmc_sq", args.workload)])
+        traffic, traffic_src = measured_hbm_traffic(wkey, kernel)
+        exe, exe_src = executed_fp64_flops(wkey, kernel)
+        sha_now, stale = stale_flags([("hbm_counters", wkey), ("pmc_fp64", wkey), ("pmc_sq", wkey)])
         per_step = [r / args.steps * 1e3 for r in regions]
         out = {
-            "metric": "Mpixel-samples/s per GN iteration (640x480, 4-lvl pyr, 8 blur samples)" if args.workload.startswith("c2")
-                      else "Mpixel-samples/s per GN iteration (%s)" % args.workload,
+            "metric": "Mpixel-samples/s per GN iteration (640x480, 4-lvl pyr, 8 blur samples)" if wkey.startswith("c2") and wkey == args.workload
+                      else "Mpixel-samples/s per GN iteration (%s)" % wkey,
             "value": round(ps_all * args.steps / elapsed / 1e6, 3), "unit": "Mpixel-samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True, "scaling": "strong" if (run.se is not None and run.mode in ("keypoints", "pairs")) else "weak",
@@ -697,11 +714,17 @@ def main():
                        "parallelism": ("workload sharded by %s over %d rank(s): evaluation -> %sONE %s of %d doubles per step"
                                        % (run.mode, world, "device merge -> " if run.mode == "frames" else "", collective_name(run), run.se.count))
                        if run.se is not None else "1 GPU"},
-            "roofline": {"bound": "fp64", "achieved": round(ach_tf, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach_tf / FP64_PEAK_TFLOPS, 5),
+            "roofline": {"bound": "fp64",
                          "frac_executed": round(exe / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5) if exe and k_ms > 0 else None,
+                         "frac_executed_label": "UTILISATION of the FP64 pipe: the FP64 flops the kernel actually issues (SQ counters of the committed "
+                                                "extract) / kernel duration / peak; bounded by 1 -- the figure to judge the kernel by",
                          "executed_fp64_flops_per_launch": exe, "executed_source": exe_src,
-                         "issue_busy_frac": issue_busy_fraction(args.workload, kernel, k_ms),
+                         "achieved": round(ach_tf, 4), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach_tf / FP64_PEAK_TFLOPS, 5),
+                         "frac_label": "REFERENCE-FLOP EQUIVALENT (the contract's achieved / peak on SURVEY.md 8(d)'s algorithmic count, i.e. the "
+                                       "reference's arithmetic as written, which the kernel undercuts by CSE): NOT a utilisation, can exceed 1 "
+                                       "(1.37-1.41 on configs[4])",
+                         "issue_busy_frac": issue_busy_fraction(wkey, kernel, k_ms),
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_source_sha": sha_now, "counter_extracts_stale": stale, "stale": bool(any(stale.values())) if stale else None,
                          "kernel": kernel, "kernel_ms": round(k_ms, 6), "launches_timed": int(nlaunch[0]),
@@ -868,10 +891,15 @@ def main():
         # named extras: the keyframe in the two lossless compact formats (mbavo_problem.grad_fp16 = 1: half pairs, 2: packed words)
         todo += [("c3_batch64_shared", False, False), ("c4_batch512", 1, False), ("c4_batch512", 2, False), ("c3_batch64", 2, False),
                  ("c2_dense", 2, False)]
-        for name, half, seq_levels in todo:
-            key = name + ("_packed" if int(half) == 2 else "_fp16grad" if half else "") + ("_sequential" if seq_levels else "")
+        todo = [t + (False, 4) for t in todo]
+        # the cost-only evaluation (half of every LM iteration) and the reference's default spline degree
+        todo += [("c2_dense", False, False, True, 4), ("c3_batch64", False, False, True, 4), ("c2_semidense", False, False, True, 4),
+                 ("c2_dense", False, False, False, 2), ("c2_semidense", False, False, False, 2), ("c2_dense", False, False, True, 2)]
+        for name, half, seq_levels, cost_only, kdeg in todo:
+            key = name + ("_k2" if kdeg == 2 else "") + ("_packed" if int(half) == 2 else "_fp16grad" if half else "") + \
+                ("_sequential" if seq_levels else "") + ("_cost_only" if cost_only else "")
             try:
-                r = Runner(M, ctx, name, dev, 0, 1, False, half, sequential=seq_levels)
+                r = Runner(M, ctx, name, dev, 0, 1, False, half, sequential=seq_levels, cost_only=cost_only, k=kdeg)
                 if seq_levels:
                     # the step is timed WITHOUT events (an event pair costs a launch gap), the levels' kernels in a second run with
                     # an event pair on EVERY launch: kernel_ms = the sum over the levels' dominant kernels (mean per launch x levels)
@@ -882,8 +910,8 @@ def main():
                     n, dt, kms, kname = bounded_run(M, ctx, r)
                 c = r.local_counts()
                 fl, nb, tf, gbs = r.figures(c, kms)
-                ex, _ = executed_fp64_flops(name, kname)
-                cfgs[key] = {"workload": r.desc, "value": round(sum(px * S for px, S, _ in c) * n / dt / 1e6, 3),
+                ex, _ = executed_fp64_flops(name + ("_k2" if kdeg == 2 else "") + ("_cost_only" if cost_only else ""), kname)
+                cfgs[key] = {"workload": r.desc, "flops_alg": "122 PS + 13 PX (cost-only)" if cost_only else "PS (363 + 48 k) + PX (2 E + 12 k + 13)", "value": round(sum(px * S for px, S, _ in c) * n / dt / 1e6, 3),
                              "unit": "Mpixel-samples/s", "steps": n, "ms_per_step": round(dt / n * 1e3, 5), "kernel": kname,
                              "kernel_ms": round(kms, 6), "frac": round(tf / FP64_PEAK_TFLOPS, 5),
                              "frac_executed": round(ex / (kms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5) if ex and kms > 0 and not seq_levels else None,
@@ -910,6 +938,10 @@ def main():
             cfgs["lm_batch64"] = lm_bench.bench_line(M, ctx, dev)
         except Exception as e:
             cfgs["lm_batch64"] = {"error": repr(e)}
+        try:  # the reference's default degree through the same loop
+            cfgs["lm_batch64_k2"] = lm_bench.bench_line_k2(M, ctx, dev)
+        except Exception as e:
+            cfgs["lm_batch64_k2"] = {"error": repr(e)}
         try:  # configs[3]'s pairs through the same loop (device side only)
             cfgs["lm_batch512"] = lm_bench.bench_line(M, ctx, dev, B=512, host_pairs=0)
         except Exception as e:

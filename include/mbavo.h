@@ -89,6 +89,17 @@ int mbavo_packed_len(int spline_deg_k);                 /* E = (6k+1)(6k+2)/2 */
 int mbavo_eval_batch(mbavo_ctx *ctx, int B, const mbavo_problem *h_problems, int spline_deg_k,
                      int with_hessian, double *d_frame_blocks, double *d_patch_cost, double *d_valid);
 
+/* The same evaluation ENDING IN THE REFERENCE'S UNIT: evaluate_cost_hessian_gradient with H / g outputs
+ * (spline_update_step.cpp:97-241) ends in merge_hessian_gradient_cost (:232-239, merge_hessian_gradient_cost.cpp:39-86),
+ * i.e. in [cost | g (6N) | H (6N x 6N, column-major, both triangles)] -- mbavo_eval_batch alone leaves the PACKED per-frame
+ * blocks.  d_systems receives mbavo_system_len(N_b) doubles per problem, back to back in problem order (the layout of
+ * mbavo_merge_device), d_frame_blocks the packed blocks as before.  Where every problem has one frame and N == k control
+ * knots (start index 0: the scatter is a plain unpack) the finalize step stores the system itself -- no merge launch, the
+ * evaluation costs what mbavo_eval_batch costs; otherwise mbavo_merge_device's kernel runs behind it (h_start_idx required).
+ * Asynchronous on the context's stream. */
+int mbavo_eval_batch_merged(mbavo_ctx *ctx, int B, const mbavo_problem *h_problems, int spline_deg_k,
+                            double *d_frame_blocks, double *d_systems, double *d_patch_cost, double *d_valid);
+
 /* synchronous single problem, host outputs == evaluate_cost_hessian_gradient
  * (spline_update_step.h:70-87): h_H is the 6N x 6N column-major system, h_g 6N;
  * pass NULL, NULL for cost-only.  d_patch_blocks (F*K*E, may be NULL) receives slot 0

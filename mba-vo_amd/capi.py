@@ -111,7 +111,7 @@ SYMBOLS = [
     "mbavo_profile", "mbavo_profile_read", "mbavo_version", "mbavo_abi_version",
     "mbavo_gradient_magnitude_u8", "mbavo_detect_semidense", "mbavo_se3_exp", "mbavo_se3_log", "mbavo_transform_mul",
     "mbavo_transform_inverse", "mbavo_spline_transform_to", "mbavo_vo_create", "mbavo_vo_destroy", "mbavo_vo_set_spline",
-    "mbavo_vo_get_spline", "mbavo_vo_last_trace", "mbavo_vo_get_state", "mbavo_vo_set_state", "mbavo_vo_set_keyframe", "mbavo_vo_num_keypoints", "mbavo_vo_get_keypoints", "mbavo_vo_track_frame", "mbavo_lm_batch",
+    "mbavo_vo_get_spline", "mbavo_eval_batch_merged", "mbavo_vo_last_trace", "mbavo_vo_get_state", "mbavo_vo_set_state", "mbavo_vo_set_keyframe", "mbavo_vo_num_keypoints", "mbavo_vo_get_keypoints", "mbavo_vo_track_frame", "mbavo_lm_batch",
     "mbavo_shard_keypoints", "mbavo_shard_frames", "mbavo_system_len", "mbavo_merge_device", "mbavo_comm_unique_id",
     "mbavo_comm_init", "mbavo_comm_ranks", "mbavo_comm_destroy", "mbavo_last_kernel", "mbavo_timing_report",
 ]
@@ -160,6 +160,7 @@ def load():
     L.mbavo_set_stream.argtypes = [vp, vp]
     L.mbavo_packed_len.argtypes = [C.c_int]
     L.mbavo_eval_batch.argtypes = [vp, C.c_int, C.POINTER(Problem), C.c_int, C.c_int, vp, vp, vp]
+    L.mbavo_eval_batch_merged.argtypes = [vp, C.c_int, C.POINTER(Problem), C.c_int, vp, vp, vp, vp]
     L.mbavo_eval.argtypes = [vp, C.POINTER(Problem), C.c_int, c_dp, c_dp, c_dp, vp]
     L.mbavo_compute_virtual_camera_poses.argtypes = [C.c_int, C.c_int, vp, vp, C.c_int, C.c_double, C.c_double,
                                                      vp, vp, vp, vp, vp]

@@ -168,6 +168,16 @@ extern "C"
         return ctx->engine->evaluate(B, probs, k, with_hessian != 0, d_frame_blocks, d_patch_cost, d_valid, nullptr);
     }
 
+    int mbavo_eval_batch_merged(mbavo_ctx *ctx, int B, const mbavo_problem *probs, int k, double *d_frame_blocks, double *d_systems,
+                                double *d_patch_cost, double *d_valid)
+    {
+        if (!ctx || !d_systems) return MBAVO_E_ARG;
+        ctx->engine->set_merge_target(d_systems);
+        const int rc = ctx->engine->evaluate(B, probs, k, true, d_frame_blocks, d_patch_cost, d_valid, nullptr);
+        ctx->engine->set_merge_target(nullptr); // (an evaluate() that failed before it took the target must not leave it armed)
+        return rc;
+    }
+
     int mbavo_eval(mbavo_ctx *ctx, const mbavo_problem *p, int k, double *h_cost, double *h_H, double *h_g,
                    double *d_patch_blocks)
     {

@@ -133,6 +133,12 @@ namespace mbavo
         Engine *companion_if_any() const { return companion_; }
         int *device_status() const { return (int *)d_status_; }
         void set_defer_finalize(bool on) { defer_finalize_ = on; }
+        // The NEXT evaluate() with H/g also leaves every problem's merged system [cost | g (6N) | H (6N x 6N, column-major)]
+        // (merge_hessian_gradient_cost.cpp:39-86; mbavo_system_len(N) doubles each, back to back) in d_systems: written by the
+        // finalize step itself where every problem has one frame and N == k (no extra launch), by the merge kernel behind it
+        // otherwise.  One-shot: cleared by that evaluate().
+        void set_merge_target(double *d_systems) { merge_target_ = d_systems; }
+        bool last_merge_fused() const { return merge_fused_last_; }
         bool finalize_deferred() const { return deferred_last_; }
         const double *device_partials() const { return (const double *)d_partials_; }
         const int *device_bf_tile_begin() const { return (const int *)d_bf_tile_begin_; }
@@ -200,6 +206,8 @@ namespace mbavo
         int sp_logs_ = 0; // > 0: the cached layout is tiled for the sample-parallel kernel with S = 2^sp_logs_
         bool flat_finalize_ = false; // many (problem, frame) slots of <= 4 tiles each: k_finalize_flat
         bool defer_finalize_ = false, deferred_last_ = false; // set_defer_finalize / what the last evaluate() did
+        double *merge_target_ = nullptr;                       // set_merge_target
+        bool merge_fused_last_ = false;
         bool external_poses_ = false;                          // set_external_poses
         void *external_table_ = nullptr;                       // ... reading another engine's table
         long long tile_target_ = 0;                            // set_tile_target

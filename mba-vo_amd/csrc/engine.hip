@@ -861,8 +861,28 @@ namespace mbavo
 #else
 #define MBAVO_STAMP(i) do { } while (0)
 #endif
+    // merge_hessian_gradient_cost (merge_hessian_gradient_cost.cpp:39-86) folded into the finalize step for lists of problems
+    // with ONE frame and N == k control knots (start index 0: the local -> global index map of :52-62 is the identity): the
+    // thread that holds entry e of the frame block also stores it into the problem's system [cost | g (6k) | H (6k x 6k,
+    // column-major, both triangles)] -- the reference's unit ends there (spline_update_step.cpp:232-239), no merge launch.
+    template <int KD>
+    __device__ __forceinline__ void store_system_entry(double *__restrict__ sys, int e, double v)
+    {
+        constexpr int M6 = 6 * KD, ND = M6 + 1, E = Pack<KD>::E;
+        if (e == E) sys[0] = v; // (the partial slot of the cost)
+        else if (e <= M6) sys[e] = v;
+        else
+        {
+            int r, c;
+            tri_decode(e - ND, M6, r, c);
+            sys[1 + M6 + c * M6 + r] = v;
+            if (r != c) sys[1 + M6 + r * M6 + c] = v;
+        }
+    }
+
     struct OneArgs
     {
+        double *systems;                         // merged outputs (store_system_entry), or null
         const int *bf_tile_begin;                // [nBF + 1]
         int *tickets;                            // [nBF], zero between launches (the last workgroup of a slot resets it)
         double *frame_blocks, *valid_out;        // outputs of the finalize step
@@ -942,6 +962,8 @@ namespace mbavo
             if (e == 0) { if (oa.valid_out) oa.valid_out[bf] = acc; }
             else if (e == E) oa.frame_blocks[(size_t)bf * E] = acc; // cost: patch costs are already scaled
             else oa.frame_blocks[(size_t)bf * E + e] = acc * inv; // (the caller's copy: the scale may live in host memory)
+            if (e != 0 && oa.systems != nullptr) // (one frame per problem: slot bf IS problem bf)
+                store_system_entry<KD>(oa.systems + (size_t)bf * (1 + 6 * KD + 36 * KD * KD), e, e == E ? acc : acc * inv);
         }
         }
         // the frame block (pinned host memory) must land before the completion word does: every wave's stores are performed
@@ -1365,7 +1387,7 @@ namespace mbavo
                                                       const int *__restrict__ bf_tile_begin,
                                                       const double *__restrict__ partials,
                                                       double *__restrict__ frame_blocks,
-                                                      double *__restrict__ valid_out)
+                                                      double *__restrict__ valid_out, double *__restrict__ systems)
     {
         constexpr int E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
         __shared__ double sm[16][17];
@@ -1401,6 +1423,9 @@ namespace mbavo
             if (e == 0) { if (valid_out) valid_out[bf] = v; }
             else if (e == E) frame_blocks[(size_t)bf * E] = v; // cost: patch costs are already scaled
             else if (WITH_J) frame_blocks[(size_t)bf * E + e] = v * (pd.inv_ptr != nullptr ? *pd.inv_ptr : pd.inv_num_residuals);
+            if (WITH_J && e != 0 && systems != nullptr)
+                store_system_entry<KD>(systems + (size_t)bf_prob[bf] * (1 + 6 * KD + 36 * KD * KD), e,
+                                       e == E ? v : v * (pd.inv_ptr != nullptr ? *pd.inv_ptr : pd.inv_num_residuals));
         }
     }
 
@@ -1413,7 +1438,7 @@ namespace mbavo
                                                            const int *__restrict__ bf_tile_begin,
                                                            const double *__restrict__ partials,
                                                            double *__restrict__ frame_blocks,
-                                                           double *__restrict__ valid_out)
+                                                           double *__restrict__ valid_out, double *__restrict__ systems)
     {
         constexpr int E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
         const int bf = blockIdx.x, e = threadIdx.x; // partial slot 0..E
@@ -1429,6 +1454,9 @@ namespace mbavo
         if (e == 0) { if (valid_out) valid_out[bf] = v; }
         else if (e == E) frame_blocks[(size_t)bf * E] = v; // cost: patch costs are already scaled
         else frame_blocks[(size_t)bf * E + e] = v * (pd.inv_ptr != nullptr ? *pd.inv_ptr : pd.inv_num_residuals);
+        if (WITH_J && e != 0 && systems != nullptr)
+            store_system_entry<KD>(systems + (size_t)bf_prob[bf] * (1 + 6 * KD + 36 * KD * KD), e,
+                                   e == E ? v : v * (pd.inv_ptr != nullptr ? *pd.inv_ptr : pd.inv_num_residuals));
     }
 
     // ------------------------------------------------------------------ host driver
@@ -1845,10 +1873,10 @@ namespace mbavo
         if (eng->take_deferral(flat_finalize)) {} // the caller's kernels sum the tile partials (engine.h: set_defer_finalize)
         else if (flat_finalize)
             hipLaunchKernelGGL((k_finalize_flat<KD, WITH_J>), dim3(nbf), dim3(KD == 2 ? 128 : 384), 0, st, descs, bf_prob, bf_tile_begin,
-                               partials, frame_blocks, valid);
+                               partials, frame_blocks, valid, oa.systems);
         else
             hipLaunchKernelGGL((k_finalize<KD, WITH_J>), dim3(nbf, (Pack<KD>::E + 1 + 15) / 16), dim3(256), 0, st, descs, bf_prob,
-                               bf_tile_begin, partials, frame_blocks, valid);
+                               bf_tile_begin, partials, frame_blocks, valid, oa.systems);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -1888,6 +1916,14 @@ namespace mbavo
         const bool one = sp_logs_ > 0 && sp_one_fits(kdeg, sp_logs_) && !empty_slots_ && env_int("MBAVO_ONE", 1) != 0;
         OneArgs oa;
         memset(&oa, 0, sizeof(oa));
+        // merged systems asked for (set_merge_target): by the finalize step itself when the merge is a plain unpack
+        double *const merge_to = with_hessian ? merge_target_ : nullptr;
+        merge_target_ = nullptr;
+        bool merge_fused = merge_to != nullptr && !defer_finalize_;
+        for (const ProblemDesc &pd : h_descs_)
+            if (pd.F != 1 || pd.N != kdeg) merge_fused = false;
+        merge_fused_last_ = merge_fused;
+        oa.systems = merge_fused ? merge_to : nullptr;
         flag_pending_ = false;
         deferred_last_ = false; // (launch_all sets it when it leaves the finalize to the caller)
         if (one)
@@ -1924,6 +1960,11 @@ namespace mbavo
 #undef MBAVO_LAUNCH
         last_kernel_id_[0] = kdeg; last_kernel_id_[1] = with_hessian; last_kernel_id_[2] = half_grad; last_kernel_id_[3] = sp_logs_;
         last_kernel_id_[4] = one; last_kernel_id_[5] = fused_pose_ok && sp_logs_ == 0 && !one && ntiles > 0;
+        if (rc == 0 && merge_to != nullptr && !merge_fused)
+        { // several frames per problem or more knots than the spline degree: the gather kernel (multi_gpu.hip) behind the finalize
+            if (deferred_last_) return MBAVO_E_ARG; // (no frame blocks were written)
+            rc = merge_device(B, probs, kdeg, d_frame_blocks, merge_to);
+        }
         return rc;
     }
 

@@ -307,6 +307,12 @@ class ShardedEvaluation:
 
     def evaluate_local(self, with_hessian=True):
         lib, ctx = self.ctx.lib, self.ctx
+        if self.mode == "frames" and with_hessian and self.n_live == self.B:
+            # every problem has frames on this rank: evaluation and merge in one call (the finalize step stores the systems itself
+            # where the shard is one frame on N == k knots -- bench.py's joint workload --, the merge kernel runs behind it otherwise)
+            capi.check(lib.mbavo_eval_batch_merged(ctx.handle, self.B, self.live, self.k, self.frame_blocks.data_ptr(), self.systems.data_ptr(),
+                                                   None, self.valid.data_ptr()), "mbavo_eval_batch_merged")
+            return
         if self.n_live:
             capi.check(lib.mbavo_eval_batch(ctx.handle, self.n_live, self.live, self.k, 1 if with_hessian else 0,
                                             self.frame_blocks.data_ptr(), None, self.valid.data_ptr()), "mbavo_eval_batch")

@@ -340,12 +340,8 @@ class RenderedPairBatch:
                     [h["cap"]], [h["exp"]], h["t0"], 0.5, h["kt"], h["kR"], h["huber"],
                     grad=h["grad"].float().cpu().numpy().reshape(H, W, 2))
 
-    def step(self, ctx, with_hessian=True, out=None):
-        fb = self.frame_blocks if out is None else out
-        rc = ctx.lib.mbavo_eval_batch(ctx.handle, self.B, self.array, self.k, 1 if with_hessian else 0,
-                                      fb.data_ptr(), None, self.valid.data_ptr())
-        if rc != 0:
-            raise RuntimeError("mbavo_eval_batch failed: %d" % rc)
+    def step(self, ctx, with_hessian=True, out=None, merged=True):
+        _step(self, ctx, with_hessian, out, merged)
 
 
 class DeviceWorkload:
@@ -407,14 +403,29 @@ class DeviceWorkload:
         """(knots_t, knots_R) device tensors of problem b (updated in place by mbavo_lm_batch)."""
         return self._knots[b]
 
-    def step(self, ctx, with_hessian=True, out=None):
+    def step(self, ctx, with_hessian=True, out=None, merged=True):
         """One GN-iteration evaluation of every problem (asynchronous on the context's stream); `out` replaces the
         default output tensor (double buffering under an asynchronous all-reduce)."""
-        fb = self.frame_blocks if out is None else out
-        rc = ctx.lib.mbavo_eval_batch(ctx.handle, self.B, self.array, self.k, 1 if with_hessian else 0,
-                                      fb.data_ptr(), None, self.valid.data_ptr())
-        if rc != 0:
-            raise RuntimeError("mbavo_eval_batch failed: %d" % rc)
+        _step(self, ctx, with_hessian, out, merged)
+
+
+def _step(w, ctx, with_hessian, out, merged):
+    """One pass of the hot path over the workload's problem list.  With H / g the pass ends in the reference's unit
+    (evaluate_cost_hessian_gradient, spline_update_step.cpp:97-241): every problem's merged system [cost | g (6N) | H (6N x 6N)]
+    in `w.systems` on the device (mbavo_eval_batch_merged: the merge of :232-239 is part of the finalize step where every
+    problem has one frame and N == k, a kernel behind it otherwise) next to the packed frame blocks; merged=False keeps
+    mbavo_eval_batch alone (packed blocks only: what the batched LM and the multi-GPU collectives consume)."""
+    import torch
+    fb = w.frame_blocks if out is None else out
+    if with_hessian and merged:
+        if getattr(w, "systems", None) is None:
+            w.systems = torch.zeros(sum(1 + 6 * int(w.array[b].N) + 36 * int(w.array[b].N) ** 2 for b in range(w.B)), dtype=torch.float64,
+                                    device=fb.device)
+        rc = ctx.lib.mbavo_eval_batch_merged(ctx.handle, w.B, w.array, w.k, fb.data_ptr(), w.systems.data_ptr(), None, w.valid.data_ptr())
+    else:
+        rc = ctx.lib.mbavo_eval_batch(ctx.handle, w.B, w.array, w.k, 1 if with_hessian else 0, fb.data_ptr(), None, w.valid.data_ptr())
+    if rc != 0:
+        raise RuntimeError("mbavo_eval_batch%s failed: %d" % ("_merged" if with_hessian and merged else "", rc))
 
 
 def algorithmic_flops(probs, valid_pixels=None):

@@ -337,3 +337,64 @@ def test_patch_centre_near_integer_takes_reference_order(orc, mbavo, gpu_ctx):
         assert np.array_equal(valid, _oracle_valid_counts(orc, sc))
         assert _rel(fb, ro["frame_blocks"]) < RTOL
         assert _rel(pc, ro["patch_blocks"][:, :, 0].ravel()) < RTOL
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# a8 inside the evaluation: mbavo_eval_batch_merged ends in the reference's unit
+# [cost | g | H] per problem (spline_update_step.cpp:232-239 -> merge_hessian_gradient_cost.cpp:39-86) -- stored by the finalize
+# step itself for lists of one-frame problems on N == k knots, by the merge kernel behind it otherwise.
+MERGED_CASES = {
+    # finalize KERNEL (one dense problem, many tiles), F = 1, N == k: fused
+    "dense_k4": ([dict(H=120, W=160, S=4, F=1, k=4, P=1, kp="dense", margin=2)], 4),
+    "dense_k2": ([dict(H=120, W=160, S=4, F=1, k=2, P=1, kp="dense", margin=2)], 2),
+    # sample-parallel single launch (ticket epilogue), F = 1, N == k: fused
+    "semidense_one_launch_k4": ([dict(S=8, F=1, k=4, P=8, K=145)], 4),
+    "semidense_one_launch_k2": ([dict(S=8, F=1, k=2, P=8, K=145)], 2),
+    # many slots of few tiles: the flat finalize kernel, fused
+    "batch_flat_k4": ([dict(H=96, W=128, S=8, F=1, k=4, P=8, K=90 + 3 * i, seed=i) for i in range(70)], 4),
+    # not a plain unpack: two frames, or more knots than the degree -> the gather kernel behind the finalize
+    "two_frames_k4": ([dict(S=8, F=2, k=4, P=8, K=145)], 4),
+    "six_knots_k4": ([dict(H=135, W=240, S=16, F=2, k=4, P=1, kp="dense", margin=2, N=6)], 4),
+    "mixed_batch_k2": ([dict(H=96, W=128, S=4, F=1 + (i % 2), k=2, P=8, K=60, seed=i) for i in range(5)], 2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MERGED_CASES))
+def test_eval_batch_merged_equals_eval_then_merge(mbavo, gpu_ctx, name):
+    """Bit-identical to mbavo_eval_batch followed by mbavo_merge_device (itself bit-exact against the reference-executed merge
+    fixture, tests/test_golden_blocks.py), packed frame blocks unchanged, every system symmetric; the single-problem host path
+    (mbavo_eval: host merge) gives the same H, g, cost."""
+    import torch
+    specs, k = MERGED_CASES[name]
+    scs = [scenes.Scene(**s) for s in specs]
+    ds = [scenes.DeviceScene(sc) for sc in scs]
+    B, E = len(ds), synth.packed_len(k)
+    arr = (mbavo.capi.Problem * B)(*[d.problem() for d in ds])
+    nbf = sum(sc.F for sc in scs)
+    lens = [1 + 6 * sc.N + 36 * sc.N * sc.N for sc in scs]
+    fb_a = torch.zeros(nbf * E, dtype=torch.float64, device="cuda:0")
+    fb_b = torch.full((nbf * E,), -3.0, dtype=torch.float64, device="cuda:0")
+    sys_a = torch.full((sum(lens),), -1.0, dtype=torch.float64, device="cuda:0")
+    sys_b = torch.full((sum(lens),), -2.0, dtype=torch.float64, device="cuda:0")
+    lib, h = gpu_ctx.lib, gpu_ctx.handle
+    assert lib.mbavo_eval_batch(h, B, arr, k, 1, fb_a.data_ptr(), None, None) == 0
+    assert lib.mbavo_merge_device(h, B, arr, k, fb_a.data_ptr(), sys_a.data_ptr()) == 0
+    assert lib.mbavo_eval_batch_merged(h, B, arr, k, fb_b.data_ptr(), sys_b.data_ptr(), None, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(fb_a, fb_b)
+    assert torch.equal(sys_a, sys_b)
+    # a plain evaluation afterwards does not write systems (the target is one-shot)
+    sys_b.fill_(-7.0)
+    assert lib.mbavo_eval_batch(h, B, arr, k, 1, fb_b.data_ptr(), None, None) == 0
+    torch.cuda.synchronize()
+    assert bool((sys_b == -7.0).all())
+    off = 0
+    sa = sys_a.cpu().numpy()
+    for sc, d, n_sys in zip(scs, ds, lens):
+        n = 6 * sc.N
+        Hm = sa[off + 1 + n:off + n_sys].reshape(n, n)
+        assert np.array_equal(Hm, Hm.T)
+        r = scenes.gpu_eval(gpu_ctx, d)
+        assert abs(r["cost"] - sa[off]) <= 1e-12 * abs(r["cost"]) and _rel(sa[off + 1:off + 1 + n], r["g"]) < 1e-12 and _rel(Hm, r["H"]) < 1e-12
+        off += n_sys
+    assert lib.mbavo_eval_batch_merged(h, B, arr, k, fb_b.data_ptr(), None, None, None) == -1

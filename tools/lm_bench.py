@@ -11,11 +11,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 
-def device_lm(M, ctx, batch, solver, iterations, reps=3, min_dec=0.0):
-    """mbavo_lm_batch on a RenderedPairBatch: best of `reps` runs from the same initial knots."""
+def device_lm(M, ctx, batch, solver, iterations, reps=3, min_dec=0.0, N=None):
+    """mbavo_lm_batch on a RenderedPairBatch: best of `reps` runs from the same initial knots (N: the first N of a pair's four knots)."""
     import torch
     capi = M.capi
     B = batch.B
+    arr = batch.array
+    if N is not None:
+        arr = (capi.Problem * B)()
+        for b in range(B):
+            C.memmove(C.byref(arr[b]), C.byref(batch.array[b]), C.sizeof(capi.Problem))
+            arr[b].N = N
     o = capi.LmBatchOpts()
     o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = batch.k, iterations, 5
     o.solver_type, o.sync_every = solver, int(os.environ.get("MBAVO_LM_SYNC_EVERY", "0"))
@@ -26,7 +32,7 @@ def device_lm(M, ctx, batch, solver, iterations, reps=3, min_dec=0.0):
         batch.reset_knots()
         torch.cuda.synchronize()
         t = time.perf_counter()
-        rc = ctx.lib.mbavo_lm_batch(ctx.handle, B, batch.array, C.byref(o), res, None, 0)
+        rc = ctx.lib.mbavo_lm_batch(ctx.handle, B, arr, C.byref(o), res, None, 0)
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t)
         assert rc == 0, rc
@@ -69,6 +75,18 @@ def host_lm(M, ctx, batch, solver, iterations, pairs):
         it_host += max(r.iter for r in trace[:n])
     return {"pairs_timed": pairs, "ms_total": round(1e3 * t_host, 4), "lm_iterations": it_host,
             "us_per_pair_iteration": round(1e6 * t_host / max(it_host, 1), 3)}
+
+
+def bench_line_k2(M, ctx, dev, B=64, iterations=10):
+    """bench.py `configs.lm_batch64_k2`: the same pairs aligned with the reference's DEFAULT spline degree (k = 2 on the pair's
+    first two knots, blur_aware_direct_tracker.h:50), both solver types."""
+    from mba_vo_amd import workloads
+    batch = workloads.RenderedPairBatch(ctx, B, S=8, k=2, device=dev, seed=1)
+    out = {"workload": "%d pairs of the rendered blurred sequence (configs[2] data), k = 2 on N = 2 control knots (12 x 12 systems), device-side LM, "
+                       "%d iterations per pair, no early exit" % (B, iterations), "B": B, "max_iterations": iterations}
+    for solver, name in ((0, "svd"), (1, "ldlt")):
+        out["device_" + name] = device_lm(M, ctx, batch, solver, iterations, N=2)
+    return out
 
 
 def bench_line(M, ctx, dev, B=64, iterations=10, host_pairs=8):
