@@ -63,11 +63,13 @@ def parse():
     ap.add_argument("--workload", default="c2_dense", choices=WORKLOADS)
     ap.add_argument("--shard", default=None, choices=["pairs", "keypoints", "frames", "frame_blocks"],
                     help="N > 1 sharding (default: the workload's own -- frames for a single pair, pairs for a batch of pairs)")
-    ap.add_argument("--comm", default="rccl", choices=["rccl", "gloo"],
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "gloo", "p2p", "p2p-shared"],
                     help="N > 1 only.  rccl: one GPU per rank, the product's collectives on the context's RCCL communicator.  gloo: the "
                          "ranks SHARE the visible GPU(s) (rank r on GPU r %% device_count) and a gloo collective on a pinned host copy "
                          "stands in for RCCL (shard.HostStagedCollective) -- executes every line of the N > 1 path on a one-GPU box "
-                         "except ncclAllReduce / ncclAllGather themselves; its timings are not scaling figures")
+                         "except ncclAllReduce / ncclAllGather themselves; its timings are not scaling figures.  p2p: one GPU per rank, the product's "
+                         "ONE-SHOT collectives over peer-mapped receive regions (csrc/p2p_comm.hip, no RCCL) as the collective of the step.  "
+                         "p2p-shared: the same collectives between ranks that share the visible GPU(s) (gloo only carries the rendezvous)")
     ap.add_argument("--collective", default="allgather", choices=["allgather", "allreduce"],
                     help="pair sharding: ONE in-place all-gather of equal slices (default) or, as BASELINE.json words it, ONE "
                          "all-reduce of a send buffer that is zero outside the rank's slice (twice the bytes on the wire)")
@@ -534,7 +536,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    shared_gpu = args.comm == "gloo"  # the ranks share the visible GPU(s); gloo stands in for RCCL (see --comm)
+    shared_gpu = args.comm in ("gloo", "p2p-shared")  # the ranks share the visible GPU(s); gloo is the process group (see --comm)
+    use_p2p = args.comm in ("p2p", "p2p-shared")
     if shared_gpu:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -555,7 +558,10 @@ def main():
     stream = torch.cuda.current_stream()
     ctx = M.capi.Context(local_rank, stream=stream.cuda_stream)
     rccl_ranks, coll = 0, None
-    if use_dist and shared_gpu:
+    if use_dist and use_p2p:
+        coll = shard.P2PCollective(ctx, rank, world, max_doubles=1 << 18)
+        rccl_ranks = world
+    elif use_dist and shared_gpu:
         coll = shard.HostStagedCollective(ctx, rank, world)
     elif use_dist:
         rccl_ranks = shard.comm_init(ctx, rank, world, shard.torch_bcast(dev))
@@ -613,6 +619,9 @@ def main():
     def collective_name(r):
         call = ("mbavo_allgather_blocks" if r.se.pair_collective == "allgather" else "mbavo_allreduce_blocks_to") if r.mode == "pairs" \
             else ("mbavo_allreduce_blocks_to" if r.mode == "frame_blocks" else "mbavo_allreduce_blocks")
+        if use_p2p:
+            return call.replace("mbavo_allgather_blocks", "mbavo_allgather_blocks_p2p").replace("mbavo_allreduce_blocks_to", "copy + mbavo_allreduce_blocks_p2p") \
+                .replace("mbavo_allreduce_blocks", "mbavo_allreduce_blocks_p2p") + " [one-shot over peer-mapped regions, no RCCL%s]" % (": ranks share one GPU" if shared_gpu else "")
         return call + (" [RCCL]" if not shared_gpu else " -> STAND-IN: gloo on a pinned host copy (ranks share one GPU)")
 
     def comm_profile(run, n=40):
@@ -767,7 +776,8 @@ def main():
                               "evaluation; never `value`)" % int(run.dw.frame_blocks.numel())
         if use_dist:
             out["rccl_ranks"] = rccl_ranks
-            out["comm"] = "rccl" if not shared_gpu else "gloo stand-in, %d ranks on %d GPU(s): NOT a scaling measurement" % (world, torch.cuda.device_count())
+            out["comm"] = ("p2p one-shot collectives" + (", %d ranks on %d GPU(s): NOT a scaling measurement" % (world, torch.cuda.device_count()) if shared_gpu else "")) if use_p2p \
+                else "rccl" if not shared_gpu else "gloo stand-in, %d ranks on %d GPU(s): NOT a scaling measurement" % (world, torch.cuda.device_count())
             out["reduction_check"] = reduction
             out["per_rank"] = {"kernel_ms": [round(v, 6) for v in k_ms_ranks],
                                "local_evaluation_ms": [round(v, 6) for v in comm_ms[0]],
@@ -776,6 +786,31 @@ def main():
                                        "local_evaluation_ms / collective_ms: event pairs around the rank's evaluation (+ merge) "
                                        "and around the collective in a separate pass of 40 steps -- the collective's figure "
                                        "includes waiting for the slowest rank"}
+    # Both collectives' timings in the N > 1 line: with RCCL as the step's collective, the SAME sharded
+    # evaluation once more through the one-shot p2p collectives -- per-rank duration of the collective alone and the reduction check
+    if use_dist and not use_p2p and not shared_gpu and world > 1 and os.environ.get("MBAVO_BENCH_P2P", "1") != "0":
+        p2p_line = None
+        try:
+            c2 = shard.P2PCollective(ctx, rank, world, max_doubles=max(int(run.se.count), 1 << 12))
+            r2 = Runner(M, ctx, args.workload, dev, rank, world, True, 2 if args.packed_keyframes else int(args.grad_fp16), shard_mode=args.shard,
+                        coll=c2, pair_collective=args.collective, pairs=args.batch_pairs if args.batch_pairs != 512 else None)
+            use_p2p = True  # (collective_name / reduction_check label what they describe)
+            loc2, red2 = comm_profile(r2)
+            chk2 = reduction_check(r2)
+            n2, dt2, _, _ = bounded_run(M, ctx, r2, min_steps=60, sync=sync)
+            dt2 = max_over_ranks(dt2)
+            lr2, rr2 = per_rank(loc2), per_rank(red2)
+            use_p2p = False
+            p2p_line = {"collective": chk2["collective"], "ms_per_step": round(dt2 / n2 * 1e3, 5), "steps": n2,
+                        "per_rank": {"local_evaluation_ms": [round(v, 6) for v in lr2], "collective_ms": [round(v, 6) for v in rr2]},
+                        "reduction_check": chk2}
+            c2.close()
+            del r2
+        except Exception as e:
+            use_p2p = False
+            p2p_line = {"error": repr(e)}
+        if rank == 0:
+            out["comm_profile_p2p"] = p2p_line
     fb_gpu = None
     if rank == 0 and world == 1 and run.se is None:
         run.step()
@@ -831,7 +866,7 @@ def main():
                 mine = sh.pairs_of_rank(BT, rank, world)
                 batch = wl.RenderedPairBatch(ctx, BT, S=8, k=4, device=dev, seed=1, pairs=mine, grad_fp16=2)
                 r = Runner.__new__(Runner)
-                r.M, r.ctx, r.name, r.world, r.rank, r.mode, r.sequential, r.wl = M, ctx, "c4_batch512", world, rank, "pairs", False, wl
+                r.M, r.ctx, r.name, r.world, r.rank, r.mode, r.sequential, r.wl, r.cost_only = M, ctx, "c4_batch512", world, rank, "pairs", False, wl, False
                 r.dw, r.probs = batch, [batch.probs[b] for b in mine]
                 r.desc = "%d pairs PER RANK of one rendered blurred sequence of %d (packed keyframes), pair b on rank b %% N" % (NP, BT)
                 r.se = sh.ShardedEvaluation(ctx, batch.array, 4, rank, world, "pairs", dev, collective=coll, frames_per_pair=[1] * BT)

@@ -21,6 +21,7 @@ extern "C" {
 #define MBAVO_E_ARG (-1)      /* bad argument (null pointer, unsupported spline degree, ...) */
 #define MBAVO_E_RANGE (-2)    /* a blur sample fell outside the spline's knot range (SplineFunctor.h:13-19 has no check) */
 #define MBAVO_E_NODEVICE (-3) /* no HIP device: the product has no CPU fallback */
+#define MBAVO_E_TIMEOUT (-4)  /* a bounded device-side wait ran out (a peer rank never arrived; a wedged device) */
 
 typedef struct mbavo_ctx mbavo_ctx;
 
@@ -348,6 +349,29 @@ int mbavo_allreduce_blocks_to(mbavo_ctx *ctx, void *rccl_comm, const double *d_s
 /* In-place ncclAllGather of equal slices: rank r's `count_per_rank` doubles sit at d_blocks + r * count_per_rank on entry,
  * every rank holds all slices on return (half the all-reduce's traffic for disjoint slices; needs equal slice lengths). */
 int mbavo_allgather_blocks(mbavo_ctx *ctx, void *rccl_comm, double *d_blocks, long long count_per_rank);
+
+/* ---- the same two collectives WITHOUT RCCL, sized for this path's messages (19 KB of one joint system ... 1.3 MB of 512 packed
+ * blocks: latency-bound, where a ring pays a hop per rank): every rank maps every peer's receive region (hipIpcGetMemHandle /
+ * hipIpcOpenMemHandle) and a collective is ONE kernel on the context's stream -- store this rank's slice into every peer's
+ * region, raise a per-step flag there, wait for the peers' flags in the own region, then copy the slots out (all-gather) or
+ * add them in rank order (all-reduce: every rank gets the same bits).  Replaces the exchange at the reference's reduction
+ * point, merge_hessian_gradient_cost.cpp:39-86 / spline_update_step.cpp:232-239, like mbavo_allreduce_blocks above.
+ *   mbavo_p2p_create   allocates this rank's region (2 x world slots of max_doubles_per_slot doubles: the largest
+ *                      count_per_rank of an all-gather / count of an all-reduce that will be asked for) and returns its
+ *                      64-byte IPC handle; the caller hands every rank's handle to every rank (all-gather of 64 bytes, as
+ *                      with the RCCL id) and calls
+ *   mbavo_p2p_connect  with the world x 64 bytes in rank order.  At most 16 ranks, all on GPUs of one node (ranks may share a GPU).
+ *   Every rank must issue the same sequence of p2p collectives.  A peer that does not arrive within 20 s ends the kernel:
+ *   mbavo_p2p_status (synchronises the stream) then returns MBAVO_E_TIMEOUT.  All ranks must have finished their last
+ *   collective (a barrier of the caller) before any of them calls mbavo_p2p_destroy / mbavo_destroy. */
+#define MBAVO_P2P_HANDLE_BYTES 64
+int mbavo_p2p_create(mbavo_ctx *ctx, int rank, int world, long long max_doubles_per_slot, unsigned char *h_handle_out /*64*/);
+int mbavo_p2p_connect(mbavo_ctx *ctx, const unsigned char *h_all_handles /* world x 64, rank order */);
+int mbavo_p2p_ranks(mbavo_ctx *ctx); /* world once connected, else 0 */
+int mbavo_allgather_blocks_p2p(mbavo_ctx *ctx, double *d_blocks, long long count_per_rank); /* in place, as mbavo_allgather_blocks */
+int mbavo_allreduce_blocks_p2p(mbavo_ctx *ctx, double *d_blocks, long long count);          /* in place, as mbavo_allreduce_blocks */
+int mbavo_p2p_status(mbavo_ctx *ctx);
+int mbavo_p2p_destroy(mbavo_ctx *ctx);
 
 /* ---- measurement: HIP-event timing of the dominant kernel (the fused residual/Jacobian/JtJ
  * kernel) on the context's stream, attached to the kernel's own dispatch (hipExtLaunchKernelGGL: begin / end

@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-result"
 mkdir -p build
 pids=()
-for f in csrc/engine.hip csrc/ba_tracker.hip csrc/image_ops.hip csrc/keyframe_ops.hip csrc/lm_batch.hip csrc/multi_gpu.hip; do
+for f in csrc/engine.hip csrc/ba_tracker.hip csrc/image_ops.hip csrc/keyframe_ops.hip csrc/lm_batch.hip csrc/multi_gpu.hip csrc/p2p_comm.hip; do
   o=build/$(basename "$f").o
   if [ ! -f "$o" ] || [ -n "$(find csrc -newer "$o" -print -quit)" ] || [ ../include/mbavo.h -nt "$o" ]; then
     # engine.hip without the SLP vectorizer: it packs the fp32 bilinear blend into v_pk_mul/add_f32 and then needs

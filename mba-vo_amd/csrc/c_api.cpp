@@ -572,6 +572,21 @@ extern "C"
         return 0;
     }
 
+    int mbavo_p2p_create(mbavo_ctx *ctx, int rank, int world, long long max_doubles_per_slot, unsigned char *handle_out)
+    {
+        if (!ctx) return MBAVO_E_ARG;
+        return ctx->engine->p2p_create(rank, world, max_doubles_per_slot, handle_out);
+    }
+    int mbavo_p2p_connect(mbavo_ctx *ctx, const unsigned char *all_handles) { return ctx ? ctx->engine->p2p_connect(all_handles) : MBAVO_E_ARG; }
+    int mbavo_p2p_ranks(mbavo_ctx *ctx) { return ctx ? ctx->engine->p2p_ranks() : 0; }
+    int mbavo_allgather_blocks_p2p(mbavo_ctx *ctx, double *d, long long count_per_rank)
+    {
+        return ctx ? ctx->engine->p2p_collective(0, d, count_per_rank) : MBAVO_E_ARG;
+    }
+    int mbavo_allreduce_blocks_p2p(mbavo_ctx *ctx, double *d, long long count) { return ctx ? ctx->engine->p2p_collective(1, d, count) : MBAVO_E_ARG; }
+    int mbavo_p2p_status(mbavo_ctx *ctx) { return ctx ? ctx->engine->p2p_status() : MBAVO_E_ARG; }
+    int mbavo_p2p_destroy(mbavo_ctx *ctx) { return ctx ? ctx->engine->p2p_destroy() : MBAVO_E_ARG; }
+
     int mbavo_profile(mbavo_ctx *ctx, int enable)
     {
         if (!ctx) return MBAVO_E_ARG;

@@ -57,6 +57,8 @@ namespace mbavo
         int prob, frame, kp_begin, kp_count;
     };
 
+    struct P2PState;
+
     class Engine
     {
     public:
@@ -181,6 +183,13 @@ namespace mbavo
         int comm_init(const unsigned char *unique_id, int rank, int world);
         int comm_ranks() const;
         int comm_destroy();
+        // One-shot collectives over peer-mapped receive regions (p2p_comm.hip): no RCCL, one kernel per collective
+        int p2p_create(int rank, int world, long long max_doubles_per_slot, unsigned char *handle_out /* MBAVO_P2P_HANDLE_BYTES */);
+        int p2p_connect(const unsigned char *all_handles /* world x MBAVO_P2P_HANDLE_BYTES, rank order */);
+        int p2p_ranks() const;
+        int p2p_collective(int mode /* 0 all-gather in place, 1 all-reduce in place */, double *d_buf, long long count);
+        int p2p_status();
+        int p2p_destroy();
         int allreduce(void *caller_comm_or_null, const double *d_send, double *d_recv, long long count);
         int allgather(void *caller_comm_or_null, double *d, long long count_per_rank);
         int merge_device(int B, const mbavo_problem *probs, int kdeg, const double *d_frame_blocks, double *d_systems);
@@ -264,6 +273,7 @@ namespace mbavo
         int last_kernel_id_[6] = {0, 0, 0, 0, 0, 0};
         std::vector<ProblemDesc> scratch_descs_;
         void *comm_ = nullptr;          // ncclComm_t owned by this context (comm_init)
+        struct P2PState *p2p_ = nullptr; // peer-mapped receive regions (p2p_create)
         std::vector<char> merge_descs_; // what merge_device last uploaded (re-uploaded only when it changes)
         std::vector<int> merge_start_;
         int merge_kdeg_ = 0;

@@ -1487,6 +1487,7 @@ namespace mbavo
         delete companion_;
         (void)persistent_end_all();
         (void)comm_destroy();
+        (void)p2p_destroy();
         void *bufs[] = {d_layout_, d_poses_, d_rho_, d_partials_,
                         d_status_, d_tickets_};
         if (h_flag_) (void)hipHostFree(h_flag_);

@@ -136,6 +136,68 @@ class RcclCollective:
         capi.check(self.ctx.lib.mbavo_allgather_blocks(self.ctx.handle, None, buf.data_ptr(), count_per_rank), "mbavo_allgather_blocks")
 
 
+class P2PCollective:
+    """The product's one-shot collectives over peer-mapped receive regions (csrc/p2p_comm.hip: mbavo_allgather_blocks_p2p /
+    mbavo_allreduce_blocks_p2p): ONE kernel per collective on the evaluation's stream, no RCCL -- every rank stores its slice
+    into every peer's region, raises a flag, waits for the peers' flags, gathers / adds in rank order.  Sized for this path's
+    latency-bound messages (19 KB ... 1.3 MB).  The ranks may share a GPU (the one-GPU tests) or sit on the GPUs of one node.
+    torch.distributed (any backend) carries the 64-byte IPC handles once per (re)allocation and the barrier before a region is
+    released; the regions grow on demand -- every rank sees the same sequence of counts, so they grow together."""
+    name = "p2p(one-shot, peer-mapped regions)"
+
+    def __init__(self, ctx, rank, world, group=None, max_doubles=1 << 15):
+        self.ctx, self.rank, self.world, self.group, self.cap = ctx, rank, world, group, 0
+        self._ensure(max_doubles)
+
+    def _ensure(self, doubles):
+        import torch
+        import torch.distributed as dist
+        if doubles <= self.cap:
+            return
+        lib, h = self.ctx.lib, self.ctx.handle
+        if self.cap:
+            torch.cuda.synchronize()
+            if self.world > 1:
+                dist.barrier(group=self.group)  # nobody is still reading or writing the old regions
+            capi.check(lib.mbavo_p2p_destroy(h), "mbavo_p2p_destroy")
+        cap = max(int(doubles), 2 * self.cap)
+        mine = C.create_string_buffer(64)
+        capi.check(lib.mbavo_p2p_create(h, self.rank, self.world, cap, mine), "mbavo_p2p_create")
+        if self.world > 1:
+            every = [None] * self.world
+            dist.all_gather_object(every, mine.raw, group=self.group)
+            raw = b"".join(every)
+        else:
+            raw = mine.raw
+        capi.check(lib.mbavo_p2p_connect(h, raw), "mbavo_p2p_connect")
+        assert lib.mbavo_p2p_ranks(h) == self.world
+        self.cap = cap
+
+    def allreduce(self, send, recv, count):
+        self._ensure(count)
+        if send.data_ptr() != recv.data_ptr():
+            with ctx_stream(self.ctx):
+                recv[:count].copy_(send[:count], non_blocking=True)
+        capi.check(self.ctx.lib.mbavo_allreduce_blocks_p2p(self.ctx.handle, recv.data_ptr(), count), "mbavo_allreduce_blocks_p2p")
+
+    def allgather(self, buf, count_per_rank):
+        self._ensure(count_per_rank)
+        capi.check(self.ctx.lib.mbavo_allgather_blocks_p2p(self.ctx.handle, buf.data_ptr(), count_per_rank), "mbavo_allgather_blocks_p2p")
+
+    def close(self):
+        """All ranks together, after their last collective has completed."""
+        import torch
+        import torch.distributed as dist
+        if self.cap:
+            torch.cuda.synchronize()
+            st = self.ctx.lib.mbavo_p2p_status(self.ctx.handle)
+            if self.world > 1:
+                dist.barrier(group=self.group)
+            capi.check(self.ctx.lib.mbavo_p2p_destroy(self.ctx.handle), "mbavo_p2p_destroy")
+            self.cap = 0
+            capi.check(st, "mbavo_p2p_status")
+
+
 class HostStagedCollective:
     """STAND-IN for RcclCollective where RCCL cannot form the communicator: several ranks on ONE GPU (RCCL refuses duplicate
     devices) -- the two-process -m gpu test and `bench.py --comm gloo`, which execute every line of the N > 1 path on a

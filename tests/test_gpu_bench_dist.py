@@ -79,3 +79,23 @@ def test_bench_two_ranks_on_one_gpu(mbavo):
             return ["list"]
         return s
     assert strip(s1) == strip(s2)
+
+
+def test_bench_two_ranks_p2p_collectives_on_one_gpu(mbavo):
+    """`bench.py --comm p2p-shared`: the same N = 2 run with the PRODUCT's one-shot collectives over
+    peer-mapped regions (csrc/p2p_comm.hip) as the collective of every step and config -- end to end, every reduction_check ok
+    (the reduced object equals the single-GPU evaluation to 1e-12), labelled as what it is."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    port = 29900 + (os.getpid() % 90)
+    two = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                 "--master-port", str(port), "bench.py", "--gpus", "2", "--comm", "p2p-shared"] + COMMON, {})
+    assert two["n_gpus"] == 2 and two["comm"].startswith("p2p") and two["value"] > 0
+    assert two["reduction_check"]["ok"] and "p2p" in two["reduction_check"]["collective"]
+    cfg = two["configs"]
+    for k in ("c4_batch512_pairs", "c4_batch512_pairs_allreduce", "c4_batch512_keypoints", "c4_batch512_pairs_packed", "c4_batch512_pairs_weak_packed"):
+        assert "error" not in cfg[k], (k, cfg[k])
+        assert cfg[k]["reduction_check"]["ok"] and "p2p" in cfg[k]["collective"], (k, cfg[k])
+    for k in ("lm_batch512_pairs", "lm_batch_pairs_weak"):
+        assert "error" not in cfg[k] and cfg[k]["gather_check"], (k, cfg[k])
