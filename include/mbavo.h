@@ -30,9 +30,10 @@ typedef struct mbavo_ctx mbavo_ctx;
  * reads (spline_update_step.h:18-58), as POD.  All pointers are DEVICE pointers
  * except h_start_idx.
  * ZERO-INITIALISE the struct (memset / `= {0}`) before filling it in: fields appended by later library versions
- * (grad_fp16, num_residuals -- ABI 0.2) select optional behaviour and must read 0 when a caller does not know them.
+ * (grad_fp16, num_residuals -- ABI 2; the scheduling / solver-form tails of the option structs -- ABI 3) select optional
+ * behaviour and must read 0 when a caller does not know them.
  * mbavo_abi_version() returns the struct revision the loaded library expects (MBAVO_ABI_VERSION of this header). */
-#define MBAVO_ABI_VERSION 2
+#define MBAVO_ABI_VERSION 3
 typedef struct mbavo_problem {
     int S;                                /* n_vir_poses_per_frame */
     int F;                                /* n_frames */
@@ -76,6 +77,32 @@ typedef struct mbavo_problem {
 int mbavo_create(mbavo_ctx **out, int device_id);
 int mbavo_destroy(mbavo_ctx *ctx);
 int mbavo_set_stream(mbavo_ctx *ctx, void *hip_stream); /* NULL = default stream */
+/* sizeof of the library's own structs, for a foreign-language binding to check its mirror against: 0 mbavo_problem,
+ * 1 mbavo_track_opts, 2 mbavo_lm_batch_opts, 3 mbavo_vo_options, 4 mbavo_engine_opts, 5 mbavo_vo_state, 6 mbavo_trace_rec,
+ * 7 mbavo_level, 8 mbavo_lm_batch_result, 9 mbavo_vo_info */
+int mbavo_sizeof(int which);
+
+/* ---- options instead of environment variables (ABI 3).  The reference configures everything through one plain struct
+ * (BlurAwareDirectTrackerOptions, blur_aware_direct_tracker.h:15-67); so does this library: every switch that changes results or
+ * scheduling is a field -- here for the evaluation engine (all callers of the context), in the tails of mbavo_track_opts /
+ * mbavo_vo_options / mbavo_lm_batch_opts for the LM loops.  A ZEROED struct is the default everywhere: flags are tri-state
+ * (0 default, 1 on, -1 off), numbers 0 = default.  The MBAVO_* environment variables of the A/B tools still override an option
+ * (one reader: csrc/options.h read_env_overrides); only the diagnostics MBAVO_TIMING / MBAVO_LM_STAMPS / MBAVO_LM_STATS are
+ * environment-only. */
+typedef struct mbavo_engine_opts {
+    int sample_parallel;        /* small lists on the sample-parallel kernel: 0 by size, 1 wherever the list allows, -1 never [MBAVO_SP] */
+    int single_launch;          /* small lists in ONE launch (pose prologue + ticket epilogue); default on            [MBAVO_ONE] */
+    int fused_pose;             /* pose entries as the fused kernel's prologue; default on                            [MBAVO_FUSED_POSE] */
+    int fused_pose_max_samples; /* ... up to this many blur samples; default 8                                        [MBAVO_FUSED_POSE_MAX_S] */
+    int persistent;             /* persistent evaluation kernels under the host-driven LM loop; default on            [MBAVO_PERSIST] */
+    int prelaunch;              /* next pyramid level's persistent kernel enqueued behind the running one; default on [MBAVO_PRELAUNCH] */
+    int tiles_per_cu;           /* default 1                                                                          [MBAVO_TILES_PER_CU] */
+    int min_tile_pixels;        /* default 256                                                                        [MBAVO_MIN_TILE_PX] */
+    int sp_max_slot_tiles;      /* default 64                                                                         [MBAVO_SP_MAX_SLOT_TILES] */
+    int reserved[7];
+} mbavo_engine_opts;
+int mbavo_set_engine_opts(mbavo_ctx *ctx, const mbavo_engine_opts *opts); /* NULL = all defaults */
+int mbavo_get_engine_opts(mbavo_ctx *ctx, mbavo_engine_opts *opts_out);   /* what was set (not the environment's overrides) */
 int mbavo_packed_len(int spline_deg_k);                 /* E = (6k+1)(6k+2)/2 */
 
 /* ---- fused evaluation of B independent problems in one pass (poses -> residual /
@@ -188,6 +215,12 @@ typedef struct mbavo_track_opts {
     int num_levels, spline_deg_k, max_num_iterations, max_consecutive_nonmonotonic_steps, solver_type;
     double intrinsics[4]; /* level 0 */
     double huber_k, min_step_quality, min_abs_cost_decrease, max_chi_square_error;
+    /* ABI 3 -- zero = default.  Solver form: the pivot ratio up to which LDL^T stands in for solve_normal_equation.h's
+     * solvers (0: 1e8; < 0: never -- the Jacobi SVD / pivoted LDL^T for every system; > 1: that ratio)        [MBAVO_FAST_SOLVE] */
+    double fast_solve_ratio;
+    int speculate;      /* candidates evaluated WITH H / g: 0 on the persistent levels, 1 every level, -1 never [MBAVO_SPECULATE] */
+    int persist_levels; /* one persistent kernel for all levels of a call; default on                          [MBAVO_PERSIST_LEVELS] */
+    int reserved[4];
 } mbavo_track_opts;
 typedef struct mbavo_trace_rec {
     int level, iter, kind; /* 0 initial evaluation, 1 accepted, 2 rejected, 3 invalid step */
@@ -212,6 +245,16 @@ int mbavo_optimize_trajectory(mbavo_ctx *ctx, const mbavo_track_opts *opts, cons
 typedef struct mbavo_lm_batch_opts {
     int spline_deg_k, max_num_iterations, max_consecutive_nonmonotonic_steps, solver_type, sync_every;
     double min_step_quality, min_abs_cost_decrease, max_chi_square_error;
+    /* ABI 3 -- zero = default */
+    double fast_solve_ratio; /* as mbavo_track_opts.fast_solve_ratio                                                [MBAVO_FAST_SOLVE] */
+    double refined_ratio;    /* pivot ratio up to which the stand-in, refined with double-double residuals, is admitted:
+                                0: 1e13; < 0: never (plain stand-in only); > 1: that ratio                          [MBAVO_LM_REFINE] */
+    int eig;                 /* the wide workgroup (eigenvalue Jacobi as the fallback) for n <= 48; default on       [MBAVO_LM_EIG] */
+    int pose_entries;        /* the solve launch writes the candidate's pose entries; default on                     [MBAVO_LM_POSES] */
+    int defer_finalize;      /* the LM kernels sum the tile partials themselves; default on                          [MBAVO_LM_DEFER] */
+    int retile;              /* a second, finer tiling for the late slots of big batches; default on                 [MBAVO_LM_RETILE] */
+    int groups;              /* independent groups on their own streams: 0 = 2 from 384 problems, else 1; 1 .. 8     [MBAVO_LM_GROUPS] */
+    int reserved[5];
 } mbavo_lm_batch_opts;
 typedef struct mbavo_lm_batch_result {
     int iterations, accepted, rejected, invalid, num_outliers, num_trace;
@@ -274,6 +317,11 @@ typedef struct mbavo_vo_options { /* BlurAwareDirectTrackerOptions (blur_aware_d
     double dt_frame, dt_ctrl_knot, max_chi_square_error;
     double keyframe_max_flow_mag0, keyframe_max_flow_mag1, keyframe_max_flow_mag2, keyframe_max_blur_kernel_mag;
     float score_threshold; int grid_selection_cell_H, grid_selection_cell_W; /* reference: 25 / 30 / 30 (.cpp:353-358) */
+    /* ABI 3 -- zero = default; the first three as in mbavo_track_opts */
+    double fast_solve_ratio;
+    int speculate, persist_levels;
+    int keyframe_levels_at_once; /* pyramid, gradients and grid selection of ALL levels in three launches; default on [MBAVO_KF_MULTI] */
+    int reserved[5];
 } mbavo_vo_options;
 typedef struct mbavo_vo_info {
     int is_keyframe, num_keypoints0, num_trace, start_idx;

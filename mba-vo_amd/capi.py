@@ -43,7 +43,16 @@ class TrackOpts(C.Structure):
         ("max_consecutive_nonmonotonic_steps", C.c_int), ("solver_type", C.c_int),
         ("intrinsics", C.c_double * 4), ("huber_k", C.c_double), ("min_step_quality", C.c_double),
         ("min_abs_cost_decrease", C.c_double), ("max_chi_square_error", C.c_double),
+        # ABI 3: zero = default (include/mbavo.h)
+        ("fast_solve_ratio", C.c_double), ("speculate", C.c_int), ("persist_levels", C.c_int), ("reserved", C.c_int * 4),
     ]
+
+
+class EngineOpts(C.Structure):
+    """struct mbavo_engine_opts (tri-state flags: 0 default, 1 on, -1 off; numbers: 0 default)"""
+    _fields_ = [("sample_parallel", C.c_int), ("single_launch", C.c_int), ("fused_pose", C.c_int), ("fused_pose_max_samples", C.c_int),
+                ("persistent", C.c_int), ("prelaunch", C.c_int), ("tiles_per_cu", C.c_int), ("min_tile_pixels", C.c_int),
+                ("sp_max_slot_tiles", C.c_int), ("reserved", C.c_int * 7)]
 
 
 class VoState(C.Structure):
@@ -67,7 +76,10 @@ class LmBatchOpts(C.Structure):
     """struct mbavo_lm_batch_opts"""
     _fields_ = [("spline_deg_k", C.c_int), ("max_num_iterations", C.c_int), ("max_consecutive_nonmonotonic_steps", C.c_int),
                 ("solver_type", C.c_int), ("sync_every", C.c_int), ("min_step_quality", C.c_double),
-                ("min_abs_cost_decrease", C.c_double), ("max_chi_square_error", C.c_double)]
+                ("min_abs_cost_decrease", C.c_double), ("max_chi_square_error", C.c_double),
+                # ABI 3: zero = default (include/mbavo.h)
+                ("fast_solve_ratio", C.c_double), ("refined_ratio", C.c_double), ("eig", C.c_int), ("pose_entries", C.c_int),
+                ("defer_finalize", C.c_int), ("retile", C.c_int), ("groups", C.c_int), ("reserved", C.c_int * 5)]
 
 
 class LmBatchResult(C.Structure):
@@ -89,6 +101,9 @@ class VoOptions(C.Structure):
         ("keyframe_max_flow_mag0", C.c_double), ("keyframe_max_flow_mag1", C.c_double),
         ("keyframe_max_flow_mag2", C.c_double), ("keyframe_max_blur_kernel_mag", C.c_double),
         ("score_threshold", C.c_float), ("grid_selection_cell_H", C.c_int), ("grid_selection_cell_W", C.c_int),
+        # ABI 3: zero = default (include/mbavo.h)
+        ("fast_solve_ratio", C.c_double), ("speculate", C.c_int), ("persist_levels", C.c_int), ("keyframe_levels_at_once", C.c_int),
+        ("reserved", C.c_int * 5),
     ]
 
 
@@ -111,7 +126,7 @@ SYMBOLS = [
     "mbavo_profile", "mbavo_profile_read", "mbavo_version", "mbavo_abi_version",
     "mbavo_gradient_magnitude_u8", "mbavo_detect_semidense", "mbavo_se3_exp", "mbavo_se3_log", "mbavo_transform_mul",
     "mbavo_transform_inverse", "mbavo_spline_transform_to", "mbavo_vo_create", "mbavo_vo_destroy", "mbavo_vo_set_spline",
-    "mbavo_vo_get_spline", "mbavo_eval_batch_merged", "mbavo_p2p_create", "mbavo_p2p_connect", "mbavo_p2p_ranks", "mbavo_allgather_blocks_p2p",
+    "mbavo_vo_get_spline", "mbavo_sizeof", "mbavo_set_engine_opts", "mbavo_get_engine_opts", "mbavo_eval_batch_merged", "mbavo_p2p_create", "mbavo_p2p_connect", "mbavo_p2p_ranks", "mbavo_allgather_blocks_p2p",
     "mbavo_allreduce_blocks_p2p", "mbavo_p2p_status", "mbavo_p2p_destroy", "mbavo_vo_last_trace", "mbavo_vo_get_state", "mbavo_vo_set_state", "mbavo_vo_set_keyframe", "mbavo_vo_num_keypoints", "mbavo_vo_get_keypoints", "mbavo_vo_track_frame", "mbavo_lm_batch",
     "mbavo_shard_keypoints", "mbavo_shard_frames", "mbavo_system_len", "mbavo_merge_device", "mbavo_comm_unique_id",
     "mbavo_comm_init", "mbavo_comm_ranks", "mbavo_comm_destroy", "mbavo_last_kernel", "mbavo_timing_report",
@@ -161,6 +176,8 @@ def load():
     L.mbavo_set_stream.argtypes = [vp, vp]
     L.mbavo_packed_len.argtypes = [C.c_int]
     L.mbavo_eval_batch.argtypes = [vp, C.c_int, C.POINTER(Problem), C.c_int, C.c_int, vp, vp, vp]
+    L.mbavo_set_engine_opts.argtypes = [vp, C.POINTER(EngineOpts)]
+    L.mbavo_get_engine_opts.argtypes = [vp, C.POINTER(EngineOpts)]
     L.mbavo_eval_batch_merged.argtypes = [vp, C.c_int, C.POINTER(Problem), C.c_int, vp, vp, vp, vp]
     L.mbavo_eval.argtypes = [vp, C.POINTER(Problem), C.c_int, c_dp, c_dp, c_dp, vp]
     L.mbavo_compute_virtual_camera_poses.argtypes = [C.c_int, C.c_int, vp, vp, C.c_int, C.c_double, C.c_double,
@@ -277,6 +294,15 @@ class Context:
         self.device_id, self.stream = int(device_id), stream  # (None / 0: the null stream)
         if stream is not None:
             check(self.lib.mbavo_set_stream(self.handle, vp(stream)), "mbavo_set_stream")
+
+    def engine_opts(self, **kw):
+        """mbavo_set_engine_opts: the named fields (tri-state flags 1 / -1, numbers), every other field at its default."""
+        o = EngineOpts()
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise AttributeError(k)
+            setattr(o, k, int(v))
+        check(self.lib.mbavo_set_engine_opts(self.handle, C.byref(o)), "mbavo_set_engine_opts")
 
     def close(self):
         if self.handle:

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -94,6 +95,7 @@ struct mbavo_ctx
     std::vector<hipStream_t> extra_streams;
     std::vector<GroupWorker *> workers;
     hipEvent_t fork = nullptr;
+    mbavo::Engine::Options engine_opts; // (new group engines start with the context's options)
 };
 struct mbavo_vo
 {
@@ -121,6 +123,23 @@ extern "C"
 {
     const char *mbavo_version(void) { return "mbavo-mi355x 0.2 (gfx950)"; }
     int mbavo_abi_version(void) { return MBAVO_ABI_VERSION; }
+    int mbavo_sizeof(int which)
+    { // what the library was compiled with, for a binding to check its own mirror of the structs against
+        switch (which)
+        {
+        case 0: return (int)sizeof(mbavo_problem);
+        case 1: return (int)sizeof(mbavo_track_opts);
+        case 2: return (int)sizeof(mbavo_lm_batch_opts);
+        case 3: return (int)sizeof(mbavo_vo_options);
+        case 4: return (int)sizeof(mbavo_engine_opts);
+        case 5: return (int)sizeof(mbavo_vo_state);
+        case 6: return (int)sizeof(mbavo_trace_rec);
+        case 7: return (int)sizeof(mbavo_level);
+        case 8: return (int)sizeof(mbavo_lm_batch_result);
+        case 9: return (int)sizeof(mbavo_vo_info);
+        default: return MBAVO_E_ARG;
+        }
+    }
 
     int mbavo_packed_len(int k) { return packed_len(k); }
 
@@ -158,6 +177,33 @@ extern "C"
     {
         if (!ctx) return MBAVO_E_ARG;
         ctx->engine->set_stream((hipStream_t)s);
+        return 0;
+    }
+
+    int mbavo_set_engine_opts(mbavo_ctx *ctx, const mbavo_engine_opts *o)
+    {
+        if (!ctx) return MBAVO_E_ARG;
+        mbavo::Engine::Options e;
+        if (o)
+        {
+            e.sample_parallel = o->sample_parallel; e.single_launch = o->single_launch; e.fused_pose = o->fused_pose;
+            e.fused_pose_max_samples = o->fused_pose_max_samples; e.persistent = o->persistent; e.prelaunch = o->prelaunch;
+            e.tiles_per_cu = o->tiles_per_cu; e.min_tile_pixels = o->min_tile_pixels; e.sp_max_slot_tiles = o->sp_max_slot_tiles;
+        }
+        ctx->engine->set_options(e);
+        for (mbavo::Engine *x : ctx->extra_engines) x->set_options(e);
+        ctx->engine_opts = e;
+        return 0;
+    }
+
+    int mbavo_get_engine_opts(mbavo_ctx *ctx, mbavo_engine_opts *o)
+    {
+        if (!ctx || !o) return MBAVO_E_ARG;
+        const mbavo::Engine::Options &e = ctx->engine->options();
+        memset(o, 0, sizeof(*o));
+        o->sample_parallel = e.sample_parallel; o->single_launch = e.single_launch; o->fused_pose = e.fused_pose;
+        o->fused_pose_max_samples = e.fused_pose_max_samples; o->persistent = e.persistent; o->prelaunch = e.prelaunch;
+        o->tiles_per_cu = e.tiles_per_cu; o->min_tile_pixels = e.min_tile_pixels; o->sp_max_slot_tiles = e.sp_max_slot_tiles;
         return 0;
     }
 
@@ -341,12 +387,16 @@ extern "C"
         // 512 pairs 159-163 / 144-145 / 145-149 (packed keyframes 143 / 132 / 132-136), 256 pairs 109 / 115, 128 pairs 86 / 102,
         // 64 pairs 74 / 96 -- below ~400 problems a group's passes no longer fill the machine and every phase is latency-bound
         // either way, so smaller batches stay one group.  Two groups of a 512-pair batch keep the single group's tiling (one
-        // tile per pair): identical records.  MBAVO_LM_GROUPS=n overrides (1 .. 8).
-        const char *ge = getenv("MBAVO_LM_GROUPS");
-        int groups = ge && *ge ? atoi(ge) : (B >= 384 ? 2 : 1);
+        // tile per pair): identical records.  mbavo_lm_batch_opts.groups = n overrides (1 .. 8).
+        const int genv = mbavo::read_env_overrides().lm_groups;
+        int groups = genv != mbavo::kEnvUnset ? genv : (o->groups > 0 ? o->groups : (B >= 384 ? 2 : 1));
         if (groups > 8) groups = 8;
         if (groups > B) groups = B;
-        if (groups < 2) return mbavo::lm_batch(*ctx->engine, B, probs, *o, results, trace, trace_cap);
+        if (groups < 2)
+        {
+            try { return mbavo::lm_batch(*ctx->engine, B, probs, *o, results, trace, trace_cap); }
+            catch (...) { (void)hipStreamSynchronize(ctx->engine->stream()); return MBAVO_E_ARG; }
+        }
         const int dev = ctx->engine->device();
         if (hipSetDevice(dev) != hipSuccess) return MBAVO_E_NODEVICE;
         if (!ctx->fork && hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming) != hipSuccess) return MBAVO_E_NODEVICE;
@@ -357,27 +407,54 @@ extern "C"
             ctx->extra_streams.push_back(s);
             ctx->extra_engines.push_back(new mbavo::Engine(dev));
             ctx->extra_engines.back()->set_stream(s);
+            ctx->extra_engines.back()->set_options(ctx->engine_opts);
             ctx->workers.push_back(new GroupWorker());
         }
         // whatever the caller enqueued on the context's stream (knot resets, uploads) comes before the other groups' work too
         if (hipEventRecord(ctx->fork, ctx->engine->stream()) != hipSuccess) return MBAVO_E_NODEVICE;
-        std::vector<int> rcs(groups, 0);
+        // What the whole batch decides is decided ONCE and handed to every group: the largest knot count (array strides,
+        // the solve kernel's form -- wide workgroup or one wave -- and its LDS) and the largest sample count.  A group's own list is
+        // still tiled for itself, so the grouping of the partial sums -- and with it the last bits of costs and knots -- can differ
+        // from the single-group run (as with `retile`); the discrete records do not (tests: mixed N, B just under 2 x CUs).
+        mbavo::LmBatchShared shared;
+        for (int b = 0; b < B; ++b)
+        {
+            shared.max_N = probs[b].N > shared.max_N ? probs[b].N : shared.max_N;
+            shared.max_S = probs[b].S > shared.max_S ? probs[b].S : shared.max_S;
+        }
+        // shared state of the groups lives on the heap and the workers are ALWAYS waited for, also when this thread's own group throws
+        // (std::bad_alloc from a vector): no exception crosses the C boundary and no worker writes into a dead frame
+        struct Rcs { std::vector<int> v; };
+        auto rcs = std::make_shared<Rcs>();
+        rcs->v.assign(groups, 0);
         std::vector<int> posted;
-        auto first_of = [&](int g) { return (int)((long long)B * g / groups); }; // contiguous, near-equal shares
+        auto first_of = [B, groups](int g) { return (int)((long long)B * g / groups); }; // contiguous, near-equal shares
+        const mbavo_lm_batch_opts opts = *o;
         for (int g = 1; g < groups; ++g)
         {
-            if (hipStreamWaitEvent(ctx->extra_streams[g - 1], ctx->fork, 0) != hipSuccess) { rcs[g] = MBAVO_E_NODEVICE; continue; }
-            ctx->workers[g - 1]->post([&, g]() {
+            if (hipStreamWaitEvent(ctx->extra_streams[g - 1], ctx->fork, 0) != hipSuccess) { rcs->v[g] = MBAVO_E_NODEVICE; continue; }
+            mbavo::Engine *eng = ctx->extra_engines[g - 1];
+            ctx->workers[g - 1]->post([=]() {
                 const int b0 = first_of(g), n = first_of(g + 1) - b0;
-                rcs[g] = mbavo::lm_batch(*ctx->extra_engines[g - 1], n, probs + b0, *o, results ? results + b0 : nullptr,
-                                         trace ? trace + (size_t)b0 * trace_cap : nullptr, trace_cap);
+                int rc;
+                try
+                {
+                    rc = mbavo::lm_batch(*eng, n, probs + b0, opts, results ? results + b0 : nullptr,
+                                         trace ? trace + (size_t)b0 * trace_cap : nullptr, trace_cap, &shared);
+                }
+                catch (...) { rc = MBAVO_E_ARG; (void)hipStreamSynchronize(eng->stream()); }
+                rcs->v[g] = rc;
             });
             posted.push_back(g - 1);
         }
-        rcs[0] = mbavo::lm_batch(*ctx->engine, first_of(1), probs, *o, results, trace, trace_cap);
-        for (int w : posted) ctx->workers[w]->wait(); // (every call returns synchronised with its stream)
+        try
+        {
+            rcs->v[0] = mbavo::lm_batch(*ctx->engine, first_of(1), probs, opts, results, trace, trace_cap, &shared);
+        }
+        catch (...) { rcs->v[0] = MBAVO_E_ARG; (void)hipStreamSynchronize(ctx->engine->stream()); }
+        for (int w : posted) ctx->workers[w]->wait(); // (every call returns synchronised with its streams, failed or not)
         for (int g = 0; g < groups; ++g)
-            if (rcs[g] != 0) return rcs[g];
+            if (rcs->v[g] != 0) return rcs->v[g];
         return 0;
     }
 
@@ -466,6 +543,8 @@ extern "C"
         v.keyframe_max_flow_mag2 = o->keyframe_max_flow_mag2; v.keyframe_max_blur_kernel_mag = o->keyframe_max_blur_kernel_mag;
         v.score_threshold = o->score_threshold;
         v.grid_selection_cell_H = o->grid_selection_cell_H; v.grid_selection_cell_W = o->grid_selection_cell_W;
+        v.fast_solve_ratio = o->fast_solve_ratio; v.speculate = o->speculate; v.persist_levels = o->persist_levels;
+        v.keyframe_levels_at_once = o->keyframe_levels_at_once;
         if (v.spline_deg_k != 2 && v.spline_deg_k != 4) return MBAVO_E_ARG;
         mbavo_vo *h = new (std::nothrow) mbavo_vo(*ctx->engine, v);
         if (!h) return MBAVO_E_ARG;

@@ -17,6 +17,7 @@
 #ifndef MBAVO_ENGINE_H
 #define MBAVO_ENGINE_H
 
+#include "options.h"
 #include "../../include/mbavo.h"
 #include <hip/hip_runtime.h>
 #include <map>
@@ -134,6 +135,13 @@ namespace mbavo
         Engine *companion();
         Engine *companion_if_any() const { return companion_; }
         int *device_status() const { return (int *)d_status_; }
+        // scheduling options (include/mbavo.h: mbavo_engine_opts; all zero = the defaults) and what they resolve to under the
+        // environment's override layer (options.h)
+        struct Options { int sample_parallel = 0, single_launch = 0, fused_pose = 0, fused_pose_max_samples = 0, persistent = 0, prelaunch = 0,
+                             tiles_per_cu = 0, min_tile_pixels = 0, sp_max_slot_tiles = 0; };
+        void set_options(const Options &o) { opts_ = o; layout_uploaded_ = false; h_descs_.clear(); }
+        const Options &options() const { return opts_; }
+        EngineTuning tuning() const;
         void set_defer_finalize(bool on) { defer_finalize_ = on; }
         // The NEXT evaluate() with H/g also leaves every problem's merged system [cost | g (6N) | H (6N x 6N, column-major)]
         // (merge_hessian_gradient_cost.cpp:39-86; mbavo_system_len(N) doubles each, back to back) in d_systems: written by the
@@ -215,6 +223,7 @@ namespace mbavo
         int sp_logs_ = 0; // > 0: the cached layout is tiled for the sample-parallel kernel with S = 2^sp_logs_
         bool flat_finalize_ = false; // many (problem, frame) slots of <= 4 tiles each: k_finalize_flat
         bool defer_finalize_ = false, deferred_last_ = false; // set_defer_finalize / what the last evaluate() did
+        Options opts_;
         double *merge_target_ = nullptr;                       // set_merge_target
         bool merge_fused_last_ = false;
         bool external_poses_ = false;                          // set_external_poses
@@ -229,8 +238,21 @@ namespace mbavo
         // The trackers cycle through a few layouts (one per pyramid level, the same ones frame after frame until the
         // keyframe changes): the layouts that are not active wait here with their device arenas, and a problem list that
         // matches one is a pointer swap instead of a tiling pass and an upload (4 uploads per tracked frame otherwise).
+        // what a layout depends on besides the problem list: part of the cache key (a changed tile target or tiling option
+        // must not find a stale layout)
+        struct LayoutKey
+        {
+            long long tile_target = 0;
+            int tiles_per_cu = 1, sample_parallel = -1, min_tile_pixels = 256, sp_max_slot_tiles = 64;
+            bool operator==(const LayoutKey &o) const
+            {
+                return tile_target == o.tile_target && tiles_per_cu == o.tiles_per_cu && sample_parallel == o.sample_parallel &&
+                       min_tile_pixels == o.min_tile_pixels && sp_max_slot_tiles == o.sp_max_slot_tiles;
+            }
+        };
         struct ParkedLayout
         {
+            LayoutKey key;
             std::vector<ProblemDesc> descs;
             std::vector<TileDesc> tiles;
             std::vector<int> bf_tile_begin, bf_prob, entry_prob;
@@ -244,6 +266,10 @@ namespace mbavo
         ParkedLayout parked_[kParkedLayouts];
         int parked_victim_ = 0;
         void swap_layout(ParkedLayout &s);
+        LayoutKey layout_key_;              // of the active layout
+        unsigned long long layout_gen_ = 0; // bumped whenever the active layout changes (rebuild, swap): evaluate(same_list) checks it
+        unsigned long long same_list_gen_ = 0;
+        const mbavo_problem *same_list_probs_ = nullptr;
         void *d_poses_ = nullptr; size_t cap_poses_ = 0;
         void *d_rho_ = nullptr; size_t cap_rho_ = 0;
         void *d_partials_ = nullptr; size_t cap_partials_ = 0;

@@ -1471,6 +1471,7 @@ namespace mbavo
     {
         if (!companion_) companion_ = new Engine(device_);
         companion_->set_stream(stream_);
+        companion_->opts_ = opts_; // (plain copy: set_options would drop its layout)
         return companion_;
     }
 
@@ -1479,7 +1480,9 @@ namespace mbavo
         if (B < 1 || !probs || (kdeg != 2 && kdeg != 4) || persist_mask_) return MBAVO_E_ARG;
         int cur = -1;
         if (hipGetDevice(&cur) != hipSuccess || cur != device_) HIP_TRY(hipSetDevice(device_));
-        return rebuild_layout(B, probs, kdeg, d_active, d_inv);
+        const int rc = rebuild_layout(B, probs, kdeg, d_active, d_inv);
+        if (rc == 0) { same_list_probs_ = probs; same_list_gen_ = layout_gen_; }
+        return rc;
     }
 
     Engine::~Engine()
@@ -1547,10 +1550,21 @@ namespace mbavo
         return pinned_[slot];
     }
 
-    static int env_int(const char *name, int dflt)
+    // The engine's scheduling choices: mbavo_engine_opts (set_options) under the environment's override layer (options.h).
+    EngineTuning Engine::tuning() const
     {
-        const char *v = getenv(name);
-        return v && *v ? atoi(v) : dflt;
+        const EnvOverrides e = read_env_overrides();
+        EngineTuning t;
+        t.sample_parallel = e.sp != kEnvUnset ? (e.sp == 0 ? 0 : (e.sp == 1 ? 1 : -1)) : (opts_.sample_parallel == 0 ? -1 : (opts_.sample_parallel > 0 ? 1 : 0));
+        t.single_launch = opt_flag(opts_.single_launch, e.one, true);
+        t.fused_pose = opt_flag(opts_.fused_pose, e.fused_pose, true);
+        t.fused_pose_max_samples = opt_number(opts_.fused_pose_max_samples, e.fused_pose_max_s, 8);
+        t.persistent = opt_flag(opts_.persistent, e.persist, true);
+        t.prelaunch = opt_flag(opts_.prelaunch, e.prelaunch, true);
+        t.tiles_per_cu = opt_number(opts_.tiles_per_cu, e.tiles_per_cu, 1);
+        t.min_tile_pixels = opt_number(opts_.min_tile_pixels, e.min_tile_px, 256);
+        t.sp_max_slot_tiles = opt_number(opts_.sp_max_slot_tiles, e.sp_max_slot_tiles, 64);
+        return t;
     }
 
     void Engine::swap_layout(ParkedLayout &s)
@@ -1563,6 +1577,8 @@ namespace mbavo
         std::swap(d_layout_, s.d_layout); std::swap(cap_layout_, s.cap_layout);
         std::swap(d_descs_, s.d_descs); std::swap(d_tiles_, s.d_tiles); std::swap(d_bf_tile_begin_, s.d_bf_tile_begin);
         std::swap(d_bf_prob_, s.d_bf_prob); std::swap(d_entry_prob_, s.d_entry_prob);
+        std::swap(layout_key_, s.key);
+        ++layout_gen_;
     }
 
     int Engine::rebuild_layout(int B, const mbavo_problem *probs, int kdeg, const int *d_active, const double *d_inv, bool cached_only)
@@ -1600,7 +1616,11 @@ namespace mbavo
             pixels += (long long)p.F * p.K * p.P;
             patches += (long long)p.F * p.K;
         }
-        const bool same = kdeg == cached_kdeg_ && descs.size() == h_descs_.size() &&
+        const EngineTuning tune = tuning();
+        LayoutKey key;
+        key.tile_target = tile_target_; key.tiles_per_cu = tune.tiles_per_cu; key.sample_parallel = tune.sample_parallel;
+        key.min_tile_pixels = tune.min_tile_pixels; key.sp_max_slot_tiles = tune.sp_max_slot_tiles;
+        const bool same = kdeg == cached_kdeg_ && key == layout_key_ && descs.size() == h_descs_.size() &&
                           memcmp(descs.data(), h_descs_.data(), descs.size() * sizeof(ProblemDesc)) == 0;
         if (same && layout_uploaded_) return 0;
         if (cached_only && B > 8) return 2;
@@ -1608,7 +1628,7 @@ namespace mbavo
         { // a parked layout of the same problem list?  Otherwise the active one is parked (oldest slot) and the new one
           // is built over that slot's buffers (stream order protects an arena a queued kernel still reads)
             for (ParkedLayout &s : parked_)
-                if (s.uploaded && s.kdeg == kdeg && s.descs.size() == descs.size() &&
+                if (s.uploaded && s.kdeg == kdeg && s.key == key && s.descs.size() == descs.size() &&
                     memcmp(descs.data(), s.descs.data(), descs.size() * sizeof(ProblemDesc)) == 0)
                 {
                     swap_layout(s);
@@ -1626,7 +1646,7 @@ namespace mbavo
         // tiles: contiguous keypoint ranges of one (problem, frame).  One workgroup is resident per CU (LDS), so
         // the tile count must not exceed CUs x rounds or a nearly empty extra round doubles the time: take the
         // smallest tile size (in pixels) whose tile count fits, found by bisection.
-        const int tiles_per_cu = env_int("MBAVO_TILES_PER_CU", 1);
+        const int tiles_per_cu = tune.tiles_per_cu;
         const long long target_tiles = tile_target_ > 0 ? tile_target_ : (long long)num_cus_ * (tiles_per_cu > 0 ? tiles_per_cu : 1);
         auto count_tiles = [&](long long ppt) {
             long long n = 0;
@@ -1648,11 +1668,11 @@ namespace mbavo
             bool ok = (1 << lg) == S0 && lg >= 2 && lg <= 5;
             for (int b = 0; b < B && ok; ++b) ok = descs[b].S == S0 && descs[b].grad_fp16 == 0;
             const long long round_px = (long long)kSpWaves * (64 >> lg);
-            const int force = env_int("MBAVO_SP", -1);
+            const int force = tune.sample_parallel;
             if (ok && force != 0 && (force == 1 || pixels <= 2 * round_px * num_cus_)) sp_logs = lg;
         }
         auto tile_px = [&](int logs) {
-            long long lo = logs ? (long long)kSpWaves * (64 >> logs) : env_int("MBAVO_MIN_TILE_PX", 256), hi = pixels > lo ? pixels : lo;
+            long long lo = logs ? (long long)kSpWaves * (64 >> logs) : tune.min_tile_pixels, hi = pixels > lo ? pixels : lo;
             if (count_tiles(lo) > target_tiles)
             {
                 while (lo < hi)
@@ -1664,7 +1684,7 @@ namespace mbavo
             return lo;
         };
         long long px_per_tile = tile_px(sp_logs);
-        if (sp_logs && env_int("MBAVO_SP", -1) != 1)
+        if (sp_logs && tune.sample_parallel != 1)
         { // The single-launch form ends with ONE workgroup summing its slot's partials (ticket_finalize): fine for the handful of
           // tiles of a semi-dense level, slow for a slot of hundreds (a dense 160 x 120 level alone: 253 tiles, 38.1 us against 20.5
           // for the lane-per-pixel kernel + finalize kernel; tools/level_bench.py).  Such lists take the lane-per-pixel kernel.
@@ -1677,7 +1697,7 @@ namespace mbavo
             }
             // (the summing workgroup has threads / padded-entries tile-lanes: 4 for k = 2, 1 for k = 4; 64 partials per lane at most)
             const int lanes = kdeg == 2 ? kSpWaves * 64 / 128 : (kSpWaves * 64 >= 384 ? kSpWaves * 64 / 384 : 1);
-            if (worst > (long long)env_int("MBAVO_SP_MAX_SLOT_TILES", 64) * lanes)
+            if (worst > (long long)tune.sp_max_slot_tiles * lanes)
             {
                 sp_logs = 0;
                 px_per_tile = tile_px(0);
@@ -1714,6 +1734,8 @@ namespace mbavo
         for (size_t i = 0; i + 1 < bf_tile_begin.size(); ++i) empty_slots_ = empty_slots_ || bf_tile_begin[i + 1] == bf_tile_begin[i];
 
         h_descs_ = descs;
+        layout_key_ = key;
+        ++layout_gen_;
         h_tiles_.swap(tiles);
         h_bf_tile_begin_.swap(bf_tile_begin);
         h_bf_prob_.swap(bf_prob);
@@ -1896,7 +1918,12 @@ namespace mbavo
             // the enqueue time of an evaluation); hipGetDevice is a thread-local read
             int cur = -1;
             if (hipGetDevice(&cur) != hipSuccess || cur != device_) HIP_TRY(hipSetDevice(device_));
-            rc = same_list && layout_uploaded_ && (int)h_descs_.size() == B && cached_kdeg_ == kdeg ? 0 : rebuild_layout(B, probs, kdeg, d_active, d_inv);
+            // same_list: the caller vouches for the list; the engine still checks that it is the list pointer it built this very
+            // layout from and that nothing has replaced the layout since
+            const bool reuse = same_list && layout_uploaded_ && (int)h_descs_.size() == B && cached_kdeg_ == kdeg && same_list_probs_ == probs &&
+                               same_list_gen_ == layout_gen_;
+            rc = reuse ? 0 : rebuild_layout(B, probs, kdeg, d_active, d_inv);
+            if (rc == 0) { same_list_probs_ = probs; same_list_gen_ = layout_gen_; }
         }
         if (rc) return rc;
         const ProblemDesc *descs = (const ProblemDesc *)d_descs_;
@@ -1914,7 +1941,8 @@ namespace mbavo
         // MBAVO_ONE=0 forces three launches.
         // A slot without tiles (K == 0: a pyramid level with no surviving keypoint, a keypoint shard of K < world) has no
         // workgroup to finalize it: such lists take the finalize KERNEL, which writes the all-zero block and valid count.
-        const bool one = sp_logs_ > 0 && sp_one_fits(kdeg, sp_logs_) && !empty_slots_ && env_int("MBAVO_ONE", 1) != 0;
+        const EngineTuning tune = tuning();
+        const bool one = sp_logs_ > 0 && sp_one_fits(kdeg, sp_logs_) && !empty_slots_ && tune.single_launch;
         OneArgs oa;
         memset(&oa, 0, sizeof(oa));
         // merged systems asked for (set_merge_target): by the finalize step itself when the merge is a plain unpack
@@ -1950,8 +1978,8 @@ namespace mbavo
         // (rebuild_layout sizes it for that).  MBAVO_FUSED_POSE=0 keeps the pose kernel.
         // Measured (profiles/r02_kfused_experiments.txt 16.): S = 8: the prologue costs a workgroup 4.8 us against the pose
         // kernel's 5.7; S = 16: 7.4 us, slower than the kernel.
-        const bool fused_pose_ok = !external_poses_ && ntiles <= num_cus_ && max_S <= env_int("MBAVO_FUSED_POSE_MAX_S", 8) && max_S <= kPoseSPB &&
-                                   env_int("MBAVO_FUSED_POSE", 1) != 0;
+        const bool fused_pose_ok = !external_poses_ && ntiles <= num_cus_ && max_S <= tune.fused_pose_max_samples && max_S <= kPoseSPB &&
+                                   tune.fused_pose;
 #define MBAVO_LAUNCH(KD, WJ)                                                                                      \
     launch_all<KD, WJ>(this, stream_, max_S, half_grad, sp_logs_, one, flat_finalize_, descs, (const int *)d_entry_prob_, total_entries_, tiles, ntiles, (const int *)d_bf_prob_,                 \
                        (const int *)d_bf_tile_begin_, total_bf_, external_poses_ && external_table_ ? external_table_ : d_poses_, (double *)d_rho_, d_patch_cost,        \
@@ -1985,7 +2013,7 @@ namespace mbavo
     void *Engine::push_block(int slot, size_t bytes)
     {
         if (slot < 0 || slot >= kPushSlots || !kHostCanPush) return nullptr;
-        if (env_int("MBAVO_PERSIST", 1) == 0) return nullptr; // opt-out before anything touches device memory from the CPU
+        if (!tuning().persistent) return nullptr; // opt-out before anything touches device memory from the CPU
         if (push_probe_ == 0)
         { // CPU stores into device memory need the whole VRAM behind the PCIe BAR (large / resizable BAR); without it the
           // allocation below still succeeds and the first store faults
@@ -2021,9 +2049,10 @@ namespace mbavo
         if (B < 1 || B > 15 || !probs) return MBAVO_E_ARG;
         const mbavo_problem &p = probs[0];
         if (slot < 0 || slot >= kPushSlots || persistent_active(slot) || !h_frame_blocks || !h_inv || (kdeg != 2 && kdeg != 4)) return MBAVO_E_ARG;
-        if (env_int("MBAVO_PERSIST", 1) == 0 || env_int("MBAVO_ONE", 1) == 0) return 1;
+        const EngineTuning tune = tuning();
+        if (!tune.persistent || !tune.single_launch) return 1;
         if (!d_push_ || push_stride_ == 0) return 1; // no CPU-writable device memory: the caller takes the per-evaluation launches
-        if (cached_only && env_int("MBAVO_PRELAUNCH", 1) == 0) return 1;
+        if (cached_only && !tune.prelaunch) return 1;
         int cur = -1;
         if (hipGetDevice(&cur) != hipSuccess || cur != device_) HIP_TRY(hipSetDevice(device_));
         int rc = rebuild_layout(B, probs, kdeg, nullptr, h_inv, cached_only);

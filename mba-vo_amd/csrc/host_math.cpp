@@ -381,20 +381,29 @@ namespace mbavo
         return true;
     }
 
-    double fast_solve_ratio_env()
-    { // MBAVO_FAST_SOLVE=0 always takes the Jacobi SVD; a number sets the admitted pivot ratio (default 1e8)
-        const char *e = getenv("MBAVO_FAST_SOLVE");
-        if (!e || !*e) return 1e8;
-        const double r = atof(e);
-        return r > 1.0 ? r : (r == 1.0 ? 1e8 : 0.0);
+    EnvOverrides read_env_overrides()
+    { // THE reader of the environment for every switch that changes results or scheduling (options.h); the A/B tools' override layer
+        auto num = [](const char *name) { const char *v = getenv(name); return v && *v ? atoi(v) : kEnvUnset; };
+        auto real = [](const char *name) { const char *v = getenv(name); return v && *v ? atof(v) : -2.0; };
+        EnvOverrides e;
+        e.sp = num("MBAVO_SP"); e.one = num("MBAVO_ONE"); e.fused_pose = num("MBAVO_FUSED_POSE");
+        e.fused_pose_max_s = num("MBAVO_FUSED_POSE_MAX_S"); e.persist = num("MBAVO_PERSIST"); e.prelaunch = num("MBAVO_PRELAUNCH");
+        e.tiles_per_cu = num("MBAVO_TILES_PER_CU"); e.min_tile_px = num("MBAVO_MIN_TILE_PX"); e.sp_max_slot_tiles = num("MBAVO_SP_MAX_SLOT_TILES");
+        e.speculate = num("MBAVO_SPECULATE"); e.persist_levels = num("MBAVO_PERSIST_LEVELS"); e.kf_multi = num("MBAVO_KF_MULTI");
+        e.lm_eig = num("MBAVO_LM_EIG"); e.lm_poses = num("MBAVO_LM_POSES"); e.lm_defer = num("MBAVO_LM_DEFER");
+        e.lm_retile = num("MBAVO_LM_RETILE"); e.lm_groups = num("MBAVO_LM_GROUPS");
+        e.fast_solve = real("MBAVO_FAST_SOLVE"); e.lm_refine = real("MBAVO_LM_REFINE");
+        if (e.fast_solve < 0.0 && e.fast_solve > -2.0) e.fast_solve = 0.0; // (a negative number in the variable: off)
+        if (e.lm_refine < 0.0 && e.lm_refine > -2.0) e.lm_refine = 0.0;
+        return e;
     }
 
     int solve_normal_equation_host(const double *A, const double *b, int n, int solver_type, double *x, double fast_ratio)
     {
-        // fast_ratio < 0: ask the environment now.  The LM loops read it ONCE per call (optimize_trajectory, lm_batch) and pass
-        // it down, so that the host loop and the batched LM of one process always run the same solver (a value
-        // latched in a function static could differ from what mbavo_lm_batch read later)
-        if (fast_ratio < 0.0) fast_ratio = fast_solve_ratio_env();
+        // fast_ratio < 0: the library default under the environment's override.  The LM loops resolve it ONCE per call from
+        // their options (optimize_trajectory, lm_batch) and pass it down, so that the host loop and the batched LM of one process
+        // always run the same solver
+        if (fast_ratio < 0.0) fast_ratio = opt_fast_ratio(0.0, read_env_overrides().fast_solve);
         int rank;
         if (solver_type == 0 && fast_ratio > 0.0 && solve_spd_fast(A, b, n, x, fast_ratio)) rank = n;
         else if (solver_type == 0) rank = solve_svd(A, b, n, x);

@@ -10,6 +10,7 @@
 #ifndef MBAVO_HOST_MATH_H
 #define MBAVO_HOST_MATH_H
 
+#include "options.h"
 #include <vector>
 
 namespace mbavo
@@ -21,7 +22,7 @@ namespace mbavo
     // fast_ratio: pivot ratio up to which LDL^T stands in for the Jacobi SVD (solver type 0); 0 = never; < 0 = ask the
     // environment now (MBAVO_FAST_SOLVE, default 1e8).  The LM loops read it once per call and pass it down.
     int solve_normal_equation_host(const double *A_colmajor, const double *b, int n, int solver_type, double *x, double fast_ratio = -1.0);
-    double fast_solve_ratio_env(); // MBAVO_FAST_SOLVE read from the environment at every call
+    // (the admitted pivot ratio of the LDL^T stand-in: options.h opt_fast_ratio)
 } // namespace mbavo
 
 namespace SLAM

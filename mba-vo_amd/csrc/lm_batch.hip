@@ -32,6 +32,7 @@
 #include "lm_solvers.h"
 #include "lm_state.h"
 #include "host_math.h"
+#include "tracker.h"
 #include "pose_entries.h"
 
 #include <cfloat>
@@ -84,6 +85,11 @@ namespace mbavo
         unsigned long long *ticket = reinterpret_cast<unsigned long long *>(num_done + 6);
         const unsigned long long old = atomicAdd(ticket, 1ull + (done_now ? 1ull << 32 : 0ull));
         if ((unsigned)(old & 0xffffffffull) + 1u != (unsigned)(slot + 1) * (unsigned)B) return;
+        // The completing workgroup: every other workgroup made its stores (final states in pinned memory, the status counter)
+        // visible with a system-scope fence BEFORE its relaxed ticket; this acquire fence after the ticket that read theirs
+        // pairs with those fences (fence-to-fence synchronisation), so the release store of the word below publishes all of
+        // them -- by the memory model, not only by how gfx9 drains a system fence.
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const unsigned nd = (unsigned)(old >> 32) + (done_now ? 1u : 0u);
         if (status_src != nullptr)
             __hip_atomic_store(reinterpret_cast<int *>(host_word + 4), __hip_atomic_load(status_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
@@ -522,7 +528,7 @@ namespace mbavo
     } while (0)
 
     int lm_batch(Engine &eng, int B, const mbavo_problem *probs, const mbavo_lm_batch_opts &opt, mbavo_lm_batch_result *results,
-                 mbavo_trace_rec *trace, int trace_cap)
+                 mbavo_trace_rec *trace, int trace_cap, const LmBatchShared *shared)
     {
         const int k = opt.spline_deg_k;
         if (B < 1 || !probs || (k != 2 && k != 4) || (opt.solver_type != 0 && opt.solver_type != 1) || opt.max_num_iterations < 0)
@@ -545,30 +551,29 @@ namespace mbavo
             total_K += probs[b].K > 0 ? probs[b].K : 1;
             total_patches += (long long)probs[b].F * probs[b].K;
         }
+        if (shared && shared->max_N > max_N) max_N = shared->max_N; // (a group of a bigger batch: the batch's strides and kernel form)
         const int max_n = 6 * max_N;
         LmOpts o;
         o.max_it = opt.max_num_iterations; o.max_nonmono = opt.max_consecutive_nonmonotonic_steps; o.solver = opt.solver_type;
         o.trace_cap = trace ? trace_cap : 0; o.max_n = max_n; o.max_N = max_N;
         o.min_q = opt.min_step_quality; o.min_dec = opt.min_abs_cost_decrease; o.chi = opt.max_chi_square_error;
-        o.fast_ratio = fast_solve_ratio_env(); // MBAVO_FAST_SOLVE (default 1e8; 0: the Jacobi solvers / the pivoted LDL^T only)
-        {
-            const char *e = getenv("MBAVO_LM_REFINE"); // 0: no refined stand-in; a number > 1: the admitted pivot ratio
-            const double r = e && *e ? atof(e) : 1.0;
-            o.refined_ratio = o.fast_ratio > 0.0 ? (r > 1.0 ? r : (r == 1.0 ? 1e13 : 0.0)) : 0.0;
-        }
+        // the solver forms and the schedule of this call: mbavo_lm_batch_opts' tail under the environment's override layer (options.h)
+        const EnvOverrides env = read_env_overrides();
+        o.fast_ratio = opt_fast_ratio(opt.fast_solve_ratio, env.fast_solve);                 // default 1e8; 0: the Jacobi solvers / the pivoted LDL^T only
+        o.refined_ratio = opt_refined_ratio(opt.refined_ratio, env.lm_refine, o.fast_ratio); // default 1e13; 0: the plain stand-in only
         // every system within the wide workgroup's reach (k_lm_solve<KD, kEigT>: solver 0 falls back to the workgroup-parallel
         // eigenvalue Jacobi there, solver 1 to the pivoted LDL^T on wave 0; both get their candidates' pose entries from it);
-        // MBAVO_LM_EIG=0 keeps the one-wave one-sided sweeps
-        const char *eig_env = getenv("MBAVO_LM_EIG");
+        // mbavo_lm_batch_opts.eig = -1 keeps the one-wave one-sided sweeps
         // (solver type 1 takes the wide workgroup as well: its stand-in is the same, its fallback the pivoted LDL^T on wave 0)
-        const bool eig = max_n <= kEigMaxN && !(eig_env && eig_env[0] == '0');
+        const bool eig = max_n <= kEigMaxN && opt_flag(opt.eig, env.lm_eig, true);
         const size_t lds_solver = eig ? (eig_lds_doubles(max_n) + 3 * max_n + (size_t)max_n * max_n) * sizeof(double) + (size_t)(4 + 2 * max_n) * sizeof(int)
                                : ((size_t)2 * max_n * (max_n + 1) + 6 * max_n) * sizeof(double) + (size_t)max_n * sizeof(int);
         // the solve kernel's pose entries (eigenvalue-Jacobi form only: it has the KD waves): candidate knots + the segments of
         // a frame's samples in the solvers' area
         int max_S = 1;
         for (int b = 0; b < B; ++b) max_S = probs[b].S > max_S ? probs[b].S : max_S;
-        const bool ext_poses = eig && !(getenv("MBAVO_LM_POSES") && getenv("MBAVO_LM_POSES")[0] == '0');
+        if (shared && shared->max_S > max_S) max_S = shared->max_S;
+        const bool ext_poses = eig && opt_flag(opt.pose_entries, env.lm_poses, true);
         const size_t lds_pose = ext_poses ? (size_t)8 * max_N * sizeof(double) + (size_t)(max_S < kPoseSPB ? max_S : kPoseSPB) * (k - 1) * sizeof(SplineSeg) : 0;
         const size_t lds = lds_solver > lds_pose ? lds_solver : lds_pose;
         if (lds > 160 * 1024) return MBAVO_E_ARG;
@@ -645,8 +650,8 @@ namespace mbavo
                 *h_word = 0; // (no kernel that writes them is in flight: every call ends with a stream synchronisation)
                 *h_word2 = 0;
             }
-            // MBAVO_LM_DEFER=0: the engine's finalize kernels write frame blocks and the LM kernels read those
-            eng.set_defer_finalize(!(getenv("MBAVO_LM_DEFER") && getenv("MBAVO_LM_DEFER")[0] == '0'));
+            // defer_finalize = -1: the engine's finalize kernels write frame blocks and the LM kernels read those
+            eng.set_defer_finalize(opt_flag(opt.defer_finalize, env.lm_defer, true));
             // iteration 0 (:604): also builds the layout (device descriptors) the LM kernels read
             if ((rc = eng.evaluate(B, work.data(), k, true, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
             const ProblemDesc *descs = eng.device_descs();
@@ -659,11 +664,11 @@ namespace mbavo
             // pair is active.  A second layout of the same list with four tiles per pair lives in the engine's companion (built while
             // the first evaluation runs); once few enough pairs are left that their fine tiles fit the CUs, both passes of a slot go
             // through it: one round per workgroup.  The LM kernels are told per launch whose partials to sum (FinSrc).
-            // MBAVO_LM_RETILE=0: one layout.
+            // retile = -1: one layout.
             Engine *fine = nullptr;
             FinSrc fs_fine = fs;
             if (sync_every <= 0 && fs.deferred && ext_poses && eng.num_tiles() < 4 * nbf && eng.num_tiles() * 2 >= eng.num_cus() &&
-                !(getenv("MBAVO_LM_RETILE") && getenv("MBAVO_LM_RETILE")[0] == '0'))
+                opt_flag(opt.retile, env.lm_retile, true))
             {
                 fine = eng.companion();
                 fine->set_tile_target(4ll * nbf);
@@ -701,6 +706,7 @@ namespace mbavo
 #endif
                     if ((spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t_spin > std::chrono::seconds(10)) return 0;
                 }
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
                 return w;
             };
 #define LM_DECIDE_ARGS descs, states, o, fs_cost, pc, inv, ct, cR, act, d_trace, num_done, d_word2, slot, B
@@ -738,7 +744,7 @@ namespace mbavo
                     if (!last && slot > 0 && B <= 128)
                     {
                         const unsigned long long w2 = spin_for(h_word2, (unsigned long long)slot);
-                        if (w2 == 0) { LM_HIP(hipStreamSynchronize(st)); LM_HIP(hipGetLastError()); rc = MBAVO_E_RANGE; goto done; }
+                        if (w2 == 0) { LM_HIP(hipStreamSynchronize(st)); LM_HIP(hipGetLastError()); rc = MBAVO_E_TIMEOUT; goto done; }
                         ending = (int)(unsigned)(w2 & 0xffffffffull) >= B;
                     }
                     auto enqueue_passes = [&]() -> int {
@@ -770,7 +776,7 @@ namespace mbavo
                     { // a launch failed or the device is wedged: let the runtime say which
                         LM_HIP(hipStreamSynchronize(st));
                         LM_HIP(hipGetLastError());
-                        rc = MBAVO_E_RANGE;
+                        rc = MBAVO_E_TIMEOUT; // (not MBAVO_E_RANGE: a wedged device is not an out-of-range capture time)
                         goto done;
                     }
                     h_done = (int)(unsigned)(w & 0xffffffffull);
@@ -801,6 +807,7 @@ namespace mbavo
                 while ((q = hipStreamQuery(st)) == hipErrorNotReady)
                     if (std::chrono::steady_clock::now() - t_q > std::chrono::seconds(10)) break;
                 if (q != hipSuccess) LM_HIP(hipStreamSynchronize(st));
+                __atomic_thread_fence(__ATOMIC_ACQUIRE); // the device's release store of the word -> the final states and the status below
                 *h_status = *reinterpret_cast<volatile int *>(const_cast<unsigned long long *>(h_word) + 4);
             }
             else
@@ -846,7 +853,13 @@ namespace mbavo
     done:
         // an error exit may leave solve launches queued that still store into the pinned done word and the arena: drain them
         // before the next call re-arms the word or regrows either buffer
-        if (rc != 0) (void)hipStreamSynchronize(st);
+        if (rc != 0)
+        {
+            (void)hipStreamSynchronize(st);
+            // range-status increments of the failed call must not be reported by the next, successful one: bring
+            // the engine's `seen` count up to the device's counter
+            (void)eng.fetch_status();
+        }
         eng.set_external_poses(false);
         eng.set_defer_finalize(false);
         if (Engine *c = eng.companion_if_any()) { c->set_external_poses(false); c->set_defer_finalize(false); }

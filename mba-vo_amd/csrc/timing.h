@@ -2,6 +2,7 @@
 // Development aid for the latency work on the single-pair path; costs two clock reads per phase when enabled.
 #ifndef MBAVO_TIMING_H
 #define MBAVO_TIMING_H
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -11,8 +12,9 @@ namespace mbavo
     struct PhaseTimers
     {
         enum { kUpload, kKeyframe, kEnqueue, kWait, kMerge, kSolve, kOutliers, kLevel, kTrack, kFlagsChanged, kFlagsSame, kCount };
-        double sec[kCount] = {};
-        long calls[kCount] = {};
+        // (atomics: mbavo_lm_batch's groups time their evaluations from two host threads; nanoseconds so that the sum is an integer add)
+        std::atomic<long long> nsec[kCount] = {};
+        std::atomic<long> calls[kCount] = {};
         bool on;
         PhaseTimers() { const char *v = getenv("MBAVO_TIMING"); on = v && *v && *v != '0'; }
         ~PhaseTimers() { report(); }
@@ -22,8 +24,10 @@ namespace mbavo
             static const char *names[kCount] = {"upload+pyramid", "keyframe processing", "evaluate enqueue", "evaluate wait", "host merge",
                                                 "host solve+step", "outlier detection", "level setup", "trackFrame (all)", "accepted: flags changed", "accepted: flags same"};
             for (int i = 0; i < kCount; ++i)
-                if (calls[i]) fprintf(stderr, "mbavo timing: %-20s %8ld calls  %9.3f ms total  %7.2f us each\n", names[i], calls[i], sec[i] * 1e3, sec[i] * 1e6 / calls[i]);
-            for (int i = 0; i < kCount; ++i) { sec[i] = 0; calls[i] = 0; }
+                if (calls[i].load())
+                    fprintf(stderr, "mbavo timing: %-20s %8ld calls  %9.3f ms total  %7.2f us each\n", names[i], calls[i].load(), nsec[i].load() * 1e-6,
+                            nsec[i].load() * 1e-3 / calls[i].load());
+            for (int i = 0; i < kCount; ++i) { nsec[i] = 0; calls[i] = 0; }
         }
         static PhaseTimers &get() { static PhaseTimers t; return t; }
     };
@@ -39,8 +43,8 @@ namespace mbavo
             if (!on) return;
             on = false;
             PhaseTimers &t = PhaseTimers::get();
-            t.sec[id] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            ++t.calls[id];
+            t.nsec[id].fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+            t.calls[id].fetch_add(1, std::memory_order_relaxed);
         }
     };
 } // namespace mbavo

@@ -76,7 +76,8 @@ namespace mbavo
         const int n = 6 * N, ndim = 6 * k + 1, E = ndim * (ndim + 1) / 2;
         int rc_ = 0, ntrace = 0;
         hipStream_t st = eng.stream();
-        const double fast_ratio = fast_solve_ratio_env(); // MBAVO_FAST_SOLVE, once per call (mbavo_lm_batch does the same)
+        const EnvOverrides env = read_env_overrides(); // (options.h: the A/B tools' override layer over the options below)
+        const double fast_ratio = opt_fast_ratio(o.fast_solve_ratio, env.fast_solve); // once per call (mbavo_lm_batch does the same)
 
         SLAM::Core::SplineSE3 spline(t0, dt);
         spline.setSplineDegK(k);
@@ -87,15 +88,16 @@ namespace mbavo
         if (start_idx_out) memcpy(start_idx_out, start_idx.data(), sizeof(int) * F);
 
         std::vector<double> H((size_t)n * n), g(n), step(n), cand_t(3 * N), cand_R(4 * N);
-        // Speculation (MBAVO_SPECULATE=1): the candidate is evaluated WITH H / g.  An accepted step is followed by an H / g evaluation
+        // Speculation (mbavo_track_opts.speculate): the candidate is evaluated WITH H / g.  An accepted step is followed by an H / g evaluation
         // at the very same knots (:896-903); it differs from the candidate's only through the outlier flags and the residual scale
         // detectOutliers may have changed in between (:639-699) -- where it changed neither, the candidate's H, g and cost ARE that
         // evaluation's, bit for bit, and it is skipped.
         // Worth it where an evaluation is latency-bound and H / g cost little more than the cost alone: the levels that run on
         // persistent kernels (trackFrame 0.330 -> 0.322 ms per frame, 172 -> 154 evaluations of 12.8 / 14.2 us over 8 tracked
         // frames, identical records and poses); dense levels pay twice the cost-only pass for a one-in-three hit.
-        // MBAVO_SPECULATE=0 / 1: never / on every level.
-        static const int speculate_env = [] { const char *e = getenv("MBAVO_SPECULATE"); return e && (e[0] == '0' || e[0] == '1') ? e[0] - '0' : -1; }();
+        // mbavo_track_opts.speculate = -1 / 1: never / on every level.
+        const int speculate_env = env.speculate != kEnvUnset ? (env.speculate == 0 ? 0 : (env.speculate == 1 ? 1 : -1))
+                                                              : (o.speculate == 0 ? -1 : (o.speculate > 0 ? 1 : 0)); // -1: on the persistent levels
         std::vector<double> Hs(speculate_env != 0 ? (size_t)n * n : 0), gs(speculate_env != 0 ? n : 0);
         std::vector<unsigned char> shadow;
         SLAM::VO::LevenbergMarquardtStrategy lm;
@@ -214,11 +216,10 @@ namespace mbavo
         // ONE persistent kernel for ALL levels of the call where they fit one list (round 3: a launch and a level set-up cost the
         // host ~14 us each, only partly hidden behind evaluations; trackFrame 0.366 -> see profiles/r03_kfused_experiments.txt 7.):
         // the levels are the problems of one layout, they share the knot buffer of slot 0's push block, every level has its own
-        // scale word and flag bytes there, and a command names its level.  MBAVO_PERSIST_LEVELS=0 keeps one kernel per level.
+        // scale word and flag bytes there, and a command names its level.  mbavo_track_opts.persist_levels = -1 keeps one kernel per level.
         bool joint = false;
         size_t joint_pc_off[8] = {};
-        const char *env_joint = getenv("MBAVO_PERSIST_LEVELS");
-        if (o.num_levels > 1 && (env_joint == nullptr || atoi(env_joint) != 0))
+        if (o.num_levels > 1 && opt_flag(o.persist_levels, env.persist_levels, true))
         {
             size_t flag_bytes = 0;
             for (int l = 0; l < o.num_levels; ++l) flag_bytes += ((size_t)(levels[l].K > 0 ? levels[l].K : 1) + 63) & ~(size_t)63;

@@ -276,9 +276,9 @@ namespace SLAM
               // pinned staging -- the 4 H x W bytes of depth never cross the bus
                 int rc = ensureGridBuffers();
                 if (rc != 0) return rc;
-                static const bool levels_at_once = [] { const char *e = getenv("MBAVO_KF_MULTI"); return !(e && e[0] == '0'); }();
+                const bool levels_at_once = mbavo::opt_flag(mOptions.keyframe_levels_at_once, mbavo::read_env_overrides().kf_multi, true);
                 if (levels_at_once)
-                { // pyramid, gradient images and grid selection of ALL levels: three launches (MBAVO_KF_MULTI=0: three per level)
+                { // pyramid, gradient images and grid selection of ALL levels: three launches (keyframe_levels_at_once = -1: three per level)
                     int ncell[8] = {};
                     rc = mbavo::keyframe_levels_enqueue(mEngine, mRef, mGrad, H, W, L, mOptions.grid_selection_cell_H, mOptions.grid_selection_cell_W,
                                                         mOptions.score_threshold, mPicksDev, ncell);
@@ -353,7 +353,7 @@ namespace SLAM
             const int H = mOptions.im_size_HW[0], W = mOptions.im_size_HW[1];
             hipStream_t st = mEngine.stream();
             VO_HIP(hipMemcpyAsync(mCur[0], f.image, (size_t)H * W, hipMemcpyHostToDevice, st));
-            static const bool levels_at_once = [] { const char *e = getenv("MBAVO_KF_MULTI"); return !(e && e[0] == '0'); }();
+            const bool levels_at_once = mbavo::opt_flag(mOptions.keyframe_levels_at_once, mbavo::read_env_overrides().kf_multi, true);
             if (levels_at_once)
             {
                 const int rc = mbavo::pyramid_enqueue(mEngine, mCur, H, W, mOptions.num_pyramid_levels);
@@ -388,6 +388,7 @@ namespace SLAM
             for (int i = 0; i < 4; ++i) o.intrinsics[i] = mOptions.intrinsics[i];
             o.huber_k = mOptions.huber_k; o.min_step_quality = mOptions.min_step_quality;
             o.min_abs_cost_decrease = mOptions.min_abs_cost_decrease; o.max_chi_square_error = mOptions.max_chi_square_error;
+            o.fast_solve_ratio = mOptions.fast_solve_ratio; o.speculate = mOptions.speculate; o.persist_levels = mOptions.persist_levels;
             const int n = mbavo::optimize_trajectory(mEngine, o, lv, 1, &mCurCap, &mCurExp, mSpline.getStartTime(),
                                                      mSpline.getSamplingFreq(), mSpline.get_knot_data_t(), mSpline.get_knot_data_R(),
                                                      (int)mSpline.get_num_knots(), start_idx, &mEvaluationPointCost, mTrace, kTraceCap);

@@ -95,6 +95,9 @@ namespace SLAM
             // FeatureDetectorOptions as tmpProcessKeyframe sets them (blur_aware_direct_tracker.cpp:353-358)
             float score_threshold = 25.f;
             int grid_selection_cell_H = 30, grid_selection_cell_W = 30;
+            // scheduling / solver form (include/mbavo.h: the ABI 3 tail of mbavo_vo_options; zero = default)
+            double fast_solve_ratio = 0.0;
+            int speculate = 0, persist_levels = 0, keyframe_levels_at_once = 0;
         };
 
         struct FrameView

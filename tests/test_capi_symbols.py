@@ -64,3 +64,30 @@ def test_product_does_not_reference_oracle():
                 if re.search(r"oracle[/.]|mbavo_oracle|orc_[a-z]", txt) and f not in ("__init__.py",):
                     bad.append(os.path.join(dp_, f))
     assert not bad, bad
+
+
+def test_binding_structs_mirror_the_library(mbavo):
+    """ABI 3: the ctypes mirrors of every struct that crosses the boundary have the size the library was compiled with
+    (mbavo_sizeof), and the header's revision is the library's."""
+    lib, capi = mbavo.load(), mbavo.capi
+    assert lib.mbavo_abi_version() == 3
+    mirrors = [capi.Problem, capi.TrackOpts, capi.LmBatchOpts, capi.VoOptions, capi.EngineOpts, capi.VoState, capi.TraceRec, capi.Level,
+               capi.LmBatchResult, capi.VoInfo]
+    for which, cls in enumerate(mirrors):
+        assert lib.mbavo_sizeof(which) == C.sizeof(cls), (which, cls.__name__, lib.mbavo_sizeof(which), C.sizeof(cls))
+    assert lib.mbavo_sizeof(len(mirrors)) == -1
+
+
+def test_environment_is_read_in_one_place():
+    """the switches that change results or scheduling are options; the environment is an override layer
+    read by ONE function (csrc/options.h: read_env_overrides); at most four getenv names (diagnostics) elsewhere."""
+    names = {}
+    base = os.path.join(ROOT, "mba-vo_amd", "csrc")
+    for f in os.listdir(base):
+        txt = open(os.path.join(base, f), errors="ignore").read()
+        if f == "host_math.cpp":  # the one reader: cut its body out
+            a = txt.index("EnvOverrides read_env_overrides()")
+            txt = txt[:a] + txt[txt.index("return e;", a):]
+        for m in re.finditer(r'getenv\("(MBAVO_[A-Z0-9_]+)"\)', txt):
+            names.setdefault(m.group(1), set()).add(f)
+    assert set(names) <= {"MBAVO_TIMING", "MBAVO_LM_STAMPS", "MBAVO_LM_STATS"}, names

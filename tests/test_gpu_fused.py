@@ -255,14 +255,14 @@ def test_many_small_problems_flat_finalize(orc, mbavo, gpu_ctx):
 
 
 @pytest.mark.parametrize("sp", ["0", "1"])
-def test_non_finite_depth_is_dropped_in_both_kernels(orc, mbavo, sp, monkeypatch):
+def test_non_finite_depth_is_dropped_in_both_kernels(orc, mbavo, sp):
     """A keypoint with inf / NaN depth passes the detector's `!(z < 1e-2)` test (blur_aware_direct_tracker.cpp:403-405)
     and reaches the path: its pixels must be dropped (invalid: zero residual, zero row), not weighted by zero --
-    0 * NaN would turn the frame's H and g into NaN.  Both the lane-per-pixel kernel (MBAVO_SP=0) and the
-    sample-parallel kernel (MBAVO_SP=1) against the oracle."""
+    0 * NaN would turn the frame's H and g into NaN.  Both the lane-per-pixel kernel (mbavo_engine_opts.sample_parallel = -1) and
+    the sample-parallel kernel (= 1) against the oracle."""
     import torch
-    monkeypatch.setenv("MBAVO_SP", sp)
-    ctx = mbavo.capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)  # the switch is read per layout
+    ctx = mbavo.capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    ctx.engine_opts(sample_parallel=1 if sp == "1" else -1)
     try:
         for k in (4, 2):
             sc = scenes.Scene(S=8, F=2, k=k, P=8, K=90, seed=21)
@@ -281,14 +281,13 @@ def test_non_finite_depth_is_dropped_in_both_kernels(orc, mbavo, sp, monkeypatch
 
 @pytest.mark.parametrize("name", ["k4_dense_S8", "k4_dense_S1", "k4_P8_lane_per_pixel", "k4_batch_mixed_S", "k2_dense_S8", "k2_P8_three_frames",
                                   "k2_batch_mixed_S"])
-def test_pose_prologue_equals_pose_kernel(orc, mbavo, monkeypatch, name):
+def test_pose_prologue_equals_pose_kernel(orc, mbavo, name):
     """Tiles <= CUs, S <= 8: the pose entries are the fused kernel's prologue (k_fused<.., POSE>, two launches);
-    MBAVO_FUSED_POSE=0 keeps k_pose_table (three launches).  Same arithmetic per entry -> the frame blocks, per-patch
+    mbavo_engine_opts.fused_pose = -1 keeps k_pose_table (three launches).  Same arithmetic per entry -> the frame blocks, per-patch
     costs and valid counts must be IDENTICAL, H/g and cost-only, and both must match the oracle (1e-9).  k = 2 -- the
     reference's default degree, blur_aware_direct_tracker.h:50 -- takes the prologue since round 4 (through the two stages:
     the one-lane chain spilled at the k = 2 kernels' 128-register budget)."""
     import torch
-    monkeypatch.setenv("MBAVO_SP", "0")  # the lane-per-pixel kernel whatever the size
     kws = {"k4_dense_S8": [dict(H=96, W=128, S=8, F=2, k=4, P=1, kp="dense", margin=0)],
            "k4_dense_S1": [dict(H=60, W=80, S=1, F=1, k=4, P=1, kp="dense", margin=0)],
            "k4_P8_lane_per_pixel": [dict(S=8, F=3, k=4, P=8, K=211, N=6)],
@@ -302,8 +301,8 @@ def test_pose_prologue_equals_pose_kernel(orc, mbavo, monkeypatch, name):
     scs = [scenes.Scene(**kw) for kw in kws]
     got = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("MBAVO_FUSED_POSE", mode)
         ctx = mbavo.capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        ctx.engine_opts(sample_parallel=-1, fused_pose=1 if mode == "1" else -1)  # the lane-per-pixel kernel whatever the size
         try:
             ds = [scenes.DeviceScene(sc) for sc in scs]
             fb, pc, valid = scenes.gpu_eval_batch(ctx, ds, kdeg)

@@ -36,7 +36,7 @@ def _scene(B, k, N, F, seed, H=96, W=128, S=4):
     return probs
 
 
-def _host_lm(mbavo, ctx, dw, b, p, solver, trace_cap=64):
+def _host_lm(mbavo, ctx, dw, b, p, solver, trace_cap=64, fast_solve_ratio=0.0):
     capi = mbavo.capi
     lv = (capi.Level * 1)()
     q, a = lv[0], dw.array[b]
@@ -50,6 +50,7 @@ def _host_lm(mbavo, ctx, dw, b, p, solver, trace_cap=64):
         o.intrinsics[i] = float(p.intr[i])
     o.huber_k, o.min_step_quality = p.huber, OPTS["min_q"]
     o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_dec"], OPTS["chi"]
+    o.fast_solve_ratio = fast_solve_ratio  # (0: the default stand-in up to a pivot ratio of 1e8; -1: the reference's solvers for every system)
     kt, kR = p.knots_t.copy(), p.knots_R.copy()
     start, cost = np.zeros(p.F, np.int32), np.zeros(1)
     trace = (capi.TraceRec * trace_cap)()
@@ -64,19 +65,19 @@ def _host_lm(mbavo, ctx, dw, b, p, solver, trace_cap=64):
                                                    (4, 16, 2, 0, None), (4, 8, 2, 0, None),
                                                    (4, 4, 1, 0, None), (2, 2, 1, 0, None), (2, 3, 2, 0, None), (2, 3, 2, 1, "0"), (4, 4, 1, 1, "0"),
                                                    (4, 6, 3, 0, None), (2, 5, 4, 0, None), (4, 6, 3, 1, None)])  # n = 36, 30 with data on every knot: the workgroup LDL^T
-def test_lm_batch_matches_host_loop(mbavo, gpu_ctx, monkeypatch, k, N, F, solver, fast):
-    """fast = "0" (MBAVO_FAST_SOLVE=0): solver type 0 through the Jacobi solvers only -- n = 24, 36 (three blocks per thread), 12:
+def test_lm_batch_matches_host_loop(mbavo, gpu_ctx, k, N, F, solver, fast):
+    """fast = "0" (fast_solve_ratio = -1 in both option structs): solver type 0 through the Jacobi solvers only -- n = 24, 36 (three blocks per thread), 12:
     eigenvalue Jacobi; solver type 1 through the pivoted LDL^T only.  Default: LDL^T in registers, refined in double-double above a
     pivot ratio of 1e8, stands in for either (n = 12, 18, 24); n = 96: one-wave sweeps, 48: the eigenvalue Jacobi's largest."""
     import torch
-    if fast is not None:
-        monkeypatch.setenv("MBAVO_FAST_SOLVE", fast)
+    ratio = -1.0 if fast == "0" else 0.0
     capi = mbavo.capi
     B = 6
     probs = _scene(B, k, N, F, seed=11 + k + N)
     dw = workloads.DeviceWorkload(probs)
-    host = [_host_lm(mbavo, gpu_ctx, dw, b, p, solver) for b, p in enumerate(probs)]  # does not touch the device knots
+    host = [_host_lm(mbavo, gpu_ctx, dw, b, p, solver, fast_solve_ratio=ratio) for b, p in enumerate(probs)]  # does not touch the device knots
     o = capi.LmBatchOpts()
+    o.fast_solve_ratio = ratio
     o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, OPTS["max_it"], OPTS["max_nonmono"]
     o.solver_type, o.sync_every = solver, 3
     o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
@@ -110,20 +111,20 @@ def test_lm_batch_matches_host_loop(mbavo, gpu_ctx, monkeypatch, k, N, F, solver
     assert 1 in kinds_seen and (2 in kinds_seen or 3 in kinds_seen)
 
 
-def test_lm_batch_eigenvalue_jacobi_matches_one_wave_sweeps(mbavo, gpu_ctx, monkeypatch):
+def test_lm_batch_eigenvalue_jacobi_matches_one_wave_sweeps(mbavo, gpu_ctx):
     """Solver type 0 through the workgroup-parallel eigenvalue Jacobi (default for n <= 48) and through the one-wave one-sided
-    sweeps (MBAVO_LM_EIG=0): the same records, costs to 1e-6 relative (both solve to rounding x cond(H), cond ~1e9)."""
+    sweeps (mbavo_lm_batch_opts.eig = -1): the same records, costs to 1e-6 relative (both solve to rounding x cond(H), cond ~1e9)."""
     import torch
     capi = mbavo.capi
     B, k, N, F = 8, 4, 4, 1
     out = {}
     for eig in ("1", "0", "fast"):
         # "fast": the default -- LDL^T in registers where the pivot ratio allows; the other two: Jacobi solvers only
-        monkeypatch.setenv("MBAVO_LM_EIG", "1" if eig == "fast" else eig)
-        monkeypatch.setenv("MBAVO_FAST_SOLVE", "1" if eig == "fast" else "0")
         probs = _scene(B, k, N, F, seed=23)
         dw = workloads.DeviceWorkload(probs)
         o = capi.LmBatchOpts()
+        o.eig = -1 if eig == "0" else 1
+        o.fast_solve_ratio = 0.0 if eig == "fast" else -1.0
         o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, OPTS["max_it"], OPTS["max_nonmono"]
         o.solver_type, o.sync_every = 0, 0  # (0: the event-lagged done check)
         o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
@@ -142,23 +143,22 @@ def test_lm_batch_eigenvalue_jacobi_matches_one_wave_sweeps(mbavo, gpu_ctx, monk
 
 
 @pytest.mark.parametrize("k,N,F,sync_every", [(4, 6, 2, 0), (2, 3, 1, 0), (4, 4, 1, 3)])
-def test_lm_batch_deferred_finalize_same_bits(mbavo, gpu_ctx, monkeypatch, k, N, F, sync_every):
+def test_lm_batch_deferred_finalize_same_bits(mbavo, gpu_ctx, k, N, F, sync_every):
     """Lists of >= 64 (problem, frame) slots: the LM kernels sum the tile partials themselves (no finalize launch; engine.h:
     set_defer_finalize) in the finalize kernel's order -- every trace record and every final knot is bit-identical to the run with
-    the finalize kernels (MBAVO_LM_DEFER=0); the done word in pinned host memory (sync_every 0) against the stream-drain scheme.
-    (MBAVO_LM_RETILE=0: the second, finer tiling of the late slots -- which only exists with deferred sums -- would change the grouping
+    the finalize kernels (mbavo_lm_batch_opts.defer_finalize = -1); the done word in pinned host memory (sync_every 0) against the stream-drain scheme.
+    (retile = -1: the second, finer tiling of the late slots -- which only exists with deferred sums -- would change the grouping
     of the sums; test_lm_batch_retiled_late_slots covers it.)"""
     import torch
     capi = mbavo.capi
     B = 70
     out = {}
-    monkeypatch.setenv("MBAVO_LM_RETILE", "0")
     for defer in ("1", "0"):
-        monkeypatch.setenv("MBAVO_LM_DEFER", defer)
         probs = _scene(B, k, N, F, seed=31)
         dw = workloads.DeviceWorkload(probs)
         dw.array[3].K = 0  # a pair without keypoints: its slots have no tile (all-zero sums either way)
         o = capi.LmBatchOpts()
+        o.retile, o.defer_finalize = -1, (1 if defer == "1" else -1)
         o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, 12, OPTS["max_nonmono"]
         o.solver_type, o.sync_every = 0, sync_every
         o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
@@ -319,23 +319,20 @@ def _oracle_alignment(orc, batch, b, k, N, solver):
 
 @pytest.mark.parametrize("k,N,solver,env", [
     (4, 4, 0, {}),                                                     # refined LDL^T stand-in in registers (default)
-    (4, 4, 0, {"MBAVO_LM_REFINE": "0"}),                               # plain LDL^T up to a pivot ratio of 1e8, the Jacobi solver above
-    (4, 4, 0, {"MBAVO_FAST_SOLVE": "0"}),                              # workgroup-parallel eigenvalue Jacobi for every system
-    (4, 4, 0, {"MBAVO_FAST_SOLVE": "0", "MBAVO_LM_EIG": "0"}),         # one-wave one-sided Jacobi SVD: solve_normal_equation.h case 0
+    (4, 4, 0, {"refined_ratio": -1.0}),                               # plain LDL^T up to a pivot ratio of 1e8, the Jacobi solver above
+    (4, 4, 0, {"fast_solve_ratio": -1.0}),                              # workgroup-parallel eigenvalue Jacobi for every system
+    (4, 4, 0, {"fast_solve_ratio": -1.0, "eig": -1}),         # one-wave one-sided Jacobi SVD: solve_normal_equation.h case 0
     (4, 4, 1, {}),                                                     # solver type 1 through the refined stand-in
-    (4, 4, 1, {"MBAVO_FAST_SOLVE": "0"}),                              # pivoted LDL^T: solve_normal_equation.h case 1 (wave 0 of the wide workgroup)
-    (4, 4, 1, {"MBAVO_FAST_SOLVE": "0", "MBAVO_LM_EIG": "0"}),         # the same in the one-wave workgroup
-    (2, 2, 0, {}), (2, 2, 0, {"MBAVO_FAST_SOLVE": "0"}), (2, 2, 1, {}),  # the reference's default degree, both solver types
+    (4, 4, 1, {"fast_solve_ratio": -1.0}),                              # pivoted LDL^T: solve_normal_equation.h case 1 (wave 0 of the wide workgroup)
+    (4, 4, 1, {"fast_solve_ratio": -1.0, "eig": -1}),         # the same in the one-wave workgroup
+    (2, 2, 0, {}), (2, 2, 0, {"fast_solve_ratio": -1.0}), (2, 2, 1, {}),  # the reference's default degree, both solver types
     (2, 4, 0, {}),                                                     # RANK-DEFICIENT: knots 2 and 3 have no data -> pseudo-inverse
-    (2, 4, 0, {"MBAVO_LM_EIG": "0"}),
+    (2, 4, 0, {"eig": -1}),
 ])
-def test_lm_batch_rendered_pairs_against_oracle(orc, mbavo, gpu_ctx, monkeypatch, k, N, solver, env):
+def test_lm_batch_rendered_pairs_against_oracle(orc, mbavo, gpu_ctx, k, N, solver, env):
+    """`env`: the solver-form fields of mbavo_lm_batch_opts (they were environment variables until round 5)."""
     import torch
     import tracking
-    for name in ("MBAVO_FAST_SOLVE", "MBAVO_LM_EIG", "MBAVO_LM_REFINE"):
-        monkeypatch.delenv(name, raising=False)
-    for name, v in env.items():
-        monkeypatch.setenv(name, v)
     capi = mbavo.capi
     batch = _rendered(gpu_ctx, k)
     B = batch.B
@@ -348,6 +345,8 @@ def test_lm_batch_rendered_pairs_against_oracle(orc, mbavo, gpu_ctx, monkeypatch
     o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, OPTS["max_it"], OPTS["max_nonmono"]
     o.solver_type, o.sync_every = solver, 0
     o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
+    for name, v in env.items():
+        setattr(o, name, v)
     cap = 64
     res = (capi.LmBatchResult * B)()
     trace = (capi.TraceRec * (B * cap))()
@@ -378,9 +377,9 @@ def test_lm_batch_rendered_pairs_against_oracle(orc, mbavo, gpu_ctx, monkeypatch
     assert abs(ate_g - ate_o) <= 1e-5, (ate_g, ate_o)
 
 
-def test_lm_batch_groups_same_records(mbavo, gpu_ctx, monkeypatch):
+def test_lm_batch_groups_same_records(mbavo, gpu_ctx):
     """mbavo_lm_batch on big batches runs as independent GROUPS (round 4: the second on its own engine, stream and host thread;
-    default from 384 problems).  Forced here on 11 pairs (MBAVO_LM_GROUPS = 2 and 3, uneven shares) against one group: the same
+    default from 384 problems).  Forced here on 11 pairs (mbavo_lm_batch_opts.groups = 2 and 3, uneven shares) against one group: the same
     trace records per pair (kinds, iterations, outlier counts), costs 1e-9 relative (a group's list may be tiled differently),
     knots 1e-9; traces land at the pair's own rows."""
     import torch
@@ -388,10 +387,10 @@ def test_lm_batch_groups_same_records(mbavo, gpu_ctx, monkeypatch):
     B, k, N, F = 11, 4, 4, 1
     out = {}
     for groups in ("1", "2", "3"):
-        monkeypatch.setenv("MBAVO_LM_GROUPS", groups)
         probs = _scene(B, k, N, F, seed=53)
         dw = workloads.DeviceWorkload(probs)
         o = capi.LmBatchOpts()
+        o.groups = int(groups)
         o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, OPTS["max_it"], OPTS["max_nonmono"]
         o.solver_type, o.sync_every = 0, 0
         o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
@@ -446,11 +445,11 @@ def test_lm_batch_results_without_trace_come_from_pinned_memory(mbavo, gpu_ctx):
     assert got[0] == got[1] and sum(r[1] for r in got[0]) > 0
 
 
-def test_lm_batch_retiled_late_slots(orc, mbavo, gpu_ctx, monkeypatch):
+def test_lm_batch_retiled_late_slots(orc, mbavo, gpu_ctx):
     """Round 4: a batch of more pairs than its coarse tiling has tiles per CU (one or two tiles per pair) switches both passes of a slot
     to a second layout with four tiles per pair once few pairs are left (lm_batch.hip "RE-TILING"); the LM kernels are told per launch
     whose partials to sum.  160 rendered 480x640 pairs (two coarse tiles per pair), early exit so that the pairs finish at different
-    slots: against MBAVO_LM_RETILE=0 the same iteration / accept / reject / invalid / outlier counts for every pair, final costs 1e-9,
+    slots: against mbavo_lm_batch_opts.retile = -1 the same iteration / accept / reject / invalid / outlier counts for every pair, final costs 1e-9,
     knots 1e-9 (another grouping of the sums, rounding only); three pairs against the oracle's loop (pose at capture 1e-5)."""
     import torch
     import tracking
@@ -459,9 +458,9 @@ def test_lm_batch_retiled_late_slots(orc, mbavo, gpu_ctx, monkeypatch):
     batch = workloads.RenderedPairBatch(gpu_ctx, B, H=480, W=640, S=8, k=4, seed=3)
     out = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("MBAVO_LM_RETILE", mode)
         batch.reset_knots()
         o = capi.LmBatchOpts()
+        o.retile = 1 if mode == "1" else -1
         o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = 4, OPTS["max_it"], OPTS["max_nonmono"]
         o.solver_type, o.sync_every = 0, 0
         o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
@@ -489,3 +488,109 @@ def test_lm_batch_retiled_late_slots(orc, mbavo, gpu_ctx, monkeypatch):
         pg, qg = tracking.pose_at(orc, 4, sc["t0"], sc["dt"], kn[:12].reshape(4, 3), kn[12:].reshape(4, 4), tc)
         po, qo = tracking.pose_at(orc, 4, sc["t0"], sc["dt"], want["kt"], want["kR"], tc)
         assert np.abs(pg - po).max() <= 1e-5 and np.abs(qg - qo).max() <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The host machinery around the groups under FAILURE: one group fails while the others run,
+# destruction with parked / just-failed workers, decisions shared by the groups on mixed batches.
+def _lm_opts(capi, k, groups=0, max_it=None):
+    o = capi.LmBatchOpts()
+    o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = k, OPTS["max_it"] if max_it is None else max_it, OPTS["max_nonmono"]
+    o.solver_type, o.sync_every = 0, 0
+    o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = OPTS["min_q"], OPTS["min_dec"], OPTS["chi"]
+    o.groups = groups
+    return o
+
+
+def _run_lm(capi, ctx, dw, B, o, cap=48):
+    import torch
+    res = (capi.LmBatchResult * B)()
+    trace = (capi.TraceRec * (B * cap))()
+    rc = ctx.lib.mbavo_lm_batch(ctx.handle, B, dw.array, C.byref(o), res, trace, cap)
+    torch.cuda.synchronize()
+    recs = [[(t.iter, t.kind, t.num_outliers) for t in trace[b * cap:b * cap + res[b].num_trace]] for b in range(B)]
+    return rc, recs, [r.final_cost for r in res]
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("groups", [2, 4])
+def test_lm_batch_one_group_fails_the_others_run(mbavo, groups):
+    """A capture time outside the spline in ONE pair of the last group (the pose entries clamp the segment and count it: A2,
+    MBAVO_E_RANGE) while the other groups run their loops on their own streams and host threads: the call returns the error
+    with every stream drained, the next call on the context -- the same batch, repaired -- succeeds with the records of a fresh
+    context, and the failed call's range count is not reported again.  Then mbavo_destroy right after a failed
+    call, workers just finished."""
+    import time
+    import torch
+    capi = mbavo.capi
+    B, k, N, F = 12, 4, 4, 1
+    ctx = capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    try:
+        dw = workloads.DeviceWorkload(_scene(B, k, N, F, seed=71))
+        bad = torch.tensor([1.0e3], dtype=torch.float64, device="cuda:0")  # far beyond the four knots
+        dw.array[B - 2].d_cap_time = bad.data_ptr()
+        rc, _, _ = _run_lm(capi, ctx, dw, B, _lm_opts(capi, k, groups))
+        assert rc == -2, rc                                                      # MBAVO_E_RANGE, from the group that owns the pair
+        assert torch.cuda.current_stream().query()                               # nothing of the call is still in flight
+        dw2 = workloads.DeviceWorkload(_scene(B, k, N, F, seed=71))              # (the failed call moved some pairs' knots)
+        rc2, recs2, costs2 = _run_lm(capi, ctx, dw2, B, _lm_opts(capi, k, groups))
+        assert rc2 == 0, rc2
+        fresh = capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        try:
+            dw3 = workloads.DeviceWorkload(_scene(B, k, N, F, seed=71))
+            rc3, recs3, costs3 = _run_lm(capi, fresh, dw3, B, _lm_opts(capi, k, groups))
+        finally:
+            fresh.close()
+        assert rc3 == 0 and recs2 == recs3 and costs2 == costs3
+        # fail again and destroy at once
+        dw2.array[B - 1].d_cap_time = bad.data_ptr()
+        rc4, _, _ = _run_lm(capi, ctx, dw2, B, _lm_opts(capi, k, groups))
+        assert rc4 == -2
+    finally:
+        t0 = time.perf_counter()
+        ctx.close()
+        assert time.perf_counter() - t0 < 5.0
+
+
+@pytest.mark.timeout(300)
+def test_destroy_with_parked_group_workers(mbavo):
+    """mbavo_destroy right after a grouped call (helper threads still spinning) and after the helpers went to sleep on their
+    condition variable (200 us after their last job): both return promptly; a context that never ran a grouped call too."""
+    import time
+    import torch
+    capi = mbavo.capi
+    for pause in (0.0, 0.05):
+        ctx = capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+        dw = workloads.DeviceWorkload(_scene(9, 2, 2, 1, seed=5))
+        rc, recs, _ = _run_lm(capi, ctx, dw, 9, _lm_opts(capi, 2, 3))
+        assert rc == 0 and all(len(r) > 1 for r in recs)
+        time.sleep(pause)
+        t0 = time.perf_counter()
+        ctx.close()
+        assert time.perf_counter() - t0 < 5.0
+    ctx = capi.Context(0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", ["mixed_N", "just_under_two_per_cu"])
+def test_lm_batch_groups_on_mixed_batches(mbavo, gpu_ctx, case):
+    """the groups take the batch's largest knot count (kernel form, strides) from the whole batch, so a batch that
+    mixes N = 4 and N = 6 problems -- whose halves would otherwise pick different kernels -- and a batch just under two problems
+    per CU (whose halves fall under the CU count and are tiled finer) give the single-group run's records: identical
+    (iteration, kind, outliers), final costs to 1e-9 relative (another grouping of the tile sums)."""
+    capi = mbavo.capi
+    if case == "mixed_N":
+        a, b = _scene(8, 4, 4, 1, seed=61), _scene(8, 4, 6, 2, seed=62)
+        probs = a[:5] + b[:3] + a[5:] + b[3:]     # first half mostly N = 4, second half mostly N = 6
+    else:
+        probs = _scene(500, 4, 4, 1, seed=63)
+    B = len(probs)
+    out = {}
+    for groups in (1, 2):
+        dw = workloads.DeviceWorkload(probs)
+        rc, recs, costs = _run_lm(capi, gpu_ctx, dw, B, _lm_opts(capi, 4, groups, max_it=8), cap=24)
+        assert rc == 0
+        out[groups] = (recs, costs)
+    assert out[1][0] == out[2][0]
+    assert np.allclose(out[1][1], out[2][1], rtol=1e-9, atol=0)
+    assert sum(1 for r in out[1][0] for t in r if t[1] == 1) >= B // 2

@@ -49,9 +49,9 @@ def test_tracker_matches_oracle(orc, mbavo, gpu_ctx, name, kw):
 
 
 @pytest.mark.parametrize("kw", [dict(H=120, W=160, levels=3, S=8, k=2, seed=2), dict(H=480, W=640, levels=4, S=8, k=4, F=2, seed=7)])
-def test_tracker_evaluation_paths_agree(orc, mbavo, gpu_ctx, kw, monkeypatch):
+def test_tracker_evaluation_paths_agree(orc, mbavo, gpu_ctx, kw):
     """The three ways an evaluation of the host-driven LM loop reaches the GPU -- commands to a persistent kernel (default),
-    one single-launch kernel per evaluation (MBAVO_PERSIST=0), three launches per evaluation (MBAVO_ONE=0) -- run the same
+    one single-launch kernel per evaluation (mbavo_engine_opts.persistent = -1), three launches per evaluation (single_launch = -1) -- run the same
     arithmetic per pixel and differ only in the order the tile partials are added (1e-16 per evaluation, amplified by the
     conditioning of the normal equations along the iterates): identical accept / reject / outlier traces; costs 1e-6 and knots 1e-4, the
     tolerances of the oracle comparison above (observed here: 1e-7 on the k = 4 scene, whose outer knots are weakly
@@ -59,12 +59,12 @@ def test_tracker_evaluation_paths_agree(orc, mbavo, gpu_ctx, kw, monkeypatch):
     import tracking
     sc = tracking.make_tracking_scene(orc, **kw)
     runs = {}
-    for name, env in (("persistent", {}), ("one_launch", {"MBAVO_PERSIST": "0"}), ("three_launches", {"MBAVO_PERSIST": "0", "MBAVO_ONE": "0"})):
-        for k in ("MBAVO_PERSIST", "MBAVO_ONE"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        runs[name] = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, dict(tracking.OPTS))
+    try:
+        for name, eo in (("persistent", {}), ("one_launch", {"persistent": -1}), ("three_launches", {"persistent": -1, "single_launch": -1})):
+            gpu_ctx.engine_opts(**eo)
+            runs[name] = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, dict(tracking.OPTS))
+    finally:
+        gpu_ctx.engine_opts()  # back to the defaults for the session's other tests
     ref = runs["persistent"]
     for name in ("one_launch", "three_launches"):
         r = runs[name]
@@ -82,18 +82,17 @@ def test_tracker_evaluation_paths_agree(orc, mbavo, gpu_ctx, kw, monkeypatch):
     ("k4_ldlt", dict(H=120, W=160, levels=3, S=8, k=4, seed=4)),
 ])
 @pytest.mark.parametrize("fast_solve", ["1", "0"])
-def test_lm_loop_shapes_and_solvers_match_oracle(orc, mbavo, gpu_ctx, monkeypatch, name, kw, fast_solve):
+def test_lm_loop_shapes_and_solvers_match_oracle(orc, mbavo, gpu_ctx, name, kw, fast_solve):
     """The host-driven loop on the shapes the (removed, round 4) resident LM loop was held to -- three frames on one spline,
     k = 4 with the Jacobi SVD, solver type 1 -- against the oracle's loop, with the LDL^T stand-in of solver type 0 on
-    (default) and off (MBAVO_FAST_SOLVE=0: solve_normal_equation.h case 0 for every system): identical knot start indices,
+    (default) and off (mbavo_track_opts.fast_solve_ratio = -1: solve_normal_equation.h case 0 for every system): identical knot start indices,
     accept / reject / invalid sequence and outlier counts, costs 1e-6, poses at capture time 1e-5."""
     sc = tracking.make_tracking_scene(orc, **kw)
     opts = dict(tracking.OPTS)
     if "ldlt" in name:
         opts["solver_type"] = 1
     ro = tracking.run_oracle_tracker(orc, sc, opts)
-    monkeypatch.setenv("MBAVO_FAST_SOLVE", fast_solve)
-    rg = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, opts)
+    rg = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, dict(opts, fast_solve_ratio=0.0 if fast_solve == "1" else -1.0))
     assert gpu_ctx.lib.mbavo_last_kernel(gpu_ctx.handle).decode().startswith("k_fused_sp<")
     assert np.array_equal(ro["start"], rg["start"]) and len(ro["trace"]) == len(rg["trace"])
     for a, b in zip(ro["trace"], rg["trace"]):
