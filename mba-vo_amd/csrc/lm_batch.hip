@@ -54,15 +54,23 @@ namespace mbavo
         const double *partials;  // deferred: tile partials, `stride` doubles each: [valid | g, H sums | cost | spare]
         const int *tile_begin;   // deferred: slot bf owns tiles [tile_begin[bf], tile_begin[bf + 1])
         int stride, deferred;
+        int f1;                  // every problem has ONE frame: slot == problem index, so the slot's tile range, start index and residual
+                                 // scale can be fetched at kernel entry, beside the descriptor instead of behind it (round 5: the merge
+                                 // was a chain descriptor -> tile range -> partials of three memory latencies)
+        const double *inv;       // f1: the residual scales, [problem]
     };
-    __device__ __forceinline__ double slot_sum(const FinSrc &fs, int bf, int e)
+    __device__ __forceinline__ double slot_sum_range(const FinSrc &fs, int t0, int n, int e)
     {
-        const int t0 = fs.tile_begin[bf], n = fs.tile_begin[bf + 1] - t0;
         double t[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (i < n) t[i] = fs.partials[(size_t)(t0 + i) * fs.stride + e];
         return (t[0] + t[2]) + (t[1] + t[3]);
+    }
+    __device__ __forceinline__ double slot_sum(const FinSrc &fs, int bf, int e)
+    {
+        const int t0 = fs.tile_begin[bf];
+        return slot_sum_range(fs, t0, fs.tile_begin[bf + 1] - t0, e);
     }
     template <int E>
     __device__ __forceinline__ double slot_cost(const FinSrc &fs, int bf)
@@ -133,6 +141,14 @@ namespace mbavo
         extern __shared__ __attribute__((aligned(16))) double lds[];
         const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
         const ProblemDesc &d = descs[b];
+        // one-frame batches: the first slot's tile range, start index and scale do not wait for the descriptor
+        int e_t0 = 0, e_t1 = 0, e_st0 = 0;
+        double e_inv = 0.0;
+        if (fs.f1 && fs.deferred)
+        {
+            e_t0 = fs.tile_begin[b]; e_t1 = fs.tile_begin[b + 1]; e_st0 = start_idx[b];
+            e_inv = fs.inv[b];
+        }
         const int N = d.N, n = 6 * N, F = d.F;
         LmState s = states[b]; // (slot 0: the initial state, uploaded by the host with the head of the arena)
         if (s.done)
@@ -171,17 +187,21 @@ namespace mbavo
             // costs, and scattered after the bookkeeping: one memory latency for all of it instead of a dependent chain cost ->
             // bookkeeping -> g -> H (the kernel is a chain of such round trips: 11 700 of its 37 000 cycles were this merge).
             constexpr int kEntries = E - 1, kPer = (kEntries + T - 1) / T;
-            const double inv = fs.deferred ? (d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals) : 0.0;
-            const int bf0 = d.bf_base, st0 = start_idx[bf0];
+            const bool early = fs.f1 && fs.deferred;
+            const double inv = early ? e_inv : (fs.deferred ? (d.inv_ptr != nullptr ? *d.inv_ptr : d.inv_num_residuals) : 0.0);
+            const int bf0 = early ? b : d.bf_base, st0 = early ? e_st0 : start_idx[bf0];
             double val[kPer];
 #pragma unroll
             for (int q = 0; q < kPer; ++q)
             {
                 const int p = 1 + tid + q * T;
-                val[q] = p <= kEntries ? (fs.deferred ? slot_sum(fs, bf0, p) * inv : fs.fb[(size_t)bf0 * E + p]) : 0.0;
+                val[q] = p <= kEntries ? (early ? slot_sum_range(fs, e_t0, e_t1 - e_t0, p) * inv
+                                                : (fs.deferred ? slot_sum(fs, bf0, p) * inv : fs.fb[(size_t)bf0 * E + p])) : 0.0;
             }
             double cost = 0.0;
-            for (int f = 0; f < F; ++f) cost += slot_cost<E>(fs, d.bf_base + f);
+            if (early) cost = slot_sum_range(fs, e_t0, e_t1 - e_t0, E);
+            else
+                for (int f = 0; f < F; ++f) cost += slot_cost<E>(fs, d.bf_base + f);
             s.eval_cost = cost;
             if (s.pending_accept)
             { // handleSuccessfulStep (:896-903)
@@ -427,6 +447,9 @@ namespace mbavo
         constexpr int ND = 6 * KD + 1, E = ND * (ND + 1) / 2;
         const int b = blockIdx.x, lane = threadIdx.x;
         const ProblemDesc &d = descs[b];
+        int e_t0 = 0, e_t1 = 0;
+        const bool early = fs.f1 && fs.deferred; // (see FinSrc::f1)
+        if (early) { e_t0 = fs.tile_begin[b]; e_t1 = fs.tile_begin[b + 1]; }
         LmState s = states[b];
         if (s.done || active[b] == 0)
         { // finished, or an invalid step: nothing was evaluated
@@ -443,7 +466,9 @@ namespace mbavo
 #pragma unroll
         for (int q = 0; q < kPre; ++q) pcv[q] = (pre && lane + 64 * q < d.K) ? pc[lane + 64 * q] : 0.0;
         double cost = 0.0;
-        for (int f = 0; f < d.F; ++f) cost += slot_cost<E>(fs, d.bf_base + f);
+        if (early) cost = slot_sum_range(fs, e_t0, e_t1 - e_t0, E);
+        else
+            for (int f = 0; f < d.F; ++f) cost += slot_cost<E>(fs, d.bf_base + f);
         s.cand_cost = cost;
         s.abs_dec = s.eval_cost - s.cand_cost; // recorded before the accept test (:624)
         s.quality = tr_quality(s, s.cand_cost, s.model);
@@ -659,6 +684,8 @@ namespace mbavo
             fs.fb = fb; fs.partials = eng.device_partials(); fs.tile_begin = eng.device_bf_tile_begin();
             fs.stride = E + 2; // engine.hip: Pack<k>::PSTRIDE
             fs.deferred = eng.finalize_deferred() ? 1 : 0;
+            fs.f1 = nbf == B ? 1 : 0; // (every F >= 1 was checked above: nbf == B means every F == 1)
+            fs.inv = inv;
             // RE-TILING for the late slots of a big batch (round 4).  A batch of more pairs than CUs is tiled one tile per pair -- three
             // rounds of pixels per workgroup, the right grain while most pairs are active -- and a pass then lasts ~38 us as long as ONE
             // pair is active.  A second layout of the same list with four tiles per pair lives in the engine's companion (built while

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 
-def device_lm(M, ctx, batch, solver, iterations, reps=3, min_dec=0.0, N=None):
+def device_lm(M, ctx, batch, solver, iterations, reps=3, min_dec=0.0, N=None, **tail):
     """mbavo_lm_batch on a RenderedPairBatch: best of `reps` runs from the same initial knots (N: the first N of a pair's four knots)."""
     import torch
     capi = M.capi
@@ -26,6 +26,8 @@ def device_lm(M, ctx, batch, solver, iterations, reps=3, min_dec=0.0, N=None):
     o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = batch.k, iterations, 5
     o.solver_type, o.sync_every = solver, int(os.environ.get("MBAVO_LM_SYNC_EVERY", "0"))
     o.min_step_quality, o.min_abs_cost_decrease, o.max_chi_square_error = 0.5, min_dec, 3.0  # min_dec 0: run all iterations
+    for name, v in tail.items():  # the ABI 3 tail of mbavo_lm_batch_opts (solver form, schedule)
+        setattr(o, name, v)
     res = (capi.LmBatchResult * B)()
     times = []
     for _ in range(reps):
@@ -102,6 +104,9 @@ def bench_line(M, ctx, dev, B=64, iterations=10, host_pairs=8):
         out["device_" + name] = device_lm(M, ctx, batch, solver, iterations)
     if host_pairs > 0:
         out["host_svd"] = host_lm(M, ctx, batch, 0, iterations, host_pairs)
+    # what the double-double refinement of the LDL^T stand-in costs: the plain stand-in admitted for every pivot ratio (NOT the default:
+    # the refined solution is the centre of the cond * eps ball the reference's SVD lands in, the plain one a point of it)
+    out["device_svd_plain_standin_not_default"] = device_lm(M, ctx, batch, 0, iterations, fast_solve_ratio=1e13, refined_ratio=-1.0)
     del batch
     # the same pairs with packed keyframes (mbavo_problem.grad_fp16 = 2: one word per pixel, identical tap values)
     packed = workloads.RenderedPairBatch(ctx, B, S=8, k=4, device=dev, seed=1, grad_fp16=2)
