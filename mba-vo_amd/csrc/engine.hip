@@ -315,6 +315,10 @@ namespace mbavo
     // (MI355X: per-XCD L2s, a CU's L1 is never refreshed by other CUs' stores).  Ordered by s_waitcnt vmcnt(0) before the flag.
     __device__ __forceinline__ double ld_fresh(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     __device__ __forceinline__ void st_fresh(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    // (tile partials: plain stores behind the agent-scope release of ticket_finalize, sc1 loads by the summing workgroup.  The fence-free
+    // form -- sc0 sc1 stores and loads on both sides, MI355X_MICROARCH.md "valid forms" -- is correct once the per-patch costs bound for
+    // pinned host memory are stored the same way, and exactly as fast: profiles/r05_kfused_experiments.txt 2.)
+    __device__ __forceinline__ double ld_part(const double *p) { return ld_fresh(p); }
 
     // 1 / ((K - bad) F P) of a problem.  Device-side LM and the host-driven loop keep it outside the descriptor (inv_ptr:
     // device memory -- for the host-driven loop a word of the CPU-writable push block, see Engine::push_block): read FRESH
@@ -915,19 +919,25 @@ namespace mbavo
         // Round 3 tried the hand-over WITHOUT the two cache-wide fences (partials stored and loaded with sc1 accesses, vmcnt(0),
         // ticket): 27 parity tests failed and trackFrame was no longer reproducible run to run -- and it was not faster
         // (0.384 vs 0.376 ms per frame; profiles/r03_kfused_experiments.txt 4.).
+        // A slot of ONE tile (the coarse pyramid levels of a semi-dense pair) has nobody to hand over to: this workgroup's own
+        // partial is in its XCD's L2 once its stores are acknowledged (the L1 is write-through) and the sc1 loads below read it
+        // there -- no agent-scope release, no ticket, no acquire (round 5; ~2.5 us of such an evaluation).
+        const int n_tiles = oa.bf_tile_begin[bf + 1] - oa.bf_tile_begin[bf];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0)
+        if (n_tiles > 1)
         {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            const int n = oa.bf_tile_begin[bf + 1] - oa.bf_tile_begin[bf];
-            const int last = atomicAdd(&oa.tickets[bf], 1) == n - 1 ? 1 : 0;
-            if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the other workgroups' partials (other XCDs' L2s) are read from memory
-            s_last = last;
+            if (threadIdx.x == 0)
+            {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                const int last = atomicAdd(&oa.tickets[bf], 1) == n_tiles - 1 ? 1 : 0;
+                if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // the other workgroups' partials (other XCDs' L2s) are read from memory
+                s_last = last;
+            }
+            __syncthreads();
+            if (!s_last) return false;
         }
-        __syncthreads();
-        if (!s_last) return false;
         MBAVO_STAMP(2);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int t0 = oa.bf_tile_begin[bf], t1 = oa.bf_tile_begin[bf + 1];
@@ -944,11 +954,11 @@ namespace mbavo
             int t = t0 + l;
             for (; t + 3 * LANES < t1; t += 4 * LANES)
             { // four loads in flight, added in tile order
-                const double a = ld_fresh(pp + (size_t)t * PS + e), b = ld_fresh(pp + (size_t)(t + LANES) * PS + e);
-                const double c = ld_fresh(pp + (size_t)(t + 2 * LANES) * PS + e), dd = ld_fresh(pp + (size_t)(t + 3 * LANES) * PS + e);
+                const double a = ld_part(pp + (size_t)t * PS + e), b = ld_part(pp + (size_t)(t + LANES) * PS + e);
+                const double c = ld_part(pp + (size_t)(t + 2 * LANES) * PS + e), dd = ld_part(pp + (size_t)(t + 3 * LANES) * PS + e);
                 acc += a; acc += b; acc += c; acc += dd;
             }
-            for (; t < t1; t += LANES) acc += ld_fresh(pp + (size_t)t * PS + e);
+            for (; t < t1; t += LANES) acc += ld_part(pp + (size_t)t * PS + e);
         }
         if (LANES > 1)
         {
@@ -977,7 +987,7 @@ namespace mbavo
         __syncthreads();
         if (threadIdx.x == 0)
         {
-            __hip_atomic_store(&oa.tickets[bf], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next evaluation
+            if (n_tiles > 1) __hip_atomic_store(&oa.tickets[bf], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next evaluation
             if (to_host) __threadfence_system(); // THIS slot's frame block is on its way to the host before the slot counts as done
             // (one slot -- one frame, the tracker's case -- needs no count: a device-memory round trip less before the word)
             if (to_host && (oa.nbf == 1 || atomicAdd(oa.slots_done, 1) == oa.nbf - 1))
