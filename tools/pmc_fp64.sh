@@ -8,11 +8,13 @@ WL=${@:-c2_dense}
 export TMPDIR=/tmp
 mkdir -p profiles gpurun_out
 rocprofv3 -L 2>/dev/null | grep -o "SQ_INSTS_VALU[A-Z0-9_]*\|SQ_[A-Z_]*F64[A-Z0-9_]*" | sort -u > gpurun_out/sq_valu_counters.txt
+# a workload token may carry the variant of the evaluation: c2_dense_cost_only, c2_dense_k2, c3_batch64_cost_only, ...
+wl_args() { local w=$1 a=""; case $w in *_cost_only) a="$a --cost-only"; w=${w%_cost_only};; esac; case $w in *_k2) a="$a --spline-k 2"; w=${w%_k2};; esac; echo "--workload $w$a"; }
 for W in $WL; do
   OUT=${PROF_SCRATCH:-gpurun_out}/pmc_fp64_$W
   rm -rf "$OUT"; mkdir -p "$OUT"
   for C in SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU SQ_INSTS_MFMA; do
-    rocprofv3 --pmc $C --output-format csv -d "$OUT/$C" -o p -- python bench.py --steps 10 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-configs --workload $W > /dev/null 2> "$OUT/err_$C.txt" || echo "pass $C failed: $(tail -1 $OUT/err_$C.txt)"
+    rocprofv3 --pmc $C --output-format csv -d "$OUT/$C" -o p -- python bench.py --steps 10 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-configs $(wl_args $W) > /dev/null 2> "$OUT/err_$C.txt" || echo "pass $C failed: $(tail -1 $OUT/err_$C.txt)"
   done
   SUF=""; [ "$W" != "c2_dense" ] && SUF="_$W"
   python - "$OUT" "profiles/${TAG}_pmc_fp64${SUF}.json" <<'PY'

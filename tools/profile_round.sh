@@ -16,7 +16,7 @@ for k, v in h.items():
     if "k_fused" in k or "calib" in k: print(k[:90], round(v["mean"], 1), v["n"])
 PY
 done
-bash tools/pmc_fp64.sh $TAG c2_dense c3_batch64 c4_batch512 c5_1080p c2_semidense c1_dense 2>&1 | tail -12
+bash tools/pmc_fp64.sh $TAG c2_dense c3_batch64 c4_batch512 c5_1080p c2_semidense c1_dense c2_dense_cost_only c3_batch64_cost_only c2_semidense_cost_only c2_dense_k2 2>&1 | tail -16
 bash tools/pmc_all.sh $TAG > gpurun_out/${TAG}_pmc_all.log 2>&1; tail -3 gpurun_out/${TAG}_pmc_all.log | cut -c1-300
 # gpurun only merges gpurun_out/ back: hand the artefacts over through it (copy them into profiles/ at home)
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
