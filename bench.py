@@ -620,8 +620,9 @@ def main():
         call = ("mbavo_allgather_blocks" if r.se.pair_collective == "allgather" else "mbavo_allreduce_blocks_to") if r.mode == "pairs" \
             else ("mbavo_allreduce_blocks_to" if r.mode == "frame_blocks" else "mbavo_allreduce_blocks")
         if use_p2p:
-            return call.replace("mbavo_allgather_blocks", "mbavo_allgather_blocks_p2p").replace("mbavo_allreduce_blocks_to", "copy + mbavo_allreduce_blocks_p2p") \
-                .replace("mbavo_allreduce_blocks", "mbavo_allreduce_blocks_p2p") + " [one-shot over peer-mapped regions, no RCCL%s]" % (": ranks share one GPU" if shared_gpu else "")
+            name = {"mbavo_allgather_blocks": "mbavo_allgather_blocks_p2p", "mbavo_allreduce_blocks_to": "copy + mbavo_allreduce_blocks_p2p",
+                    "mbavo_allreduce_blocks": "mbavo_allreduce_blocks_p2p"}[call]
+            return name + " [one-shot over peer-mapped regions, no RCCL%s]" % (": ranks share one GPU" if shared_gpu else "")
         return call + (" [RCCL]" if not shared_gpu else " -> STAND-IN: gloo on a pinned host copy (ranks share one GPU)")
 
     def comm_profile(run, n=40):
