@@ -15,6 +15,10 @@ passes = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 ctx = M.capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 seq = sequence.make_sequence(ctx, H=480, W=640, M=8)
 sequence.track_sequence(ctx, seq)
+if os.environ.get("MBAVO_TIMING"):  # the warm-up pass' phases (allocations, code objects) are reported and reset here
+    print("-- warm-up pass", file=sys.stderr)
+    ctx.lib.mbavo_timing_report()
+    print("-- timed passes", file=sys.stderr)
 runs = [sequence.track_sequence(ctx, seq) for _ in range(passes)]
 pf = sorted(sum(f["seconds"] for f in r) / len(r) for r in runs)
 dig = hashlib.sha256(b"".join(np.ascontiguousarray(f["T"]).tobytes() for f in runs[0])).hexdigest()[:10]
