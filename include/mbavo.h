@@ -321,7 +321,9 @@ typedef struct mbavo_vo_options { /* BlurAwareDirectTrackerOptions (blur_aware_d
     double fast_solve_ratio;
     int speculate, persist_levels;
     int keyframe_levels_at_once; /* pyramid, gradients and grid selection of ALL levels in three launches; default on [MBAVO_KF_MULTI] */
-    int reserved[5];
+    int speculate_keyframe;      /* keyframe pre-processing started under the LM loop, on a second stream, when the predicted motion
+                                    already passes the keyframe test (identical results); default on              [MBAVO_KF_SPECULATE] */
+    int reserved[4];
 } mbavo_vo_options;
 typedef struct mbavo_vo_info {
     int is_keyframe, num_keypoints0, num_trace, start_idx;

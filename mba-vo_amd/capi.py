@@ -103,7 +103,7 @@ class VoOptions(C.Structure):
         ("score_threshold", C.c_float), ("grid_selection_cell_H", C.c_int), ("grid_selection_cell_W", C.c_int),
         # ABI 3: zero = default (include/mbavo.h)
         ("fast_solve_ratio", C.c_double), ("speculate", C.c_int), ("persist_levels", C.c_int), ("keyframe_levels_at_once", C.c_int),
-        ("reserved", C.c_int * 5),
+        ("speculate_keyframe", C.c_int), ("reserved", C.c_int * 4),
     ]
 
 

@@ -331,24 +331,26 @@ namespace mbavo
         *num_cells = nc;
         return (int)hipGetLastError();
     }
-    int pyramid_enqueue(Engine &eng, unsigned char *const *d_levels, int H0, int W0, int L)
-    { // levels 1 .. L-1 from level 0, three per launch
+    int pyramid_enqueue(Engine &eng, unsigned char *const *d_levels, int H0, int W0, int L, hipStream_t on)
+    { // levels 1 .. L-1 from level 0, three per launch (`on`: another stream than the engine's, or null)
         if (!d_levels || L < 1 || L > 8 || H0 < 1 || W0 < 1) return MBAVO_E_ARG;
+        hipStream_t st_ = on ? on : eng.stream();
         for (int l = 0; l + 1 < L; l += 3)
         {
             const int n = L - 1 - l < 3 ? L - 1 - l : 3, Hs = H0 >> l, Ws = W0 >> l;
             if (Hs < 2 || Ws < 2) return MBAVO_E_ARG;
-            hipLaunchKernelGGL(k_pyr_down_multi, dim3((Ws / 2 + 15) / 16, (Hs / 2 + 15) / 16), dim3(256), 0, eng.stream(), d_levels[l], Hs, Ws,
+            hipLaunchKernelGGL(k_pyr_down_multi, dim3((Ws / 2 + 15) / 16, (Hs / 2 + 15) / 16), dim3(256), 0, st_, d_levels[l], Hs, Ws,
                                d_levels[l + 1], n >= 2 ? d_levels[l + 2] : nullptr, n >= 3 ? d_levels[l + 3] : nullptr, n);
         }
         return (int)hipGetLastError();
     }
 
     int keyframe_levels_enqueue(Engine &eng, unsigned char *const *d_levels, float *const *d_grads, int H0, int W0, int L, int cell_H, int cell_W,
-                                float thr, CellPick *d_picks, int *cells_per_level)
+                                float thr, CellPick *d_picks, int *cells_per_level, hipStream_t on)
     {
         if (!d_levels || !d_grads || L < 1 || L > 8) return MBAVO_E_ARG;
-        int rc = pyramid_enqueue(eng, d_levels, H0, W0, L);
+        hipStream_t st_ = on ? on : eng.stream();
+        int rc = pyramid_enqueue(eng, d_levels, H0, W0, L, on);
         if (rc != 0) return rc;
         PyramidLevels lv;
         memset(&lv, 0, sizeof(lv));
@@ -373,8 +375,8 @@ namespace mbavo
                 if (cells_per_level) cells_per_level[l] = cells_h * cells_w;
             }
         }
-        hipLaunchKernelGGL(k_gradients_multi, dim3((W0 + 255) / 256, lv.row0[L]), dim3(256), 0, eng.stream(), lv);
-        if (grid) hipLaunchKernelGGL(k_detect_cells_multi, dim3(lv.cell0[L]), dim3(64), 0, eng.stream(), lv, thr, W0, d_picks);
+        hipLaunchKernelGGL(k_gradients_multi, dim3((W0 + 255) / 256, lv.row0[L]), dim3(256), 0, st_, lv);
+        if (grid) hipLaunchKernelGGL(k_detect_cells_multi, dim3(lv.cell0[L]), dim3(64), 0, st_, lv, thr, W0, d_picks);
         return (int)hipGetLastError();
     }
 } // namespace mbavo

@@ -6,6 +6,7 @@
 #include "se3_math.h"
 #include "tracker.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -162,12 +163,13 @@ namespace SLAM
 
         BlurAwareDirectTracker::BlurAwareDirectTracker(mbavo::Engine &engine, const BlurAwareDirectTrackerOptions &options)
             : mEngine(engine), mOptions(options), mPrevTimestamp(0), mEvaluationPointCost(0), mIsFirstFrame(true),
-              mCurCap(0), mCurExp(0), mStatus(0), mTrace(new mbavo_trace_rec[kTraceCap]), mNumTrace(0), mDepth(nullptr), mKpArena(nullptr), mPicksDev(nullptr), mPicksHost(nullptr), mKpStage(nullptr)
+              mCurCap(0), mCurExp(0), mStatus(0), mTrace(new mbavo_trace_rec[kTraceCap]), mNumTrace(0), mDepth(nullptr), mKpArena(nullptr), mKpArena2(nullptr), mKfStream(nullptr), mKfInFlight(false), mPicksDev(nullptr), mPicksHost(nullptr), mKpStage(nullptr)
         { // blur_aware_direct_tracker.cpp:14-34; the shared storages are the engine's
             for (int i = 0; i < 6; ++i) mNeighFrameVelocity[i] = mSplineVelocity[i] = 0;
             for (int l = 0; l < 8; ++l)
             {
                 mRef[l] = mCur[l] = nullptr; mGrad[l] = nullptr; mCurPtr[l] = nullptr; mKpXY[l] = mKpZ[l] = nullptr;
+                mRef2[l] = nullptr; mGrad2[l] = nullptr; mKpXY2[l] = mKpZ2[l] = nullptr;
                 mPattern[l] = nullptr; mKpCap[l] = mNumKeypoints[l] = 0;
             }
             mSpline.setSamplingFreq(mOptions.dt_ctrl_knot);
@@ -201,6 +203,22 @@ namespace SLAM
             {
                 mKpXY[l] = mKpArena + mStageOff[l];
                 mKpZ[l] = mKpXY[l] + 2 * (size_t)mKpCap[l];
+            }
+            // the spare keyframe set + its stream (grid selection only: the other detector path reads the depth map on the device)
+            if (grid && mStatus == 0 && mbavo::opt_flag(mOptions.speculate_keyframe, mbavo::read_env_overrides().kf_speculate, true))
+            {
+                for (int l = 0; l < L && mStatus == 0; ++l)
+                {
+                    const size_t n = (size_t)(H >> l) * (W >> l);
+                    alloc((void **)&mRef2[l], n); alloc((void **)&mGrad2[l], n * 2 * sizeof(float));
+                }
+                alloc((void **)&mKpArena2, sizeof(double) * mStageOff[L]);
+                for (int l = 0; l < L && mStatus == 0; ++l)
+                {
+                    mKpXY2[l] = mKpArena2 + mStageOff[l];
+                    mKpZ2[l] = mKpXY2[l] + 2 * (size_t)mKpCap[l];
+                }
+                if (mStatus == 0 && hipStreamCreateWithFlags(&mKfStream, hipStreamNonBlocking) != hipSuccess) { mKfStream = nullptr; (void)hipGetLastError(); }
             }
         }
 
@@ -255,7 +273,9 @@ namespace SLAM
         BlurAwareDirectTracker::~BlurAwareDirectTracker()
         {
             delete[] mTrace;
-            (void)hipFree(mDepth); (void)hipFree(mKpArena);
+            if (mKfStream) { (void)hipStreamSynchronize(mKfStream); (void)hipStreamDestroy(mKfStream); }
+            (void)hipFree(mDepth); (void)hipFree(mKpArena); (void)hipFree(mKpArena2);
+            for (int l = 0; l < 8; ++l) { (void)hipFree(mRef2[l]); (void)hipFree(mGrad2[l]); }
             (void)hipFree(mPicksDev); (void)hipHostFree(mPicksHost); (void)hipHostFree(mKpStage);
             for (int l = 0; l < 8; ++l)
             {
@@ -264,11 +284,65 @@ namespace SLAM
             }
         }
 
+        int BlurAwareDirectTracker::finishKeyframe(const float *depth_z, bool spare_set)
+        { // the host half of the grid-selection path: depth test (:398-404) and ordered compaction of the cells' picks (already in
+          // mPicksHost), ONE keypoint upload; spare_set: the picks belong to the spare keyframe set, which becomes the active one
+            const int W = mOptions.im_size_HW[1], L = mOptions.num_pyramid_levels;
+            hipStream_t st = mEngine.stream();
+            for (int l = 0; l < L; ++l)
+            {
+                const double scale = std::pow(2, l);
+                double *xy = mKpStage + mStageOff[l], *z = xy + 2 * (size_t)mKpCap[l];
+                int n = 0;
+                for (int c = 0; c < mKpCap[l]; ++c)
+                {
+                    const mbavo::CellPick &p = mPicksHost[mPickOff[l] + c];
+                    if (!p.keep) continue;
+                    const int x0 = (int)((float)p.x * scale + 0.5), y0 = (int)((float)p.y * scale + 0.5); // :398-400
+                    const float zz = depth_z[(size_t)y0 * W + x0];
+                    if ((double)zz < 1e-2) continue;
+                    xy[2 * n] = (double)p.x; xy[2 * n + 1] = (double)p.y; z[n] = (double)zz;
+                    ++n;
+                }
+                mNumKeypoints[l] = n;
+            }
+            if (spare_set)
+            { // adopt: the spare set's images are complete (its stream was drained by the caller); swap the pointers
+                for (int l = 0; l < 8; ++l) { std::swap(mRef[l], mRef2[l]); std::swap(mGrad[l], mGrad2[l]); std::swap(mKpXY[l], mKpXY2[l]); std::swap(mKpZ[l], mKpZ2[l]); }
+                std::swap(mKpArena, mKpArena2);
+            }
+            // ONE upload for all levels: the device arena has the staging's layout (eight small copies cost ~4 us of host time each)
+            VO_HIP(hipMemcpyAsync(mKpArena, mKpStage, sizeof(double) * mStageOff[L], hipMemcpyHostToDevice, st));
+            mHostKpXY0.assign(mKpStage, mKpStage + 2 * (size_t)mNumKeypoints[0]);
+            mHostKpZ0.assign(mKpStage + 2 * (size_t)mKpCap[0], mKpStage + 2 * (size_t)mKpCap[0] + mNumKeypoints[0]);
+            return 0;
+        }
+
+        int BlurAwareDirectTracker::speculateKeyframe(const FrameView &kf)
+        { // upload + pyramid + gradient images + grid selection of `kf` into the SPARE set, on the spare stream; nothing waits
+            if (!mKfStream || !mRef2[0]) return 1;
+            mbavo::PhaseScope ps(mbavo::PhaseTimers::kKeyframe);
+            const int H = mOptions.im_size_HW[0], W = mOptions.im_size_HW[1], L = mOptions.num_pyramid_levels;
+            int rc = ensureGridBuffers();
+            if (rc != 0) return rc;
+            VO_HIP(hipMemcpyAsync(mRef2[0], kf.image, (size_t)H * W, hipMemcpyHostToDevice, mKfStream));
+            int ncell[8] = {};
+            rc = mbavo::keyframe_levels_enqueue(mEngine, mRef2, mGrad2, H, W, L, mOptions.grid_selection_cell_H, mOptions.grid_selection_cell_W,
+                                                mOptions.score_threshold, mPicksDev, ncell, mKfStream);
+            if (rc != 0) return rc;
+            for (int l = 0; l < L; ++l)
+                if (ncell[l] != mKpCap[l]) return MBAVO_E_ARG;
+            VO_HIP(hipMemcpyAsync(mPicksHost, mPicksDev, sizeof(mbavo::CellPick) * mPickOff[L], hipMemcpyDeviceToHost, mKfStream));
+            mKfInFlight = true;
+            return 0;
+        }
+
         int BlurAwareDirectTracker::tmpProcessKeyframe(const FrameView &kf, const float *depth_z)
         { // blur_aware_direct_tracker.cpp:342-415: pyramid, gradients, semi-dense keypoints with depth -- all on device
             mbavo::PhaseScope ps(mbavo::PhaseTimers::kKeyframe);
             const int H = mOptions.im_size_HW[0], W = mOptions.im_size_HW[1], L = mOptions.num_pyramid_levels;
             hipStream_t st = mEngine.stream();
+            if (mKfInFlight) { VO_HIP(hipStreamSynchronize(mKfStream)); mKfInFlight = false; } // (a discarded speculation still owns the pick buffers)
             VO_HIP(hipMemcpyAsync(mRef[0], kf.image, (size_t)H * W, hipMemcpyHostToDevice, st));
             if (mOptions.grid_selection_cell_H > 0 && mOptions.grid_selection_cell_W > 0)
             { // grid selection: every level's kernels back to back, ONE read-back (the cells' picks) and ONE synchronisation;
@@ -300,28 +374,7 @@ namespace SLAM
                 }
                 VO_HIP(hipMemcpyAsync(mPicksHost, mPicksDev, sizeof(mbavo::CellPick) * mPickOff[L], hipMemcpyDeviceToHost, st));
                 VO_HIP(hipStreamSynchronize(st));
-                for (int l = 0; l < L; ++l)
-                {
-                    const double scale = std::pow(2, l);
-                    double *xy = mKpStage + mStageOff[l], *z = xy + 2 * (size_t)mKpCap[l];
-                    int n = 0;
-                    for (int c = 0; c < mKpCap[l]; ++c)
-                    {
-                        const mbavo::CellPick &p = mPicksHost[mPickOff[l] + c];
-                        if (!p.keep) continue;
-                        const int x0 = (int)((float)p.x * scale + 0.5), y0 = (int)((float)p.y * scale + 0.5); // :398-400
-                        const float zz = depth_z[(size_t)y0 * W + x0];
-                        if ((double)zz < 1e-2) continue;
-                        xy[2 * n] = (double)p.x; xy[2 * n + 1] = (double)p.y; z[n] = (double)zz;
-                        ++n;
-                    }
-                    mNumKeypoints[l] = n;
-                }
-                // ONE upload for all levels: the device arena has the staging's layout (eight small copies cost ~4 us of host time each)
-                VO_HIP(hipMemcpyAsync(mKpArena, mKpStage, sizeof(double) * mStageOff[L], hipMemcpyHostToDevice, st));
-                mHostKpXY0.assign(mKpStage, mKpStage + 2 * (size_t)mNumKeypoints[0]);
-                mHostKpZ0.assign(mKpStage + 2 * (size_t)mKpCap[0], mKpStage + 2 * (size_t)mKpCap[0] + mNumKeypoints[0]);
-                return 0;
+                return finishKeyframe(depth_z, false);
             }
             VO_HIP(hipMemcpyAsync(mDepth, depth_z, sizeof(float) * (size_t)H * W, hipMemcpyHostToDevice, st));
             for (int l = 0; l < L; ++l)
@@ -470,6 +523,17 @@ namespace SLAM
             mSpline.setStartTime(blur.capture_time - 0.5 * blur.exposure_time);
             mSpline.TransformByRight(dTspline.getRotationData(), dTspline.getTranslationData());
 
+            // the keyframe test on the PREDICTED spline: if it already says "keyframe", the sharp frame's pre-processing starts now, on
+            // the spare stream, and runs under the LM loop (a wrong prediction costs the enqueue and some idle GPU time, never a result)
+            bool speculated = false;
+            if (mKfStream && sharp.image && isKeyframe(nullptr, nullptr))
+            {
+                if (mKfInFlight) { VO_HIP(hipStreamSynchronize(mKfStream)); mKfInFlight = false; } // (a discarded earlier speculation still owns the pick buffers)
+                const int sr = speculateKeyframe(sharp);
+                if (sr < 0 || sr > 1) return sr;
+                speculated = sr == 0;
+            }
+
             int ntrace = 0, start = 0;
             if ((rc = optimizeTrajectory(&ntrace, &start)) != 0) return rc;
 
@@ -487,7 +551,18 @@ namespace SLAM
 
             if (is_kf)
             { // :176-188: the sharp companion becomes the keyframe, the spline is re-expressed relative to it
-                if ((rc = tmpProcessKeyframe(sharp, depth_z)) != 0) return rc;
+                if (speculated)
+                { // the spare set holds this frame's pyramid, gradients and picks: drain its stream (long done), finish on the host
+                    mbavo::PhaseScope ps_kf(mbavo::PhaseTimers::kKeyframe);
+                    VO_HIP(hipStreamSynchronize(mKfStream));
+                    mKfInFlight = false;
+                    if ((rc = finishKeyframe(depth_z, true)) != 0) return rc;
+                }
+                else
+                {
+                    if (mKfInFlight) { VO_HIP(hipStreamSynchronize(mKfStream)); mKfInFlight = false; } // (its D2H copy targets mPicksHost)
+                    if ((rc = tmpProcessKeyframe(sharp, depth_z)) != 0) return rc;
+                }
                 mSpline.GetPose(blur.capture_time, q, t);
                 mTKeyframe = mTKeyframe * Core::Transformation(q, t);
                 const double qi[4] = {0, 0, 0, 1}, ti[3] = {0, 0, 0};

@@ -38,9 +38,9 @@ namespace mbavo
                              int cell_W, float thr, CellPick *d_picks, int *num_cells);    // A keyframe's (or a frame's) levels in one launch each: the pyramid below d_levels[0] (three levels per launch), and with
     // keyframe_levels_enqueue also every level's gradient image and -- d_picks non-null -- every level's grid selection (picks in
     // level order, cells_per_level[l] of them).  Same integer / fp32 operations as the per-level kernels.
-    int pyramid_enqueue(Engine &eng, unsigned char *const *d_levels, int H0, int W0, int L);
+    int pyramid_enqueue(Engine &eng, unsigned char *const *d_levels, int H0, int W0, int L, hipStream_t on = nullptr);
     int keyframe_levels_enqueue(Engine &eng, unsigned char *const *d_levels, float *const *d_grads, int H0, int W0, int L, int cell_H, int cell_W,
-                                float thr, CellPick *d_picks, int *cells_per_level);
+                                float thr, CellPick *d_picks, int *cells_per_level, hipStream_t on = nullptr);
 }
 
 namespace SLAM
@@ -97,7 +97,7 @@ namespace SLAM
             int grid_selection_cell_H = 30, grid_selection_cell_W = 30;
             // scheduling / solver form (include/mbavo.h: the ABI 3 tail of mbavo_vo_options; zero = default)
             double fast_solve_ratio = 0.0;
-            int speculate = 0, persist_levels = 0, keyframe_levels_at_once = 0;
+            int speculate = 0, persist_levels = 0, keyframe_levels_at_once = 0, speculate_keyframe = 0;
         };
 
         struct FrameView
@@ -148,6 +148,13 @@ namespace SLAM
 
         private:
             int tmpProcessKeyframe(const FrameView &keyframe, const float *depth_z);
+            // Keyframe pre-processing AHEAD of the decision (round 5): when the constant-velocity prediction already says "keyframe",
+            // the sharp frame's upload, pyramid, gradient images and grid selection are enqueued on a second stream into the SPARE
+            // keyframe set while the LM loop runs (its evaluations are latency-bound and leave most of the GPU idle); if the
+            // decision after the optimisation is "keyframe", what is left is the depth test of the picks on the host and the
+            // keypoint upload, and the sets swap.  Same kernels on the same inputs: identical keypoints, bit for bit.
+            int speculateKeyframe(const FrameView &keyframe);
+            int finishKeyframe(const float *depth_z, bool spare_set);
             int ensureGridBuffers();
             int uploadCurrentFrame(const FrameView &frame);
             int optimizeTrajectory(int *num_trace, int *start_idx);
@@ -176,6 +183,12 @@ namespace SLAM
             std::vector<double> mHostKpXY0, mHostKpZ0; // level-0 keypoints for the keyframe test
             // grid selection: the cells' picks of all levels (device + pinned host copy) and the pinned staging of the
             // compacted keypoints [level][xy | z]
+            // the spare keyframe set (speculateKeyframe): swapped with the active pointers above when its keyframe is adopted
+            unsigned char *mRef2[8];
+            float *mGrad2[8];
+            double *mKpArena2, *mKpXY2[8], *mKpZ2[8];
+            hipStream_t mKfStream;
+            bool mKfInFlight;
             mbavo::CellPick *mPicksDev, *mPicksHost;
             double *mKpStage;
             size_t mPickOff[9], mStageOff[9];
