@@ -223,3 +223,25 @@ def test_pyramid_levels_in_one_launch_match_level_by_level(mbavo, gpu_ctx):
         torch.cuda.synchronize()
         for l in range(1, L):
             assert torch.equal(a[l], b[l]), (H, W, l)
+
+
+def test_keyframe_preprocessing_ahead_of_the_decision_changes_nothing(orc, mbavo, gpu_ctx):
+    """mbavo_vo_options.speculate_keyframe (default on): the sharp frame's upload, pyramid, gradients and grid selection run on a
+    second stream into a spare keyframe set while the LM loop runs, whenever the predicted motion already passes the keyframe test.
+    Against the tracker with it switched off, on a sequence with many keyframe changes (predicted and unpredicted ones, and
+    speculations that are discarded): every pose bit-identical, the same decisions, keypoint sets and LM records; also through a
+    state restore in the middle (mbavo_vo_set_state / _set_keyframe while a speculation may be in flight)."""
+    from mba_vo_amd import sequence
+    seq = sequence.make_sequence(gpu_ctx, H=480, W=640, M=24, trajectory="loop")
+    cfg = dict(sequence.REFERENCE_CFG)
+    on = frontend.run_gpu_vo(mbavo, gpu_ctx, seq, cfg)
+    off = frontend.run_gpu_vo(mbavo, gpu_ctx, seq, dict(cfg, speculate_keyframe=-1))
+    assert sum(f["is_keyframe"] for f in on) >= 8
+    for a, b in zip(on, off):
+        assert np.array_equal(a["T"], b["T"]) and a["is_keyframe"] == b["is_keyframe"] and a["K"] == b["K"] and a["trace"] == b["trace"]
+    assert np.array_equal(on[-1]["kp0"][0], off[-1]["kp0"][0]) and np.array_equal(on[-1]["kp0"][1], off[-1]["kp0"][1])
+    # teacher forcing against the oracle re-makes keyframes through mbavo_vo_set_keyframe between speculations
+    want = frontend.run_oracle_vo(orc, seq, cfg)
+    tf = frontend.run_gpu_vo(mbavo, gpu_ctx, seq, cfg, teacher=want)
+    for a, b in zip(tf, want):
+        assert a["is_keyframe"] == b["is_keyframe"] and a["K"] == b["K"] and np.abs(a["T"] - b["T"]).max() < 1e-6
