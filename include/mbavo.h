@@ -220,7 +220,9 @@ typedef struct mbavo_track_opts {
     double fast_solve_ratio;
     int speculate;      /* candidates evaluated WITH H / g: 0 on the persistent levels, 1 every level, -1 never [MBAVO_SPECULATE] */
     int persist_levels; /* one persistent kernel for all levels of a call; default on                          [MBAVO_PERSIST_LEVELS] */
-    int reserved[4];
+    int ride_along;     /* the next pyramid level's first evaluation rides along with this level's candidates (same
+                           results, one dependent evaluation less per level); default on                       [MBAVO_RIDE_ALONG] */
+    int reserved[3];
 } mbavo_track_opts;
 typedef struct mbavo_trace_rec {
     int level, iter, kind; /* 0 initial evaluation, 1 accepted, 2 rejected, 3 invalid step */
@@ -323,7 +325,8 @@ typedef struct mbavo_vo_options { /* BlurAwareDirectTrackerOptions (blur_aware_d
     int keyframe_levels_at_once; /* pyramid, gradients and grid selection of ALL levels in three launches; default on [MBAVO_KF_MULTI] */
     int speculate_keyframe;      /* keyframe pre-processing started under the LM loop, on a second stream, when the predicted motion
                                     already passes the keyframe test (identical results); default on              [MBAVO_KF_SPECULATE] */
-    int reserved[4];
+    int ride_along;              /* as mbavo_track_opts.ride_along */
+    int reserved[3];
 } mbavo_vo_options;
 typedef struct mbavo_vo_info {
     int is_keyframe, num_keypoints0, num_trace, start_idx;

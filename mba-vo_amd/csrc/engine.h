@@ -108,8 +108,14 @@ namespace mbavo
         // nullptr when the platform cannot do it (or the blocks would have to grow while a persistent kernel runs).
         void *push_block(int slot, size_t bytes);
         static constexpr size_t kPushHeader = 64;
-        int persistent_post(int slot, bool with_hessian, int prob = 0);
+        // prob2 >= 0 (round 5): the command ALSO evaluates problem prob2 of the kernel's list, with H / g, at the knots the caller put
+        // into the second knot area (7 N doubles behind the first); persistent_wait() waits for `prob` only, the second problem's
+        // completion is asked for by the sequence number of its post (posted_seq())
+        int persistent_post(int slot, bool with_hessian, int prob = 0, int prob2 = -1);
         int persistent_wait();
+        unsigned long long posted_seq() const { return pending_seq_; }
+        bool persistent_second_done(unsigned long long seq) const;
+        int persistent_wait_second(unsigned long long seq);
         int persistent_eval(int slot, bool with_hessian, int prob = 0) { const int r = persistent_post(slot, with_hessian, prob); return r ? r : persistent_wait(); }
         int persistent_end(int slot);
         int persistent_end_all();

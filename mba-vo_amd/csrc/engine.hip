@@ -1314,9 +1314,13 @@ namespace mbavo
     {
         unsigned long long word;
     };
-    static inline unsigned long long persist_word(unsigned long long seq, int gen, int mode, int prob = 0)
+    // (round 5) `prob2` < 15: a SECOND problem of the kernel's list evaluated by the same command, with H / g, at the knots of the
+    // second knot area -- the next pyramid level's first evaluation riding along with this level's candidate (tracker.cpp); its
+    // completion word is the second line of the pinned flag area.  15: none.
+    static inline unsigned long long persist_word(unsigned long long seq, int gen, int mode, int prob = 0, int prob2 = 15)
     {
-        return (seq << 20) | ((unsigned long long)(gen & 0xfff) << 8) | ((unsigned long long)(prob & 0xf) << 4) | (unsigned long long)(mode & 0xf);
+        return (seq << 20) | ((unsigned long long)(prob2 & 0xf) << 16) | ((unsigned long long)(gen & 0xff) << 8) | ((unsigned long long)(prob & 0xf) << 4) |
+               (unsigned long long)(mode & 0xf);
     }
     template <int KD, int LOGS>
     __global__ __launch_bounds__((kSpWaves * 64)) void k_sp_persist(const ProblemDesc *__restrict__ descs, const TileDesc *__restrict__ tiles,
@@ -1326,7 +1330,7 @@ namespace mbavo
     {
         extern __shared__ __attribute__((aligned(16))) double lds[];
         __shared__ unsigned long long s_seq;
-        __shared__ int s_mode;
+        __shared__ int s_mode, s_second;
         __shared__ double knots_lds[7 * 16]; // this command's control knots [t (3N) | R (4N)], N <= 16
         // One kernel may serve SEVERAL problems (round 3: the pyramid levels of a tracked frame, one launch per frame instead of
         // one per level): a command names its problem, the workgroups of the other problems' tiles skip it.
@@ -1337,7 +1341,7 @@ namespace mbavo
             {
                 unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
                 unsigned long long q;
-                int m = 0, pr = 0;
+                int m = 0, pr = 0, second = 0;
                 for (;;)
                 { // relaxed: an acquire here would invalidate the caches on every poll
                     const unsigned long long w = __hip_atomic_load(&cmd->word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1346,8 +1350,10 @@ namespace mbavo
                     {
                         m = (int)(w & 0xf);
                         pr = (int)((w >> 4) & 0xf);
-                        if ((int)((w >> 8) & 0xfff) != (gen & 0xfff)) m = 0;
-                        if (m == 0 || pr == my_prob) break;
+                        if ((int)((w >> 8) & 0xff) != (gen & 0xff)) m = 0;
+                        second = m != 0 && (int)((w >> 16) & 0xf) == my_prob && pr != my_prob; // the command's second problem: H / g
+                        if (second) m = 2;
+                        if (m == 0 || pr == my_prob || second) break;
                         last_seq = q; // another problem's evaluation: not for this workgroup
                         t0 = __builtin_amdgcn_s_memrealtime(); // ... but the host is alive: the give-up timer starts over
                     }
@@ -1356,6 +1362,7 @@ namespace mbavo
                 }
                 s_seq = q;
                 s_mode = m;
+                s_second = second;
             }
             __syncthreads();
             const int mode = s_mode;
@@ -1369,11 +1376,17 @@ namespace mbavo
             // are used.  No acquire fence: the images, keypoints and descriptors stay in the caches across commands.
             const ProblemDesc &d0 = descs[my_prob];
             double *kn = knots_lds;
+            // (the second problem of a command reads the SECOND knot area, 7 N doubles behind the first, and answers on the second
+            // line of the flag area)
+            const int second = s_second, koff = second ? 7 * d0.N : 0;
             for (int i = threadIdx.x; i < 7 * d0.N; i += kSpWaves * 64)
-                kn[i] = __hip_atomic_load(i < 3 * d0.N ? d0.knots_t + i : d0.knots_R + (i - 3 * d0.N), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                kn[i] = __hip_atomic_load((i < 3 * d0.N ? d0.knots_t + i : d0.knots_R + (i - 3 * d0.N)) + koff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
+            OneArgs oa_cmd = oa;
+            OneArgs &oa = oa_cmd; // (shadows the kernel argument for the body below)
             oa.nbf = d0.F; // the slots of THIS problem's evaluation
             oa.seq = last_seq;
+            if (second) { oa.host_flag += 8; oa.slots_done += 1; }
 #if defined(MBAVO_PERSIST_STAMPS)
             oa.t_seen = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1786,7 +1799,7 @@ namespace mbavo
         {   // ticket counters of the single-launch kernels: one per (problem, frame) slot + the slots-done counter;
             // zero between launches by construction, so only (re)allocation clears them
             const size_t before = cap_tickets_;
-            if ((rc = ensure(&d_tickets_, &cap_tickets_, (size_t)(bf + 1) * sizeof(int)))) return rc;
+            if ((rc = ensure(&d_tickets_, &cap_tickets_, (size_t)(bf + 2) * sizeof(int)))) return rc; // (+ the second problem's slots-done counter)
             if (cap_tickets_ != before) HIP_TRY(hipMemsetAsync(d_tickets_, 0, cap_tickets_, stream_));
         }
         if (!d_status_)
@@ -1974,7 +1987,7 @@ namespace mbavo
             oa.nbf = total_bf_;
             if (signal_host && !d_active && ntiles > 0)
             { // completion word in pinned host memory: the caller spins on it instead of synchronising the stream
-                if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 64, hipHostMallocDefault) != hipSuccess) h_flag_ = nullptr;
+                if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 128, hipHostMallocDefault) != hipSuccess) h_flag_ = nullptr;
                 if (h_flag_)
                 {
                     oa.host_flag = (unsigned long long *)h_flag_;
@@ -2072,7 +2085,7 @@ namespace mbavo
         if (sp_logs_ <= 0 || !sp_one_fits(kdeg, sp_logs_) || ntiles < 1 || ntiles > num_cus_ || h_descs_[0].grad_fp16 || p.N > 16 || empty_slots_) return 1;
         for (int b = 1; b < B; ++b) // (one knot buffer for all the problems of a persistent kernel)
             if (probs[b].N != p.N || probs[b].d_knots_t != p.d_knots_t || probs[b].d_knots_R != p.d_knots_R) return 1;
-        if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 64, hipHostMallocDefault) != hipSuccess) { h_flag_ = nullptr; return (int)hipErrorOutOfMemory; }
+        if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 128, hipHostMallocDefault) != hipSuccess) { h_flag_ = nullptr; return (int)hipErrorOutOfMemory; }
         volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
         cmd->word = persist_word(flag_seq_, ++persist_gen_, 0);
         host_store_fence();
@@ -2116,13 +2129,13 @@ namespace mbavo
         return 0;
     }
 
-    int Engine::persistent_post(int slot, bool with_hessian, int prob)
+    int Engine::persistent_post(int slot, bool with_hessian, int prob, int prob2)
     {
-        if (!persistent_active(slot) || prob < 0 || prob > 15) return MBAVO_E_ARG;
+        if (!persistent_active(slot) || prob < 0 || prob > 14 || prob2 > 14 || prob2 == prob) return MBAVO_E_ARG;
         volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
         const unsigned long long seq = ++flag_seq_;
         host_store_fence(); // the inputs (knots, flags, scale: the push block, write-combining) are out ...
-        cmd->word = persist_word(seq, persist_gen_of_[slot], with_hessian ? 2 : 1, prob);
+        cmd->word = persist_word(seq, persist_gen_of_[slot], with_hessian ? 2 : 1, prob, prob2 < 0 ? 15 : prob2);
         host_store_fence(); // ... before the command word, which leaves the write-combining buffer now
         pending_seq_ = seq;
         return 0;
@@ -2156,6 +2169,29 @@ namespace mbavo
         }
         fprintf(stderr, "mbavo: persistent evaluation timed out\n");
         persist_mask_ = 0; // the workgroups give up by themselves (~2 s each kernel)
+        (void)hipStreamSynchronize(stream_);
+        (void)hipMemsetAsync(d_tickets_, 0, cap_tickets_, stream_);
+        return (int)hipErrorLaunchTimeOut;
+    }
+
+    // the SECOND problem of the command posted with sequence number `seq`: has it completed (no waiting)? / wait for it
+    bool Engine::persistent_second_done(unsigned long long seq) const
+    {
+        return h_flag_ && ((volatile unsigned long long *)h_flag_)[8] == seq;
+    }
+    int Engine::persistent_wait_second(unsigned long long seq)
+    {
+        if (!persist_mask_ || !h_flag_) return MBAVO_E_ARG;
+        const auto t0 = std::chrono::steady_clock::now();
+        volatile unsigned long long *f = (volatile unsigned long long *)h_flag_ + 8;
+        for (long spins = 1;; ++spins)
+        {
+            if (*f == seq) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return 0; }
+            host_spin_pause();
+            if ((spins & 0xffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) break;
+        }
+        fprintf(stderr, "mbavo: persistent evaluation (second problem) timed out\n");
+        persist_mask_ = 0;
         (void)hipStreamSynchronize(stream_);
         (void)hipMemsetAsync(d_tickets_, 0, cap_tickets_, stream_);
         return (int)hipErrorLaunchTimeOut;

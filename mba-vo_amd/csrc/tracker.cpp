@@ -223,12 +223,13 @@ namespace mbavo
         {
             size_t flag_bytes = 0;
             for (int l = 0; l < o.num_levels; ++l) flag_bytes += ((size_t)(levels[l].K > 0 ? levels[l].K : 1) + 63) & ~(size_t)63;
-            char *push = (char *)eng.push_block(0, Engine::kPushHeader + 64 + sizeof(double) * 7 * N + flag_bytes + 64);
+            // [8 scale words | knots t, R (7 N) | SECOND knot area (7 N): the knots of a command's second problem | flag bytes per level]
+            char *push = (char *)eng.push_block(0, Engine::kPushHeader + 64 + sizeof(double) * 14 * N + flag_bytes + 64);
             if (push)
             {
                 double *b = (double *)(push + Engine::kPushHeader);
                 mbavo_problem lp[8];
-                unsigned char *fl = (unsigned char *)(b + 8 + 7 * N);
+                unsigned char *fl = (unsigned char *)(b + 8 + 14 * N);
                 size_t pc_off = 0;
                 bool ok = true;
                 for (int li = 0; li < o.num_levels && ok; ++li)
@@ -254,6 +255,18 @@ namespace mbavo
                     for (int li = 0; li < o.num_levels; ++li) runs[li].prepared = false; // per-level kernels: their own slots
             }
         }
+
+        // THE NEXT LEVEL'S FIRST EVALUATION RIDES ALONG (round 5; mbavo_track_opts.ride_along, default on, joint persistent kernel
+        // only).  A level almost always ends with a rejected candidate (A16: abs_dec goes negative), i.e. at the knots it had BEFORE
+        // that candidate -- which are known when the candidate is posted.  So every candidate's command also names the next finer
+        // level as its second problem, evaluated with H / g at the CURRENT knots by that level's own, otherwise idle, workgroups.  If
+        // the level then ends at those very knots (compared bit for bit), the next level's iteration 0 is already there: one
+        // dependent evaluation (~13.5 us) less per pyramid level.  A wasted ride-along costs idle GPU time, never a result.
+        const bool ride_along = opt_flag(o.ride_along, env.ride_along, true);
+        std::vector<double> ride_kt(3 * (size_t)N), ride_kR(4 * (size_t)N);
+        int ride_level = -1;                 // the level (li) the last ride-along evaluated, or -1
+        unsigned long long ride_seq = 0;     // ... and the sequence number of its command
+        long ride_hits = 0, ride_posts = 0;
 
         for (int li = 0; li < o.num_levels; ++li)
         {
@@ -293,7 +306,8 @@ namespace mbavo
             // one evaluation at the given knots: knots into the pinned buffer, ONE launch for these problem sizes (pose
             // prologue + fused + last-workgroup finalize) whose frame blocks land in pinned host memory (h_pin), then a
             // spin on the kernel's completion word: no copies, no stream synchronisation
-            auto evaluate = [&](const double *kt, const double *kR, bool with_h, double *cost, double *Hout = nullptr, double *gout = nullptr) -> int {
+            auto evaluate = [&](const double *kt, const double *kR, bool with_h, double *cost, double *Hout = nullptr, double *gout = nullptr,
+                                bool with_ride_along = false) -> int {
                 if (!Hout) { Hout = H.data(); gout = g.data(); }
                 int r;
                 {
@@ -301,6 +315,18 @@ namespace mbavo
                     memcpy(w_kt, kt, sizeof(double) * 3 * N);
                     memcpy(w_kR, kR, sizeof(double) * 4 * N);
                     if (!persistent) r = eng.evaluate(1, &p, k, with_h, h_pin, d_pc, nullptr, nullptr, nullptr, h_inv, true);
+                    else if (joint && with_ride_along && ride_along && li + 1 < o.num_levels && runs[li + 1].p.K > 0 &&
+                             (ride_level < 0 || eng.persistent_second_done(ride_seq)))
+                    { // (a new ride-along only behind a finished one: its workgroups must not miss a command that concerns them)
+                        memcpy(w_kt + 7 * N, spline.get_knot_data_t(), sizeof(double) * 3 * N); // the CURRENT point, second knot area
+                        memcpy(w_kR + 7 * N, spline.get_knot_data_R(), sizeof(double) * 4 * N);
+                        memcpy(ride_kt.data(), spline.get_knot_data_t(), sizeof(double) * 3 * N);
+                        memcpy(ride_kR.data(), spline.get_knot_data_R(), sizeof(double) * 4 * N);
+                        r = eng.persistent_post(0, with_h, li, li + 1);
+                        ride_level = li + 1;
+                        ride_seq = eng.posted_seq();
+                        ++ride_posts;
+                    }
                     else r = joint ? eng.persistent_post(0, with_h, li) : eng.persistent_post(li, with_h);
                 }
                 if (r) return r;
@@ -336,7 +362,25 @@ namespace mbavo
                 ++ntrace;
             };
 
-            if ((rc_ = evaluate(spline.get_knot_data_t(), spline.get_knot_data_R(), true, &eval_cost))) goto done; // iteration 0
+            // iteration 0 -- already evaluated by the previous level's last ride-along if that was taken at these very knots
+            if (joint && ride_level == li && memcmp(ride_kt.data(), spline.get_knot_data_t(), sizeof(double) * 3 * N) == 0 &&
+                memcmp(ride_kR.data(), spline.get_knot_data_R(), sizeof(double) * 4 * N) == 0)
+            {
+                {
+                    PhaseScope ps(PhaseTimers::kWait);
+                    if ((rc_ = eng.persistent_wait_second(ride_seq))) goto done;
+                }
+                PhaseScope ps(PhaseTimers::kMerge);
+                merge_blocks_host(F, k, lvl_pin, start_idx.data(), N, &eval_cost, H.data(), g.data());
+                ++ride_hits;
+            }
+            else
+            {
+                // (a ride-along taken at other knots may still be running on this level's workgroups: they take this command after it,
+                // and its results are overwritten -- but its completion must not be mistaken for a later one's, so forget it)
+                if ((rc_ = evaluate(spline.get_knot_data_t(), spline.get_knot_data_R(), true, &eval_cost))) goto done;
+            }
+            if (ride_level == li) ride_level = -1;
             lm.reset();
             evaluator.reset(eval_cost);
             record(0, 0, 0.0, 0.0, 0.0);
@@ -370,7 +414,7 @@ namespace mbavo
                 spline.Plus_t(step.data(), cand_t.data());
                 spline.Plus_R(step.data() + 3 * N, cand_R.data());
                 double cand_cost = 0.0;
-                if ((rc_ = evaluate(cand_t.data(), cand_R.data(), speculate, &cand_cost, Hs.data(), gs.data()))) goto done;
+                if ((rc_ = evaluate(cand_t.data(), cand_R.data(), speculate, &cand_cost, Hs.data(), gs.data(), true))) goto done;
 
                 abs_dec = eval_cost - cand_cost;
                 const double quality = evaluator.StepQuality(cand_cost, model);

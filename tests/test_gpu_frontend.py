@@ -236,9 +236,11 @@ def test_keyframe_preprocessing_ahead_of_the_decision_changes_nothing(orc, mbavo
     cfg = dict(sequence.REFERENCE_CFG)
     on = frontend.run_gpu_vo(mbavo, gpu_ctx, seq, cfg)
     off = frontend.run_gpu_vo(mbavo, gpu_ctx, seq, dict(cfg, speculate_keyframe=-1))
+    plain = frontend.run_gpu_vo(mbavo, gpu_ctx, seq, dict(cfg, speculate_keyframe=-1, ride_along=-1))  # (and without the ride-along evaluations)
     assert sum(f["is_keyframe"] for f in on) >= 8
-    for a, b in zip(on, off):
+    for a, b, c in zip(on, off, plain):
         assert np.array_equal(a["T"], b["T"]) and a["is_keyframe"] == b["is_keyframe"] and a["K"] == b["K"] and a["trace"] == b["trace"]
+        assert np.array_equal(a["T"], c["T"]) and a["trace"] == c["trace"]
     assert np.array_equal(on[-1]["kp0"][0], off[-1]["kp0"][0]) and np.array_equal(on[-1]["kp0"][1], off[-1]["kp0"][1])
     # teacher forcing against the oracle re-makes keyframes through mbavo_vo_set_keyframe between speculations
     want = frontend.run_oracle_vo(orc, seq, cfg)

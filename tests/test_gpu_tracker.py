@@ -105,3 +105,20 @@ def test_lm_loop_shapes_and_solvers_match_oracle(orc, mbavo, gpu_ctx, name, kw, 
         po, qo = tracking.pose_at(orc, sc["k"], sc["t0"], sc["dt"], ro["kt"], ro["kR"], c)
         pg, qg = tracking.pose_at(orc, sc["k"], sc["t0"], sc["dt"], rg["kt"], rg["kR"], c)
         assert np.abs(po - pg).max() < 1e-5 and np.abs(qo - qg).max() < 1e-5
+
+
+@pytest.mark.parametrize("kw", [dict(H=120, W=160, levels=3, S=8, k=2, seed=2), dict(H=480, W=640, levels=4, S=8, k=2, seed=5),
+                                dict(H=480, W=640, levels=4, S=8, k=4, F=2, seed=7)])
+def test_next_level_first_evaluation_rides_along(orc, mbavo, gpu_ctx, kw):
+    """mbavo_track_opts.ride_along (default on): every candidate's command of the joint persistent kernel also evaluates the NEXT finer
+    level at the current knots, and a level that ends at those knots (a rejected last candidate: A16) finds its successor's iteration 0
+    done.  The evaluation is the one the loop would have made -- same kernel, same inputs -- so against the loop with it switched off:
+    the same trace records to the last bit (costs included), the same knots, bit for bit; and the oracle's trace."""
+    import tracking
+    sc = tracking.make_tracking_scene(orc, **kw)
+    on = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, dict(tracking.OPTS))
+    off = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, dict(tracking.OPTS, ride_along=-1))
+    assert on["trace"] == off["trace"] and len(on["trace"]) > 2 * kw["levels"]
+    assert np.array_equal(on["kt"], off["kt"]) and np.array_equal(on["kR"], off["kR"]) and on["cost"] == off["cost"]
+    want = tracking.run_oracle_tracker(orc, sc, dict(tracking.OPTS))
+    assert [t[:4] for t in on["trace"]] == [t[:4] for t in want["trace"]]
