@@ -415,8 +415,11 @@ int mbavo_allgather_blocks(mbavo_ctx *ctx, void *rccl_comm, double *d_blocks, lo
  *                      with the RCCL id) and calls
  *   mbavo_p2p_connect  with the world x 64 bytes in rank order.  At most 16 ranks, all on GPUs of one node (ranks may share a GPU).
  *   Every rank must issue the same sequence of p2p collectives.  A peer that does not arrive within 20 s ends the kernel:
- *   mbavo_p2p_status (synchronises the stream) then returns MBAVO_E_TIMEOUT.  All ranks must have finished their last
- *   collective (a barrier of the caller) before any of them calls mbavo_p2p_destroy / mbavo_destroy. */
+ *   mbavo_p2p_status (synchronises the stream) then returns MBAVO_E_TIMEOUT.
+ *   Tear-down is two-phase, like any shared mapping: every rank finishes its last collective and calls mbavo_p2p_disconnect
+ *   (unmaps the PEERS' regions); after a barrier of the caller -- nobody maps anybody any more -- every rank calls
+ *   mbavo_p2p_destroy (frees its OWN region; also what mbavo_destroy does).  Freeing a region a peer still maps makes a later
+ *   mbavo_p2p_create fail in hipIpcGetMemHandle (seen intermittently with three ranks when tear-down was one call). */
 #define MBAVO_P2P_HANDLE_BYTES 64
 int mbavo_p2p_create(mbavo_ctx *ctx, int rank, int world, long long max_doubles_per_slot, unsigned char *h_handle_out /*64*/);
 int mbavo_p2p_connect(mbavo_ctx *ctx, const unsigned char *h_all_handles /* world x 64, rank order */);
@@ -424,6 +427,7 @@ int mbavo_p2p_ranks(mbavo_ctx *ctx); /* world once connected, else 0 */
 int mbavo_allgather_blocks_p2p(mbavo_ctx *ctx, double *d_blocks, long long count_per_rank); /* in place, as mbavo_allgather_blocks */
 int mbavo_allreduce_blocks_p2p(mbavo_ctx *ctx, double *d_blocks, long long count);          /* in place, as mbavo_allreduce_blocks */
 int mbavo_p2p_status(mbavo_ctx *ctx);
+int mbavo_p2p_disconnect(mbavo_ctx *ctx);
 int mbavo_p2p_destroy(mbavo_ctx *ctx);
 
 /* ---- measurement: HIP-event timing of the dominant kernel (the fused residual/Jacobian/JtJ

@@ -128,7 +128,7 @@ SYMBOLS = [
     "mbavo_gradient_magnitude_u8", "mbavo_detect_semidense", "mbavo_se3_exp", "mbavo_se3_log", "mbavo_transform_mul",
     "mbavo_transform_inverse", "mbavo_spline_transform_to", "mbavo_vo_create", "mbavo_vo_destroy", "mbavo_vo_set_spline",
     "mbavo_vo_get_spline", "mbavo_sizeof", "mbavo_set_engine_opts", "mbavo_get_engine_opts", "mbavo_eval_batch_merged", "mbavo_p2p_create", "mbavo_p2p_connect", "mbavo_p2p_ranks", "mbavo_allgather_blocks_p2p",
-    "mbavo_allreduce_blocks_p2p", "mbavo_p2p_status", "mbavo_p2p_destroy", "mbavo_vo_last_trace", "mbavo_vo_get_state", "mbavo_vo_set_state", "mbavo_vo_set_keyframe", "mbavo_vo_num_keypoints", "mbavo_vo_get_keypoints", "mbavo_vo_track_frame", "mbavo_lm_batch",
+    "mbavo_allreduce_blocks_p2p", "mbavo_p2p_status", "mbavo_p2p_disconnect", "mbavo_p2p_destroy", "mbavo_vo_last_trace", "mbavo_vo_get_state", "mbavo_vo_set_state", "mbavo_vo_set_keyframe", "mbavo_vo_num_keypoints", "mbavo_vo_get_keypoints", "mbavo_vo_track_frame", "mbavo_lm_batch",
     "mbavo_shard_keypoints", "mbavo_shard_frames", "mbavo_system_len", "mbavo_merge_device", "mbavo_comm_unique_id",
     "mbavo_comm_init", "mbavo_comm_ranks", "mbavo_comm_destroy", "mbavo_last_kernel", "mbavo_timing_report",
 ]
@@ -265,6 +265,7 @@ def load():
     L.mbavo_allgather_blocks_p2p.argtypes = [vp, vp, C.c_longlong]
     L.mbavo_allreduce_blocks_p2p.argtypes = [vp, vp, C.c_longlong]
     L.mbavo_p2p_status.argtypes = [vp]
+    L.mbavo_p2p_disconnect.argtypes = [vp]
     L.mbavo_p2p_destroy.argtypes = [vp]
     L.mbavo_profile.argtypes = [vp, C.c_int]
     L.mbavo_profile_read.argtypes = [vp, c_dp, c_ip]

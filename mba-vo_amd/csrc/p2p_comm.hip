@@ -149,13 +149,22 @@ namespace mbavo
         }
         else
         {
-            for (long long i = (long long)b * kP2PThreads + tid; i < count; i += (long long)nb * kP2PThreads)
-            {
+            // In place: an element may only be overwritten by the thread that SENT it (another workgroup of this kernel may still be in
+            // its send phase: nothing orders the workgroups of one rank against each other) -- so the sums walk the elements in the
+            // send phase's own partition: 16-byte pairs where the sends were pairs, the odd tail by the thread that sent it.
+            auto reduce_at = [&](long long i) {
                 double acc = 0.0;
                 for (int p = 0; p < a.world; ++p) // rank order, own contribution in its place: the same bits on every rank
                     acc += p == a.rank ? buf[i] : __builtin_nontemporal_load(reinterpret_cast<const double *>(base + (size_t)p * a.slot_bytes) + i);
                 buf[i] = acc;
+            };
+            if ((reinterpret_cast<size_t>(mine) & 15) == 0)
+            {
+                for (long long i = (long long)b * kP2PThreads + tid; i < pairs; i += (long long)nb * kP2PThreads) { reduce_at(2 * i); reduce_at(2 * i + 1); }
+                if ((count & 1) && b == 0 && tid == 0) reduce_at(count - 1);
             }
+            else
+                for (long long i = (long long)b * kP2PThreads + tid; i < count; i += (long long)nb * kP2PThreads) reduce_at(i);
         }
     }
 
@@ -189,7 +198,7 @@ namespace mbavo
         if (e == hipSuccess) e = hipIpcGetMemHandle(&s->handle, p);
         if (e != hipSuccess)
         {
-            fprintf(stderr, "mbavo: p2p_create: %s\n", hipGetErrorString(e));
+            fprintf(stderr, "mbavo: p2p_create (rank %d of %d, %zu bytes): %s\n", rank, world, s->total, hipGetErrorString(e));
             (void)hipFree(p); (void)hipFree(s->tickets);
             delete s;
             return (int)e;
@@ -259,6 +268,17 @@ namespace mbavo
         P2P_TRY(hipStreamSynchronize(stream_));
         P2P_TRY(hipMemcpy(&st, s->tickets + s->world, sizeof(int), hipMemcpyDeviceToHost));
         return st ? MBAVO_E_TIMEOUT : 0;
+    }
+
+    int Engine::p2p_disconnect()
+    { // unmap the peers' regions (collectives are refused from here on); the own region stays until p2p_destroy
+        P2PState *s = p2p_;
+        if (!s) return 0;
+        (void)hipStreamSynchronize(stream_);
+        for (int p = 0; p < s->world; ++p)
+            if (s->opened[p]) { (void)hipIpcCloseMemHandle(s->peer[p]); s->opened[p] = false; s->peer[p] = nullptr; }
+        s->connected = false;
+        return 0;
     }
 
     int Engine::p2p_destroy()

@@ -156,10 +156,7 @@ class P2PCollective:
             return
         lib, h = self.ctx.lib, self.ctx.handle
         if self.cap:
-            torch.cuda.synchronize()
-            if self.world > 1:
-                dist.barrier(group=self.group)  # nobody is still reading or writing the old regions
-            capi.check(lib.mbavo_p2p_destroy(h), "mbavo_p2p_destroy")
+            self._teardown()
         cap = max(int(doubles), 2 * self.cap)
         mine = C.create_string_buffer(64)
         capi.check(lib.mbavo_p2p_create(h, self.rank, self.world, cap, mine), "mbavo_p2p_create")
@@ -184,16 +181,27 @@ class P2PCollective:
         self._ensure(count_per_rank)
         capi.check(self.ctx.lib.mbavo_allgather_blocks_p2p(self.ctx.handle, buf.data_ptr(), count_per_rank), "mbavo_allgather_blocks_p2p")
 
+    def _teardown(self):
+        """Two-phase, all ranks together: collectives done -> barrier -> everybody unmaps its peers -> barrier -> everybody frees its
+        own region (a region freed while a peer still maps it makes the next hipIpcGetMemHandle fail)."""
+        import torch
+        import torch.distributed as dist
+        lib, h = self.ctx.lib, self.ctx.handle
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier(group=self.group)  # nobody is still reading or writing the regions
+        capi.check(lib.mbavo_p2p_disconnect(h), "mbavo_p2p_disconnect")
+        if self.world > 1:
+            dist.barrier(group=self.group)  # nobody maps anybody any more
+        capi.check(lib.mbavo_p2p_destroy(h), "mbavo_p2p_destroy")
+
     def close(self):
         """All ranks together, after their last collective has completed."""
         import torch
-        import torch.distributed as dist
         if self.cap:
             torch.cuda.synchronize()
             st = self.ctx.lib.mbavo_p2p_status(self.ctx.handle)
-            if self.world > 1:
-                dist.barrier(group=self.group)
-            capi.check(self.ctx.lib.mbavo_p2p_destroy(self.ctx.handle), "mbavo_p2p_destroy")
+            self._teardown()
             self.cap = 0
             capi.check(st, "mbavo_p2p_status")
 

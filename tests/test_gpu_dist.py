@@ -170,13 +170,16 @@ def rank_body(rank, world, local_rank, port, out_path, comm="rccl"):
         # the collectives alone, against torch: odd counts, unaligned slices, many steps in a row (two parities of slots), every
         # rank's result identical bits; the all-reduce adds in rank order
         g = torch.Generator(device="cpu").manual_seed(1234)
-        every = [torch.randn(5001, dtype=torch.float64, generator=g) for _ in range(world)]
+        every = [torch.randn(40001, dtype=torch.float64, generator=g) for _ in range(world)]
         want_sum = every[0].clone()
         for r in range(1, world):
             want_sum = want_sum + every[r]
         ok_sum, ok_gather = True, True
-        for step in range(40):
-            n = (5001, 1, 777, 4096)[step % 4]
+        for step in range(60):
+            # (40 001 doubles = 20 workgroups per rank: the in-place sum must walk the elements in the send phase's own partition --
+            # a workgroup that summed an element another workgroup had not sent yet was round 5's one race, seen once in three runs;
+            # tools/p2p_stress.py runs random sequences up to 300 001 doubles)
+            n = (5001, 1, 777, 4096, 40001, 20000)[step % 6]
             v = (every[rank][:n] * (step + 1)).to(dev)
             coll.allreduce(v, v, n)
             w = want_sum[:n].clone() if world == 1 else None
