@@ -792,6 +792,7 @@ def main():
     if use_dist and not use_p2p and not shared_gpu and world > 1 and os.environ.get("MBAVO_BENCH_P2P", "1") != "0":
         p2p_line = None
         try:
+            # (P2PCollective raises on EVERY rank if any rank's region cannot be created or mapped: the ranks stay in step)
             c2 = shard.P2PCollective(ctx, rank, world, max_doubles=max(int(run.se.count), 1 << 12))
             r2 = Runner(M, ctx, args.workload, dev, rank, world, True, 2 if args.packed_keyframes else int(args.grad_fp16), shard_mode=args.shard,
                         coll=c2, pair_collective=args.collective, pairs=args.batch_pairs if args.batch_pairs != 512 else None)

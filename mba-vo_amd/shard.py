@@ -158,15 +158,31 @@ class P2PCollective:
         if self.cap:
             self._teardown()
         cap = max(int(doubles), 2 * self.cap)
+        self.cap = 0
         mine = C.create_string_buffer(64)
-        capi.check(lib.mbavo_p2p_create(h, self.rank, self.world, cap, mine), "mbavo_p2p_create")
+        # Every decision below is taken on values ALL ranks hold (the gathered return codes), so a failure on one rank -- an
+        # allocation, an IPC export or import the platform refuses -- raises on every rank at the same point and leaves nobody
+        # waiting in a collective of torch.distributed or of this class.
+        rc = lib.mbavo_p2p_create(h, self.rank, self.world, cap, mine)
+        every = [(rc, mine.raw)]
         if self.world > 1:
             every = [None] * self.world
-            dist.all_gather_object(every, mine.raw, group=self.group)
-            raw = b"".join(every)
-        else:
-            raw = mine.raw
-        capi.check(lib.mbavo_p2p_connect(h, raw), "mbavo_p2p_connect")
+            dist.all_gather_object(every, (rc, mine.raw), group=self.group)
+        if any(r != 0 for r, _ in every):
+            if rc == 0:
+                lib.mbavo_p2p_destroy(h)
+            raise RuntimeError("mbavo_p2p_create failed on rank(s) %s (codes %s)" % ([i for i, (r, _) in enumerate(every) if r != 0], [r for r, _ in every]))
+        rc = lib.mbavo_p2p_connect(h, b"".join(raw for _, raw in every))
+        codes = [rc]
+        if self.world > 1:
+            codes = [None] * self.world
+            dist.all_gather_object(codes, rc, group=self.group)
+        if any(r != 0 for r in codes):
+            lib.mbavo_p2p_disconnect(h)
+            if self.world > 1:
+                dist.barrier(group=self.group)  # nobody maps anybody any more
+            lib.mbavo_p2p_destroy(h)
+            raise RuntimeError("mbavo_p2p_connect failed on rank(s) %s (codes %s)" % ([i for i, r in enumerate(codes) if r != 0], codes))
         assert lib.mbavo_p2p_ranks(h) == self.world
         self.cap = cap
 
