@@ -712,7 +712,41 @@ namespace mbavo
         SampleInFlight fa, fb;
 #define MBAVO_TAB(i) table[i]
         int s;
-        if (S >= 2)
+#ifndef MBAVO_COST_GROUP
+#define MBAVO_COST_GROUP 4
+#endif
+        if constexpr (!WITH_J && MBAVO_COST_GROUP > 2)
+        { // COST-ONLY passes (round 5): a sample is ~60 instructions between its taps and there is no Jacobian state to keep, so the taps
+          // of FOUR samples are in flight at once (7 registers each: four blend weights, two rows, the flag) -- the exposed memory
+          // latencies of a round are S / 4 instead of S / 2.  Same arithmetic per sample, intensities added in sample order.
+            constexpr int G = MBAVO_COST_GROUP;
+            SampleInFlight f[G];
+            ok = true;
+            isum = 0.0;
+            bool first = true;
+            for (s = 0; s + G - 1 < S; s += G)
+            {
+#pragma unroll
+                for (int j = 0; j < G; ++j) sample_issue<KDEG, false, HALF_GRAD>(MBAVO_TAB(s + j), ray, depth, iz, cam, I_ref, G_ref, f[j]);
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+                {
+                    ok = ok && f[j].taps.ok;
+                    if (first && j == 0) sample_retire<KDEG, false, true, HALF_GRAD>(MBAVO_TAB(s), f[0], ray, depth, iz, cam, isum, Jrow);
+                    else sample_retire<KDEG, false, false, HALF_GRAD>(MBAVO_TAB(s + j), f[j], ray, depth, iz, cam, isum, Jrow);
+                }
+                first = false;
+            }
+            for (; s < S; ++s)
+            { // the remainder, one at a time (S not a multiple of the group: S = 1, 3, ...)
+                sample_issue<KDEG, false, HALF_GRAD>(MBAVO_TAB(s), ray, depth, iz, cam, I_ref, G_ref, fa);
+                ok = ok && fa.taps.ok;
+                if (first) sample_retire<KDEG, false, true, HALF_GRAD>(MBAVO_TAB(s), fa, ray, depth, iz, cam, isum, Jrow);
+                else sample_retire<KDEG, false, false, HALF_GRAD>(MBAVO_TAB(s), fa, ray, depth, iz, cam, isum, Jrow);
+                first = false;
+            }
+        }
+        else if (S >= 2)
         { // the first pair sets the accumulators
             sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(0), ray, depth, iz, cam, I_ref, G_ref, fa);
             sample_issue<KDEG, WITH_J, HALF_GRAD>(MBAVO_TAB(1), ray, depth, iz, cam, I_ref, G_ref, fb);
