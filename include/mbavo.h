@@ -222,7 +222,10 @@ typedef struct mbavo_track_opts {
     int persist_levels; /* one persistent kernel for all levels of a call; default on                          [MBAVO_PERSIST_LEVELS] */
     int ride_along;     /* the next pyramid level's first evaluation rides along with this level's candidates (same
                            results, one dependent evaluation less per level); default on                       [MBAVO_RIDE_ALONG] */
-    int reserved[3];
+    int resum;          /* the H / g evaluation behind an accepted step whose outlier flags changed is the candidate's,
+                           summed again on the device under the new flags and scale (bit-identical results, no pixel
+                           work); default on                                                                   [MBAVO_RESUM] */
+    int reserved[2];
 } mbavo_track_opts;
 typedef struct mbavo_trace_rec {
     int level, iter, kind; /* 0 initial evaluation, 1 accepted, 2 rejected, 3 invalid step */
@@ -326,7 +329,8 @@ typedef struct mbavo_vo_options { /* BlurAwareDirectTrackerOptions (blur_aware_d
     int speculate_keyframe;      /* keyframe pre-processing started under the LM loop, on a second stream, when the predicted motion
                                     already passes the keyframe test (identical results); default on              [MBAVO_KF_SPECULATE] */
     int ride_along;              /* as mbavo_track_opts.ride_along */
-    int reserved[3];
+    int resum;                   /* as mbavo_track_opts.resum */
+    int reserved[2];
 } mbavo_vo_options;
 typedef struct mbavo_vo_info {
     int is_keyframe, num_keypoints0, num_trace, start_idx;

@@ -45,7 +45,7 @@ class TrackOpts(C.Structure):
         ("min_abs_cost_decrease", C.c_double), ("max_chi_square_error", C.c_double),
         # ABI 3: zero = default (include/mbavo.h)
         ("fast_solve_ratio", C.c_double), ("speculate", C.c_int), ("persist_levels", C.c_int), ("ride_along", C.c_int),
-        ("reserved", C.c_int * 3),
+        ("resum", C.c_int), ("reserved", C.c_int * 2),
     ]
 
 
@@ -104,7 +104,7 @@ class VoOptions(C.Structure):
         ("score_threshold", C.c_float), ("grid_selection_cell_H", C.c_int), ("grid_selection_cell_W", C.c_int),
         # ABI 3: zero = default (include/mbavo.h)
         ("fast_solve_ratio", C.c_double), ("speculate", C.c_int), ("persist_levels", C.c_int), ("keyframe_levels_at_once", C.c_int),
-        ("speculate_keyframe", C.c_int), ("ride_along", C.c_int), ("reserved", C.c_int * 3),
+        ("speculate_keyframe", C.c_int), ("ride_along", C.c_int), ("resum", C.c_int), ("reserved", C.c_int * 2),
     ]
 
 

@@ -544,7 +544,7 @@ extern "C"
         v.score_threshold = o->score_threshold;
         v.grid_selection_cell_H = o->grid_selection_cell_H; v.grid_selection_cell_W = o->grid_selection_cell_W;
         v.fast_solve_ratio = o->fast_solve_ratio; v.speculate = o->speculate; v.persist_levels = o->persist_levels;
-        v.keyframe_levels_at_once = o->keyframe_levels_at_once; v.speculate_keyframe = o->speculate_keyframe; v.ride_along = o->ride_along;
+        v.keyframe_levels_at_once = o->keyframe_levels_at_once; v.speculate_keyframe = o->speculate_keyframe; v.ride_along = o->ride_along; v.resum = o->resum;
         if (v.spline_deg_k != 2 && v.spline_deg_k != 4) return MBAVO_E_ARG;
         mbavo_vo *h = new (std::nothrow) mbavo_vo(*ctx->engine, v);
         if (!h) return MBAVO_E_ARG;

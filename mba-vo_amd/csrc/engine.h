@@ -112,6 +112,12 @@ namespace mbavo
         // into the second knot area (7 N doubles behind the first); persistent_wait() waits for `prob` only, the second problem's
         // completion is asked for by the sequence number of its post (posted_seq())
         int persistent_post(int slot, bool with_hessian, int prob = 0, int prob2 = -1);
+        // (round 5) The H / g evaluation that was problem `prob`'s LAST command, summed again under the outlier flags and the residual
+        // scale as the push block holds them NOW -- what an H / g evaluation at the same knots would return, bit for bit, without
+        // the pixel work (engine.hip: sp_resum_body).  persistent_resum_ok: the kernel of `slot` can do that for `prob` (one patch
+        // per wave, tiles of one round); the caller guarantees that no other command went to that problem in between.
+        bool persistent_resum_ok(int slot, int prob = 0) const { return persistent_active(slot) && prob >= 0 && prob < 15 && (persist_resum_[slot] >> prob & 1u) != 0; }
+        int persistent_post_resum(int slot, int prob = 0);
         int persistent_wait();
         unsigned long long posted_seq() const { return pending_seq_; }
         bool persistent_second_done(unsigned long long seq) const;
@@ -292,6 +298,7 @@ namespace mbavo
         unsigned long long pending_seq_ = 0;           // sequence number of the evaluation posted last
         int persist_gen_ = 0;
         int persist_gen_of_[kPushSlots] = {};          // generation of the kernel enqueued on each slot
+        unsigned persist_resum_[kPushSlots] = {};      // per slot: the problems of its kernel's list that can be summed again (persistent_resum_ok)
         int status_seen_ = 0;
         void *h_fb_ = nullptr; size_t cap_hfb_ = 0;
         static constexpr int kPinnedSlots = 8; // 0-4 host-driven LM loop (tracker.cpp), 7 lm_batch

@@ -1018,7 +1018,7 @@ namespace mbavo
     template <int KD, bool WITH_J, int LOGS, bool ONE>
     struct SpLds
     {
-        static constexpr size_t kBase = ((WITH_J ? (size_t)kSpWaves * OuterAcc<6 * KD + 1>::SLAB : 0) + 2 * kSpWaves) * sizeof(double);
+        static constexpr size_t kBase = ((WITH_J ? (size_t)kSpWaves * OuterAcc<6 * KD + 1>::SLAB : 0) + 4 * kSpWaves) * sizeof(double);
         static constexpr size_t kEntries = ((size_t)1 << LOGS) * sizeof(PoseEntry<KD>);
         static constexpr bool kFits = kBase + kEntries <= 160 * 1024;
         static constexpr bool kStage = (WITH_J || ONE) && kFits;
@@ -1027,6 +1027,9 @@ namespace mbavo
         static constexpr size_t kSegs = (size_t)(((1 << LOGS) < kPoseSPB ? (1 << LOGS) : kPoseSPB) * (KD - 1)) * sizeof(SplineSeg);
         static constexpr size_t kEpilogue = ONE && !WITH_J ? (kSegs > (size_t)kSpWaves * 64 * sizeof(double) ? kSegs : (size_t)kSpWaves * 64 * sizeof(double)) : 0;
         static constexpr size_t kBytes = kBase + (kStage ? kEntries : 0) + kEpilogue;
+        // the persistent kernel keeps the slabs of an H / g evaluation for a re-summation (sp_resum_body): its ticket epilogue
+        // takes an area of its own there too
+        static constexpr size_t kPersistBytes = kBytes + (ONE && WITH_J ? (size_t)kSpWaves * 64 * sizeof(double) : 0);
     };
     // can the single-launch form of the sample-parallel kernel run this (k, S)?  (k = 4, S = 32: the entries do not fit)
     static bool sp_one_fits(int kdeg, int logs)
@@ -1034,6 +1037,10 @@ namespace mbavo
         if (kdeg == 2) return logs >= 2 && logs <= 5;
         return logs >= 2 && logs <= 4;
     }
+
+    template <int KD, bool WITH_J, int LOGS, bool ONE, bool PERSIST>
+    __device__ __forceinline__ bool sp_tile_finish(double *lds, const ProblemDesc &d, int tile_id, int frame, double *__restrict__ partials,
+                                                   const OneArgs &oa, double inv);
 
     // the body of k_fused_sp (one tile of one evaluation); also run, evaluation after evaluation, by the persistent kernel
     template <int KD, bool WITH_J, int HALF_GRAD, int LOGS, bool ONE, bool PERSIST = false>
@@ -1046,13 +1053,13 @@ namespace mbavo
                                                  double *__restrict__ partials, const OneArgs &oa,
                                                  const double *knots_t_fresh = nullptr, const double *knots_R_fresh = nullptr)
     {
-        constexpr int ND = Pack<KD>::ND, E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
+        constexpr int ND = Pack<KD>::ND, E = Pack<KD>::E;
         constexpr int kWavesPerGroup = kSpWaves, kThreads = kWavesPerGroup * 64;
         constexpr int SS = 1 << LOGS, PXW = 64 >> LOGS, PXG = kWavesPerGroup * PXW; // lanes per pixel, pixels per wave / per round
         constexpr int SLAB = OuterAcc<ND>::SLAB;     // doubles per wave: rows, and the parked accumulators at the end
         constexpr int RS = OuterAcc<ND>::STRIDE;     // row stride (>= ND, zero padded)
         double *rows = lds;                                               // [12 waves][64 pixels][ND] (WITH_J only)
-        double *red = lds + (WITH_J ? kWavesPerGroup * SLAB : 0);         // [2][12]
+        double *red = lds + (WITH_J ? kWavesPerGroup * SLAB : 0);         // [4][waves]: cost, valid pixels; (persistent kernel) the wave's unscaled patch cost, its valid pixels
 
         const int lane = threadIdx.x & 63;
         const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1068,7 +1075,7 @@ namespace mbavo
         const int npx = tile.kp_count * P;
         constexpr bool STAGE = SpLds<KD, WITH_J, LOGS, ONE>::kStage;
         static_assert(!ONE || STAGE, "the single-launch kernel keeps its pose entries in LDS");
-        double *stage = red + 2 * kSpWaves;
+        double *stage = red + 4 * kSpWaves;
         const PoseEntry<KD> *__restrict__ ftab = table + d.pose_base + frame * S; // S == SS (checked by the host)
         if constexpr (ONE)
         {
@@ -1104,7 +1111,7 @@ namespace mbavo
         acc.init(lane);
         double *slab = rows + wave * SLAB;
         int nvalid = 0;
-        double cost_local = 0.0;
+        double cost_local = 0.0, x_keep = 0.0;
         const double inv = residual_scale<PERSIST>(d, lane);
         // Power-of-two patches that fit the pixels of one wave round (the 8-pixel pattern at S <= 8): the patch cost is
         // reduced across the wave in the order of the reference's reduce() -- no rho scratch, no second pass.
@@ -1170,6 +1177,7 @@ namespace mbavo
                         if (patch_cost) patch_cost[d.patch_base + patch] = c;
                         if (patch_blocks_strided) patch_blocks_strided[patch * E] = c;
                         if (!flagged) cost_local += c;
+                        if constexpr (PERSIST && WITH_J) x_keep = x; // (sp_resum_body: one patch per wave, lane 0's)
                     }
                     nvalid += valid ? 1 : 0;
                 }
@@ -1246,10 +1254,26 @@ namespace mbavo
         }
         const double wc = wave_sum(cost_local);
         const double wv = wave_sum((double)nvalid);
-        if (lane == 0) { red[wave] = wc; red[kWavesPerGroup + wave] = wv; }
+        if (lane == 0)
+        {
+            red[wave] = wc; red[kWavesPerGroup + wave] = wv;
+            if constexpr (PERSIST && WITH_J) { red[2 * kWavesPerGroup + wave] = x_keep; red[3 * kWavesPerGroup + wave] = wv; }
+        }
         // every wave parks its accumulators in its slab; entry e = (i, j) of the packed block is then the sum
         // over waves (and pixel groups) in a fixed order.  One barrier for the scratch and the slabs.
         if (WITH_J) acc.store(slab, lane);
+        return sp_tile_finish<KD, WITH_J, LOGS, ONE, PERSIST>(lds, d, tile_id, frame, partials, oa, inv);
+    }
+
+    // the end of a tile (after the waves parked their sums in `red` and their accumulators in the slabs): the tile's partial
+    // block, and in the single-launch forms the ticket of its slot
+    template <int KD, bool WITH_J, int LOGS, bool ONE, bool PERSIST>
+    __device__ __forceinline__ bool sp_tile_finish(double *lds, const ProblemDesc &d, int tile_id, int frame, double *__restrict__ partials,
+                                                   const OneArgs &oa, double inv)
+    {
+        constexpr int ND = Pack<KD>::ND, E = Pack<KD>::E, PS = Pack<KD>::PSTRIDE;
+        constexpr int kWavesPerGroup = kSpWaves, kThreads = kWavesPerGroup * 64, SS = 1 << LOGS;
+        double *rows = lds, *red = lds + (WITH_J ? kWavesPerGroup * OuterAcc<ND>::SLAB : 0), *stage = red + 4 * kSpWaves;
         __syncthreads();
         double *out = partials + (size_t)tile_id * PS;
         auto put = [&](int e, double v) { out[e] = v; };
@@ -1271,13 +1295,55 @@ namespace mbavo
         }
         if constexpr (ONE)
         {
-            // scratch for the tile-lane sums: the slabs (every thread is past its gather after the barrier inside),
-            // or the kernel's epilogue area when there are none
-            double *scratch = WITH_J ? rows : stage + SS * (int)(sizeof(PoseEntry<KD>) / sizeof(double));
+            // scratch for the tile-lane sums: the slabs (every thread is past its gather after the barrier inside), or the
+            // kernel's epilogue area when there are none -- or when they are kept (persistent kernel: sp_resum_body)
+            double *scratch = WITH_J && !PERSIST ? rows : stage + SS * (int)(sizeof(PoseEntry<KD>) / sizeof(double));
             MBAVO_STAMP(1);
             return ticket_finalize<KD, WITH_J, kThreads>(d, d.bf_base + frame, partials, oa, scratch, inv);
         }
         return false;
+    }
+
+    // RE-SUMMATION of the H / g evaluation this workgroup ran LAST, under outlier flags and a residual scale the host changed since
+    // (round 5; persistent kernel, command mode 3).  An accepted LM step is followed by an H / g evaluation at the very knots of
+    // the candidate just evaluated (blur_aware_direct_tracker.cpp:896-903); what differs is detectOutliers' doing (:639-699): a few
+    // more patches flagged, hence another 1 / ((K - bad) F P).  Neither enters a pixel's row: a flagged patch's rows are parked as
+    // zeros, the scale is applied to the finished sums.  Where a wave's accumulators hold exactly ONE patch (P pixels == the pixels
+    // of a wave, tiles of one round -- Engine::persistent_resum_ok) they are still in its slab: the newly flagged patches' slabs are
+    // zeroed (what their waves would have accumulated: 0 + 0 * 0), the waves' cost shares rebuilt from the kept unscaled patch
+    // costs, and the tile ends as it did before -- same partial sums in the same order, bit for bit the evaluation the reference
+    // runs, without pose entries, taps or Jacobians (~6 of its ~13.5 us).
+    template <int KD, int LOGS>
+    __device__ __forceinline__ bool sp_resum_body(double *lds, const ProblemDesc *__restrict__ descs, const TileDesc *__restrict__ tiles,
+                                                  double *__restrict__ patch_cost, double *__restrict__ partials, const OneArgs &oa)
+    {
+        constexpr int ND = Pack<KD>::ND;
+        constexpr int kWavesPerGroup = kSpWaves, PXW = 64 >> LOGS, SLAB = OuterAcc<ND>::SLAB, NI = OuterAcc<ND>::NI;
+        double *rows = lds, *red = lds + kWavesPerGroup * SLAB;
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int tile_id = xcd_tile_of_block((int)blockIdx.x, (int)gridDim.x);
+        const TileDesc tile = tiles[tile_id];
+        const ProblemDesc &d = descs[tile.prob];
+        const double inv = residual_scale<true>(d, lane);
+        const bool has = wave < tile.kp_count; // (P == PXW: wave w holds patch kp_begin + w)
+        const int kp = tile.kp_begin + wave;
+        const bool flagged = has && d.outlier != nullptr && outlier_flag<true>(d.outlier, kp) == 1;
+        if (flagged)
+        {
+            double *slab = rows + wave * SLAB;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) slab[i * 64 + lane] = 0.0;
+        }
+        if (lane == 0)
+        {
+            const double c = red[2 * kWavesPerGroup + wave] * inv;
+            if (has && patch_cost) patch_cost[d.patch_base + (long long)tile.frame * d.K + kp] = c;
+            red[wave] = has && !flagged ? c : 0.0;
+            red[kWavesPerGroup + wave] = red[3 * kWavesPerGroup + wave];
+        }
+        (void)PXW;
+        return sp_tile_finish<KD, true, LOGS, true, true>(lds, d, tile_id, tile.frame, partials, oa, inv);
     }
 
     template <int KD, bool WITH_J, int HALF_GRAD, int LOGS, bool ONE>
@@ -1309,7 +1375,8 @@ namespace mbavo
     //   bits 20..63 sequence number   bits 8..19 generation: which launch the command is for (workgroups of an earlier launch
     //   that have not seen their exit command yet leave when they meet a command of a later generation)
     //   bits 4..7 problem of the kernel's list the command is for (the pyramid level when one kernel serves all levels)
-    //   bits 0..3 mode: 0 = exit, 1 = cost-only evaluation, 2 = H/g evaluation
+    //   bits 0..3 mode: 0 = exit, 1 = cost-only evaluation, 2 = H/g evaluation, 3 = the last H/g evaluation summed again under the
+    //   flags and the scale as they are now (sp_resum_body)
     struct PersistCmd
     {
         unsigned long long word;
@@ -1390,7 +1457,9 @@ namespace mbavo
 #if defined(MBAVO_PERSIST_STAMPS)
             oa.t_seen = __builtin_amdgcn_s_memrealtime();
 #endif
-            if (mode == 2)
+            if (mode == 3)
+                (void)sp_resum_body<KD, LOGS>(lds, descs, tiles, patch_cost, partials, oa);
+            else if (mode == 2)
                 (void)sp_tile_body<KD, true, false, LOGS, true, true>(lds, descs, tiles, nullptr, rho_out, patch_cost, nullptr, partials, oa, kn, kn + 3 * d0.N);
             else
                 (void)sp_tile_body<KD, false, false, LOGS, true, true>(lds, descs, tiles, nullptr, rho_out, patch_cost, nullptr, partials, oa, kn, kn + 3 * d0.N);
@@ -2103,8 +2172,8 @@ namespace mbavo
     {                                                                                                                             \
         if constexpr (SpLds<KD, true, LG, true>::kFits)                                                                           \
         {                                                                                                                         \
-            const size_t lds_sp = SpLds<KD, true, LG, true>::kBytes > SpLds<KD, false, LG, true>::kBytes                          \
-                                      ? SpLds<KD, true, LG, true>::kBytes : SpLds<KD, false, LG, true>::kBytes;                    \
+            const size_t lds_sp = SpLds<KD, true, LG, true>::kPersistBytes > SpLds<KD, false, LG, true>::kBytes                   \
+                                      ? SpLds<KD, true, LG, true>::kPersistBytes : SpLds<KD, false, LG, true>::kBytes;             \
             HIP_TRY(ensure_lds((const void *)k_sp_persist<KD, LG>, lds_sp));                                                      \
             hipLaunchKernelGGL((k_sp_persist<KD, LG>), dim3(ntiles), dim3(kSpWaves * 64), lds_sp, st, (const ProblemDesc *)d_descs_, \
                                (const TileDesc *)d_tiles_, (double *)d_rho_, h_patch_cost, (double *)d_partials_, oa,             \
@@ -2125,6 +2194,14 @@ namespace mbavo
         HIP_TRY(hipGetLastError());
         persist_mask_ |= 1u << slot;
         persist_gen_of_[slot] = persist_gen_;
+        // problems whose waves hold ONE patch each: as many pixels per patch as a wave has, every tile a single round
+        persist_resum_[slot] = 0;
+        for (int b = 0; b < B; ++b)
+        {
+            bool ok = h_descs_[b].P == (64 >> sp_logs_) && h_descs_[b].outlier != nullptr;
+            for (const TileDesc &t : h_tiles_) ok = ok && (t.prob != b || t.kp_count <= kSpWaves);
+            if (ok) persist_resum_[slot] |= 1u << b;
+        }
         last_kernel_id_[0] = kdeg; last_kernel_id_[1] = 1; last_kernel_id_[2] = 0; last_kernel_id_[3] = sp_logs_; last_kernel_id_[4] = 1;
         return 0;
     }
@@ -2137,6 +2214,17 @@ namespace mbavo
         host_store_fence(); // the inputs (knots, flags, scale: the push block, write-combining) are out ...
         cmd->word = persist_word(seq, persist_gen_of_[slot], with_hessian ? 2 : 1, prob, prob2 < 0 ? 15 : prob2);
         host_store_fence(); // ... before the command word, which leaves the write-combining buffer now
+        pending_seq_ = seq;
+        return 0;
+    }
+    int Engine::persistent_post_resum(int slot, int prob)
+    {
+        if (!persistent_resum_ok(slot, prob)) return MBAVO_E_ARG;
+        volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
+        const unsigned long long seq = ++flag_seq_;
+        host_store_fence(); // (the flags and the scale are out before the command word, as in persistent_post)
+        cmd->word = persist_word(seq, persist_gen_of_[slot], 3, prob);
+        host_store_fence();
         pending_seq_ = seq;
         return 0;
     }

@@ -389,7 +389,7 @@ namespace mbavo
         e.sp = num("MBAVO_SP"); e.one = num("MBAVO_ONE"); e.fused_pose = num("MBAVO_FUSED_POSE");
         e.fused_pose_max_s = num("MBAVO_FUSED_POSE_MAX_S"); e.persist = num("MBAVO_PERSIST"); e.prelaunch = num("MBAVO_PRELAUNCH");
         e.tiles_per_cu = num("MBAVO_TILES_PER_CU"); e.min_tile_px = num("MBAVO_MIN_TILE_PX"); e.sp_max_slot_tiles = num("MBAVO_SP_MAX_SLOT_TILES");
-        e.speculate = num("MBAVO_SPECULATE"); e.persist_levels = num("MBAVO_PERSIST_LEVELS"); e.kf_multi = num("MBAVO_KF_MULTI"); e.kf_speculate = num("MBAVO_KF_SPECULATE"); e.ride_along = num("MBAVO_RIDE_ALONG");
+        e.speculate = num("MBAVO_SPECULATE"); e.persist_levels = num("MBAVO_PERSIST_LEVELS"); e.kf_multi = num("MBAVO_KF_MULTI"); e.kf_speculate = num("MBAVO_KF_SPECULATE"); e.ride_along = num("MBAVO_RIDE_ALONG"); e.resum = num("MBAVO_RESUM");
         e.lm_eig = num("MBAVO_LM_EIG"); e.lm_poses = num("MBAVO_LM_POSES"); e.lm_defer = num("MBAVO_LM_DEFER");
         e.lm_retile = num("MBAVO_LM_RETILE"); e.lm_groups = num("MBAVO_LM_GROUPS");
         e.fast_solve = real("MBAVO_FAST_SOLVE"); e.lm_refine = real("MBAVO_LM_REFINE");

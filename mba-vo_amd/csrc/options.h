@@ -18,7 +18,7 @@ namespace mbavo
     struct EnvOverrides
     { // kEnvUnset / a negative ratio sentinel (-2) = the variable is not set
         int sp, one, fused_pose, fused_pose_max_s, persist, prelaunch, tiles_per_cu, min_tile_px, sp_max_slot_tiles; // engine
-        int speculate, persist_levels, kf_multi, kf_speculate, ride_along;                                                                    // host LM loop, front end
+        int speculate, persist_levels, kf_multi, kf_speculate, ride_along, resum;                                                                   // host LM loop, front end
         int lm_eig, lm_poses, lm_defer, lm_retile, lm_groups;                                                       // batched LM
         double fast_solve, lm_refine; // the variable's number; -2: unset
     };

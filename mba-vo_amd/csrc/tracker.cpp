@@ -267,6 +267,12 @@ namespace mbavo
         int ride_level = -1;                 // the level (li) the last ride-along evaluated, or -1
         unsigned long long ride_seq = 0;     // ... and the sequence number of its command
         long ride_hits = 0, ride_posts = 0;
+        // THE ACCEPTED STEP'S EVALUATION AS A RE-SUMMATION (round 5; mbavo_track_opts.resum, default on, persistent kernels).  Two of
+        // three accepted steps flag new outliers, so the candidate's H / g (speculation above) are not the accepted point's -- but
+        // they differ from it only in which patches' rows count and in the residual scale: the kernel's workgroups still hold the
+        // candidate's per-patch sums and add them up again under the new flags (Engine::persistent_post_resum) -- the evaluation's
+        // result bit for bit, without pose entries, taps and Jacobians.
+        const bool resum = opt_flag(o.resum, env.resum, true);
 
         for (int li = 0; li < o.num_levels; ++li)
         {
@@ -349,6 +355,19 @@ namespace mbavo
                 PhaseScope ps(PhaseTimers::kMerge);
 
                 merge_blocks_host(F, k, lvl_pin, start_idx.data(), N, cost, with_h ? Hout : nullptr, with_h ? gout : nullptr);
+                return 0;
+            };
+            // the candidate's evaluation (this level's last command, with H / g) summed again under the flags and the scale as they are now
+            auto evaluate_again = [&](double *cost) -> int {
+                int r = joint ? eng.persistent_post_resum(0, li) : eng.persistent_post_resum(li);
+                if (r) return r;
+                {
+                    PhaseScope ps(PhaseTimers::kWait);
+                    r = eng.persistent_wait();
+                }
+                if (r) return r;
+                PhaseScope ps(PhaseTimers::kMerge);
+                merge_blocks_host(F, k, lvl_pin, start_idx.data(), N, cost, H.data(), g.data());
                 return 0;
             };
             auto record = [&](int iter, int kind, double cc, double model, double q) {
@@ -437,6 +456,10 @@ namespace mbavo
                         H.swap(Hs);
                         g.swap(gs);
                         eval_cost = cand_cost;
+                    }
+                    else if (speculate && resum && persistent && (joint ? eng.persistent_resum_ok(0, li) : eng.persistent_resum_ok(li)))
+                    {
+                        if ((rc_ = evaluate_again(&eval_cost))) goto done;
                     }
                     else if ((rc_ = evaluate(spline.get_knot_data_t(), spline.get_knot_data_R(), true, &eval_cost))) goto done;
                     lm.step_accepted(quality);

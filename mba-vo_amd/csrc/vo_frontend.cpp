@@ -442,7 +442,7 @@ namespace SLAM
             o.huber_k = mOptions.huber_k; o.min_step_quality = mOptions.min_step_quality;
             o.min_abs_cost_decrease = mOptions.min_abs_cost_decrease; o.max_chi_square_error = mOptions.max_chi_square_error;
             o.fast_solve_ratio = mOptions.fast_solve_ratio; o.speculate = mOptions.speculate; o.persist_levels = mOptions.persist_levels;
-            o.ride_along = mOptions.ride_along;
+            o.ride_along = mOptions.ride_along; o.resum = mOptions.resum;
             const int n = mbavo::optimize_trajectory(mEngine, o, lv, 1, &mCurCap, &mCurExp, mSpline.getStartTime(),
                                                      mSpline.getSamplingFreq(), mSpline.get_knot_data_t(), mSpline.get_knot_data_R(),
                                                      (int)mSpline.get_num_knots(), start_idx, &mEvaluationPointCost, mTrace, kTraceCap);

@@ -97,7 +97,7 @@ namespace SLAM
             int grid_selection_cell_H = 30, grid_selection_cell_W = 30;
             // scheduling / solver form (include/mbavo.h: the ABI 3 tail of mbavo_vo_options; zero = default)
             double fast_solve_ratio = 0.0;
-            int speculate = 0, persist_levels = 0, keyframe_levels_at_once = 0, speculate_keyframe = 0, ride_along = 0;
+            int speculate = 0, persist_levels = 0, keyframe_levels_at_once = 0, speculate_keyframe = 0, ride_along = 0, resum = 0;
         };
 
         struct FrameView

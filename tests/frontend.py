@@ -101,7 +101,7 @@ def fill_gpu_opts(capi, seq, cfg):
     o.keyframe_max_flow_mag0, o.keyframe_max_flow_mag1 = cfg["flow0"], cfg["flow1"]
     o.keyframe_max_flow_mag2, o.keyframe_max_blur_kernel_mag = cfg["flow2"], cfg["kernel"]
     o.score_threshold, o.grid_selection_cell_H, o.grid_selection_cell_W = cfg["thr"], cfg["cell"], cfg["cell"]
-    for name in ("fast_solve_ratio", "speculate", "persist_levels", "keyframe_levels_at_once", "speculate_keyframe", "ride_along"):  # ABI 3 tail (zero = default)
+    for name in ("fast_solve_ratio", "speculate", "persist_levels", "keyframe_levels_at_once", "speculate_keyframe", "ride_along", "resum"):  # ABI 3 tail (zero = default)
         if name in cfg:
             setattr(o, name, cfg[name])
     return o, pats

@@ -122,3 +122,23 @@ def test_next_level_first_evaluation_rides_along(orc, mbavo, gpu_ctx, kw):
     assert np.array_equal(on["kt"], off["kt"]) and np.array_equal(on["kR"], off["kR"]) and on["cost"] == off["cost"]
     want = tracking.run_oracle_tracker(orc, sc, dict(tracking.OPTS))
     assert [t[:4] for t in on["trace"]] == [t[:4] for t in want["trace"]]
+
+
+@pytest.mark.parametrize("kw", [dict(H=120, W=160, levels=3, S=8, k=2, seed=2), dict(H=480, W=640, levels=4, S=8, k=2, seed=5),
+                                dict(H=480, W=640, levels=4, S=8, k=4, F=2, seed=7), dict(H=480, W=640, levels=4, S=8, k=4, seed=11)])
+def test_accepted_step_is_summed_again(orc, mbavo, gpu_ctx, kw):
+    """mbavo_track_opts.resum (default on): an accepted step whose outlier detection flagged new patches does not evaluate its
+    point again (blur_aware_direct_tracker.cpp:896-903 at the candidate's knots) -- the persistent kernel's workgroups add the
+    candidate's per-patch sums up again under the new flags and the new residual scale.  Same leaves, same order of additions:
+    against the loop with it switched off the trace records (costs included), the knots and the final cost are equal to the
+    last bit; the steps that flag something exist in these scenes (outlier counts grow along the trace); and the oracle's trace."""
+    import tracking
+    sc = tracking.make_tracking_scene(orc, **kw)
+    on = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, dict(tracking.OPTS))
+    off = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, dict(tracking.OPTS, resum=-1))
+    assert on["trace"] == off["trace"] and len(on["trace"]) > 2 * kw["levels"]
+    assert np.array_equal(on["kt"], off["kt"]) and np.array_equal(on["kR"], off["kR"]) and on["cost"] == off["cost"]
+    grew = sum(1 for a, b in zip(on["trace"], on["trace"][1:]) if b[2] == 1 and a[0] == b[0] and b[3] > a[3])
+    assert grew >= 1, "no accepted step of this scene flags a new outlier: the test exercises nothing"
+    want = tracking.run_oracle_tracker(orc, sc, dict(tracking.OPTS))
+    assert [t[:4] for t in on["trace"]] == [t[:4] for t in want["trace"]]

@@ -114,7 +114,7 @@ def run_gpu_tracker(mbavo, ctx, sc, opts=OPTS, trace_cap=1024):
         o.intrinsics[i] = float(sc["intr"][i])
     o.huber_k, o.min_step_quality = opts["huber_k"], opts["min_step_quality"]
     o.min_abs_cost_decrease, o.max_chi_square_error = opts["min_abs_cost_decrease"], opts["max_chi_square_error"]
-    for name in ("fast_solve_ratio", "speculate", "persist_levels", "ride_along"):  # ABI 3 tail of mbavo_track_opts (zero = default)
+    for name in ("fast_solve_ratio", "speculate", "persist_levels", "ride_along", "resum"):  # ABI 3 tail of mbavo_track_opts (zero = default)
         if name in opts:
             setattr(o, name, opts[name])
     kt, kR = sc["kt0"].ravel().copy(), sc["kR0"].ravel().copy()
