@@ -296,6 +296,7 @@ namespace mbavo
         int push_probe_ = 0;                           // 0 = not probed, 1 = the CPU can store into device memory (large BAR), -1 = it cannot
         unsigned persist_mask_ = 0;                    // slots with a persistent kernel enqueued and not ended
         unsigned long long pending_seq_ = 0;           // sequence number of the evaluation posted last
+        int pending_mode_ = 0;                         // ... and its mode (1 cost-only, 2 H / g, 3 summed again): the timing aid's key
         int persist_gen_ = 0;
         int persist_gen_of_[kPushSlots] = {};          // generation of the kernel enqueued on each slot
         unsigned persist_resum_[kPushSlots] = {};      // per slot: the problems of its kernel's list that can be summed again (persistent_resum_ok)

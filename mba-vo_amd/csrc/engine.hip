@@ -993,6 +993,11 @@ namespace mbavo
             if (to_host && (oa.nbf == 1 || atomicAdd(oa.slots_done, 1) == oa.nbf - 1))
             {
                 if (oa.nbf > 1) __hip_atomic_store(oa.slots_done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(MBAVO_PERSIST_STAMPS) // the summing workgroup's own times beside the completion word (persistent_wait prints their means)
+                oa.host_flag[2] = oa.t_seen; oa.host_flag[3] = stamp_area()[0]; oa.host_flag[4] = stamp_area()[1];
+                oa.host_flag[5] = stamp_area()[2]; oa.host_flag[1] = __builtin_amdgcn_s_memrealtime();
+                __threadfence_system();
+#endif
                 __hip_atomic_store(oa.host_flag, oa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (ordered by the fence above)
             }
         }
@@ -1325,6 +1330,7 @@ namespace mbavo
         const int tile_id = xcd_tile_of_block((int)blockIdx.x, (int)gridDim.x);
         const TileDesc tile = tiles[tile_id];
         const ProblemDesc &d = descs[tile.prob];
+        MBAVO_STAMP(0);
         const double inv = residual_scale<true>(d, lane);
         const bool has = wave < tile.kp_count; // (P == PXW: wave w holds patch kp_begin + w)
         const int kp = tile.kp_begin + wave;
@@ -2215,6 +2221,7 @@ namespace mbavo
         cmd->word = persist_word(seq, persist_gen_of_[slot], with_hessian ? 2 : 1, prob, prob2 < 0 ? 15 : prob2);
         host_store_fence(); // ... before the command word, which leaves the write-combining buffer now
         pending_seq_ = seq;
+        pending_mode_ = with_hessian ? 2 : 1;
         return 0;
     }
     int Engine::persistent_post_resum(int slot, int prob)
@@ -2226,6 +2233,7 @@ namespace mbavo
         cmd->word = persist_word(seq, persist_gen_of_[slot], 3, prob);
         host_store_fence();
         pending_seq_ = seq;
+        pending_mode_ = 3;
         return 0;
     }
     int Engine::persistent_wait()
@@ -2241,13 +2249,14 @@ namespace mbavo
                 __atomic_thread_fence(__ATOMIC_ACQUIRE);
 #if defined(MBAVO_PERSIST_STAMPS)
                 {
-                    static double sum = 0, host = 0; static long cnt = 0;
-                    static double ph[3] = {0, 0, 0};
-                    sum += (double)(f[1] - f[2]) * 0.01; host += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6;
-                    ph[0] += (double)(f[3] - f[2]) * 0.01; ph[1] += (double)(f[4] - f[3]) * 0.01; ph[2] += (double)(f[5] - f[4]) * 0.01;
-                    if (++cnt % 50 == 0)
-                        fprintf(stderr, "persist: kernel-side %.2f us (pose prologue %.2f, tile %.2f, partial + ticket wait %.2f, final %.2f), host round trip %.2f us (mean of %ld)\n",
-                                sum / cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, (sum - ph[0] - ph[1] - ph[2]) / cnt, host / cnt, cnt);
+                    // (per command mode; the summing workgroup's own stamps; a re-summation has no prologue: its stamp 0 is its start)
+                    static double sum[4] = {}, host[4] = {}, ph[4][3] = {}; static long cnt[4] = {};
+                    const int m = pending_mode_ & 3;
+                    sum[m] += (double)(f[1] - f[2]) * 0.01; host[m] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6;
+                    ph[m][0] += (double)(f[3] - f[2]) * 0.01; ph[m][1] += (double)(f[4] - f[3]) * 0.01; ph[m][2] += (double)(f[5] - f[4]) * 0.01;
+                    if (++cnt[m] % 50 == 0)
+                        fprintf(stderr, "persist: mode %d kernel-side %.2f us (pose prologue %.2f, tile %.2f, partial + ticket wait %.2f, final %.2f), host round trip %.2f us (mean of %ld)\n",
+                                m, sum[m] / cnt[m], ph[m][0] / cnt[m], ph[m][1] / cnt[m], ph[m][2] / cnt[m], (sum[m] - ph[m][0] - ph[m][1] - ph[m][2]) / cnt[m], host[m] / cnt[m], cnt[m]);
                 }
 #endif
                 return 0;
