@@ -903,6 +903,9 @@ namespace mbavo
     // ... in order, then the lanes are added in order (for slots of up to four tiles and LANES = 2 that is
     // (t0 + t2) + (t1 + t3), the order of k_finalize_flat) -- and writes the frame block.  `scratch`: LANES * EPAD
     // doubles of LDS nobody else is using any more.
+#ifndef MBAVO_FIN_INFLIGHT
+#define MBAVO_FIN_INFLIGHT 16
+#endif
     template <int KD, bool WITH_J, int NTHREADS>
     __device__ __forceinline__ bool ticket_finalize(const ProblemDesc &d, int bf, const double *__restrict__ partials,
                                                     const OneArgs &oa, double *scratch, double inv)
@@ -951,6 +954,20 @@ namespace mbavo
         if (mine)
         {
             const double *pp = partials;
+#if MBAVO_FIN_INFLIGHT > 4
+            // every partial of this tile-lane in flight at once (predicated loads), added in tile order: each load is a miss to
+            // another XCD's L2 or to memory, and a lane of a semi-dense level has 3 .. 16 of them -- as batches of four plus a
+            // serial remainder they were up to six latencies in a row
+            for (int t = t0 + l; t < t1; t += MBAVO_FIN_INFLIGHT * LANES)
+            {
+                double v[MBAVO_FIN_INFLIGHT];
+#pragma unroll
+                for (int u = 0; u < MBAVO_FIN_INFLIGHT; ++u) v[u] = t + u * LANES < t1 ? ld_part(pp + (size_t)(t + u * LANES) * PS + e) : 0.0;
+#pragma unroll
+                for (int u = 0; u < MBAVO_FIN_INFLIGHT; ++u)
+                    if (t + u * LANES < t1) acc += v[u];
+            }
+#else
             int t = t0 + l;
             for (; t + 3 * LANES < t1; t += 4 * LANES)
             { // four loads in flight, added in tile order
@@ -959,6 +976,7 @@ namespace mbavo
                 acc += a; acc += b; acc += c; acc += dd;
             }
             for (; t < t1; t += LANES) acc += ld_part(pp + (size_t)t * PS + e);
+#endif
         }
         if (LANES > 1)
         {
