@@ -858,7 +858,7 @@ namespace mbavo
 #if defined(MBAVO_PERSIST_STAMPS)
     __device__ __forceinline__ unsigned long long *stamp_area()
     {
-        __shared__ unsigned long long st[4];
+        __shared__ unsigned long long st[24];
         return st;
     }
 #define MBAVO_STAMP(i) do { if (threadIdx.x == 0) stamp_area()[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -1014,6 +1014,8 @@ namespace mbavo
 #if defined(MBAVO_PERSIST_STAMPS) // the summing workgroup's own times beside the completion word (persistent_wait prints their means)
                 oa.host_flag[2] = oa.t_seen; oa.host_flag[3] = stamp_area()[0]; oa.host_flag[4] = stamp_area()[1];
                 oa.host_flag[5] = stamp_area()[2]; oa.host_flag[1] = __builtin_amdgcn_s_memrealtime();
+                for (int i = 4; i < 8; ++i) oa.host_flag[5 + i] = stamp_area()[i]; // (tile sub-stamps: words 9 .. 12)
+                for (int i = 0; i < 8; ++i) oa.host_flag[16 + i] = stamp_area()[16 + i]; // (the waves' arrivals at the tile's last barrier)
                 __threadfence_system();
 #endif
                 __hip_atomic_store(oa.host_flag, oa.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (ordered by the fence above)
@@ -1180,6 +1182,7 @@ namespace mbavo
                         one_sample(ftab[sidx]);
                 }
             }
+            MBAVO_STAMP(4); // (thread 0's sample done: keypoint, centre, taps, Jacobian terms)
             // the pixel is valid iff all its samples are (A9); intensities summed in sample order
             const bool valid = in && (__ballot(ok_l) & gmask) == gmask;
             double isum = 0.0;
@@ -1187,6 +1190,7 @@ namespace mbavo
             for (int j = 0; j < SS; ++j) isum += __shfl(val, lane0 + j, 64);
             if (valid) res = quotient(isum, fS) - cur;
             huber_weight(res, d.huber_a, w, rho);
+            MBAVO_STAMP(5);
             if (wave_patches)
             { // b[i] += b[i + s], s = P/2 .. 1 (reduction.h:43-54): pixel pw + s sits SS * s lanes up
                 double x = rho;
@@ -1257,6 +1261,7 @@ namespace mbavo
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
+            MBAVO_STAMP(6);
         }
 
         // per-patch cost = slot 0 of the reference's patch block (:232-238), and the
@@ -1285,6 +1290,10 @@ namespace mbavo
         // every wave parks its accumulators in its slab; entry e = (i, j) of the packed block is then the sum
         // over waves (and pixel groups) in a fixed order.  One barrier for the scratch and the slabs.
         if (WITH_J) acc.store(slab, lane);
+#if defined(MBAVO_PERSIST_STAMPS)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (lane == 0) stamp_area()[16 + wave] = __builtin_amdgcn_s_memrealtime(); // (each wave's arrival at the tile's last barrier)
+#endif
         return sp_tile_finish<KD, WITH_J, LOGS, ONE, PERSIST>(lds, d, tile_id, frame, partials, oa, inv);
     }
 
@@ -1298,6 +1307,7 @@ namespace mbavo
         constexpr int kWavesPerGroup = kSpWaves, kThreads = kWavesPerGroup * 64, SS = 1 << LOGS;
         double *rows = lds, *red = lds + (WITH_J ? kWavesPerGroup * OuterAcc<ND>::SLAB : 0), *stage = red + 4 * kSpWaves;
         __syncthreads();
+        MBAVO_STAMP(7);
         double *out = partials + (size_t)tile_id * PS;
         auto put = [&](int e, double v) { out[e] = v; };
         if (threadIdx.x == 0)
@@ -2080,7 +2090,7 @@ namespace mbavo
             oa.nbf = total_bf_;
             if (signal_host && !d_active && ntiles > 0)
             { // completion word in pinned host memory: the caller spins on it instead of synchronising the stream
-                if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 128, hipHostMallocDefault) != hipSuccess) h_flag_ = nullptr;
+                if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 256, hipHostMallocDefault) != hipSuccess) h_flag_ = nullptr;
                 if (h_flag_)
                 {
                     oa.host_flag = (unsigned long long *)h_flag_;
@@ -2178,7 +2188,7 @@ namespace mbavo
         if (sp_logs_ <= 0 || !sp_one_fits(kdeg, sp_logs_) || ntiles < 1 || ntiles > num_cus_ || h_descs_[0].grad_fp16 || p.N > 16 || empty_slots_) return 1;
         for (int b = 1; b < B; ++b) // (one knot buffer for all the problems of a persistent kernel)
             if (probs[b].N != p.N || probs[b].d_knots_t != p.d_knots_t || probs[b].d_knots_R != p.d_knots_R) return 1;
-        if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 128, hipHostMallocDefault) != hipSuccess) { h_flag_ = nullptr; return (int)hipErrorOutOfMemory; }
+        if (!h_flag_ && hipHostMalloc((void **)&h_flag_, 256, hipHostMallocDefault) != hipSuccess) { h_flag_ = nullptr; return (int)hipErrorOutOfMemory; }
         volatile PersistCmd *cmd = (volatile PersistCmd *)((char *)d_push_ + (size_t)slot * push_stride_);
         cmd->word = persist_word(flag_seq_, ++persist_gen_, 0);
         host_store_fence();
@@ -2272,6 +2282,16 @@ namespace mbavo
                     const int m = pending_mode_ & 3;
                     sum[m] += (double)(f[1] - f[2]) * 0.01; host[m] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() * 1e6;
                     ph[m][0] += (double)(f[3] - f[2]) * 0.01; ph[m][1] += (double)(f[4] - f[3]) * 0.01; ph[m][2] += (double)(f[5] - f[4]) * 0.01;
+                    static double sub[4][4] = {};
+                    if (m == 2) { sub[m][0] += (double)(long long)(f[9] - f[3]) * 0.01; sub[m][1] += (double)(long long)(f[10] - f[9]) * 0.01; sub[m][2] += (double)(long long)(f[11] - f[10]) * 0.01; sub[m][3] += (double)(long long)(f[12] - f[11]) * 0.01; }
+                    static double arr[8] = {};
+                    if (m == 2) for (int i = 0; i < 8; ++i) arr[i] += (double)(long long)(f[16 + i] - f[3]) * 0.01;
+                    if (m == 2 && (cnt[m] + 1) % 50 == 0)
+                        fprintf(stderr, "persist: waves at the last barrier, us after the prologue: %.2f %.2f %.2f %.2f %.2f %.2f %.2f %.2f\n", arr[0] / (cnt[m] + 1), arr[1] / (cnt[m] + 1),
+                                arr[2] / (cnt[m] + 1), arr[3] / (cnt[m] + 1), arr[4] / (cnt[m] + 1), arr[5] / (cnt[m] + 1), arr[6] / (cnt[m] + 1), arr[7] / (cnt[m] + 1));
+                    if (m == 2 && (cnt[m] + 1) % 50 == 0)
+                        fprintf(stderr, "persist: tile of mode 2: sample done %.2f | intensity sum + weight %.2f | rows parked, summed, outer product %.2f | accumulators parked + barrier %.2f us\n",
+                                sub[m][0] / (cnt[m] + 1), sub[m][1] / (cnt[m] + 1), sub[m][2] / (cnt[m] + 1), sub[m][3] / (cnt[m] + 1));
                     if (++cnt[m] % 50 == 0)
                         fprintf(stderr, "persist: mode %d kernel-side %.2f us (pose prologue %.2f, tile %.2f, partial + ticket wait %.2f, final %.2f), host round trip %.2f us (mean of %ld)\n",
                                 m, sum[m] / cnt[m], ph[m][0] / cnt[m], ph[m][1] / cnt[m], ph[m][2] / cnt[m], (sum[m] - ph[m][0] - ph[m][1] - ph[m][2]) / cnt[m], host[m] / cnt[m], cnt[m]);
