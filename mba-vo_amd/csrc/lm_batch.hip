@@ -677,8 +677,13 @@ namespace mbavo
             }
             // defer_finalize = -1: the engine's finalize kernels write frame blocks and the LM kernels read those
             eng.set_defer_finalize(opt_flag(opt.defer_finalize, env.lm_defer, true));
+            const auto t_sub0 = std::chrono::steady_clock::now();
             // iteration 0 (:604): also builds the layout (device descriptors) the LM kernels read
             if ((rc = eng.evaluate(B, work.data(), k, true, fb, pc, nullptr, nullptr, act, inv)) != 0) goto done;
+            const auto t_sub1 = std::chrono::steady_clock::now();
+            if (stamps)
+                fprintf(stderr, "mbavo lm_batch:   first evaluation: %.1f us before the call (trace memset, words), %.1f us inside Engine::evaluate\n",
+                        std::chrono::duration<double, std::micro>(t_sub0 - tp[2]).count(), std::chrono::duration<double, std::micro>(t_sub1 - t_sub0).count());
             const ProblemDesc *descs = eng.device_descs();
             FinSrc fs;
             fs.fb = fb; fs.partials = eng.device_partials(); fs.tile_begin = eng.device_bf_tile_begin();
