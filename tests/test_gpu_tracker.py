@@ -142,3 +142,40 @@ def test_accepted_step_is_summed_again(orc, mbavo, gpu_ctx, kw):
     assert grew >= 1, "no accepted step of this scene flags a new outlier: the test exercises nothing"
     want = tracking.run_oracle_tracker(orc, sc, dict(tracking.OPTS))
     assert [t[:4] for t in on["trace"]] == [t[:4] for t in want["trace"]]
+
+
+def test_two_trackers_at_once(orc, mbavo, gpu_ctx):
+    """Two contexts (two engines, two streams, two push blocks, two pinned completion areas) driven from two host threads at the same
+    time: each LM loop's persistent kernels, commands and re-summations must stay its own.  Every run returns what the same scene
+    returns alone, bit for bit (records with costs, knots, final cost)."""
+    import threading
+    import torch
+    import tracking
+    scs = [tracking.make_tracking_scene(orc, H=240, W=320, levels=3, S=8, k=2, seed=21),
+           tracking.make_tracking_scene(orc, H=120, W=160, levels=3, S=8, k=4, F=2, seed=22)]
+    alone = [tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, dict(tracking.OPTS)) for sc in scs]
+    streams = [torch.cuda.Stream() for _ in scs]
+    ctxs = [mbavo.capi.Context(0, stream=s.cuda_stream) for s in streams]
+    out, err = [[] for _ in scs], []
+
+    def work(i):
+        try:
+            for _ in range(4):
+                out[i].append(tracking.run_gpu_tracker(mbavo, ctxs[i], scs[i], dict(tracking.OPTS)))
+        except BaseException as e:  # noqa: BLE001 (reported below, in the test's thread)
+            err.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(scs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a tracker did not return"
+    assert not err, err
+    for i, want in enumerate(alone):
+        assert len(out[i]) == 4
+        for got in out[i]:
+            assert got["trace"] == want["trace"] and got["cost"] == want["cost"]
+            assert np.array_equal(got["kt"], want["kt"]) and np.array_equal(got["kR"], want["kR"])
+    for c in ctxs:
+        c.close()
