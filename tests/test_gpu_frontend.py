@@ -236,7 +236,7 @@ def test_keyframe_preprocessing_ahead_of_the_decision_changes_nothing(orc, mbavo
     cfg = dict(sequence.REFERENCE_CFG)
     on = frontend.run_gpu_vo(mbavo, gpu_ctx, seq, cfg)
     off = frontend.run_gpu_vo(mbavo, gpu_ctx, seq, dict(cfg, speculate_keyframe=-1))
-    plain = frontend.run_gpu_vo(mbavo, gpu_ctx, seq, dict(cfg, speculate_keyframe=-1, ride_along=-1))  # (and without the ride-along evaluations)
+    plain = frontend.run_gpu_vo(mbavo, gpu_ctx, seq, dict(cfg, speculate_keyframe=-1, ride_along=-1, resum=-1))  # (and without the ride-along evaluations and the re-summations)
     assert sum(f["is_keyframe"] for f in on) >= 8
     for a, b, c in zip(on, off, plain):
         assert np.array_equal(a["T"], b["T"]) and a["is_keyframe"] == b["is_keyframe"] and a["K"] == b["K"] and a["trace"] == b["trace"]
@@ -247,3 +247,39 @@ def test_keyframe_preprocessing_ahead_of_the_decision_changes_nothing(orc, mbavo
     tf = frontend.run_gpu_vo(mbavo, gpu_ctx, seq, cfg, teacher=want)
     for a, b in zip(tf, want):
         assert a["is_keyframe"] == b["is_keyframe"] and a["K"] == b["K"] and np.abs(a["T"] - b["T"]).max() < 1e-6
+
+
+def test_two_front_ends_at_once(orc, mbavo, gpu_ctx):
+    """Two BlurAwareDirectTrackers on two contexts, fed from two host threads at the same time (each with its persistent LM kernels,
+    its spare keyframe set and stream): every frame's pose, decision, keypoint count and LM records equal what the same sequence gives
+    alone, bit for bit."""
+    import threading
+    import torch
+    from mba_vo_amd import sequence
+    cfg = dict(sequence.REFERENCE_CFG)
+    seqs = [sequence.make_sequence(gpu_ctx, H=480, W=640, M=10, trajectory="loop"), sequence.make_sequence(gpu_ctx, H=240, W=320, M=10, seed=5)]
+    alone = [frontend.run_gpu_vo(mbavo, gpu_ctx, sq, cfg) for sq in seqs]
+    streams = [torch.cuda.Stream() for _ in seqs]
+    ctxs = [mbavo.capi.Context(0, stream=s.cuda_stream) for s in streams]
+    out, err = [None] * len(seqs), []
+
+    def work(i):
+        try:
+            for _ in range(2):
+                out[i] = frontend.run_gpu_vo(mbavo, ctxs[i], seqs[i], cfg)
+        except BaseException as e:  # noqa: BLE001 (reported below, in the test's thread)
+            err.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(seqs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in threads), "a tracker did not return"
+    assert not err, err
+    for got, want in zip(out, alone):
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert np.array_equal(a["T"], b["T"]) and a["is_keyframe"] == b["is_keyframe"] and a["K"] == b["K"] and a["trace"] == b["trace"]
+    for c in ctxs:
+        c.close()
