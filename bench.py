@@ -22,6 +22,10 @@ torch.distributed (backend nccl == RCCL) is the rendezvous, the barrier and the 
 timed region the reduced normal equations are compared with a single-GPU evaluation of the whole workload (rank 0;
 1e-12; pairs: bit-exact).  value = pixel-samples of all ranks / max-over-ranks time.  At N > 1 the line also carries, per
 rank, the dominant kernel's duration and the all-reduce's, and under "configs" the 512-pair batch in both shardings.
+The step's collective at N > 1 is SELECTED between the product's two: the RCCL run above, then -- after a canary child process per
+rank has set the one-shot p2p collectives up and checked them, so that a platform fault costs a child, not the line -- the same
+step through mbavo_all*_blocks_p2p by the same timing procedure; verified (reduction check) and faster, it is the line's step
+(`comm`, config.parallelism and comm_profile_p2p.selected_as_the_step say so; the other run's figures are in comm_profile_rccl).
 
 The timed region (exactly K steps between barrier + synchronize) is repeated until >= 0.3 s have been timed and the
 MEDIAN region is reported, so that K = 20 does not rest on 1 ms of GPU work.  At N = 1 every other BASELINE config is
@@ -90,6 +94,9 @@ def parse():
     ap.add_argument("--no-spin-sync", action="store_true", help="synchronize without polling the stream first (A/B of the bracket's own cost)")
     ap.add_argument("--max-repeats", type=int, default=200)
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="budget of EACH bounded CPU baseline sample (1 and T threads)")
+    ap.add_argument("--p2p-canary", action="store_true",
+                    help="(internal) child process of an N > 1 run: sets the one-shot p2p collectives up between the ranks' GPUs and checks an "
+                         "all-reduce and an all-gather, so that a platform that faults on peer-mapped memory costs a child, not the bench line")
     return ap.parse_args()
 
 
@@ -520,8 +527,63 @@ def trackframe_long_horizon(ctx, frames=120):
                     "Teacher-forced, every frame is a one-step comparison from identical inputs."}
 
 
+def p2p_canary_child():
+    """The one-shot p2p collectives between this run's ranks, in a process of their own (gloo carries the handles): exit code 0 iff
+    set-up, 20 all-reduces and 20 all-gathers ran and returned the right numbers on this rank."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MBAVO_CANARY_SHARED") == "1":
+        local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    import mba_vo_amd as M
+    from mba_vo_amd import shard
+    dev = "cuda:%d" % local_rank
+    ctx = M.capi.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    c = shard.P2PCollective(ctx, rank, world, max_doubles=1 << 12)
+    n, m = 2437, 501
+    ramp = torch.arange(n, dtype=torch.float64, device=dev) * 1e-3
+    want = torch.zeros(n, dtype=torch.float64, device=dev)
+    for r in range(world):
+        want += (r + 1.0) + ramp
+    ok = True
+    for it in range(20):
+        x = (rank + 1.0) + ramp
+        c.allreduce(x, x, n)
+        buf = torch.zeros(world * m, dtype=torch.float64, device=dev)
+        buf[rank * m:(rank + 1) * m] = rank + 1.0 + it
+        c.allgather(buf, m)
+        torch.cuda.synchronize()
+        ok = ok and bool(torch.allclose(x, want, rtol=1e-14, atol=0.0))
+        ok = ok and all(bool((buf[r * m:(r + 1) * m] == r + 1.0 + it).all()) for r in range(world))
+    c.close()
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 3
+
+
+def run_p2p_canary(shared_gpu):
+    """this rank's canary child (p2p_canary_child): True iff it exited with 0 within its time"""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29511")) + 37)  # a rendezvous of its own, beside the parent's
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)                        # (rank 0 of the children hosts that store itself)
+    if shared_gpu:
+        env["MBAVO_CANARY_SHARED"] = "1"
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--p2p-canary"], env=env, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.PIPE, timeout=240)
+    except subprocess.TimeoutExpired:
+        return False, "timeout"
+    return p.returncode == 0, "rc %d%s" % (p.returncode, (": " + p.stderr.decode(errors="replace").strip().splitlines()[-1][:200]) if p.returncode and p.stderr.strip() else "")
+
+
 def main():
     args = parse()
+    if args.p2p_canary:
+        raise SystemExit(p2p_canary_child())
     # The one JSON line goes to the REAL stdout; everything else written to file descriptor 1 by this process or by the
     # libraries it loads goes to stderr.  RCCL prints a version banner to C stdout when the first communicator is
     # created, block-buffered when stdout is a pipe and flushed only at exit -- i.e. AFTER the JSON line.
@@ -652,26 +714,30 @@ def main():
     # key of the committed counter extracts: the workload plus the variant of the evaluation
     wkey = args.workload + ("_k2" if args.spline_k == 2 else "") + ("_cost_only" if args.cost_only else "")
 
-    for _ in range(args.warmup):
-        run.step()
-    sync()
-    ctx.lib.mbavo_profile(ctx.handle, args.time_every)  # HIP-event pair on the dominant kernel's dispatch, every n-th step
-    regions, total = [], 0.0
-    while not regions or (total < args.min_seconds and len(regions) < args.max_repeats):
+    def time_regions(r):
+        """W warm-up steps, then the K-step region between barrier + synchronize, repeated until min_seconds were timed:
+        (regions, their median, the dominant kernel's mean duration, its timed launches)"""
+        for _ in range(args.warmup):
+            r.step()
         sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run.step()
-        sync()
-        dt = max_over_ranks(time.perf_counter() - t0)  # the same number on every rank: all ranks repeat equally often
-        regions.append(dt)
-        total += dt
-    fused_ms, nlaunch = np.zeros(1), np.zeros(1, np.int32)
-    M.capi.check(ctx.lib.mbavo_profile_read(ctx.handle, M.capi.dp(fused_ms), M.capi.ip(nlaunch)), "mbavo_profile_read")
-    ctx.lib.mbavo_profile(ctx.handle, 0)
-    elapsed = statistics.median(regions)
+        ctx.lib.mbavo_profile(ctx.handle, args.time_every)  # HIP-event pair on the dominant kernel's dispatch, every n-th step
+        regs, total = [], 0.0
+        while not regs or (total < args.min_seconds and len(regs) < args.max_repeats):
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                r.step()
+            sync()
+            dt = max_over_ranks(time.perf_counter() - t0)  # the same number on every rank: all ranks repeat equally often
+            regs.append(dt)
+            total += dt
+        ms, nl = np.zeros(1), np.zeros(1, np.int32)
+        M.capi.check(ctx.lib.mbavo_profile_read(ctx.handle, M.capi.dp(ms), M.capi.ip(nl)), "mbavo_profile_read")
+        ctx.lib.mbavo_profile(ctx.handle, 0)
+        return regs, statistics.median(regs), float(ms[0]) / max(int(nl[0]), 1), nl
+
+    regions, elapsed, k_ms, nlaunch = time_regions(run)
     kernel = kernel_name(ctx)
-    k_ms = float(fused_ms[0]) / max(int(nlaunch[0]), 1)
 
     reduction = reduction_check(run) if run.se is not None else None
     k_ms_ranks = per_rank(k_ms)
@@ -787,30 +853,59 @@ def main():
                                        "local_evaluation_ms / collective_ms: event pairs around the rank's evaluation (+ merge) "
                                        "and around the collective in a separate pass of 40 steps -- the collective's figure "
                                        "includes waiting for the slowest rank"}
-    # Both collectives' timings in the N > 1 line: with RCCL as the step's collective, the SAME sharded
-    # evaluation once more through the one-shot p2p collectives -- per-rank duration of the collective alone and the reduction check
-    if use_dist and not use_p2p and not shared_gpu and world > 1 and os.environ.get("MBAVO_BENCH_P2P", "1") != "0":
+    # Both collectives in the N > 1 line.  With RCCL as the step's collective above, the SAME sharded
+    # evaluation once more through the product's one-shot p2p collectives, timed by the same procedure -- behind a CANARY: the
+    # set-up and a few collectives first run in a child process per rank, so that a platform that faults on peer-mapped memory
+    # costs a child and not this line.  Where the p2p run is verified (reduction check) and faster, IT is the line's step: value,
+    # ms_per_step and the collective named in config.parallelism are its own, RCCL's figures move to comm_profile_rccl.
+    # (--comm gloo, ranks sharing a GPU, runs the same selection with the gloo stand-in in RCCL's place: the mechanics on one GPU.)
+    if use_dist and not use_p2p and world > 1 and os.environ.get("MBAVO_BENCH_P2P", "1") != "0":
         p2p_line = None
-        try:
-            # (P2PCollective raises on EVERY rank if any rank's region cannot be created or mapped: the ranks stay in step)
-            c2 = shard.P2PCollective(ctx, rank, world, max_doubles=max(int(run.se.count), 1 << 12))
-            r2 = Runner(M, ctx, args.workload, dev, rank, world, True, 2 if args.packed_keyframes else int(args.grad_fp16), shard_mode=args.shard,
-                        coll=c2, pair_collective=args.collective, pairs=args.batch_pairs if args.batch_pairs != 512 else None)
-            use_p2p = True  # (collective_name / reduction_check label what they describe)
-            loc2, red2 = comm_profile(r2)
-            chk2 = reduction_check(r2)
-            n2, dt2, _, _ = bounded_run(M, ctx, r2, min_steps=60, sync=sync)
-            dt2 = max_over_ranks(dt2)
-            lr2, rr2 = per_rank(loc2), per_rank(red2)
-            use_p2p = False
-            p2p_line = {"collective": chk2["collective"], "ms_per_step": round(dt2 / n2 * 1e3, 5), "steps": n2,
-                        "per_rank": {"local_evaluation_ms": [round(v, 6) for v in lr2], "collective_ms": [round(v, 6) for v in rr2]},
-                        "reduction_check": chk2}
-            c2.close()
-            del r2
-        except Exception as e:
-            use_p2p = False
-            p2p_line = {"error": repr(e)}
+        ok_mine, why = run_p2p_canary(shared_gpu)
+        canary = per_rank(1.0 if ok_mine else 0.0)
+        if min(canary) < 1.0:
+            p2p_line = {"skipped": "the canary child failed on rank(s) %s (rank %d: %s)" % ([i for i, v in enumerate(canary) if v < 1.0], rank, why)}
+        else:
+            try:
+                # (P2PCollective raises on EVERY rank if any rank's region cannot be created or mapped: the ranks stay in step)
+                c2 = shard.P2PCollective(ctx, rank, world, max_doubles=max(int(run.se.count), 1 << 12))
+                r2 = Runner(M, ctx, args.workload, dev, rank, world, True, 2 if args.packed_keyframes else int(args.grad_fp16), shard_mode=args.shard,
+                            coll=c2, pair_collective=args.collective, pairs=args.batch_pairs if args.batch_pairs != 512 else None,
+                            cost_only=args.cost_only, k=args.spline_k)
+                use_p2p = True  # (collective_name / reduction_check label what they describe)
+                loc2, red2 = comm_profile(r2)
+                chk2 = reduction_check(r2)
+                regions2, elapsed2, k_ms2, nl2 = time_regions(r2)
+                lr2, rr2, kr2 = per_rank(loc2), per_rank(red2), per_rank(k_ms2)
+                par2 = "workload sharded by %s over %d rank(s): evaluation -> %sONE %s of %d doubles per step" \
+                       % (r2.mode, world, "device merge -> " if r2.mode == "frames" else "", collective_name(r2), r2.se.count)
+                use_p2p = False
+                p2p_line = {"collective": chk2["collective"], "ms_per_step": round(elapsed2 / args.steps * 1e3, 5), "steps": args.steps,
+                            "repeats": len(regions2),
+                            "per_rank": {"kernel_ms": [round(v, 6) for v in kr2], "local_evaluation_ms": [round(v, 6) for v in lr2],
+                                         "collective_ms": [round(v, 6) for v in rr2]},
+                            "reduction_check": chk2}
+                faster = bool(chk2["ok"]) and elapsed2 < elapsed  # (elapsed: max over the ranks -> the same decision on every rank)
+                if faster and rank == 0:
+                    out["comm_profile_rccl" if not shared_gpu else "comm_profile_standin"] = {
+                        "collective": out["reduction_check"]["collective"], "ms_per_step": out["ms_per_step"], "value": out["value"],
+                        "per_rank": out["per_rank"], "reduction_check": out["reduction_check"]}
+                    per2 = [r_ / args.steps * 1e3 for r_ in regions2]
+                    out.update({"value": round(ps_all * args.steps / elapsed2 / 1e6, 3), "ms_per_step": round(elapsed2 / args.steps * 1e3, 5),
+                                "repeats": len(regions2), "ms_per_step_min_max": [round(min(per2), 5), round(max(per2), 5)],
+                                "reduction_check": chk2})
+                    out["per_rank"] = dict(out["per_rank"], **p2p_line["per_rank"])
+                    out["config"]["parallelism"] = par2
+                    out["comm"] = "p2p one-shot collectives (selected: verified against the single-GPU evaluation and faster than %s, " \
+                                  "whose run of the same step is in comm_profile_%s)" % (("RCCL", "rccl") if not shared_gpu else ("the gloo stand-in", "standin"))
+                    out["roofline"]["step_frac"] = round(out["roofline"]["algorithmic_flops_per_launch"] / (elapsed2 / args.steps) / 1e12 / FP64_PEAK_TFLOPS, 5) \
+                        if "algorithmic_flops_per_launch" in out["roofline"] else out["roofline"].get("step_frac")
+                p2p_line["selected_as_the_step"] = faster
+                c2.close()
+                del r2
+            except Exception as e:
+                use_p2p = False
+                p2p_line = {"error": repr(e)}
         if rank == 0:
             out["comm_profile_p2p"] = p2p_line
     fb_gpu = None

@@ -44,8 +44,20 @@ def test_bench_two_ranks_on_one_gpu(mbavo):
     port = 29700 + (os.getpid() % 200)
     two = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                  "--master-port", str(port), "bench.py", "--gpus", "2", "--comm", "gloo"] + COMMON, {})
-    assert two["n_gpus"] == 2 and two["comm"].startswith("gloo") and two["scaling"] == "weak" and two["value"] > 0
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["value"] > 0
     assert two["reduction_check"]["ok"] and two["reduction_check"]["sharding"] == "frame_blocks"
+    # the step's collective is SELECTED: the stand-in's run first, then -- behind the canary child -- the same step through the
+    # product's one-shot p2p collectives by the same timing procedure; verified and faster, it becomes the line's step and the
+    # stand-in's figures move aside (on a node: RCCL in the stand-in's place, comm_profile_rccl)
+    p2p = two["comm_profile_p2p"]
+    assert "error" not in p2p and "skipped" not in p2p, p2p
+    assert p2p["reduction_check"]["ok"] and "p2p" in p2p["collective"] and len(p2p["per_rank"]["collective_ms"]) == 2
+    if p2p["selected_as_the_step"]:
+        other = two["comm_profile_standin"]
+        assert two["comm"].startswith("p2p one-shot") and "p2p" in two["reduction_check"]["collective"] and "p2p" in two["config"]["parallelism"]
+        assert two["ms_per_step"] == p2p["ms_per_step"] and two["ms_per_step"] < other["ms_per_step"] and "gloo" in other["collective"]
+    else:
+        assert two["comm"].startswith("gloo") and two["ms_per_step"] <= p2p["ms_per_step"]
     pr = two["per_rank"]
     assert len(pr["kernel_ms"]) == len(pr["local_evaluation_ms"]) == len(pr["collective_ms"]) == 2 and min(pr["kernel_ms"]) > 0
     cfg = two["configs"]
@@ -74,7 +86,7 @@ def test_bench_two_ranks_on_one_gpu(mbavo):
 
     def strip(s):  # per-rank arrays have the world's length; everything else must coincide
         if isinstance(s, dict):
-            return {k: strip(v) for k, v in s.items() if k != "sampled_pairs"}
+            return {k: strip(v) for k, v in s.items() if k not in ("sampled_pairs", "comm_profile_p2p", "comm_profile_standin")}
         if isinstance(s, list) and s and s[0] == "list":
             return ["list"]
         return s
