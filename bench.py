@@ -12,8 +12,10 @@ level a P=1 patch).
 N > 1 (one process per GPU, launched by torch.distributed.run): the workload is sharded over the ranks --
   * c2_dense (default) and the other single-pair workloads: ONE joint problem of N blurred frames against the same
     keyframe on one spline segment, frame r on rank r (weak scaling: the per-GPU work is the N = 1 workload); every rank
-    scatters its frame's packed blocks into the 6N x 6N normal equations on the device (mbavo_merge_device) and the
-    partial systems are summed with ONE all-reduce per step over xGMI;
+    evaluates its frame's packed block straight into its slice of the result buffer and ONE in-place all-gather of equal
+    slices per step over xGMI leaves every frame's block on every rank (--collective allreduce: an out-of-place all-reduce
+    of a send buffer that is zero elsewhere, as BASELINE.json words it; --shard frames: the 6N x 6N systems merged on the
+    device and summed by an all-reduce);
   * c4_batch512 / c3_batch64 (independent keyframe pairs): pair b on rank b % N, whole (--shard pairs, the default;
     strong scaling): every rank evaluates its pairs into its slice of a zero B x E send buffer and ONE out-of-place
     all-reduce leaves every pair's packed blocks on every rank; --shard keypoints splits every pair's keypoints instead
@@ -680,7 +682,7 @@ def main():
 
     def collective_name(r):
         call = ("mbavo_allgather_blocks" if r.se.pair_collective == "allgather" else "mbavo_allreduce_blocks_to") if r.mode == "pairs" \
-            else ("mbavo_allreduce_blocks_to" if r.mode == "frame_blocks" else "mbavo_allreduce_blocks")
+            else (("mbavo_allgather_blocks" if r.se.fb_allgather else "mbavo_allreduce_blocks_to") if r.mode == "frame_blocks" else "mbavo_allreduce_blocks")
         if use_p2p:
             name = {"mbavo_allgather_blocks": "mbavo_allgather_blocks_p2p", "mbavo_allreduce_blocks_to": "copy + mbavo_allreduce_blocks_p2p",
                     "mbavo_allreduce_blocks": "mbavo_allreduce_blocks_p2p"}[call]

@@ -13,8 +13,10 @@ equations (the reference's reduction point is merge_hessian_gradie
     slices sit in a zero send buffer and ONE out-of-place all-reduce (`mbavo_allreduce_blocks_to`) sums x + 0 + ... + 0 --
     exact and bit-identical, at twice the bytes on the wire.
   * ONE joint problem, frames sharded, packed blocks summed ('frame_blocks', bench.py's default for a single pair): as
-    'frames' below, but every rank's frame blocks go into its slice of a zero send buffer and the all-reduce carries the
-    packed blocks; the scatter into the 6N x 6N system is the consumer's (no merge kernel in the step).
+    'frames' below, but what travels are the packed blocks: with the same number of frame rows on every rank (frame r on rank r)
+    the rank's evaluation writes straight into its slice of the result buffer and ONE in-place all-gather of equal slices
+    moves them (round 5; `pair_collective="allreduce"` or ragged shares: a zero send buffer and an out-of-place all-reduce);
+    the scatter into the 6N x 6N system is the consumer's (no merge kernel in the step).
   * ONE joint problem, frames sharded (`mbavo_shard_frames`): rank r owns a contiguous frame range; every rank scatters
     its frames' blocks into the 6N x 6N system on the device (`mbavo_merge_device`) and the partial systems
     [cost | g | H] are summed: one all-reduce of 1 + 6N + 36N^2 doubles per problem.
@@ -286,7 +288,8 @@ class ShardedEvaluation:
         assert mode in ("keypoints", "frames", "frame_blocks", "pairs") and pair_collective in ("allgather", "allreduce")
         self.ctx, self.whole, self.k, self.rank, self.world, self.mode = ctx, whole, k, rank, world, mode
         self.coll = collective if collective is not None else RcclCollective(ctx)
-        self.pair_collective = pair_collective if mode == "pairs" else None
+        self.pair_collective = pair_collective if mode in ("pairs", "frame_blocks") else None
+        self.fb_allgather = False
         self.B = len(whole)
         lib = ctx.lib
         self.E = lib.mbavo_packed_len(k)
@@ -334,11 +337,21 @@ class ShardedEvaluation:
         assert sorted(perm) == list(range(self.nbf_whole)) and self.row_base[rank + 1] - self.row_base[rank] == self.nbf
         self.sys_len = 0
         z = lambda n: torch.zeros(max(n, 1), dtype=torch.float64, device=device)
-        self.send = z(self.nbf_whole * self.E)
-        self.frame_blocks = self.send[self.row_base[rank] * self.E:self.row_base[rank + 1] * self.E] if self.nbf else z(1)
+        # every rank holds the same number of frame rows (bench.py's default: frame r on rank r) and the caller did not ask for the
+        # all-reduce: ONE in-place all-gather of equal slices instead -- the rank's evaluation writes straight into its slice of the
+        # result buffer, half the bytes on the wire, no send buffer (and for the p2p collective no copy in front of it)
+        self.fb_allgather = world > 1 and self.pair_collective == "allgather" and self.nbf > 0 and \
+            all(self.row_base[r + 1] - self.row_base[r] == self.nbf for r in range(world))
+        if self.fb_allgather:
+            self.reduced = z(self.nbf_whole * self.E)
+            self.send = self.reduced
+            self.frame_blocks = self.reduced[self.row_base[rank] * self.E:self.row_base[rank + 1] * self.E]
+        else:
+            self.send = z(self.nbf_whole * self.E)
+            self.frame_blocks = self.send[self.row_base[rank] * self.E:self.row_base[rank + 1] * self.E] if self.nbf else z(1)
+            self.reduced = z(self.nbf_whole * self.E) if world > 1 else self.send  # (one rank: its slice is the whole buffer)
         self.valid = z(self.nbf)
         self.systems = None
-        self.reduced = z(self.nbf_whole * self.E) if world > 1 else self.send  # (one rank: its slice is the whole buffer)
         self.count = self.nbf_whole * self.E
         self._ref_fb, self._ref_sys = z(self.nbf_whole * self.E), None
         self._perm = torch.from_numpy(np.array(perm, np.int64)).to(device)
@@ -417,6 +430,8 @@ class ShardedEvaluation:
     def _reduce(self):
         if self.mode == "pairs" and self.pair_collective == "allgather":
             self.coll.allgather(self.reduced, self.slice_rows * self.E)
+        elif self.mode == "frame_blocks" and self.fb_allgather:
+            self.coll.allgather(self.reduced, self.nbf * self.E)
         elif self.mode in ("pairs", "frame_blocks"):
             self.coll.allreduce(self.send, self.reduced, self.count)
         else:
