@@ -937,7 +937,26 @@ def main():
                                  "collective_ms": [round(v, 6) for v in rr]},
                     "reduction_check": chk, "collective_doubles": int(r.se.count)}
 
+        # the headline workload in north_star's own words -- "a final RCCL all-reduce of the normal equations": frame r on rank r,
+        # the rank's block scattered into the 6N x 6N system on the device (mbavo_eval_batch_merged), ONE in-place all-reduce of the
+        # systems (the line's own step moves the packed blocks by an all-gather and leaves the scatter to the consumer)
+        try:
+            r = Runner(M, ctx, "c2_dense", dev, rank, world, True, 0, shard_mode="frames", coll=coll)
+            n, dt, kms, kname = bounded_run(M, ctx, r, min_steps=60, sync=sync)
+            dt = max_over_ranks(dt)
+            e = batch_entry(r, n, dt, kms, kname, "weak", reduction_check(r))
+            e.pop("pairs_per_rank", None)
+            if rank == 0:
+                cfgs["c2_dense_frames_allreduce_of_systems"] = e
+            del r
+            torch.cuda.empty_cache()
+        except Exception as e:
+            if rank == 0:
+                cfgs["c2_dense_frames_allreduce_of_systems"] = {"error": repr(e)}
+            cfg_failed = True
         for mode, fmt, pc in (("pairs", 0, "allgather"), ("pairs", 0, "allreduce"), ("keypoints", 0, None), ("pairs", 2, "allgather")):
+            if max_over_ranks(float(cfg_failed)) != 0.0:
+                break
             key = "c4_batch512_" + mode + ("_allreduce" if pc == "allreduce" else "") + ("_packed" if fmt == 2 else "")  # (2: packed keyframes)
             try:
                 r = Runner(M, ctx, "c4_batch512", dev, rank, world, True, fmt, shard_mode=mode, coll=coll, pair_collective=pc or "allgather",

@@ -63,7 +63,10 @@ def test_bench_two_ranks_on_one_gpu(mbavo):
     cfg = two["configs"]
     want = ["c4_batch512_pairs", "c4_batch512_pairs_allreduce", "c4_batch512_keypoints", "c4_batch512_pairs_packed",
             "c4_batch512_pairs_weak_packed", "lm_batch512_pairs", "lm_batch_pairs_weak"]
-    assert sorted(cfg) == sorted(want)
+    lit = cfg["c2_dense_frames_allreduce_of_systems"]  # north_star's wording: the 6N x 6N systems summed by ONE all-reduce
+    assert "error" not in lit and lit["reduction_check"]["ok"] and lit["sharding"] == "frames" and "allreduce" in lit["collective"]
+    assert lit["scaling"] == "weak" and lit["collective_doubles"] == 4 * (1 + 24 + 576) and lit["value"] > 0  # (four pyramid levels, N = 4 knots)
+    assert sorted(cfg) == sorted(want + ["c2_dense_frames_allreduce_of_systems"])
     for k in want:
         assert "error" not in cfg[k], (k, cfg[k])
     for k in want[:5]:
