@@ -67,6 +67,29 @@ def test_solve_normal_equation(orc, mbavo):
     assert np.abs(out[24:]).max() == 0 and np.abs(out - ref).max() <= 1e-10 * np.abs(ref).max()
 
 
+def test_host_svd_solve_rank_threshold_is_eigens(mbavo):
+    """The product's solver type 0 on systems with a prescribed spectrum (tests/test_oracle_harness_checks.py does the same for
+    the oracle): singular values below epsilon * n * sigma_max are cut (Eigen's default JacobiSVD threshold,
+    solve_normal_equation.h:20-26), everything above takes part -- against LAPACK's truncated pseudo-inverse at the same
+    relative cut-off.  Well-conditioned systems take the LDL^T stand-in (ratio <= 1e8), the others the Jacobi SVD."""
+    L = mbavo.load()
+    rng = np.random.default_rng(21)
+    n = 24
+    eps = np.finfo(np.float64).eps
+    for trial, (lows, rank) in enumerate([((), n), ((1e-19, 1e-18), n - 2), ((1e-12,), n), ((1e-12, 1e-20, 0.0), n - 2)]):
+        Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+        s = np.concatenate([np.logspace(0, -6, n - len(lows)), np.array(lows, float)]) * 37.0
+        A = (Q * s) @ Q.T
+        A = 0.5 * (A + A.T)
+        b = rng.uniform(-1, 1, n)
+        out = np.zeros(n)
+        assert L.mbavo_solve_normal_equation(mbavo.capi.dp(A.ravel(order="F").copy()), mbavo.capi.dp(b), n, 0, mbavo.capi.dp(out)) == 0
+        ref = -np.linalg.pinv(A, rcond=eps * n, hermitian=True) @ b
+        kept = np.sort(s)[::-1][:rank]
+        tol = 1e-13 * kept[0] / kept[-1] * max(1.0, np.abs(ref).max())
+        assert np.abs(out - ref).max() < tol, (trial, np.abs(out - ref).max(), tol)
+
+
 def test_lm_and_trust_region_follow_reference_script(mbavo):
     """Same script as tests/golden (outputs produced by the reference's own classes): bit-exact."""
     L = mbavo.load()

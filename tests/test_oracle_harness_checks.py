@@ -321,3 +321,28 @@ def test_so3_exp_is_rodrigues(orc):
         Rr = np.eye(3) if th == 0 else np.eye(3) + np.sin(th) / th * Kx + (1 - np.cos(th)) / th ** 2 * Kx @ Kx
         assert np.abs(_rotmat(q) - Rr).max() < 1e-12
         assert abs(np.linalg.norm(q) - 1) < 1e-14
+
+
+def test_svd_solve_rank_threshold_is_eigens(orc):
+    """solve_normal_equation.h:10-35 solves with Eigen::JacobiSVD at its DEFAULT threshold: singular values up to
+    epsilon * diagSize * sigma_max count as zero (Eigen/src/SVD/SVDBase.h: threshold(), rank()), everything above takes part
+    with its full 1 / sigma.  Eigen is not in this image; what its solve() computes is the truncated pseudo-inverse, which
+    LAPACK's SVD gives independently: symmetric systems with a prescribed spectrum -- well separated from the threshold on
+    either side, so that the rank is unambiguous -- against numpy's pinv at the same relative cut-off, and the rank returned."""
+    rng = np.random.default_rng(21)
+    n = 24
+    eps = np.finfo(np.float64).eps
+    for trial, (lows, want_rank) in enumerate([((), n), ((1e-19, 1e-18), n - 2), ((1e-12,), n), ((1e-12, 1e-20, 0.0), n - 2)]):
+        Q, _ = np.linalg.qr(rng.normal(size=(n, n)))
+        s = np.concatenate([np.logspace(0, -6, n - len(lows)), np.array(lows, float)]) * 37.0
+        A = (Q * s) @ Q.T
+        A = 0.5 * (A + A.T)
+        b = rng.uniform(-1, 1, n)
+        out = np.zeros(n)
+        rank = orc.lib().orc_solve_normal_equation(orc.dp(A.ravel(order="F").copy()), orc.dp(b), n, 0, orc.dp(out))
+        assert rank == want_rank, (trial, rank)
+        ref = -np.linalg.pinv(A, rcond=eps * n, hermitian=True) @ b
+        # the kept directions' error scales with 1 / sigma_min(kept) relative to sigma_max
+        kept = np.sort(s)[::-1][:want_rank]
+        tol = 1e-13 * kept[0] / kept[-1] * max(1.0, np.abs(ref).max())
+        assert np.abs(out - ref).max() < tol, (trial, np.abs(out - ref).max(), tol)
