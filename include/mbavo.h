@@ -221,7 +221,8 @@ typedef struct mbavo_track_opts {
     int speculate;      /* candidates evaluated WITH H / g: 0 on the persistent levels, 1 every level, -1 never [MBAVO_SPECULATE] */
     int persist_levels; /* one persistent kernel for all levels of a call; default on                          [MBAVO_PERSIST_LEVELS] */
     int ride_along;     /* the next pyramid level's first evaluation rides along with this level's candidates (same
-                           results, one dependent evaluation less per level); default on                       [MBAVO_RIDE_ALONG] */
+                           results, one dependent evaluation less per level); default on; 2 (tests): on, and every
+                           ride-along is treated as taken at other knots, i.e. waited out and redone           [MBAVO_RIDE_ALONG] */
     int resum;          /* the H / g evaluation behind an accepted step whose outlier flags changed is the candidate's,
                            summed again on the device under the new flags and scale (bit-identical results, no pixel
                            work); default on                                                                   [MBAVO_RESUM] */
@@ -447,6 +448,10 @@ const char *mbavo_last_kernel(mbavo_ctx *ctx);
 /* host-side phase timers of the tracking loop (enabled by MBAVO_TIMING=1 in the environment): print the totals since
  * the last report to stderr and reset them.  Development aid; a no-op when the timers are off. */
 void mbavo_timing_report(void);
+/* process-wide counters of the host LM loop's ride-along evaluations (mbavo_track_opts.ride_along) since the last call:
+ * out[0] commands that carried one, out[1] pyramid levels that started on theirs, out[2] levels that waited a wasted one
+ * out before their first command (it shares the level's ticket counters and partials with that command).  Reset on read. */
+void mbavo_ride_along_stats(long long out[3]);
 
 const char *mbavo_version(void);
 /* revision of the POD structs above (MBAVO_ABI_VERSION of the header the library was built with): compare before use */

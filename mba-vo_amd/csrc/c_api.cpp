@@ -681,6 +681,13 @@ extern "C"
     }
 
     void mbavo_timing_report(void) { mbavo::PhaseTimers::get().report(); }
+    void mbavo_ride_along_stats(long long out[3])
+    {
+        mbavo::RideAlongStats &s = mbavo::RideAlongStats::get();
+        out[0] = s.posts.exchange(0);
+        out[1] = s.hits.exchange(0);
+        out[2] = s.waits.exchange(0);
+    }
 
     const char *mbavo_last_kernel(mbavo_ctx *ctx) { return ctx ? ctx->engine->last_kernel() : ""; }
 

@@ -47,5 +47,12 @@ namespace mbavo
             t.calls[id].fetch_add(1, std::memory_order_relaxed);
         }
     };
+    // the joint persistent kernel's ride-along evaluations, process-wide (mbavo_ride_along_stats): commands that carried one, level
+    // starts that found theirs (one dependent evaluation saved), level starts that had to wait a wasted one out
+    struct RideAlongStats
+    {
+        std::atomic<long long> posts{0}, hits{0}, waits{0};
+        static RideAlongStats &get() { static RideAlongStats s; return s; }
+    };
 } // namespace mbavo
 #endif

@@ -266,7 +266,8 @@ namespace mbavo
         std::vector<double> ride_kt(3 * (size_t)N), ride_kR(4 * (size_t)N);
         int ride_level = -1;                 // the level (li) the last ride-along evaluated, or -1
         unsigned long long ride_seq = 0;     // ... and the sequence number of its command
-        long ride_hits = 0, ride_posts = 0;
+        const bool ride_waste = o.ride_along == 2; // (tests: every ride-along counts as taken at other knots -- the wasted path on every level)
+        RideAlongStats &ride_stats = RideAlongStats::get();
         // THE ACCEPTED STEP'S EVALUATION AS A RE-SUMMATION (round 5; mbavo_track_opts.resum, default on, persistent kernels).  Two of
         // three accepted steps flag new outliers, so the candidate's H / g (speculation above) are not the accepted point's -- but
         // they differ from it only in which patches' rows count and in the residual scale: the kernel's workgroups still hold the
@@ -331,7 +332,7 @@ namespace mbavo
                         r = eng.persistent_post(0, with_h, li, li + 1);
                         ride_level = li + 1;
                         ride_seq = eng.posted_seq();
-                        ++ride_posts;
+                        ride_stats.posts.fetch_add(1, std::memory_order_relaxed);
                     }
                     else r = joint ? eng.persistent_post(0, with_h, li) : eng.persistent_post(li, with_h);
                 }
@@ -382,7 +383,7 @@ namespace mbavo
             };
 
             // iteration 0 -- already evaluated by the previous level's last ride-along if that was taken at these very knots
-            if (joint && ride_level == li && memcmp(ride_kt.data(), spline.get_knot_data_t(), sizeof(double) * 3 * N) == 0 &&
+            if (joint && ride_level == li && !ride_waste && memcmp(ride_kt.data(), spline.get_knot_data_t(), sizeof(double) * 3 * N) == 0 &&
                 memcmp(ride_kR.data(), spline.get_knot_data_R(), sizeof(double) * 4 * N) == 0)
             {
                 {
@@ -391,12 +392,22 @@ namespace mbavo
                 }
                 PhaseScope ps(PhaseTimers::kMerge);
                 merge_blocks_host(F, k, lvl_pin, start_idx.data(), N, &eval_cost, H.data(), g.data());
-                ++ride_hits;
+                ride_stats.hits.fetch_add(1, std::memory_order_relaxed);
             }
             else
             {
-                // (a ride-along taken at other knots may still be running on this level's workgroups: they take this command after it,
-                // and its results are overwritten -- but its completion must not be mistaken for a later one's, so forget it)
+                // A ride-along taken at other knots may still be running on this level's workgroups.  Its tiles share the level's
+                // ticket counters, tile partials and frame blocks with the command posted next, and the workgroups take commands
+                // independently -- one could finish its wasted tile and bump the ticket for the NEW command while a sibling is still
+                // on the old one (with two tiles: the first workgroup would count 0->1, 1->2 and sum its new partial with the
+                // sibling's stale one).  So the wasted ride-along is waited out (<= one evaluation, ~10 us, on levels that end on an
+                // accepted candidate only) before this level's first command goes out.
+                if (joint && ride_level == li)
+                {
+                    PhaseScope ps(PhaseTimers::kWait);
+                    if ((rc_ = eng.persistent_wait_second(ride_seq))) goto done;
+                    ride_stats.waits.fetch_add(1, std::memory_order_relaxed);
+                }
                 if ((rc_ = evaluate(spline.get_knot_data_t(), spline.get_knot_data_R(), true, &eval_cost))) goto done;
             }
             if (ride_level == li) ride_level = -1;

@@ -145,6 +145,7 @@ def _bind(path):
         L.orc_merge_hessian_gradient_cost.argtypes = [C.c_int, C.c_int, c_dp, c_ip, C.c_int, c_dp, c_dp, c_dp]
         L.orc_evaluate.argtypes = [C.POINTER(OrcProblem), c_dp, c_dp, c_dp, c_dp, c_dp]
         L.orc_evaluate_fast.argtypes = [C.POINTER(OrcProblem), C.c_int, c_dp, c_dp, c_dp, c_dp]
+        L.orc_count_valid.argtypes = [C.POINTER(OrcProblem), C.c_int, c_dp]
         L.orc_solve_normal_equation.argtypes = [c_dp, c_dp, C.c_int, C.c_int, c_dp]
         L.orc_tr_quality.argtypes = [C.POINTER(OrcTr), C.c_double, C.c_double]
         L.orc_tr_reset.argtypes = [C.POINTER(OrcTr), C.c_double]
@@ -340,6 +341,13 @@ def evaluate_fast(prob, num_threads=1, with_hessian=True):
     L.orc_evaluate_fast(C.byref(prob), int(num_threads), dp(frame_blocks), dp(cost), dp(H), dp(g))
     return dict(cost=float(cost[0]), H=None if H is None else H.reshape(n, n).T.copy(), g=g,
                 frame_blocks=frame_blocks.reshape(prob.F, E))
+
+
+def count_valid(prob, num_threads=1):
+    """valid pixels per frame (all S warps in bounds), as mbavo_eval_batch's d_valid counts them"""
+    v = np.zeros(prob.F)
+    lib().orc_count_valid(C.byref(prob), int(num_threads), dp(v))
+    return v
 
 
 def stages_with_reference(prob_args, with_jacobians=True):

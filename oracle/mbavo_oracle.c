@@ -859,6 +859,49 @@ void orc_evaluate_fast(const orc_problem *p, int num_threads, double *frame_bloc
     free(poses); free(Jt); free(JR); free(part);
 }
 
+/* Valid pixels per frame of one evaluation: a pixel counts iff pixel_row accepts it -- its integer location and all S warps in
+ * bounds (compute_pixel_intensity.h:25-72, compute_pixel_jacobian_residual.cu:69-120).  What the product reports in
+ * mbavo_eval_batch's d_valid; test infrastructure for the full-size comparisons (exact counts). */
+void orc_count_valid(const orc_problem *p, int num_threads, double *valid /* F */)
+{
+    const int S = p->S, F = p->F, K = p->K, P = p->P, k = p->k;
+    if (num_threads < 1) num_threads = 1;
+    double *poses = (double *)malloc(sizeof(double) * (size_t)F * S * 7);
+    long long *part = (long long *)calloc((size_t)num_threads * F, sizeof(long long));
+    orc_compute_virtual_camera_poses(S, F, p->cap, p->exp_t, k, p->t0, p->dt, p->knots_t, p->knots_R, poses, NULL, NULL, NULL);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(num_threads)
+#endif
+    {
+#ifdef _OPENMP
+        const int tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#else
+        const int tid = 0, nt = 1;
+#endif
+        double *scratch = (double *)malloc(sizeof(double) * (size_t)S * (6 * k + 1));
+        const int lo = (int)((long long)K * tid / nt), hi = (int)((long long)K * (tid + 1) / nt);
+        for (int f = 0; f < F; ++f) {
+            const double *pose_mid = poses + (size_t)(f * S + S / 2) * 7;
+            long long n = 0;
+            for (int i = lo; i < hi; ++i) {
+                double c[2], r;
+                patch_centre(pose_mid, p->kp_xy[2 * i], p->kp_xy[2 * i + 1], p->kp_z[i], p->intr, c);
+                for (int q = 0; q < P; ++q)
+                    n += pixel_row(p->ref_img, p->ref_dIxy, p->cur_imgs[f], S, poses + (size_t)f * S * 7, k, NULL, NULL, c[0], c[1], p->kp_z[i],
+                                   p->pattern[2 * q], p->pattern[2 * q + 1], p->intr, p->H, p->W, &r, NULL, scratch);
+            }
+            part[(size_t)tid * F + f] = n;
+        }
+        free(scratch);
+    }
+    for (int f = 0; f < F; ++f) {
+        long long n = 0;
+        for (int t = 0; t < num_threads; ++t) n += part[(size_t)t * F + f];
+        valid[f] = (double)n;
+    }
+    free(poses); free(part);
+}
+
 /* ------------------------------------------------------------------------ */
 /* solve_normal_equation.h:10-35.  Eigen (3.3.x, version unpinned by the     */
 /* reference) is absent: JacobiSVD (two-sided Jacobi with the real 2x2       */

@@ -113,6 +113,7 @@ void orc_evaluate(const orc_problem *p, double *patch_blocks /*F*K*E*/,
                   double *H_or_null, double *g_or_null);
 /* same result, restructured for speed (thread-parallel over keypoints, no
  * materialised intermediates).  Used only as bench.py's cpu_baseline. */
+void orc_count_valid(const orc_problem *p, int num_threads, double *valid /* F */);
 void orc_evaluate_fast(const orc_problem *p, int num_threads, double *frame_blocks,
                        double *total_cost, double *H_or_null, double *g_or_null);
 

@@ -1,4 +1,5 @@
-"""-m gpu: bench.py's N > 1 path executed END TO END on the one-GPU box (VERDICT r03 "What's missing" #1): two processes
+"""-m gpu: bench.py's output contract (ONE line of <= 6 KB with the contract's keys + a details file) and its N > 1 path executed
+END TO END on the one-GPU box (VERDICT r03 "What's missing" #1): two processes
 launched exactly as the driver launches them (python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...),
 both on GPU 0 (`--comm gloo`: RCCL cannot form a communicator over duplicate devices, so shard.HostStagedCollective -- gloo
 on a pinned host copy -- stands in for ncclAllReduce / ncclAllGather; every other line of the path is the one the RCCL run
@@ -16,16 +17,47 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 COMMON = ["--steps", "5", "--warmup", "2", "--min-seconds", "0.02", "--batch-pairs", "16", "--no-cpu-baseline"]
+LINE_LIMIT = 6000  # bytes: the whole line fits the 8 KB stdout tail the driver keeps (round 5's 26 KB line did not parse)
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "config", "roofline", "details")
 
 
-def _line(cmd, env_extra, timeout=900):
+def _line(cmd, env_extra, tmp_path, timeout=900, expect_rc=0):
+    """(the ONE JSON line bench.py printed, parsed and length-checked; the details file it wrote)"""
     env = dict(os.environ)
-    env.update(env_extra)
-    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
-    assert p.returncode == 0, p.stderr.decode()[-3000:]
-    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout.decode()[-2000:]
-    return json.loads(lines[0])
+    for k, v in env_extra.items():
+        env.pop(k, None) if v is None else env.__setitem__(k, v)
+    details = os.path.join(str(tmp_path), "details_%d.json" % len(os.listdir(str(tmp_path))))
+    p = subprocess.run(cmd + ["--details-out", details], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert p.returncode == expect_rc, p.stderr.decode()[-3000:]
+    out = p.stdout.decode()
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), out[-2000:]  # nothing but the line on stdout
+    assert len(lines[0]) <= LINE_LIMIT, len(lines[0])
+    line = json.loads(lines[0])
+    if expect_rc:
+        return line, None
+    for k in REQUIRED:
+        assert k in line, k
+    assert line["details"] == details and set(line["config"]) >= {"workload", "parallelism"}
+    rf = line["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] > 0 and "traffic" in rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["kernel_ms"] > 0 and rf["launches_timed"] > 0
+    for v in _strings(line):  # numbers and short labels, no prose
+        assert len(v) <= 120, v
+    return line, json.load(open(details))
+
+
+def _strings(x):
+    if isinstance(x, dict):
+        for k, v in x.items():
+            if k != "details":
+                yield from _strings(v)
+    elif isinstance(x, list):
+        for v in x:
+            yield from _strings(v)
+    elif isinstance(x, str):
+        yield x
 
 
 def _schema(x):
@@ -37,13 +69,61 @@ def _schema(x):
     return "v"
 
 
-def test_bench_two_ranks_on_one_gpu(mbavo):
+def test_bench_line_default_run(mbavo, tmp_path):
+    """The driver's command (`python bench.py --gpus 1 --steps 5 --warmup 2`, every side leg on): one line of <= 6 KB carrying
+    `roofline` AND `cpu_baseline` (numbers + short labels), the six side figures, the parity block with its horizon named; the
+    details file holds the side configs and the long-horizon report."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    line, full = _line([sys.executable, "bench.py", "--gpus", "1", "--steps", "5", "--warmup", "2", "--long-frames", "40"], {}, tmp_path)
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["warmup"] == 2 and line["dtype"] == "f64" and line["value"] > 1e4
+    assert line["config"]["workload"] == "c2_dense" and line["config"]["parallelism"] == "1 GPU"
+    cb = line["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == line["unit"] and len(cb["sample"]) <= 80
+    assert cb["gpu_vs_cpu_max_rel_diff"] < 1e-9
+    assert line["roofline"]["bound"] == "mfma" and 0.3 < line["roofline"]["frac"] < 1.2 and line["roofline"]["kernel"].startswith("k_fused<4,true")
+    side = line["side"]
+    for k in ("trackframe_ms_per_frame", "lm_batch64_us_per_round", "lm_batch512_us_per_round", "c2_semidense_ms_per_step",
+              "c2_dense_sequential_ms_per_step", "c2_dense_cost_only_ms_per_step"):
+        assert side[k] and side[k] > 0, (k, side)
+    par = line["parity"]
+    assert par["trackframe_discrete_results_equal"] and par["trackframe_abs_delta_ate"] <= 1e-5
+    assert par["long_frames"] == 41 and par["teacher_forced_discrete_results_equal"] and par["teacher_forced_within_1e-5_frames"] == 41
+    assert 10 <= par["free_running_within_1e-5_frames"] <= 41
+    # the details file: every side config without an error, the long descriptions
+    assert not [k for k, v in full["configs"].items() if "error" in v], [k for k, v in full["configs"].items() if "error" in v]
+    assert len(full["configs"]) >= 20 and full["value"] == line["value"] and "long_horizon" in full["cpu_baseline"]["trackframe_vs_oracle"]
+
+
+def test_bench_gpus_flag_launches_its_own_ranks(mbavo, tmp_path):
+    """`python bench.py --gpus 2 --comm p2p-shared --steps 20` WITHOUT a launcher: bench.py re-executes
+    itself under torch.distributed.run with two ranks and prints one two-rank line.  And the failure modes: more ranks than GPUs
+    without a shared-GPU mode, and a launcher whose WORLD_SIZE is not --gpus, each give a one-line JSON error object and rc 2."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    line, full = _line([sys.executable, "bench.py", "--gpus", "2", "--comm", "p2p-shared", "--steps", "20", "--warmup", "3", "--min-seconds", "0.02",
+                        "--batch-pairs", "16"], {"WORLD_SIZE": None}, tmp_path)
+    assert line["n_gpus"] == 2 and line["steps"] == 20 and line["value"] > 0 and line["comm"].startswith("p2p")
+    assert line["reduction_check"]["ok"] and len(line["per_rank"]["kernel_ms"]) == 2 and line["rccl_ranks"] == 2
+    assert not line["side"]["configs_with_errors"] and line["side"]["c4_batch512_pairs_value"] > 0
+    if torch.cuda.device_count() < 2:
+        err, _ = _line([sys.executable, "bench.py", "--gpus", "2", "--steps", "5"], {"WORLD_SIZE": None}, tmp_path, expect_rc=2)
+        assert "error" in err and err["gpus_visible"] == torch.cuda.device_count() and err["value"] is None
+    err, _ = _line([sys.executable, "bench.py", "--gpus", "2", "--steps", "5"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, tmp_path, expect_rc=2)
+    assert "WORLD_SIZE" in err["error"]
+
+
+def test_bench_two_ranks_on_one_gpu(mbavo, tmp_path):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     port = 29700 + (os.getpid() % 200)
-    two = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                 "--master-port", str(port), "bench.py", "--gpus", "2", "--comm", "gloo"] + COMMON, {})
+    line, two = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                       "--master-port", str(port), "bench.py", "--gpus", "2", "--comm", "gloo"] + COMMON, {}, tmp_path)
+    assert line["n_gpus"] == 2 and line["value"] == two["value"] and line["reduction_check"]["ok"] and len(line["per_rank"]["collective_ms"]) == 2
+    assert line["comm_profile_p2p"]["ok"] and line["comm_profile_p2p"]["selected_as_the_step"] == two["comm_profile_p2p"]["selected_as_the_step"]
     assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["value"] > 0
     assert two["reduction_check"]["ok"] and two["reduction_check"]["sharding"] == "frame_blocks"
     # the step's collective is SELECTED: the stand-in's run first, then -- behind the canary child -- the same step through the
@@ -83,7 +163,7 @@ def test_bench_two_ranks_on_one_gpu(mbavo):
         assert cfg[k]["gather_check"] and cfg[k]["lm_iterations"] > 0 and cfg[k]["n_gpus"] == 2
     assert cfg["lm_batch512_pairs"]["pairs_per_rank"] == 8 and cfg["lm_batch_pairs_weak"]["pairs_per_rank"] == 16
     # the RCCL path's schema: the same code with a communicator of one rank
-    one = _line([sys.executable, "bench.py", "--gpus", "1"] + COMMON, {"MBAVO_BENCH_FORCE_DIST": "1"})
+    _, one = _line([sys.executable, "bench.py", "--gpus", "1"] + COMMON, {"MBAVO_BENCH_FORCE_DIST": "1"}, tmp_path)
     assert one["rccl_ranks"] == 1 and one["comm"] == "rccl" and one["reduction_check"]["ok"]
     s1, s2 = _schema(one), _schema(two)
 
@@ -96,7 +176,7 @@ def test_bench_two_ranks_on_one_gpu(mbavo):
     assert strip(s1) == strip(s2)
 
 
-def test_bench_two_ranks_p2p_collectives_on_one_gpu(mbavo):
+def test_bench_two_ranks_p2p_collectives_on_one_gpu(mbavo, tmp_path):
     """`bench.py --comm p2p-shared`: the same N = 2 run with the PRODUCT's one-shot collectives over
     peer-mapped regions (csrc/p2p_comm.hip) as the collective of every step and config -- end to end, every reduction_check ok
     (the reduced object equals the single-GPU evaluation to 1e-12), labelled as what it is."""
@@ -104,8 +184,9 @@ def test_bench_two_ranks_p2p_collectives_on_one_gpu(mbavo):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     port = 29900 + (os.getpid() % 90)
-    two = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                 "--master-port", str(port), "bench.py", "--gpus", "2", "--comm", "p2p-shared"] + COMMON, {})
+    line, two = _line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                       "--master-port", str(port), "bench.py", "--gpus", "2", "--comm", "p2p-shared"] + COMMON, {}, tmp_path)
+    assert line["n_gpus"] == 2 and line["comm"].startswith("p2p") and not line["side"]["configs_with_errors"]
     assert two["n_gpus"] == 2 and two["comm"].startswith("p2p") and two["value"] > 0
     assert two["reduction_check"]["ok"] and "p2p" in two["reduction_check"]["collective"]
     cfg = two["configs"]

@@ -81,6 +81,33 @@ def test_c3_batch64_and_c5_1080p_properties(orc, mbavo, gpu_ctx):
     assert v5[0] > 0.95 * p.K
 
 
+def test_c5_1080p_whole_against_the_oracle(orc, mbavo, gpu_ctx):
+    """configs[4] AT ITS OWN SIZE against the oracle (the config whose reference-flop fraction exceeds 1
+    deserves a direct comparison, compute_hessian_gradients_cost.cu:23-283): 1920x1080, S = 16, N = 6 control poses (k = 4),
+    dense -- 2.07 M patches, 33 M pixel-samples -- the whole packed frame block against orc_evaluate_fast on all host threads,
+    1e-9 relative, and the EXACT valid-pixel count (orc_count_valid); the fp16 gradient pyramid and the packed keyframe format
+    against the same oracle block.  About 1-5 s of CPU."""
+    big = wl.pyramid_pair(1080, 1920, 1, S=16, k=4, N=6, mode="dense", seed=2)
+    p = big[0]
+    assert p.K > 2_000_000 and p.S == 16 and p.N == 6
+    op, keep = orc.make_problem(p.S, p.F, p.K, p.P, p.k, p.N, p.H, p.W, p.ref, p.grad, p.cur, p.kp_xy, p.kp_z,
+                                p.pattern, p.intr, p.cap, p.exp, p.t0, p.dt, p.knots_t, p.knots_R, p.start_idx, p.huber)
+    ro = orc.evaluate_fast(op, num_threads=16)["frame_blocks"][0]
+    vo = orc.count_valid(op, num_threads=16)
+    assert np.abs(ro).max() > 0 and vo[0] > 0.95 * p.K
+    for fmt in (0, 1, 2):  # float gradients, IEEE-half gradients (configs[4]'s "fp16 pyramid"), packed keyframe words
+        for q in big:
+            q.grad_fp16 = fmt
+        fb, valid = _run(gpu_ctx, big)
+        assert np.abs(fb[0] - ro).max() <= 1e-9 * np.abs(ro).max(), fmt
+        assert valid[0] == vo[0], (fmt, valid[0], vo[0])
+    # the cost-only pass of the same problem: the frame cost alone
+    for q in big:
+        q.grad_fp16 = 0
+    fc, vc = _run(gpu_ctx, big, with_h=False)
+    assert abs(fc[0, 0] - ro[0]) <= 1e-9 * abs(ro[0]) and vc[0] == vo[0]
+
+
 def test_c5_fp16_gradient_pyramid(orc, mbavo, gpu_ctx):
     """configs[4]: 1920x1080, S = 16, 6 control poses, fp32 vs fp16 gradient pyramid.  Stated tolerance: 1e-13
     relative on the packed blocks, exact valid-pixel counts.  Central differences of an 8-bit image are multiples of
@@ -124,7 +151,7 @@ def test_fp16_gradient_sample_parallel_remainder(orc, mbavo, gpu_ctx):
 
 
 def test_c4_batch512_full_size(orc, mbavo, gpu_ctx):
-    """configs[3] on one GPU: the whole batch of 512 semi-dense pairs in ONE evaluation.  Eight sampled pairs against
+    """configs[3] on one GPU: the whole batch of 512 semi-dense pairs in ONE evaluation.  Every 8th pair (64) against
     the oracle (1e-9 relative on the packed blocks, exact valid-pixel counts are covered by the small cases); every
     pair against the same pair evaluated alone and inside the 64-pair batch (1e-12: only the tile partition differs);
     permutation of the batch permutes the blocks; run-to-run bit reproducibility; keypoint shards of every pair
@@ -142,12 +169,13 @@ def test_c4_batch512_full_size(orc, mbavo, gpu_ctx):
     torch.cuda.synchronize()
     assert np.array_equal(dw.frame_blocks.cpu().numpy().reshape(512, dw.E), fb)
     assert np.isfinite(fb).all() and (valid == probs[0].K * probs[0].P).all() and (fb[:, 0] > 0).all()
-    for i in (0, 63, 64, 129, 255, 256, 400, 511):
+    for i in list(range(0, 512, 8)) + [63, 129, 255, 511]:
         p = probs[i]
         op, keep = orc.make_problem(p.S, p.F, p.K, p.P, p.k, p.N, p.H, p.W, p.ref, p.grad, p.cur, p.kp_xy, p.kp_z,
                                     p.pattern, p.intr, p.cap, p.exp, p.t0, p.dt, p.knots_t, p.knots_R, p.start_idx, p.huber)
-        ro = orc.evaluate(op)
-        assert np.abs(ro["frame_blocks"][0] - fb[i]).max() <= 1e-9 * np.abs(fb[i]).max()
+        ro = orc.evaluate_fast(op, num_threads=4)
+        assert np.abs(ro["frame_blocks"][0] - fb[i]).max() <= 1e-9 * np.abs(fb[i]).max(), i
+        assert orc.count_valid(op)[0] == valid[i], i
         alone, _ = _run(gpu_ctx, [p])
         assert np.abs(alone[0] - fb[i]).max() <= 1e-12 * np.abs(fb[i]).max()
     first64, _ = _run(gpu_ctx, probs[:64])
@@ -204,8 +232,8 @@ def test_c1_dense_full_size_properties(orc, mbavo, gpu_ctx):
 
 def test_c4_batch512_rendered_pairs_full_size(orc, mbavo, gpu_ctx):
     """configs[3] as the config describes it: 512 pairs of ONE rendered blurred sequence, every pair with its own keyframe,
-    gradient image, keypoints and knots (workloads.RenderedPairBatch) in ONE evaluation: reproducible bit for bit, six
-    sampled pairs against the oracle (1e-9), and the pair -> rank sharding of bench.py --gpus N (pairs b % N == r into the
+    gradient image, keypoints and knots (workloads.RenderedPairBatch) in ONE evaluation: reproducible bit for bit, every
+    8th pair (64 of them) against the oracle (1e-9, exact valid-pixel counts), and the pair -> rank sharding of bench.py --gpus N (pairs b % N == r into the
     rank's slice of the zero send buffer; ranks of a 2-, 4- and 8-rank run one after the other on this GPU): the summed
     send buffers equal the whole batch evaluated at once to 1e-12 (another tile partition), every slice untouched by the
     other ranks."""
@@ -221,12 +249,13 @@ def test_c4_batch512_rendered_pairs_full_size(orc, mbavo, gpu_ctx):
     assert np.array_equal(batch.frame_blocks.cpu().numpy().reshape(512, batch.E), fb)
     K = np.array([p.K for p in batch.probs])
     assert np.isfinite(fb).all() and (fb[:, 0] > 0).all() and K.min() > 150 and (valid > 0.9 * K * 8).all()
-    for b in (0, 63, 128, 300, 457, 511):
+    for b in list(range(0, 512, 8)) + [511]:
         p = batch.host_problem(b)
         op, keep = orc.make_problem(p.S, p.F, p.K, p.P, p.k, p.N, p.H, p.W, p.ref, p.grad, p.cur, p.kp_xy, p.kp_z, p.pattern,
                                     p.intr, p.cap, p.exp, p.t0, p.dt, p.knots_t, p.knots_R, p.start_idx, p.huber)
-        ro = orc.evaluate(op)
-        assert np.abs(ro["frame_blocks"][0] - fb[b]).max() <= 1e-9 * np.abs(fb[b]).max()
+        ro = orc.evaluate_fast(op, num_threads=4)
+        assert np.abs(ro["frame_blocks"][0] - fb[b]).max() <= 1e-9 * np.abs(fb[b]).max(), b
+        assert orc.count_valid(op)[0] == valid[b], b
     for world, coll in ((2, "allgather"), (4, "allreduce"), (8, "allgather")):
         total = None
         for r in range(world):

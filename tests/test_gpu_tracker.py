@@ -144,6 +144,33 @@ def test_accepted_step_is_summed_again(orc, mbavo, gpu_ctx, kw):
     assert [t[:4] for t in on["trace"]] == [t[:4] for t in want["trace"]]
 
 
+@pytest.mark.parametrize("kw", [dict(H=480, W=640, levels=4, S=8, k=2, seed=5), dict(H=480, W=640, levels=4, S=8, k=4, F=2, seed=7)])
+def test_wasted_ride_along_is_waited_out(orc, mbavo, gpu_ctx, kw):
+    """A ride-along taken at other knots than the level ends on shares the next level's ticket counters, tile partials and frame
+    blocks with that level's first command, and the persistent kernel's workgroups take commands independently: the host must not
+    post the command before the ride-along has finished (tracker.cpp).  ride_along = 2 treats EVERY ride-along as
+    wasted, so every level but the coarsest starts behind one that may still be running, on levels of several tiles per slot
+    (640x480: ~1000 / ~280 / ~150 keypoints).  Repeated, against the loop without ride-alongs: records with costs, knots and final
+    cost to the last bit; the counters say the wait path ran and no ride-along was used."""
+    import ctypes as C
+    import tracking
+    sc = tracking.make_tracking_scene(orc, **kw)
+    off = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, dict(tracking.OPTS, ride_along=-1))
+    st = (C.c_longlong * 3)()
+    gpu_ctx.lib.mbavo_ride_along_stats(st)
+    for _ in range(12):
+        got = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, dict(tracking.OPTS, ride_along=2))
+        assert got["trace"] == off["trace"] and got["cost"] == off["cost"]
+        assert np.array_equal(got["kt"], off["kt"]) and np.array_equal(got["kR"], off["kR"])
+    gpu_ctx.lib.mbavo_ride_along_stats(st)
+    posts, hits, waits = list(st)
+    # (a level that posts no candidate carries no ride-along: at most levels - 1 waits per run, the same number every run)
+    assert hits == 0 and posts >= waits and waits % 12 == 0 and 12 <= waits <= 12 * (kw["levels"] - 1), (posts, hits, waits)
+    on = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, dict(tracking.OPTS))
+    gpu_ctx.lib.mbavo_ride_along_stats(st)
+    assert on["trace"] == off["trace"] and st[1] >= 1, list(st)  # (the default: ride-alongs are used where the knots match)
+
+
 def test_two_trackers_at_once(orc, mbavo, gpu_ctx):
     """Two contexts (two engines, two streams, two push blocks, two pinned completion areas) driven from two host threads at the same
     time: each LM loop's persistent kernels, commands and re-summations must stay its own.  Every run returns what the same scene

@@ -57,3 +57,26 @@ def test_evaluate_with_reference_live(orc, monkeypatch, name, omp):
         got = orc.evaluate_with_reference(a, chunk=chunk, threads=threads)
         scale = np.abs(want).max(axis=1, keepdims=True)
         assert (np.abs(got - want) <= 1e-12 * scale).all(), (chunk, threads)
+
+
+@pytest.mark.parametrize("name", ["k4_S8_P8_F2", "k4_S3_P5_border_outliers", "k4_S1_dense", "k4_S16_dense_6knots"])
+def test_count_valid_against_the_reference_stage(orc, name):
+    """orc_count_valid (the exact valid-pixel counts of the full-size GPU tests): a pixel is valid iff its integer location and
+    all S warps are in bounds.  Pinned on the REFERENCE's compiled per-sample stage where oracle/_ref is present -- an invalid
+    pixel leaves residual 0 and an all-zero Jacobian row there (compute_pixel_jacobian_residual.cu:69-120), a valid one does not
+    -- else on the restatement's stage; the same on 1 and 3 threads; scenes with keypoints on the border have invalid pixels."""
+    sc = scenes.Scene(**CASES[name])
+    p, keep = sc.oracle_problem(orc)
+    v1, v3 = orc.count_valid(p, 1), orc.count_valid(p, 3)
+    assert np.array_equal(v1, v3) and (v1 <= sc.K * sc.P).all() and v1.sum() > 0
+    if orc.ref() is not None and hasattr(orc.ref(), "ref_compute_pixel_jacobian_residual"):
+        a = dict(S=sc.S, F=sc.F, K=sc.K, P=sc.P, k=sc.k, N=sc.N, H=sc.H, W=sc.W, ref_img=sc.ref, ref_dIxy=sc.grad, cur_imgs=sc.cur,
+                 kp_xy=sc.kp_xy, kp_z=sc.kp_z, pattern=sc.pattern, intr=sc.intr, cap=sc.cap, exp_t=sc.exp, t0=sc.t0, dt=sc.dt,
+                 knots_t=sc.knots_t, knots_R=sc.knots_R, huber_a=sc.huber)
+        st = orc.stages_with_reference(a)
+        res = np.asarray(st["residuals"]).reshape(sc.F, sc.K * sc.P)
+        jac = np.asarray(st["jacobians"]).reshape(sc.F, sc.K * sc.P, 6 * sc.k)
+        live = (res != 0) | (jac != 0).any(axis=2)
+        assert np.array_equal(live.sum(axis=1).astype(float), v1), (live.sum(axis=1), v1)
+    if "border" in name:
+        assert (v1 < sc.K * sc.P).all()
