@@ -42,12 +42,8 @@ def make_sequence(ctx, H=480, W=640, M=8, k_gt=4, trans_scale=0.15, rot_scale=0.
     L = ctx.lib
     I0 = synth.texture_image(H, W, seed=seed, octaves=(32, 16, 8, 4))
     intr = np.array([W / 2.0, W / 2.0, W / 2.0, H / 2.0])
-    if trajectory == "loop":
-        N = int((t_first + frame_dt * M) / 0.5) + 6
-        kt, kR = synth.loop_spline(N)
-    else:
-        N = 7
-        kt, kR = synth.harness_spline(trans_scale, rot_scale, N)
+    N = 7 if trajectory == "harness" else int((t_first + frame_dt * M) / 0.5) + 6  # (the bounded families: any M, synth.trajectory)
+    kt, kR = synth.trajectory(trajectory, N, trans_scale, rot_scale)
     kt, kR = np.ascontiguousarray(kt.ravel()), np.ascontiguousarray(kR.ravel())
     t0, dtk = 0.0, 0.5
     times = t_first + frame_dt * np.arange(M + 1)

@@ -46,6 +46,48 @@ def loop_spline(n_knots, radius=0.9, knots_per_turn=9.0, z_amp=0.25, rot_amp=0.0
     return np.ascontiguousarray(kt), np.ascontiguousarray(kR)
 
 
+def quat_mul(a, b):
+    """Hamilton product of xyzw quaternions (rotation a after b)."""
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def zigzag_spline(n_knots, trans_scale=0.1, rot_scale=0.02, period=8):
+    """The module harness's trajectory family (create_spline, test/...modules.cpp:24-67: knots on the image-plane diagonal, its
+    roll / pitch / yaw table) made bounded for long sequences: the diagonal walk 5 i is folded into a triangle wave of `period`
+    knots, so the camera sweeps back and forth over at most 2.5 * period * trans_scale metres -- constant-velocity legs with a
+    reversal every period / 2 knots, unlike loop_spline's circle."""
+    i = np.arange(n_knots)
+    tri = np.abs(((i + period // 2) % period) - period // 2).astype(np.float64)
+    kt = np.stack([5.0 * tri, 5.0 * tri, np.zeros(n_knots)], 1) * trans_scale
+    kR = np.stack([rpy_quat(*(np.array(_HARNESS_RPY[j % 7]) * np.pi * rot_scale)) for j in i])
+    return np.ascontiguousarray(kt), np.ascontiguousarray(kR)
+
+
+def tilted(kt, kR, pitch_deg=12.0, roll_deg=5.0):
+    """The same camera path looking at the plane OBLIQUELY: every knot's rotation composed with a fixed tilt (camera frame), so the
+    plane z = D of the plane frame is a tilted plane for the camera -- the depth varies across the image (frontend / sequence
+    plane_depth_map follow the pose) and so does the flow a given motion causes."""
+    tilt = rpy_quat(np.deg2rad(roll_deg), np.deg2rad(pitch_deg), 0.0)
+    return kt, np.ascontiguousarray(np.stack([quat_mul(q, tilt) for q in kR]))
+
+
+def trajectory(name, n_knots, trans_scale=0.15, rot_scale=0.02):
+    """Ground-truth spline knots by name: "harness" (7 knots, runs off the texture after ~15 frames at 640 x 480), "loop",
+    "zigzag" (the harness family, bounded), "loop_tilted" (the loop seen under a 12 degree pitch / 5 degree roll tilt)."""
+    if name == "loop":
+        return loop_spline(n_knots)
+    if name == "zigzag":
+        return zigzag_spline(n_knots)
+    if name == "loop_tilted":
+        return tilted(*loop_spline(n_knots))
+    if name == "harness":
+        return harness_spline(trans_scale, rot_scale, n_knots)
+    raise ValueError(name)
+
+
 def ramp_image(H=480, W=640):
     """create_uniform_image (test/...modules.cpp:69-81)."""
     return ((np.arange(W)[None, :] + np.arange(H)[:, None]) % 255).astype(np.uint8)

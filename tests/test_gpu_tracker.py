@@ -144,7 +144,8 @@ def test_accepted_step_is_summed_again(orc, mbavo, gpu_ctx, kw):
     assert [t[:4] for t in on["trace"]] == [t[:4] for t in want["trace"]]
 
 
-@pytest.mark.parametrize("kw", [dict(H=480, W=640, levels=4, S=8, k=2, seed=5), dict(H=480, W=640, levels=4, S=8, k=4, F=2, seed=7)])
+@pytest.mark.parametrize("kw", [dict(H=480, W=640, levels=4, S=8, k=2, seed=5), dict(H=480, W=640, levels=4, S=8, k=2, seed=9),
+                                dict(H=480, W=640, levels=4, S=8, k=4, seed=11), dict(H=240, W=320, levels=3, S=8, k=2, seed=3)])
 def test_wasted_ride_along_is_waited_out(orc, mbavo, gpu_ctx, kw):
     """A ride-along taken at other knots than the level ends on shares the next level's ticket counters, tile partials and frame
     blocks with that level's first command, and the persistent kernel's workgroups take commands independently: the host must not
@@ -164,6 +165,8 @@ def test_wasted_ride_along_is_waited_out(orc, mbavo, gpu_ctx, kw):
         assert np.array_equal(got["kt"], off["kt"]) and np.array_equal(got["kR"], off["kR"])
     gpu_ctx.lib.mbavo_ride_along_stats(st)
     posts, hits, waits = list(st)
+    if posts == 0:
+        pytest.skip("this shape does not run on the joint persistent kernel: no ride-alongs to waste")
     # (a level that posts no candidate carries no ride-along: at most levels - 1 waits per run, the same number every run)
     assert hits == 0 and posts >= waits and waits % 12 == 0 and 12 <= waits <= 12 * (kw["levels"] - 1), (posts, hits, waits)
     on = tracking.run_gpu_tracker(mbavo, gpu_ctx, sc, dict(tracking.OPTS))

@@ -1,7 +1,11 @@
 """Long-horizon parity of the HIP tracker against the CPU oracle: 300-frame rendered 640x480
 sequences through BlurAwareDirectTracker::trackFrame (blur_aware_direct_tracker.cpp:88-203, 590-699) for k = 2 and k = 4, and
 mbavo_lm_batch on ALL 64 pairs of configs[2] and a 64-pair sample of configs[3]'s 512 against the oracle's loop.
-Usage (GPU box): python tools/long_horizon.py [frames] > gpurun_out/long_horizon.txt     (copy to profiles/r05_long_horizon.txt)"""
+Round 6 adds WHOSE AMPLIFICATION IT IS: the same free-running comparison on four scenes that differ in what
+conditions the problem -- exposure, trajectory family, plane tilt -- with the per-frame growth factor of |pose_gpu - pose_oracle|, the
+first discrete divergence, |dATE| at 25 / 100 / 300 frames and the horizon over which north_star's criterion holds, next to the same
+figures for the oracle's own FMA-contracted build against the pinned oracle.
+Usage (GPU box): python tools/long_horizon.py [frames] > gpurun_out/long_horizon.txt     (copy to profiles/r06_long_horizon.txt)"""
 import json
 import os
 import sys
@@ -11,6 +15,79 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
+
+
+SCENES = (("loop, exposure 0.04 (round 5's scene)", dict(trajectory="loop", exp=0.04)),
+          ("loop, exposure 0.08 of the 0.1 frame interval", dict(trajectory="loop", exp=0.08)),
+          ("zigzag: the harness family (diagonal legs + its rpy table), bounded", dict(trajectory="zigzag", exp=0.04)),
+          ("loop seen under a 12 deg pitch / 5 deg roll tilt (depth 5.9 .. 10.8 across the image)", dict(trajectory="loop_tilted", exp=0.04)))
+
+
+def growth_factor(d, lo=2, hi=20):
+    """per-frame growth of the pose difference: exp(slope) of a least-squares line through log d over frames lo..hi"""
+    idx = np.array([i for i in range(lo, min(hi, len(d) - 1) + 1) if d[i] > 0])
+    if idx.size < 3:
+        return float("nan")
+    return float(np.exp(np.polyfit(idx, np.log(d[idx]), 1)[0]))
+
+
+def pair_summary(horizon, got, want, gt, cfg):
+    """free-running statistics of one pair of runs"""
+    st = horizon.compare(got, want, gt, min_step_quality=cfg["min_quality"], flow_thresholds=(cfg["flow0"], cfg["flow1"]))
+    d = np.array([np.abs(a["T"] - b["T"]).max() for a, b in zip(got, want)])
+    eg = np.array([np.sum((a["T"][:3] - g[:3]) ** 2) for a, g in zip(got, gt)])
+    eo = np.array([np.sum((b["T"][:3] - g[:3]) ** 2) for b, g in zip(want, gt)])
+    n = np.arange(1, len(eg) + 1)
+    d_ate = np.abs(np.sqrt(np.cumsum(eg) / n) - np.sqrt(np.cumsum(eo) / n))
+    bad = np.nonzero((d_ate > 1e-5) | (d > 1e-5))[0]
+    return dict(growth_per_frame_2_20=growth_factor(d), pose_diff_frame_1=float(d[1]), pose_diff_frame_10=float(d[min(10, len(d) - 1)]),
+                pose_diff_frame_20=float(d[min(20, len(d) - 1)]), first_discrete_divergence=st["first_discrete_divergence"],
+                first_pose_divergence_1e5=st["first_pose_divergence"]["1e-05"], within_1e5_frames=int(bad[0]) if bad.size else len(d),
+                abs_delta_ate={str(m): float(d_ate[min(m, len(d_ate)) - 1]) for m in (25, 100, 300)},
+                ate_gt=float(np.sqrt(np.mean(eg))), ate_gt_other=float(np.sqrt(np.mean(eo))),
+                keyframes=st["keyframes_oracle"], lm_records=st["lm_records_oracle"])
+
+
+def scenes_section(M, ctx, orc, frontend, horizon, sequence, frames):
+    """The free-running divergence on four scenes: is the ~1.4x per frame the tracker's or the one scene's?"""
+    fma = orc.fma_variant()
+    cfg = dict(sequence.REFERENCE_CFG)
+    rows = {}
+    print("== WHOSE AMPLIFICATION: free-running trackFrame (k = 2, reference configuration), %d frames, four scenes" % (frames + 1))
+    for name, kw in SCENES:
+        seq = sequence.make_sequence(ctx, H=480, W=640, M=frames, **kw)
+        gt = frontend.gt_relative(orc, seq)
+        want = frontend.run_oracle_vo(orc, seq, cfg)
+        got = frontend.run_gpu_vo(M, ctx, seq, cfg)
+        tf = frontend.run_gpu_vo(M, ctx, seq, cfg, teacher=want)
+        r = dict(gpu=pair_summary(horizon, got, want, gt, cfg))
+        if fma is not None:
+            r["oracle_fma"] = pair_summary(horizon, frontend.run_oracle_vo(fma, seq, cfg), want, gt, cfg)
+        stf = horizon.compare(tf, want, gt, min_step_quality=cfg["min_quality"])
+        dtf = np.array([np.abs(a["T"] - b["T"]).max() for a, b in zip(tf, want)])
+        r["teacher_forced"] = dict(first_discrete_divergence=stf["first_discrete_divergence"], abs_delta_ate=stf["abs_delta_ate"],
+                                   pose_median=float(np.median(dtf)), pose_max=float(dtf.max()))
+        rows[name] = r
+        print("-- scene: %s   [oracle: %d keyframes, %d LM records, ATE vs ground truth %.4e]" % (name, r["gpu"]["keyframes"], r["gpu"]["lm_records"], r["gpu"]["ate_gt_other"]))
+        for who, key in (("HIP tracker vs oracle", "gpu"), ("oracle built with -ffp-contract=fast -mfma vs oracle", "oracle_fma")):
+            if key not in r:
+                continue
+            q = r[key]
+            print("   %-52s growth x%.2f per frame (frames 2-20: |pose diff| %.1e -> %.1e -> %.1e); first discrete divergence at frame %s; "
+                  "criterion (poses and ATE within 1e-5) holds for %d frames; |dATE| at 25 / 100 / 300 frames: %.1e / %.1e / %.1e"
+                  % (who + ":", q["growth_per_frame_2_20"], q["pose_diff_frame_1"], q["pose_diff_frame_10"], q["pose_diff_frame_20"], q["first_discrete_divergence"],
+                     q["within_1e5_frames"], q["abs_delta_ate"]["25"], q["abs_delta_ate"]["100"], q["abs_delta_ate"]["300"]))
+        t = r["teacher_forced"]
+        print("   teacher-forced (every frame from the oracle's state):  first discrete divergence %s; one-step |pose diff| median %.1e max %.1e; |dATE| %.1e"
+              % (t["first_discrete_divergence"], t["pose_median"], t["pose_max"], t["abs_delta_ate"]))
+        del seq
+    g = [r["gpu"]["growth_per_frame_2_20"] for r in rows.values()]
+    f = [r["oracle_fma"]["growth_per_frame_2_20"] for r in rows.values() if "oracle_fma" in r]
+    h = [r["gpu"]["within_1e5_frames"] for r in rows.values()]
+    print("SUMMARY: growth per frame of the HIP-vs-oracle pose difference over the scenes: %s; of the oracle's FMA build vs the oracle: %s; "
+          "frames for which north_star's criterion holds free-running: %s (min %d)"
+          % (", ".join("x%.2f" % v for v in g), ", ".join("x%.2f" % v for v in f) or "n/a", ", ".join(str(v) for v in h), min(h)))
+    return rows
 
 
 def main():
@@ -87,6 +164,7 @@ def main():
                                                         abs_delta_ate=sf["abs_delta_ate"], rmse=sf["trajectory_rmse_gpu_vs_oracle"])
         out[name] = st
     del seq
+    out["scenes"] = scenes_section(M, ctx, orc, frontend, horizon, sequence, frames)
     for title, B, pairs, k, N in (("mbavo_lm_batch, ALL 64 pairs of configs[2], k = 4 N = 4", 64, range(64), 4, 4),
                                   ("mbavo_lm_batch, ALL 64 pairs of configs[2], k = 2 N = 2", 64, range(64), 2, 2),
                                   ("mbavo_lm_batch, configs[3]'s 512 pairs (two groups, late slots re-tiled), every 8th pair compared, k = 4 N = 4", 512, range(0, 512, 8), 4, 4)):
