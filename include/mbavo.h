@@ -419,8 +419,11 @@ int mbavo_allgather_blocks(mbavo_ctx *ctx, void *rccl_comm, double *d_blocks, lo
  *                      64-byte IPC handle; the caller hands every rank's handle to every rank (all-gather of 64 bytes, as
  *                      with the RCCL id) and calls
  *   mbavo_p2p_connect  with the world x 64 bytes in rank order.  At most 16 ranks, all on GPUs of one node (ranks may share a GPU).
- *   Every rank must issue the same sequence of p2p collectives.  A peer that does not arrive within 20 s ends the kernel:
- *   mbavo_p2p_status (synchronises the stream) then returns MBAVO_E_TIMEOUT.
+ *   Every rank must issue the same sequence of p2p collectives.  A peer that does not arrive within 20 s (mbavo_p2p_set_timeout:
+ *   any time in (0, 3600] s, for the collectives enqueued after it) ends the kernel: what it would have written -- the peers'
+ *   slices of an all-gather, the vector of an all-reduce -- is filled with NaN, so that an unreduced buffer cannot pass for a
+ *   result, and mbavo_p2p_status (synchronises the stream) returns MBAVO_E_TIMEOUT from then on (sticky: the ranks' sequence
+ *   numbers no longer agree; tear the regions down and create them again).
  *   Tear-down is two-phase, like any shared mapping: every rank finishes its last collective and calls mbavo_p2p_disconnect
  *   (unmaps the PEERS' regions); after a barrier of the caller -- nobody maps anybody any more -- every rank calls
  *   mbavo_p2p_destroy (frees its OWN region; also what mbavo_destroy does).  Freeing a region a peer still maps makes a later
@@ -432,6 +435,7 @@ int mbavo_p2p_ranks(mbavo_ctx *ctx); /* world once connected, else 0 */
 int mbavo_allgather_blocks_p2p(mbavo_ctx *ctx, double *d_blocks, long long count_per_rank); /* in place, as mbavo_allgather_blocks */
 int mbavo_allreduce_blocks_p2p(mbavo_ctx *ctx, double *d_blocks, long long count);          /* in place, as mbavo_allreduce_blocks */
 int mbavo_p2p_status(mbavo_ctx *ctx);
+int mbavo_p2p_set_timeout(mbavo_ctx *ctx, double seconds);
 int mbavo_p2p_disconnect(mbavo_ctx *ctx);
 int mbavo_p2p_destroy(mbavo_ctx *ctx);
 

@@ -664,6 +664,7 @@ extern "C"
     }
     int mbavo_allreduce_blocks_p2p(mbavo_ctx *ctx, double *d, long long count) { return ctx ? ctx->engine->p2p_collective(1, d, count) : MBAVO_E_ARG; }
     int mbavo_p2p_status(mbavo_ctx *ctx) { return ctx ? ctx->engine->p2p_status() : MBAVO_E_ARG; }
+    int mbavo_p2p_set_timeout(mbavo_ctx *ctx, double seconds) { return ctx ? ctx->engine->p2p_set_timeout(seconds) : MBAVO_E_ARG; }
     int mbavo_p2p_disconnect(mbavo_ctx *ctx) { return ctx ? ctx->engine->p2p_disconnect() : MBAVO_E_ARG; }
     int mbavo_p2p_destroy(mbavo_ctx *ctx) { return ctx ? ctx->engine->p2p_destroy() : MBAVO_E_ARG; }
 

@@ -209,6 +209,7 @@ namespace mbavo
         int p2p_ranks() const;
         int p2p_collective(int mode /* 0 all-gather in place, 1 all-reduce in place */, double *d_buf, long long count);
         int p2p_status();
+        int p2p_set_timeout(double seconds);
         int p2p_disconnect();
         int p2p_destroy();
         int allreduce(void *caller_comm_or_null, const double *d_send, double *d_recv, long long count);

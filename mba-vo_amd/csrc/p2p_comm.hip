@@ -41,7 +41,8 @@ namespace mbavo
     static constexpr int kP2PMaxWorld = 16;
     static constexpr int kP2PBlocks = 32;          // workgroups of a collective (co-resident: the wait phase needs no other block)
     static constexpr int kP2PThreads = 256;
-    static constexpr long long kP2PSpinLimit = 2000000000ll; // s_memrealtime ticks (100 MHz): 20 s
+    static constexpr long long kP2PTicksPerSecond = 100000000ll; // s_memrealtime: 100 MHz
+    static constexpr long long kP2PSpinLimit = 20 * kP2PTicksPerSecond; // default wait for a peer: 20 s (mbavo_p2p_set_timeout)
 
     struct P2PState
     {
@@ -51,6 +52,7 @@ namespace mbavo
         char *peer[kP2PMaxWorld] = {};         // every rank's region as mapped here (peer[rank] == local)
         bool opened[kP2PMaxWorld] = {};
         unsigned long long seq = 0;            // collectives enqueued so far
+        long long spin_limit = kP2PSpinLimit;  // ticks a collective waits for a peer's flag before it gives up
         int *tickets = nullptr;                // device: world counters + 1 status word
         hipIpcMemHandle_t handle;
         bool connected = false;
@@ -61,6 +63,7 @@ namespace mbavo
         char *peer[kP2PMaxWorld];
         int rank, world;
         unsigned long long seq, slot_bytes, flags_off;
+        long long spin_limit;
         int *tickets; // [world] tickets, [world] = status (1: a peer did not arrive in time)
     };
 
@@ -123,7 +126,7 @@ namespace mbavo
             while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq)
             {
                 __builtin_amdgcn_s_sleep(2);
-                if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > kP2PSpinLimit)
+                if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > a.spin_limit)
                 {
                     s_ok = 0;
                     __hip_atomic_store(a.tickets + a.world, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -132,7 +135,26 @@ namespace mbavo
             }
         }
         __syncthreads();
-        if (!s_ok) return;
+        if (!s_ok)
+        { // A peer never arrived.  The caller's buffer must not pass for a result (the call itself returned long ago): what this
+          // workgroup would have written -- the peers' slices of an all-gather, its share of an all-reduce, in the send phase's own
+          // partition (see the gather below) -- becomes NaN; mbavo_p2p_status reports MBAVO_E_TIMEOUT.
+            const double nan = __builtin_nan("");
+            if (MODE == 0)
+            {
+                for (int p = 0; p < a.world; ++p)
+                    if (p != a.rank)
+                        for (long long i = (long long)b * kP2PThreads + tid; i < count; i += (long long)nb * kP2PThreads) buf[(size_t)p * (size_t)count + i] = nan;
+            }
+            else if ((reinterpret_cast<size_t>(mine) & 15) == 0)
+            {
+                for (long long i = (long long)b * kP2PThreads + tid; i < pairs; i += (long long)nb * kP2PThreads) { buf[2 * i] = nan; buf[2 * i + 1] = nan; }
+                if ((count & 1) && b == 0 && tid == 0) buf[count - 1] = nan;
+            }
+            else
+                for (long long i = (long long)b * kP2PThreads + tid; i < count; i += (long long)nb * kP2PThreads) buf[i] = nan;
+            return;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // the peers' slot stores are visible to every thread of this workgroup
         // ---- gather
         const char *base = a.peer[a.rank] + (size_t)parity * a.world * a.slot_bytes;
@@ -226,6 +248,8 @@ namespace mbavo
             if (e != hipSuccess)
             {
                 fprintf(stderr, "mbavo: p2p_connect: hipIpcOpenMemHandle(rank %d): %s\n", p, hipGetErrorString(e));
+                for (int q = 0; q < p; ++q) // the mappings made so far are released: a retry starts from nothing
+                    if (s->opened[q]) { (void)hipIpcCloseMemHandle(s->peer[q]); s->opened[q] = false; s->peer[q] = nullptr; }
                 return (int)e;
             }
             s->peer[p] = (char *)m;
@@ -250,6 +274,7 @@ namespace mbavo
         for (int p = 0; p < s->world; ++p) a.peer[p] = s->peer[p];
         a.rank = s->rank; a.world = s->world; a.seq = ++s->seq; a.slot_bytes = s->slot_bytes; a.flags_off = s->flags_off;
         a.tickets = s->tickets;
+        a.spin_limit = s->spin_limit;
         // small messages: fewer workgroups (every one of them polls and fences); 19 KB is one workgroup's work
         long long want = (count * (long long)sizeof(double) + 16383) / 16384;
         const int nb = (int)(want < 1 ? 1 : (want > kP2PBlocks ? kP2PBlocks : want));
@@ -260,8 +285,17 @@ namespace mbavo
         return (int)hipGetLastError();
     }
 
+    int Engine::p2p_set_timeout(double seconds)
+    { // how long a collective waits for a peer before it gives up (default 20 s); applies to the collectives enqueued from here on
+        P2PState *s = p2p_;
+        if (!s || !(seconds > 0.0) || seconds > 3600.0) return MBAVO_E_ARG;
+        s->spin_limit = (long long)(seconds * (double)kP2PTicksPerSecond);
+        return 0;
+    }
+
     int Engine::p2p_status()
-    { // 0, or MBAVO_E_TIMEOUT when a collective gave up on a peer (synchronises the stream)
+    { // 0, or MBAVO_E_TIMEOUT when a collective gave up on a peer (synchronises the stream).  STICKY: after a timeout the ranks'
+      // sequence numbers no longer agree and the regions must be torn down (disconnect + destroy) and created again
         P2PState *s = p2p_;
         if (!s) return MBAVO_E_ARG;
         int st = 0;

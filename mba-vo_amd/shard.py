@@ -147,8 +147,9 @@ class P2PCollective:
     released; the regions grow on demand -- every rank sees the same sequence of counts, so they grow together."""
     name = "p2p(one-shot, peer-mapped regions)"
 
-    def __init__(self, ctx, rank, world, group=None, max_doubles=1 << 15):
-        self.ctx, self.rank, self.world, self.group, self.cap = ctx, rank, world, group, 0
+    def __init__(self, ctx, rank, world, group=None, max_doubles=1 << 15, timeout=None):
+        """timeout: seconds a collective waits for a peer before it gives up (None: the library's 20 s)"""
+        self.ctx, self.rank, self.world, self.group, self.cap, self.timeout = ctx, rank, world, group, 0, timeout
         self._ensure(max_doubles)
 
     def _ensure(self, doubles):
@@ -186,7 +187,14 @@ class P2PCollective:
             lib.mbavo_p2p_destroy(h)
             raise RuntimeError("mbavo_p2p_connect failed on rank(s) %s (codes %s)" % ([i for i, r in enumerate(codes) if r != 0], codes))
         assert lib.mbavo_p2p_ranks(h) == self.world
+        if self.timeout is not None:
+            capi.check(lib.mbavo_p2p_set_timeout(h, float(self.timeout)), "mbavo_p2p_set_timeout")
         self.cap = cap
+
+    def status(self):
+        """0, or MBAVO_E_TIMEOUT once a collective gave up on a peer (its output was filled with NaN); synchronises the stream.
+        The host-side consumer of a reduced buffer calls this before it trusts the numbers."""
+        return int(self.ctx.lib.mbavo_p2p_status(self.ctx.handle))
 
     def allreduce(self, send, recv, count):
         self._ensure(count)

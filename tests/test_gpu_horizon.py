@@ -77,8 +77,21 @@ def test_track_frame_teacher_forced_k4(orc, mbavo, gpu_ctx):
     got = frontend.run_gpu_vo(mbavo, gpu_ctx, short, cfg4, init_knots=4, teacher=want)
     st = horizon.compare(got, want, gt[:151], min_step_quality=cfg["min_quality"])
     assert st["first_discrete_divergence"] is None, st["first_divergence"]
-    rel = np.array([np.abs(a["T"] - b["T"]).max() / max(1.0, np.abs(b["T"]).max()) for a, b in zip(got, want)])
+    d = np.array([np.abs(a["T"] - b["T"]).max() for a, b in zip(got, want)])
+    size = np.array([max(1.0, np.abs(b["T"]).max()) for b in want])
+    rel = d / size
     assert np.median(rel) <= 1e-9 and np.quantile(rel, 0.9) <= 1e-6, (np.median(rel), np.quantile(rel, 0.9))
+    # THE OUTLIER, not hidden under a quantile: one frame (90 in the 300-frame record, profiles/
+    # r06_long_horizon.txt) has a one-step pose difference of 3.8e-2 on IDENTICAL discrete records.  By then the oracle's own state has
+    # run away (|translation| of the order 1e2 .. 1e3: `size`), and the frame's steps are minimum-norm solutions of a rank-deficient
+    # 24 x 24 system, whose null-space component is decided by rounding.  Held to the state's magnitude it is bounded:
+    worst = int(np.argmax(d))
+    assert rel.max() <= 1e-3, ("worst frame %d: |pose diff| %.3e on a state of size %.3e" % (worst, d[worst], size[worst]))
+    # ... and every frame whose state is still of the scene's size (|T| <= 10) agrees to 1e-6 absolutely
+    tame = size <= 10.0
+    assert tame.sum() >= 10 and d[tame].max() <= 1e-6, (int(tame.sum()), float(d[tame].max()))
+    print("k = 4 teacher-forced: worst frame %d |pose diff| %.3e, state size %.3e, relative %.3e; frames with |T| <= 10: %d, their max diff %.3e"
+          % (worst, d[worst], size[worst], rel[worst], int(tame.sum()), float(d[tame].max())))
 
 
 @pytest.mark.parametrize("B,step,k,N", [(64, 1, 4, 4), (64, 1, 2, 2), (512, 8, 4, 4)])
