@@ -452,6 +452,9 @@ const char *mbavo_last_kernel(mbavo_ctx *ctx);
 /* host-side phase timers of the tracking loop (enabled by MBAVO_TIMING=1 in the environment): print the totals since
  * the last report to stderr and reset them.  Development aid; a no-op when the timers are off. */
 void mbavo_timing_report(void);
+/* The MBAVO_* override variables of the A/B tools (csrc/options.h) are read ONCE per process; a tool that changes one inside a
+ * running process calls this afterwards.  Not for concurrent use with running API calls. */
+void mbavo_reload_env(void);
 /* process-wide counters of the host LM loop's ride-along evaluations (mbavo_track_opts.ride_along) since the last call:
  * out[0] commands that carried one, out[1] pyramid levels that started on theirs, out[2] levels that waited a wasted one
  * out before their first command (it shares the level's ticket counters and partials with that command).  Reset on read. */

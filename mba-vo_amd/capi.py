@@ -131,7 +131,7 @@ SYMBOLS = [
     "mbavo_allreduce_blocks_p2p", "mbavo_p2p_status", "mbavo_p2p_disconnect", "mbavo_p2p_destroy", "mbavo_vo_last_trace", "mbavo_vo_get_state", "mbavo_vo_set_state", "mbavo_vo_set_keyframe", "mbavo_vo_num_keypoints", "mbavo_vo_get_keypoints", "mbavo_vo_track_frame", "mbavo_lm_batch",
     "mbavo_shard_keypoints", "mbavo_shard_frames", "mbavo_system_len", "mbavo_merge_device", "mbavo_comm_unique_id",
     "mbavo_comm_init", "mbavo_comm_ranks", "mbavo_comm_destroy", "mbavo_last_kernel", "mbavo_timing_report",
-    "mbavo_ride_along_stats", "mbavo_p2p_set_timeout",
+    "mbavo_ride_along_stats", "mbavo_p2p_set_timeout", "mbavo_reload_env",
 ]
 
 
@@ -175,6 +175,7 @@ def load():
     L.mbavo_version.restype = C.c_char_p
     L.mbavo_ride_along_stats.argtypes = [C.POINTER(C.c_longlong)]
     L.mbavo_ride_along_stats.restype = None
+    L.mbavo_reload_env.restype = None
     L.mbavo_p2p_set_timeout.argtypes = [vp, C.c_double]
     L.mbavo_create.argtypes = [C.POINTER(vp), C.c_int]
     L.mbavo_destroy.argtypes = [vp]

@@ -682,6 +682,7 @@ extern "C"
     }
 
     void mbavo_timing_report(void) { mbavo::PhaseTimers::get().report(); }
+    void mbavo_reload_env(void) { mbavo::reload_env_overrides(); }
     void mbavo_ride_along_stats(long long out[3])
     {
         mbavo::RideAlongStats &s = mbavo::RideAlongStats::get();

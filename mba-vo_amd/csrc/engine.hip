@@ -1406,8 +1406,10 @@ namespace mbavo
 #endif
     // ONE 8-byte word carries the whole command (round 3: sequence number, mode and generation used to be three words, i.e. two
     // more dependent device-memory round trips before a workgroup could start): the host stores it AFTER the inputs are in place.
-    //   bits 20..63 sequence number   bits 8..19 generation: which launch the command is for (workgroups of an earlier launch
-    //   that have not seen their exit command yet leave when they meet a command of a later generation)
+    //   bits 24..63 sequence number (40 bits)   bits 20..23 second problem (below)   bits 8..19 generation (12 bits): which launch the
+    //   command is for (workgroups of an earlier launch that have not seen their exit command yet leave when they meet a command of
+    //   a later generation; joint mode starts one launch per tracked frame, so the field wraps every 4096 frames -- ADVICE r05: the
+    //   second problem's bits come out of the sequence field, not out of this one)
     //   bits 4..7 problem of the kernel's list the command is for (the pyramid level when one kernel serves all levels)
     //   bits 0..3 mode: 0 = exit, 1 = cost-only evaluation, 2 = H/g evaluation, 3 = the last H/g evaluation summed again under the
     //   flags and the scale as they are now (sp_resum_body)
@@ -1420,7 +1422,7 @@ namespace mbavo
     // completion word is the second line of the pinned flag area.  15: none.
     static inline unsigned long long persist_word(unsigned long long seq, int gen, int mode, int prob = 0, int prob2 = 15)
     {
-        return (seq << 20) | ((unsigned long long)(prob2 & 0xf) << 16) | ((unsigned long long)(gen & 0xff) << 8) | ((unsigned long long)(prob & 0xf) << 4) |
+        return (seq << 24) | ((unsigned long long)(prob2 & 0xf) << 20) | ((unsigned long long)(gen & 0xfff) << 8) | ((unsigned long long)(prob & 0xf) << 4) |
                (unsigned long long)(mode & 0xf);
     }
     template <int KD, int LOGS>
@@ -1446,13 +1448,13 @@ namespace mbavo
                 for (;;)
                 { // relaxed: an acquire here would invalidate the caches on every poll
                     const unsigned long long w = __hip_atomic_load(&cmd->word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    q = w >> 20;
+                    q = w >> 24;
                     if (q != last_seq)
                     {
                         m = (int)(w & 0xf);
                         pr = (int)((w >> 4) & 0xf);
-                        if ((int)((w >> 8) & 0xff) != (gen & 0xff)) m = 0;
-                        second = m != 0 && (int)((w >> 16) & 0xf) == my_prob && pr != my_prob; // the command's second problem: H / g
+                        if ((int)((w >> 8) & 0xfff) != (gen & 0xfff)) m = 0;
+                        second = m != 0 && (int)((w >> 20) & 0xf) == my_prob && pr != my_prob; // the command's second problem: H / g
                         if (second) m = 2;
                         if (m == 0 || pr == my_prob || second) break;
                         last_seq = q; // another problem's evaluation: not for this workgroup

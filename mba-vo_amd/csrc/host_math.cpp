@@ -4,7 +4,9 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <atomic>
 #include <cmath>
+#include <mutex>
 #include <cstdlib>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -381,7 +383,7 @@ namespace mbavo
         return true;
     }
 
-    EnvOverrides read_env_overrides()
+    static EnvOverrides scan_environment()
     { // THE reader of the environment for every switch that changes results or scheduling (options.h); the A/B tools' override layer
         auto num = [](const char *name) { const char *v = getenv(name); return v && *v ? atoi(v) : kEnvUnset; };
         auto real = [](const char *name) { const char *v = getenv(name); return v && *v ? atof(v) : -2.0; };
@@ -396,6 +398,32 @@ namespace mbavo
         if (e.fast_solve < 0.0 && e.fast_solve > -2.0) e.fast_solve = 0.0; // (a negative number in the variable: off)
         if (e.lm_refine < 0.0 && e.lm_refine > -2.0) e.lm_refine = 0.0;
         return e;
+    }
+
+    // The scan above is 22 getenv calls; the engine asks for its tuning on every evaluation of the latency-bound path and the
+    // batched LM's group threads ask concurrently (getenv beside a setenv is undefined behaviour) -- so the environment is scanned
+    // ONCE per process and again only when a tool says it changed it (mbavo_reload_env).
+    static std::mutex g_env_mutex;
+    static EnvOverrides g_env;
+    static std::atomic<bool> g_env_valid{false};
+    EnvOverrides read_env_overrides()
+    {
+        if (!g_env_valid.load(std::memory_order_acquire))
+        {
+            std::lock_guard<std::mutex> lock(g_env_mutex);
+            if (!g_env_valid.load(std::memory_order_relaxed))
+            {
+                g_env = scan_environment();
+                g_env_valid.store(true, std::memory_order_release);
+            }
+        }
+        return g_env;
+    }
+    void reload_env_overrides()
+    {
+        std::lock_guard<std::mutex> lock(g_env_mutex);
+        g_env = scan_environment();
+        g_env_valid.store(true, std::memory_order_release);
     }
 
     int solve_normal_equation_host(const double *A, const double *b, int n, int solver_type, double *x, double fast_ratio)

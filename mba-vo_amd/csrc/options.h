@@ -4,7 +4,7 @@
 // (mbavo_engine_opts on the context, the tails of mbavo_track_opts / mbavo_vo_options / mbavo_lm_batch_opts); a zeroed struct is
 // the default everywhere: tri-state ints 0 = default, 1 = on, -1 = off; numbers 0 = default.
 // The environment variables of the A/B tools still OVERRIDE an option, and read_env_overrides() below is the ONE function that
-// reads them (fresh at every API call: the tools flip them inside a process).  Pure diagnostics -- MBAVO_TIMING,
+// reads them (once per process; a tool that flips one inside a process calls mbavo_reload_env afterwards).  Pure diagnostics -- MBAVO_TIMING,
 // MBAVO_LM_STAMPS, MBAVO_LM_STATS -- change no result and no schedule and stay environment-only where they are used.
 #ifndef MBAVO_OPTIONS_H
 #define MBAVO_OPTIONS_H
@@ -22,7 +22,8 @@ namespace mbavo
         int lm_eig, lm_poses, lm_defer, lm_retile, lm_groups;                                                       // batched LM
         double fast_solve, lm_refine; // the variable's number; -2: unset
     };
-    EnvOverrides read_env_overrides(); // host_math.cpp
+    EnvOverrides read_env_overrides(); // host_math.cpp: the process's environment, scanned once and cached
+    void reload_env_overrides();       // ... scanned again (mbavo_reload_env: the A/B tools call it after they change a variable)
 
     // tri-state option (0 default / 1 on / -1 off) under an environment override (any integer: non-zero = on)
     inline bool opt_flag(int option, int env, bool dflt) { return env != kEnvUnset ? env != 0 : (option == 0 ? dflt : option > 0); }

@@ -737,13 +737,24 @@ namespace mbavo
                 }
                 first = false;
             }
-            for (; s < S; ++s)
-            { // the remainder, one at a time (S not a multiple of the group: S = 1, 3, ...)
+            for (; s + 1 < S; s += 2)
+            { // the remainder (S < 4 or S not a multiple of the group) in PAIRS, as the with-Jacobian path below issues them: two
+              // samples' taps in flight (one at a time serialised S = 2, 3 and the tails); the intensities are still
+              // added in sample order
+                sample_issue<KDEG, false, HALF_GRAD>(MBAVO_TAB(s), ray, depth, iz, cam, I_ref, G_ref, fa);
+                sample_issue<KDEG, false, HALF_GRAD>(MBAVO_TAB(s + 1), ray, depth, iz, cam, I_ref, G_ref, fb);
+                ok = ok && fa.taps.ok && fb.taps.ok;
+                if (first) sample_retire<KDEG, false, true, HALF_GRAD>(MBAVO_TAB(s), fa, ray, depth, iz, cam, isum, Jrow);
+                else sample_retire<KDEG, false, false, HALF_GRAD>(MBAVO_TAB(s), fa, ray, depth, iz, cam, isum, Jrow);
+                sample_retire<KDEG, false, false, HALF_GRAD>(MBAVO_TAB(s + 1), fb, ray, depth, iz, cam, isum, Jrow);
+                first = false;
+            }
+            if (s < S)
+            { // odd S: the last sample alone
                 sample_issue<KDEG, false, HALF_GRAD>(MBAVO_TAB(s), ray, depth, iz, cam, I_ref, G_ref, fa);
                 ok = ok && fa.taps.ok;
                 if (first) sample_retire<KDEG, false, true, HALF_GRAD>(MBAVO_TAB(s), fa, ray, depth, iz, cam, isum, Jrow);
                 else sample_retire<KDEG, false, false, HALF_GRAD>(MBAVO_TAB(s), fa, ray, depth, iz, cam, isum, Jrow);
-                first = false;
             }
         }
         else if (S >= 2)

@@ -80,13 +80,13 @@ def test_binding_structs_mirror_the_library(mbavo):
 
 def test_environment_is_read_in_one_place():
     """the switches that change results or scheduling are options; the environment is an override layer
-    read by ONE function (csrc/options.h: read_env_overrides); at most four getenv names (diagnostics) elsewhere."""
+    read by ONE function (csrc/host_math.cpp: scan_environment behind options.h's read_env_overrides, once per process); at most four getenv names (diagnostics) elsewhere."""
     names = {}
     base = os.path.join(ROOT, "mba-vo_amd", "csrc")
     for f in os.listdir(base):
         txt = open(os.path.join(base, f), errors="ignore").read()
         if f == "host_math.cpp":  # the one reader: cut its body out
-            a = txt.index("EnvOverrides read_env_overrides()")
+            a = txt.index("static EnvOverrides scan_environment()")
             txt = txt[:a] + txt[txt.index("return e;", a):]
         for m in re.finditer(r'getenv\("(MBAVO_[A-Z0-9_]+)"\)', txt):
             names.setdefault(m.group(1), set()).add(f)

@@ -8,7 +8,7 @@ for r in $(seq $R); do
   for f in tools/_ab/libmbavo_*.so; do
     v=$(basename $f .so); v=${v#libmbavo_}
     cp $f mba-vo_amd/libmbavo.so
-    python bench.py --steps 300 --warmup 40 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "
+    python bench.py --steps 300 --warmup 40 --no-cpu-baseline --details-out /dev/null "$@" 2>&1 | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print('$v', d['roofline']['kernel_ms']*1e3, d['ms_per_step']*1e3)"
   done
 done | python -c "

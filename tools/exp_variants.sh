@@ -8,7 +8,7 @@ for v in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize $defs $EXP_FLAGS -c mba-vo_amd/csrc/engine.hip -o /tmp/engine_exp.o 2>/dev/null || { echo "compile failed: $v"; continue; }
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o mba-vo_amd/libmbavo.so /tmp/engine_exp.o $(ls mba-vo_amd/build/*.o | grep -v engine) -ldl
   if [ -n "$EXP_CMD" ]; then echo "== $v"; eval "$EXP_CMD"; continue; fi
-  python bench.py --steps 100 --warmup 10 --no-cpu-baseline ${EXP_BENCH_ARGS} 2>&1 | tail -1 | python -c "
+  python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-configs --details-out /dev/null ${EXP_BENCH_ARGS} 2>&1 | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']
 print('%-28s fused %.4f ms  step %.4f ms' % ('$v', r['kernel_ms'], d['ms_per_step']))"
 done

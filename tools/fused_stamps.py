@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import mba_vo_amd as M
 from mba_vo_amd import workloads as wl
-import bench
+import bench_core as bench
 ctx = M.capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 lib = ctx.lib
 lib.mbavo_debug_fused_stamps.argtypes = [C.c_void_p, C.c_int]

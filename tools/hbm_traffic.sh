@@ -14,7 +14,7 @@ for _ in range(5):
 torch.cuda.synchronize()
 PY
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d "$OUT/bench_$C" -o p -- python bench.py --steps 20 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-configs $HBM_BENCH_ARGS > /dev/null 2> "$OUT/err_$C.txt"
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/bench_$C" -o p -- python bench.py --steps 20 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-configs --details-out /dev/null $HBM_BENCH_ARGS > /dev/null 2> "$OUT/err_$C.txt"
   rocprofv3 --pmc $C --output-format csv -d "$OUT/calib_$C" -o p -- python /tmp/calib.py > /dev/null 2>> "$OUT/err_$C.txt"
 done
 python - "$OUT" <<'PY'

@@ -52,6 +52,7 @@ for seed in range(first, first + count):
         for key in ("MBAVO_LM_REFINE", "MBAVO_FAST_SOLVE"):
             os.environ.pop(key, None)
         os.environ.update(env)
+        ctx.lib.mbavo_reload_env()  # (the library scans the environment once per process)
         dw = workloads.DeviceWorkload(probs)
         if host is None:
             host = []

@@ -26,6 +26,7 @@ for B in sizes:
             out = {}
             for mode in ("1", "0"):
                 os.environ["MBAVO_LM_RETILE"] = mode
+                ctx.lib.mbavo_reload_env()  # (the library scans the environment once per process)
                 batch.reset_knots()
                 o = capi.LmBatchOpts()
                 o.spline_deg_k, o.max_num_iterations, o.max_consecutive_nonmonotonic_steps = 4, 10, 5

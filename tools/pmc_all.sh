@@ -9,7 +9,7 @@ i=0
 for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES"; do
   i=$((i+1))
-  rocprofv3 --pmc $SET --output-format csv -d "$OUT/set$i" -o pmc -- python bench.py --steps 20 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-configs > /dev/null 2> "$OUT/err$i.txt" || tail -3 "$OUT/err$i.txt"
+  rocprofv3 --pmc $SET --output-format csv -d "$OUT/set$i" -o pmc -- python bench.py --steps 20 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-configs --details-out /dev/null > /dev/null 2> "$OUT/err$i.txt" || tail -3 "$OUT/err$i.txt"
 done
 python - "$OUT" "profiles/${TAG}_pmc_sq.json" <<'PY'
 import csv, sys, glob, collections, json

@@ -14,7 +14,7 @@ for W in $WL; do
   OUT=${PROF_SCRATCH:-gpurun_out}/pmc_fp64_$W
   rm -rf "$OUT"; mkdir -p "$OUT"
   for C in SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU SQ_INSTS_MFMA; do
-    rocprofv3 --pmc $C --output-format csv -d "$OUT/$C" -o p -- python bench.py --steps 10 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-configs $(wl_args $W) > /dev/null 2> "$OUT/err_$C.txt" || echo "pass $C failed: $(tail -1 $OUT/err_$C.txt)"
+    rocprofv3 --pmc $C --output-format csv -d "$OUT/$C" -o p -- python bench.py --steps 10 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-configs --details-out /dev/null $(wl_args $W) > /dev/null 2> "$OUT/err_$C.txt" || echo "pass $C failed: $(tail -1 $OUT/err_$C.txt)"
   done
   SUF=""; [ "$W" != "c2_dense" ] && SUF="_$W"
   python - "$OUT" "profiles/${TAG}_pmc_fp64${SUF}.json" <<'PY'

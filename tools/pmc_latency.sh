@@ -14,7 +14,7 @@ for SET in "SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_INST_CYCLES_SMEM SQ_ACTIVE_INST_
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" \
            "GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $SET --output-format csv -d "$OUT/set$i" -o pmc -- python bench.py --steps 20 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-configs --workload $W > /dev/null 2> "$OUT/err$i.txt" || tail -3 "$OUT/err$i.txt"
+  rocprofv3 --pmc $SET --output-format csv -d "$OUT/set$i" -o pmc -- python bench.py --steps 20 --warmup 3 --min-seconds 0 --no-cpu-baseline --no-configs --details-out /dev/null --workload $W > /dev/null 2> "$OUT/err$i.txt" || tail -3 "$OUT/err$i.txt"
 done
 SUF=""; [ "$W" != "c2_dense" ] && SUF="_$W"
 python - "$OUT" "profiles/${TAG}_pmc_latency${SUF}.json" <<'PY'

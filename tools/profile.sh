@@ -6,7 +6,7 @@ TAG=${1:-r01}; shift || true
 export TMPDIR=/tmp
 OUT=${PROF_SCRATCH:-gpurun_out}/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT" profiles
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o trace -- python bench.py --no-cpu-baseline --no-configs "$@" > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o trace -- python bench.py --no-cpu-baseline --no-configs --details-out /dev/null "$@" > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
 STATS=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
 cp "$STATS" profiles/${TAG}_kernel_stats.csv
 tail -1 "$OUT/bench.json" > profiles/${TAG}_bench_under_rocprof.json
