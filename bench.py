@@ -196,6 +196,22 @@ def compact_line(full, details_path):
 
 
 def main():
+    """One rank of the bench.  Whatever goes wrong after the launch checks, rank 0 still prints ONE parseable line saying so (a
+    driver that finds no line cannot tell a crash from a hang), then the exception propagates."""
+    state = {"emit": None, "rank": int(os.environ.get("RANK", "0")), "printed": False}
+    try:
+        run(state)
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001 (reported, then re-raised)
+        if state["emit"] is not None and state["rank"] == 0 and not state["printed"]:
+            import traceback
+            where = traceback.extract_tb(e.__traceback__)[-1]
+            state["emit"]({"error": short(repr(e), 300), "where": "%s:%d" % (os.path.basename(where.filename), where.lineno), "metric": None, "value": None})
+        raise
+
+
+def run(state):
     args = parse()
     if args.p2p_canary:
         import bench_side
@@ -220,6 +236,7 @@ def main():
 
     def emit(obj):
         os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+    state["emit"], state["rank"] = emit, rank
 
     if not torch.cuda.is_available():
         if rank == 0:
@@ -567,6 +584,7 @@ def main():
                     break
         sys.stdout.flush()
         os.write(real_stdout, (text + "\n").encode())
+        state["printed"] = True
     if use_dist:
         dist.barrier()
         ctx.lib.mbavo_comm_destroy(ctx.handle)

@@ -24,9 +24,11 @@ SIZES = [1, 2, 3, 325, 511, 2600, 4097, 20000, 65537, 166400, 300001]  # (325 do
 def body(rank, world, port, steps, skew, kill_rank, kill_at, timeout, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")       # (the sandboxed hosts meter CPU time: 8 ranks x a thread pool each would thrash)
     import numpy as np
     import torch
     import torch.distributed as dist
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     import mba_vo_amd as M
@@ -37,7 +39,9 @@ def body(rank, world, port, steps, skew, kill_rank, kill_at, timeout, out_dir):
     rng = np.random.default_rng(7)                      # the same sequence on every rank
     lag = np.random.default_rng(1000 + rank)            # (the delays are a rank's own)
     g = torch.Generator().manual_seed(99)
-    pool = [torch.randn(300001, dtype=torch.float64, generator=g) for _ in range(world)]
+    # every rank's vectors live on the GPU: the expected results are formed there too, in the collective's own order (rank order,
+    # fp64 adds are the same IEEE operations on either side), so the check costs the host nothing
+    pool = [torch.randn(300001, dtype=torch.float64, generator=g).to("cuda:0") for _ in range(world)]
     bad, step = 0, -1
     t0 = time.time()
     for step in range(steps):
@@ -60,13 +64,13 @@ def body(rank, world, port, steps, skew, kill_rank, kill_at, timeout, out_dir):
                 want = want + pool[r][:n] * scale
         else:
             buf = torch.zeros(world * n + off, dtype=torch.float64, device="cuda:0")[off:]
-            buf[rank * n:(rank + 1) * n] = (pool[rank][:n] + scale).to("cuda:0")
+            buf[rank * n:(rank + 1) * n] = pool[rank][:n] + scale
             coll.allgather(buf, n)
             want = torch.cat([pool[r][:n] + scale for r in range(world)])
         t_c = time.time()
         torch.cuda.synchronize()
         st = coll.status()
-        got = buf.cpu()
+        got = buf
         if kill_rank >= 0 and step >= kill_at:
             # the peer is gone: this collective must have given up within the timeout, flagged and poisoned
             if mode == 0:
@@ -81,6 +85,7 @@ def body(rank, world, port, steps, skew, kill_rank, kill_at, timeout, out_dir):
                 open(os.path.join(out_dir, "rank%d.txt" % rank), "w").write(line + "\n")
             os._exit(0 if (st == -4 and poisoned) else 5)  # (no tear-down: its barriers would wait for the lost rank)
         if st != 0 or not torch.equal(got, want):
+            got, want = got.cpu(), want.cpu()
             w = torch.nonzero(got != want).flatten()
             print("rank %d step %d mode %s n %d off %d status %d: %d wrong, first at %s (got %r want %r)" %
                   (rank, step, "allreduce" if mode == 0 else "allgather", n, off, st, w.numel(), w[:4].tolist(),

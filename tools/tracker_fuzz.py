@@ -21,7 +21,10 @@ M.load()
 ctx = M.capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-bit_bad = orc_bad = resums = accepted = 0
+bit_bad = orc_bad = resums = accepted = waste_bad = 0
+import ctypes as C
+ride = (C.c_longlong * 3)()
+ctx.lib.mbavo_ride_along_stats(ride)  # (reset)
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     H, W = [(120, 160), (240, 320), (480, 640), (96, 128)][rng.integers(4)]
@@ -31,6 +34,9 @@ for seed in range(first, first + count):
     on = tracking.run_gpu_tracker(M, ctx, sc, dict(tracking.OPTS))
     off = tracking.run_gpu_tracker(M, ctx, sc, dict(tracking.OPTS, resum=-1, ride_along=-1, speculate=-1))
     same = on["trace"] == off["trace"] and np.array_equal(on["kt"], off["kt"]) and np.array_equal(on["kR"], off["kR"]) and on["cost"] == off["cost"]
+    # every ride-along treated as taken at other knots (ride_along = 2): each level starts behind a wasted one that is waited out
+    waste = tracking.run_gpu_tracker(M, ctx, sc, dict(tracking.OPTS, ride_along=2))
+    waste_bad += 0 if (waste["trace"] == off["trace"] and np.array_equal(waste["kt"], off["kt"]) and np.array_equal(waste["kR"], off["kR"]) and waste["cost"] == off["cost"]) else 1
     want = tracking.run_oracle_tracker(orc, sc, dict(tracking.OPTS))
     seq = [t[:4] for t in on["trace"]] == [t[:4] for t in want["trace"]]
     grew = sum(1 for a, b in zip(on["trace"], on["trace"][1:]) if b[2] == 1 and a[0] == b[0] and b[3] > a[3])
@@ -40,5 +46,7 @@ for seed in range(first, first + count):
     orc_bad += 0 if seq else 1
     if not same or not seq:
         print("seed %d %s: short cuts == plain loop: %s; record sequence == oracle's: %s (%d records)" % (seed, kw, same, seq, len(on["trace"])))
+ctx.lib.mbavo_ride_along_stats(ride)
 print("seeds %d..%d: %d scene(s) where the shortened loop differs from the plain one in any bit; %d where the record sequence differs from the "
-      "oracle's; %d accepted steps, %d of them flagged new outliers (re-summations)" % (first, first + count - 1, bit_bad, orc_bad, accepted, resums))
+      "oracle's; %d accepted steps, %d of them flagged new outliers (re-summations); %d scene(s) where the loop with every ride-along WASTED "
+      "differs in any bit (ride-alongs posted %d, used %d, waited out %d)" % (first, first + count - 1, bit_bad, orc_bad, accepted, resums, waste_bad, ride[0], ride[1], ride[2]))
