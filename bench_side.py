@@ -96,7 +96,7 @@ def run_p2p_canary(shared_gpu):
         env["MBAVO_CANARY_SHARED"] = "1"
     try:
         p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--p2p-canary"], env=env, stdout=subprocess.DEVNULL,
-                           stderr=subprocess.PIPE, timeout=240)
+                           stderr=subprocess.PIPE, timeout=120)
     except subprocess.TimeoutExpired:
         return False, "timeout"
     return p.returncode == 0, "rc %d%s" % (p.returncode, (": " + p.stderr.decode(errors="replace").strip().splitlines()[-1][:200]) if p.returncode and p.stderr.strip() else "")
