@@ -132,8 +132,8 @@ def compact_line(full, details_path):
     """The line the driver parses: the contract's keys with numbers and <= 60-character labels; everything else stays in `full`
     (the DETAILS file).  Six side figures and the parity figures ride along."""
     keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-            "data", "repeats", "ms_per_step_min_max", "ms_per_step_incl_d2h")
-    line = {k: full[k] for k in keys if k in full}
+            "data", "repeats", "ms_per_step_min_max", "ms_per_step_incl_d2h", "ms_per_step_to_pinned_host", "to_pinned_host_same_bits")
+    line = {k: (short(full[k], 100) if isinstance(full[k], str) else full[k]) for k in keys if k in full}
     c = full["config"]
     line["config"] = {"workload": c["name"], "shape": short(c["shape"], 100), "problems_per_rank": c["problems_per_rank"],
                       "pixel_samples_per_step_per_rank": c["pixel_samples_per_step_per_rank"], "parallelism": short(c["parallelism_short"], 100)}
@@ -399,7 +399,7 @@ def run(state):
 
     # the D2H-inclusive step: the packed blocks copied to pinned host memory after every evaluation, which is
     # what a host-side LM consumer of the blocks waits for (N = 1 only; never `value`)
-    d2h_ms = None
+    d2h_ms = to_host_ms = to_host_same = None
     if run.se is None:
         host = torch.empty(run.dw.frame_blocks.shape, dtype=torch.float64).pin_memory()
         for _ in range(3):
@@ -415,6 +415,33 @@ def run(state):
                 pass
         torch.cuda.synchronize()
         d2h_ms = (time.perf_counter() - t0) / n_d2h * 1e3
+        # ... and without the copy: the finalize step stores the packed blocks, the merged systems and the valid counts straight into
+        # PINNED HOST memory (the C ABI takes any device-accessible pointer; this is how the library's own LM loop gets its results),
+        # the host polls the stream -- what a host-side consumer pays when it hands the library host buffers (never `value`)
+        try:
+            if args.cost_only or getattr(run.dw, "systems", None) is None:
+                raise RuntimeError("merged H/g steps only")
+            h_fb = torch.empty(run.dw.frame_blocks.shape, dtype=torch.float64).pin_memory()
+            h_sys = torch.empty(run.dw.systems.shape, dtype=torch.float64).pin_memory()
+            h_valid = torch.empty(run.dw.valid.shape, dtype=torch.float64).pin_memory()
+
+            def host_step():
+                M.capi.check(ctx.lib.mbavo_eval_batch_merged(ctx.handle, run.dw.B, run.dw.array, run.dw.k, h_fb.data_ptr(), h_sys.data_ptr(), None,
+                                                             h_valid.data_ptr()), "mbavo_eval_batch_merged")
+            for _ in range(3):
+                host_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_d2h):
+                host_step()
+                while not stream.query():
+                    pass
+            to_host_ms = (time.perf_counter() - t0) / n_d2h * 1e3
+            run.step()
+            torch.cuda.synchronize()
+            to_host_same = bool(torch.equal(h_fb, run.dw.frame_blocks.cpu()) and torch.equal(h_sys, run.dw.systems.cpu()))
+        except Exception as e:  # (a side figure must not cost the line)
+            to_host_ms, to_host_same = None, repr(e)
 
     counts = run.local_counts()
     ps_rank = sum(px * S for px, S, _ in counts)
@@ -475,6 +502,10 @@ def run(state):
             out["roofline"] = h
         if d2h_ms is not None:
             out["ms_per_step_incl_d2h"] = round(d2h_ms, 5)
+        if to_host_ms is not None:
+            out["ms_per_step_to_pinned_host"] = round(to_host_ms, 5)
+        if to_host_same is not None:
+            out["to_pinned_host_same_bits"] = to_host_same
         if use_dist:
             out["rccl_ranks"] = rccl_ranks
             out["comm"] = ("p2p one-shot collectives" + (", %d ranks on %d GPU(s): NOT a scaling measurement" % (world, torch.cuda.device_count()) if shared_gpu else "")) if use_p2p \
