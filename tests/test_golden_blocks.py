@@ -44,6 +44,77 @@ def test_oracle_reproduces_packed_blocks(orc, vec, stage, name, a):
     assert np.array_equal(fbm.reshape(F, E), vec[tag + "_frame_blocks_masked"])
 
 
+def _tree_reduce(v):
+    """reduce() of ba_tracker/reduction.h:13-55 over the last axis (power-of-two length): buffer[t] += buffer[t + s], s halving."""
+    v = np.array(v, dtype=np.float64)
+    n = v.shape[-1]
+    if n & (n - 1):  # SURVEY A10: reduce() drops elements of a non-power-of-two buffer; the defined semantics adds all, in order
+        acc = np.zeros(v.shape[:-1])
+        for i in range(n):
+            acc = acc + v[..., i]
+        return acc
+    while n > 1:
+        n //= 2
+        v = v[..., :n] + v[..., n:2 * n]
+    return v[..., 0]
+
+
+def kernel_source_blocks(res, jac, F, K, P, k, a, inv, mask=None):
+    """The two reduction kernels AS THEIR SOURCE IS WRITTEN (compute_hessian_gradients_cost.cu:165-239 and :247-283), in numpy:
+    Huber with the kernel's own fp32 islands -- sqrt_drho_dx = sqrtf(a / (sqrtf(x) + 1e-8)), rho = 2 a sqrtf(x) - a^2 -- the
+    weighted row, every product row[i] * row[j] reduced over the patch's pixels by reduce()'s tree and scaled by
+    inv_num_residuals; then per frame and entry 256 threads' strided partial sums (flagged keypoints skipped) and the tree.
+    An independent restatement from the oracle's C (the harness' formula lacks the + 1e-8 and is held
+    to 1e-8 / 1e-6; this one is held to the last bit)."""
+    m = 6 * k
+    nd = m + 1
+    r = res.reshape(F * K, P)
+    J = jac.reshape(F * K, P, m)
+    x = 0.5 * r * r
+    sx = np.sqrt(x.astype(np.float32)).astype(np.float64)                                  # sqrtf(x)
+    hub = x > a * a
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        w = np.where(hub, np.sqrt((a / (sx + 1e-8)).astype(np.float32)).astype(np.float64), 1.0)  # sqrtf(a / (sqrtf(x) + 1e-8))
+        rho = np.where(hub, 2 * a * sx - a * a, x)
+    row = np.concatenate([(w * r)[..., None], w[..., None] * J], axis=2)                   # [patch][pixel][nd]
+    E = nd * (nd + 1) // 2
+    pb = np.zeros((F * K, E))
+    e = 0
+    for i in range(nd):
+        for j in range(i, nd):
+            pb[:, e] = _tree_reduce(row[:, :, i] * row[:, :, j]) * inv
+            e += 1
+    pb[:, 0] = _tree_reduce(rho) * inv
+    fb = np.zeros((F, E))
+    pbf = pb.reshape(F, K, E)
+    for f in range(F):
+        part = np.zeros((256, E))
+        for i in range(K):  # thread i % 256 adds its keypoints in ascending order
+            if mask is not None and mask[i] == 1:
+                continue
+            part[i % 256] += pbf[f, i]
+        fb[f] = _tree_reduce(part.T)
+    return pb, fb
+
+
+@pytest.mark.parametrize("name,a", CASES)
+def test_blocks_equal_the_kernel_source_restated_in_numpy(vec, stage, name, a):
+    """a6 / a7 pinned tighter than the harness' tolerances: the committed patch and frame blocks (oracle outputs on the
+    reference-executed rows) equal a second, independent restatement of the kernels' SOURCE -- numpy, written from the .cu text
+    with its sqrtf islands, its + 1e-8 and reduce()'s tree -- to the last bit, with and without outlier flags."""
+    S, F, K, P, k = [int(v) for v in vec[name + "_in_scalars"][:5]]  # (k4: 8-pixel patches, reduce()'s tree; k2: 5 pixels, A10)
+    inv = float(vec[name + "_in_scalars"][6])
+    res, jac = np.ascontiguousarray(stage[name + "_out_residuals"]), np.ascontiguousarray(stage[name + "_out_jacobians"])
+    tag = "%s_a%g" % (name, a)
+    pb, fb = kernel_source_blocks(res, jac, F, K, P, k, a, inv)
+    assert np.array_equal(pb, vec[tag + "_patch_blocks"]), np.abs(pb - vec[tag + "_patch_blocks"]).max()
+    assert np.array_equal(fb, vec[tag + "_frame_blocks"]), np.abs(fb - vec[tag + "_frame_blocks"]).max()
+    _, fbm = kernel_source_blocks(res, jac, F, K, P, k, a, inv, mask=vec[name + "_mask"])
+    assert np.array_equal(fbm, vec[tag + "_frame_blocks_masked"])
+    if a < 1e30:
+        assert (0.5 * res * res > a * a).any(), "no pixel in the Huber branch: the case tests nothing of it"
+
+
 def test_host_merge_and_solvers_match_fixture(orc, mbavo, vec):
     """merge_hessian_gradient_cost (product host code and oracle) == the fixture exactly; the product's SVD / LDLT
     solvers on the damped system within rounding x cond(H) = 6e9 (1e-5 relative), residual ||Hx + g|| <= 1e-9 ||g||;
