@@ -115,6 +115,32 @@ def test_blocks_equal_the_kernel_source_restated_in_numpy(vec, stage, name, a):
         assert (0.5 * res * res > a * a).any(), "no pixel in the Huber branch: the case tests nothing of it"
 
 
+def test_merge_equals_the_source_restated_in_numpy(vec):
+    """a8 the same way: merge_hessian_gradient_cost.cpp:39-86 written out in numpy from its text (gradient halves at
+    3 * start and 3 * (N + start), the packed upper triangle walked row by row with the two offsets, both triangles of H, the
+    frames in ascending order) against the committed merged system, to the last bit."""
+    fb3, start = vec["merge_frame_blocks"], vec["merge_start"]
+    k, N = 4, 6
+    nd, W = 6 * k + 1, 6 * N
+    H, g, cost = np.zeros((W, W)), np.zeros(W), 0.0
+    for i in range(fb3.shape[0]):
+        st, blk = int(start[i]), fb3[i]
+        cost += blk[0]
+        g[3 * st:3 * st + 3 * k] += blk[1:1 + 3 * k]
+        g[3 * (N + st):3 * (N + st) + 3 * k] += blk[1 + 3 * k:1 + 6 * k]
+        off0, off1 = 3 * st, 3 * (N + st)
+        e = nd
+        for j in range(nd - 1):
+            r = j + (off0 if j < 3 * k else off1 - 3 * k)
+            for c_ in range(j, nd - 1):
+                c = c_ + (off0 if c_ < 3 * k else off1 - 3 * k)
+                H[r, c] += blk[e]
+                if c != r:
+                    H[c, r] += blk[e]
+                e += 1
+    assert np.array_equal(H.T.ravel(), vec["merge_H_colmajor"]) and np.array_equal(g, vec["merge_g"]) and cost == vec["merge_cost"][0]
+
+
 def test_host_merge_and_solvers_match_fixture(orc, mbavo, vec):
     """merge_hessian_gradient_cost (product host code and oracle) == the fixture exactly; the product's SVD / LDLT
     solvers on the damped system within rounding x cond(H) = 6e9 (1e-5 relative), residual ||Hx + g|| <= 1e-9 ||g||;
