@@ -61,7 +61,7 @@ namespace mbavo
             if (cost >= DBL_MAX) return -DBL_MAX;
             const double now = (s.current_cost - cost) / mcc;
             const double hist = (s.reference_cost - cost) / (s.acc_ref + mcc);
-            return fmax(now, hist);
+            return now < hist ? hist : now; // std::max(now, hist) as the reference's libstdc++ evaluates it: an unordered comparison hands back `now` (NaN included; trust_region_step_evaluator.cpp:74, tests/golden tr_edge_*)
         }
         __device__ __forceinline__ void tr_accepted(LmState &s, double cost, double mcc, int max_nonmono)
         {

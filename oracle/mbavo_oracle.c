@@ -1111,7 +1111,7 @@ double orc_tr_quality(const orc_tr *e, double cost, double model_cost_change)
     if (cost >= DBL_MAX) return -DBL_MAX;
     const double rel = (e->current_cost - cost) / model_cost_change;
     const double hist = (e->reference_cost - cost) / (e->acc_ref + model_cost_change);
-    return rel > hist ? rel : hist;
+    return rel < hist ? hist : rel; /* std::max(rel, hist) as libstdc++ evaluates it: a NaN first argument comes back (:74) */
 }
 void orc_tr_accepted(orc_tr *e, double cost, double mcc)
 {

@@ -143,6 +143,29 @@ R.ref_lm_delete(lm)
 R.ref_tr_delete(tr)
 out.update(lm_q=script_q, lm_c=script_c, lm_m=script_m, lm_radii=np.array(radii), tr_quality=np.array(quals))
 
+# ---- the evaluator's DEGENERATE quotients (round 6): StepQuality is std::max(relative, historical) of two quotients that can be
+# 0 / 0 or x / 0 (trust_region_step_evaluator.cpp:70-74) -- a tracker that has lost the scene evaluates cost 0 against cost 0 with a
+# zero model change -- and libstdc++'s std::max hands back its FIRST argument when the comparison is unordered.  Rows: reset cost, an
+# optional accepted (cost, model) before the query, the queried (cost, model); executed by the reference's compiled class.
+edge = np.array([[100.0, np.nan, np.nan, 100.0, 0.0],    # 0/0 and 0/0
+                 [100.0, 90.0, 5.0, 90.0, 0.0],          # relative 0/0, historical 10/5: NaN comes back, not 2
+                 [100.0, 90.0, 5.0, 100.0, -5.0],        # relative 2, historical 0/0: 2 comes back
+                 [0.0, np.nan, np.nan, 0.0, 0.5],        # 0 / 0.5
+                 [0.0, np.nan, np.nan, 0.0, 0.0],        # the lost tracker: cost 0 against cost 0, model change 0
+                 [100.0, np.nan, np.nan, 50.0, 0.0],     # +inf
+                 [100.0, np.nan, np.nan, 150.0, 0.0],    # -inf
+                 [100.0, np.nan, np.nan, np.finfo(np.float64).max, 1.0],  # the failure sentinel
+                 [100.0, 90.0, 5.0, 80.0, 0.0]])         # relative +inf, historical 4
+eq = []
+for row in edge:
+    tr = R.ref_tr_new(5)
+    R.ref_tr_reset(tr, float(row[0]))
+    if not np.isnan(row[1]):
+        R.ref_tr_accepted(tr, float(row[1]), float(row[2]))
+    eq.append(R.ref_tr_quality(tr, float(row[3]), float(row[4])))
+    R.ref_tr_delete(tr)
+out.update(tr_edge_script=edge, tr_edge_quality=np.array(eq))
+
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_vectors.npz")
 np.savez_compressed(path, **out)
 print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")

@@ -81,17 +81,24 @@ def test_track_frame_teacher_forced_k4(orc, mbavo, gpu_ctx):
     size = np.array([max(1.0, np.abs(b["T"]).max()) for b in want])
     rel = d / size
     assert np.median(rel) <= 1e-9 and np.quantile(rel, 0.9) <= 1e-6, (np.median(rel), np.quantile(rel, 0.9))
-    # THE OUTLIER, not hidden under a quantile: one frame (90 in the 300-frame record, profiles/
-    # r06_long_horizon.txt) has a one-step pose difference of 3.8e-2 on IDENTICAL discrete records.  By then the oracle's own state has
-    # run away (|translation| of the order 1e2 .. 1e3: `size`), and the frame's steps are minimum-norm solutions of a rank-deficient
-    # 24 x 24 system, whose null-space component is decided by rounding.  Held to the state's magnitude it is bounded:
-    worst = int(np.argmax(d))
-    assert rel.max() <= 1e-3, ("worst frame %d: |pose diff| %.3e on a state of size %.3e" % (worst, d[worst], size[worst]))
-    # ... and every frame whose state is still of the scene's size (|T| <= 10) agrees to 1e-6 absolutely
-    tame = size <= 10.0
-    assert tame.sum() >= 10 and d[tame].max() <= 1e-6, (int(tame.sum()), float(d[tame].max()))
-    print("k = 4 teacher-forced: worst frame %d |pose diff| %.3e, state size %.3e, relative %.3e; frames with |T| <= 10: %d, their max diff %.3e"
-          % (worst, d[worst], size[worst], rel[worst], int(tame.sum()), float(d[tame].max())))
+    # THE OUTLIER, not hidden under a quantile (gpurun_out / profiles: tools/k4_outlier.py).  One frame (90)
+    # has a one-step pose difference of 3.8e-2 on IDENTICAL discrete records.  It is the frame in which the ORACLE's own k = 4 run
+    # loses the scene: on the coarsest level an accepted step flags 46 outliers, the next accepted step is ~40 units long (the
+    # minimum-norm solution of a rank-deficient 24 x 24 system: four knots, one exposure) and lands where NO pixel is valid -- final
+    # cost exactly 0 on both sides, the state jumps from 1.3 to 38 and every later frame ends at cost 0.  The two ~40-unit steps agree
+    # to 1e-3 of their length; before that frame the runs agree to 1e-6 absolutely, after it (one-step comparisons of a lost
+    # tracker: nothing moves) to 1e-12 of the state.
+    cost = np.array([b["cost"] for b in want])
+    dead = np.nonzero((cost == 0.0) & (np.arange(len(cost)) > 0))[0]
+    assert dead.size > 0, "the oracle's k = 4 run no longer loses the scene: re-derive this test's statement"
+    lost = int(dead[0])
+    assert np.array_equal(dead, np.arange(lost, len(cost))) and all(a["cost"] == 0.0 for a in got[lost:])  # lost for good, on both sides
+    assert size[lost - 1] < 10.0 and size[lost] > 20.0                                                      # the jump
+    assert d[1:lost].max() <= 2e-6, (int(np.argmax(d[1:lost])) + 1, float(d[1:lost].max()))               # alive: absolute (observed 1.0e-6 at frame 1, <= 1e-7 after)
+    assert rel[lost] <= 5e-3, ("frame %d: |pose diff| %.3e on a state of size %.3e" % (lost, d[lost], size[lost]))  # observed 1.0e-3
+    assert rel[lost + 1:].max() <= 1e-9, float(rel[lost + 1:].max())
+    print("k = 4 teacher-forced: the oracle loses the scene at frame %d (state %.2f -> %.2f, final cost 0): |pose diff| there %.3e = %.2e of the state; "
+          "before: max %.2e; after: max %.2e of the state" % (lost, size[lost - 1], size[lost], d[lost], rel[lost], d[1:lost].max(), rel[lost + 1:].max()))
 
 
 @pytest.mark.parametrize("B,step,k,N", [(64, 1, 4, 4), (64, 1, 2, 2), (512, 8, 4, 4)])

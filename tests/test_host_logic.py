@@ -144,6 +144,22 @@ def test_segment_start_index_golden(mbavo):
         assert L.mbavo_segment_start_index(float(t), 0.0, 0.5) == i_ref
 
 
+def test_trust_region_degenerate_quotients_product(mbavo):
+    """The product's TrustRegionStepEvaluator on the same degenerate rows (tests/test_oracle_golden.py: executed by the reference's
+    compiled class): NaN where the reference's std::max returns NaN, the same bits elsewhere."""
+    L = mbavo.load()
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vectors.npz"))
+    L.mbavo_tr_step_quality.restype = C.c_double
+    for row, want in zip(G["tr_edge_script"], G["tr_edge_quality"]):
+        tr = L.mbavo_tr_new(5)
+        L.mbavo_tr_reset(tr, float(row[0]))
+        if not np.isnan(row[1]):
+            L.mbavo_tr_step_accepted(tr, float(row[1]), float(row[2]))
+        got = L.mbavo_tr_step_quality(tr, float(row[3]), float(row[4]))
+        L.mbavo_tr_delete(tr)
+        assert (np.isnan(got) and np.isnan(want)) or got == want, (row, got, want)
+
+
 def test_transformation_and_spline_frame_change_match_oracle(mbavo, orc):
     """Core::Transformation exp/log/*/inverse and SplineSE3::TransformTo of the product (host code, no device)
     against the oracle's restatement; tolerance 1e-14 (same closed forms, different quaternion-rotate grouping)."""

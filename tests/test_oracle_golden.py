@@ -126,6 +126,23 @@ def test_lm_and_trust_region_script(orc):
         assert lm.radius == G["lm_radii"][i]
 
 
+def test_trust_region_degenerate_quotients(orc):
+    """StepQuality where its quotients are 0 / 0 or x / 0 (a tracker that has lost the scene evaluates cost 0 against cost 0 with a
+    zero model change, tests/test_gpu_horizon.py k = 4): the reference's std::max hands back its FIRST argument when the comparison
+    is unordered (trust_region_step_evaluator.cpp:74) -- rows executed by the reference's compiled class; NaN must be NaN, numbers
+    the same bits.  (Round 6: the oracle returned the historical quotient where the relative one was NaN.)"""
+    L = orc.lib()
+    for row, want in zip(G["tr_edge_script"], G["tr_edge_quality"]):
+        tr = orc.OrcTr()
+        L.orc_tr_init(C.byref(tr), 5)
+        L.orc_tr_reset(C.byref(tr), float(row[0]))
+        if not np.isnan(row[1]):
+            L.orc_tr_accepted(C.byref(tr), float(row[1]), float(row[2]))
+        got = L.orc_tr_quality(C.byref(tr), float(row[3]), float(row[4]))
+        assert (np.isnan(got) and np.isnan(want)) or got == want, (row, got, want)
+    assert np.isnan(G["tr_edge_quality"][:2]).all() and G["tr_edge_quality"][2] == 2.0  # (the cases that tell std::max's argument order)
+
+
 def test_oracle_matches_live_reference_when_present(orc):
     """Extra, denser comparison against oracle/_ref itself (only where it has been built)."""
     R = orc.ref()
