@@ -67,9 +67,10 @@ def test_track_frame_300_frames_free_running_k2(orc, mbavo, gpu_ctx):
 
 
 def test_track_frame_teacher_forced_k4(orc, mbavo, gpu_ctx):
-    """k = 4 through trackFrame (four identity knots through getSplineTrajectory(), minimum-norm steps): the ORACLE itself runs
-    away on this sequence (four knots constrained by one short exposure: ATE 1e3 after 300 frames), so only the one-step form is a
-    parity statement: identical discrete results on every frame, poses relative to the size of the state."""
+    """k = 4 through trackFrame (four identity knots through getSplineTrajectory(), minimum-norm steps): the ORACLE itself loses the
+    scene on this sequence (four knots constrained by one short exposure: at frame 90 a minimum-norm step lands where no pixel is
+    valid), so only the one-step form is a parity statement: identical discrete results on every frame, poses to 1e-6 while the
+    oracle's tracker is alive, the losing step to 5e-3 of its length, nothing moving afterwards."""
     seq, cfg, _, gt = _long_run(orc, mbavo, gpu_ctx)
     short = dict(seq, times=seq["times"][:151])
     cfg4 = dict(cfg, k=4)
