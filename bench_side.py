@@ -4,7 +4,6 @@ canary child of the one-shot p2p collectives.  Their entries go to the DETAILS f
 handful of their numbers."""
 import os
 import sys
-import time
 
 import numpy as np
 
