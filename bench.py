@@ -45,7 +45,7 @@ os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 import numpy as np
 
 from bench_core import (FP64_PEAK_TFLOPS, HBM_PEAK_GBS, ROOT, WORKLOADS, Runner, executed_fp64_flops, issue_busy_fraction,
-                        kernel_name, launches_per_step, measured_hbm_traffic, stale_flags)
+                        kernel_name, launches_per_step, measured_hbm_traffic, rocprof_kernel_ms, stale_flags)
 
 LINE_LIMIT = 6000  # bytes of the JSON line (the driver keeps an 8 KB tail of stdout; round 5's 26 KB line did not parse)
 SHARED_COMMS = ("gloo", "p2p-shared")
@@ -142,7 +142,7 @@ def compact_line(full, details_path):
         if not r:
             continue
         keep = ("bound", "pipe", "achieved", "peak", "unit", "frac", "frac_is", "frac_executed", "frac_executed_is", "frac_of_traffic", "frac_upper",
-                "issue_busy_frac", "traffic", "kernel", "kernel_ms", "launches_timed", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch",
+                "issue_busy_frac", "traffic", "kernel", "kernel_ms", "launches_timed", "kernel_ms_rocprofv3", "frac_rocprofv3", "rocprofv3_stale", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch",
                 "executed_fp64_flops_per_launch", "step_frac", "launches_per_step", "counters_from", "stale", "kernel_source_sha")
         line[name] = {k: (short(r[k]) if isinstance(r[k], str) else r[k]) for k in keep if k in r and r[k] is not None or k == "traffic" and k in r}
     cb = full.get("cpu_baseline")
@@ -463,6 +463,7 @@ def run(state):
         exe, exe_src = executed_fp64_flops(wkey, kernel)
         sha_now, stale = stale_flags([("hbm_counters", wkey), ("pmc_fp64", wkey), ("pmc_sq", wkey)])
         per_step = [r / args.steps * 1e3 for r in regions]
+        rp_ms, rp_src, rp_stale = rocprof_kernel_ms(kernel) if wkey == "c2_dense" else (None, None, None)
         out = {
             "metric": "Mpixel-samples/s per GN iteration (640x480, 4-lvl pyr, 8 blur samples)" if wkey.startswith("c2") and wkey == args.workload
                       else "Mpixel-samples/s per GN iteration (%s)" % wkey,
@@ -484,6 +485,10 @@ def run(state):
                          "traffic": traffic, "traffic_source": traffic_src, "counters_from": "committed extracts: " + ", ".join(sorted(stale)) if stale else None,
                          "kernel_source_sha": sha_now, "counter_extracts_stale": stale, "stale": bool(any(stale.values())) if stale else None,
                          "kernel": kernel, "kernel_ms": round(k_ms, 6), "launches_timed": int(nlaunch[0]),
+                         # the committed rocprofv3 summary of the same command beside the live event timing (an event pair lengthens the
+                         # launch it is attached to by ~2 us, so the live figure -- the one frac uses -- errs low)
+                         "kernel_ms_rocprofv3": None if rp_ms is None else round(rp_ms, 6), "rocprofv3_source": rp_src, "rocprofv3_stale": rp_stale,
+                         "frac_rocprofv3": None if not rp_ms else round(flops / (rp_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 5),
                          "algorithmic_flops_per_launch": flops,
                          "step_frac": round(flops / (elapsed / args.steps) / 1e12 / FP64_PEAK_TFLOPS, 5) if elapsed > 0 else None,
                          "launches_per_step": launches_per_step(kernel)},

@@ -81,6 +81,31 @@ def committed_counters(kind, workload):
     return None, None
 
 
+def rocprof_kernel_ms(kernel):
+    """(mean duration [ms] of `kernel` in the newest committed `rocprofv3 --kernel-trace --stats` summary of the bench command,
+    its file, collected at another revision of the kernel sources?) -- profiles/rNN_kernel_stats.csv next to the line bench.py
+    printed under the profiler (rNN_bench_under_rocprof.json carries the sources' hash; tools/profile.sh writes both)."""
+    import csv
+    from mba_vo_amd import capi
+    want = kernel.replace("true", "1").replace("false", "0").replace(" ", "")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_kernel_stats.csv")), reverse=True):
+        try:
+            for row in csv.DictReader(open(path)):
+                name = row["Name"].split("(")[0].replace("void ", "").replace("mbavo::", "").replace(" ", "")
+                name = name.replace("true", "1").replace("false", "0")
+                if name == want:
+                    sha = None
+                    try:
+                        line = json.load(open(path.replace("_kernel_stats.csv", "_bench_under_rocprof.json")))
+                        sha = line["roofline"].get("kernel_source_sha")
+                    except Exception:
+                        pass
+                    return float(row["AverageNs"]) * 1e-6, os.path.basename(path), bool(sha != capi.kernel_source_sha())
+        except Exception:
+            continue
+    return None, None, None
+
+
 def stale_flags(sources):
     """{file: True/False}: was the committed extract collected at another revision of the kernel sources than the one
     this process runs?  (True also for extracts of earlier rounds that carry no hash.)"""
