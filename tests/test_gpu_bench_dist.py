@@ -83,6 +83,12 @@ def test_bench_line_default_run(mbavo, tmp_path):
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == line["unit"] and len(cb["sample"]) <= 80
     assert cb["gpu_vs_cpu_max_rel_diff"] < 1e-9
     assert line["roofline"]["bound"] == "mfma" and 0.3 < line["roofline"]["frac"] < 1.2 and line["roofline"]["kernel"].startswith("k_fused<4,true")
+    # the committed rocprofv3 summary of the same command (profiles/rNN_kernel_stats.csv) and the live event timing agree, and the
+    # committed counter extracts were collected at THIS revision of the kernel sources
+    rf = line["roofline"]
+    assert rf["stale"] is False and rf["rocprofv3_stale"] is False, (rf["stale"], rf["rocprofv3_stale"], rf["kernel_source_sha"])
+    assert abs(rf["kernel_ms_rocprofv3"] / rf["kernel_ms"] - 1.0) < 0.15 and rf["traffic"] > 1e7
+    assert line["to_pinned_host_same_bits"] is True and line["ms_per_step_to_pinned_host"] > line["ms_per_step"]
     side = line["side"]
     for k in ("trackframe_ms_per_frame", "lm_batch64_us_per_round", "lm_batch512_us_per_round", "c2_semidense_ms_per_step",
               "c2_dense_sequential_ms_per_step", "c2_dense_cost_only_ms_per_step"):
