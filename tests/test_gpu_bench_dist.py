@@ -97,6 +97,7 @@ def test_bench_line_default_run(mbavo, tmp_path):
     assert par["trackframe_discrete_results_equal"] and par["trackframe_abs_delta_ate"] <= 1e-5
     assert par["long_frames"] == 41 and par["teacher_forced_discrete_results_equal"] and par["teacher_forced_within_1e-5_frames"] == 41
     assert 10 <= par["free_running_within_1e-5_frames"] <= 41
+    assert par["exposure_0.08_free_running_within_1e-5_frames"] == 41 and par["exposure_0.08_first_discrete_divergence_frame"] is None
     # the details file: every side config without an error, the long descriptions
     assert not [k for k, v in full["configs"].items() if "error" in v], [k for k, v in full["configs"].items() if "error" in v]
     assert len(full["configs"]) >= 20 and full["value"] == line["value"] and "long_horizon" in full["cpu_baseline"]["trackframe_vs_oracle"]
