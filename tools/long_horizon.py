@@ -20,7 +20,9 @@ import numpy as np
 SCENES = (("loop, exposure 0.04 (round 5's scene)", dict(trajectory="loop", exp=0.04)),
           ("loop, exposure 0.08 of the 0.1 frame interval", dict(trajectory="loop", exp=0.08)),
           ("zigzag: the harness family (diagonal legs + its rpy table), bounded", dict(trajectory="zigzag", exp=0.04)),
-          ("loop seen under a 12 deg pitch / 5 deg roll tilt (depth 5.9 .. 10.8 across the image)", dict(trajectory="loop_tilted", exp=0.04)))
+          ("loop seen under a 12 deg pitch / 5 deg roll tilt (depth 5.9 .. 10.8 across the image)", dict(trajectory="loop_tilted", exp=0.04)),
+          ("zigzag, exposure 0.08", dict(trajectory="zigzag", exp=0.08)),
+          ("tilted loop, exposure 0.08", dict(trajectory="loop_tilted", exp=0.08)))
 
 
 def growth_factor(d, lo=2, hi=20):
@@ -53,7 +55,7 @@ def scenes_section(M, ctx, orc, frontend, horizon, sequence, frames):
     fma = orc.fma_variant()
     cfg = dict(sequence.REFERENCE_CFG)
     rows = {}
-    print("== WHOSE AMPLIFICATION: free-running trackFrame (k = 2, reference configuration), %d frames, four scenes" % (frames + 1))
+    print("== WHOSE AMPLIFICATION: free-running trackFrame (k = 2, reference configuration), %d frames, six scenes" % (frames + 1))
     for name, kw in SCENES:
         seq = sequence.make_sequence(ctx, H=480, W=640, M=frames, **kw)
         gt = frontend.gt_relative(orc, seq)
@@ -98,6 +100,7 @@ def main():
     from mba_vo_amd import sequence, workloads
     from oracle import binding as orc
     frames = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    scenes_only = len(sys.argv) > 2 and sys.argv[2] == "scenes"
     ctx = M.capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     print("# long-horizon parity, library %s" % ctx.lib.mbavo_version().decode())
     t = time.perf_counter()
@@ -106,6 +109,12 @@ def main():
           % (frames + 1, time.perf_counter() - t))
     gt = frontend.gt_relative(orc, seq)
     out = {}
+    if scenes_only:
+        del seq
+        out["scenes"] = scenes_section(M, ctx, orc, frontend, horizon, sequence, frames)
+        print("JSON " + json.dumps(out))
+        ctx.close()
+        return
     for name, cfg, knots in (("trackFrame k = 2 (the reference's default: the tracker's own two knots), Jacobi-SVD solver type", dict(sequence.REFERENCE_CFG), 0),
                              ("trackFrame k = 4, four identity knots through getSplineTrajectory(), solver type 0 (minimum-norm step)", dict(sequence.REFERENCE_CFG, k=4), 4),
                              ("trackFrame k = 2, LDLT solver type", dict(sequence.REFERENCE_CFG, solver=1), 0)):
