@@ -85,3 +85,21 @@ def test_checker_enters_bench_in_one_place():
     for f in ("bench_core.py", "bench_side.py"):
         assert "oracle" not in txt[f] and "bench_checks" not in txt[f].replace("bench_checks.py", "").replace("bench_checks.trackframe_checker", ""), f
     assert "from oracle import binding" in txt["bench_checks.py"]
+
+
+def test_bench_without_a_gpu_prints_an_error_line():
+    """No HIP device: bench.py has nothing to fall back to -- ONE parseable line with `error`, exit code 2, for N = 1 and for the
+    self-launching form (which must not spawn ranks it cannot place)."""
+    import subprocess
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    for extra in ([], ["--gpus", "2"], ["--gpus", "2", "--comm", "p2p-shared"]):
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1"] + extra, cwd=ROOT, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+        assert p.returncode == 2 and len(lines) == 1, (extra, p.returncode, p.stdout.decode()[-500:], p.stderr.decode()[-500:])
+        d = json.loads(lines[0])
+        assert "error" in d and d["value"] is None and d["metric"] is None
